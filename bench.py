@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""bench.py -- the north-star workload on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic Criteo-day0, N rows x (26 int32
+categorical + 13 int32 continuous, Arrow validity bitmaps), resident in HBM;
+one *step* = Workflow.fit + Workflow.transform of
+    C1..C26 >> Categorify()   and   I1..I13 >> FillMissing() >> Normalize()
+i.e. the reference's `--normalize` Criteo benchmark
+(bench/examples/dask-nvtabular-criteo-benchmark.py:200-214) without parquet I/O.
+
+Prints ONE JSON line (rank 0).  value = rows/s over all ranks (weak scaling:
+every rank owns its own N-row shard; fit statistics are merged over RCCL).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# Criteo-1TB categorical cardinalities (DLRM --arch-embedding-size)
+CRITEO_CARDS = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346,
+                10, 2208, 11938, 155, 4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108,
+                36]
+N_CONT = 13
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth_criteo(n, device, seed=20260923, n_cat=26, n_cont=N_CONT):
+    """Deterministic Criteo-shaped frame, generated on `device` (torch RNG).
+
+    Categorical j: bounded power law over its Criteo cardinality (exponent cycling
+    1.05..1.2), ids scrambled by an odd multiplier mod 2^31 so they are not
+    frequency-ordered; null fraction cycling {0, 0.03, 0.3}.  Continuous j:
+    floor(lognormal(2, 2)) as int32, null fraction 0..0.45."""
+    from nvtabular_amd.device import DeviceColumn, DeviceFrame, pack_bitmap_device
+
+    frame = DeviceFrame()
+    exps = [1.05, 1.1, 1.15, 1.2]
+    nulls = [0.0, 0.03, 0.3]
+    for j in range(n_cat):
+        g = torch.Generator(device=device).manual_seed(seed + j)
+        card = float(min(CRITEO_CARDS[j % len(CRITEO_CARDS)], max(n, 3)))
+        s = exps[j % 4]
+        u = torch.rand(n, device=device, dtype=torch.float64, generator=g)
+        x = ((card ** (1.0 - s) - 1.0) * u + 1.0) ** (1.0 / (1.0 - s))
+        x = x.floor().clamp_(1, card).to(torch.int64)
+        ids = ((x * 2654435761 + 97 * j) % (2**31)).to(torch.int32)
+        valid = None
+        nf = nulls[j % 3]
+        if nf > 0:
+            m = torch.rand(n, device=device, generator=g) >= nf
+            valid = pack_bitmap_device(m)
+        frame[f"C{j + 1}"] = DeviceColumn(ids.contiguous(), valid)
+        del u, x
+    for j in range(n_cont):
+        g = torch.Generator(device=device).manual_seed(seed + 100 + j)
+        z = torch.randn(n, device=device, generator=g)
+        v = torch.exp(2.0 + 2.0 * z).floor().clamp_(0, 2**31 - 1).to(torch.int32)
+        nf = 0.45 * j / max(n_cont - 1, 1)
+        valid = None
+        if nf > 0:
+            m = torch.rand(n, device=device, generator=g) >= nf
+            valid = pack_bitmap_device(m)
+        frame[f"I{j + 1}"] = DeviceColumn(v.contiguous(), valid)
+        del z
+    return frame
+
+
+def frame_to_oracle_pandas(frame, rows):
+    """First `rows` rows as the float64-with-NaN frame pandas' parquet reader gives."""
+    import pandas as pd
+
+    data = {}
+    for name, col in frame.items():
+        vals = col.data[:rows].cpu().numpy()
+        if col.valid is not None:
+            bits = np.unpackbits(col.valid[: (rows + 7) // 8].cpu().numpy(), bitorder="little")[:rows]
+            vals = vals.astype("float64")
+            vals[bits == 0] = np.nan
+        data[name] = vals
+    return pd.DataFrame(data)
+
+
+def build_workflow(cat_names, cont_names, out_path):
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    cats = cat_names >> ops.Categorify(out_path=out_path, defer_artifacts=True)
+    conts = cont_names >> ops.FillMissing() >> ops.Normalize()
+    return nvt.Workflow(cats + conts)
+
+
+def cpu_baseline(frame, cat_names, cont_names, sample_rows, tmp):
+    """The oracle (pandas restatement of the reference's CPU path) timed on this
+    box's host cores over a bounded sample of the same workload: fit + transform."""
+    import oracle as O
+
+    df = frame_to_oracle_pandas(frame, sample_rows)
+    t0 = time.perf_counter()
+    paths = O.categorify_fit([df], cat_names, os.path.join(tmp, "cpu"), tie_break="pandas")
+    filled = O.fill_missing(df[cont_names].copy(), cont_names, 0)
+    mom = O.custom_moments([filled], cont_names)
+    enc = O.categorify_transform(df, cat_names, paths)
+    filled = O.fill_missing(df[cont_names].copy(), cont_names, 0)
+    O.normalize_transform(filled, cont_names, mom["mean"].to_dict(), mom["std"].to_dict())
+    dt = time.perf_counter() - t0
+    del enc
+    return {
+        "value": sample_rows / dt,
+        "unit": "rows/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {sample_rows} rows of the same synthetic frame, fit+transform, "
+                  f"single process pandas {__import__('pandas').__version__} "
+                  f"({os.cpu_count()} host cores visible), {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=45_000_000, help="rows per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as td
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+
+    n = args.rows
+    frame = synth_criteo(n, device, seed=20260923 + 1000 * rank)
+    cat_names = [c for c in frame.columns if c.startswith("C")]
+    cont_names = [c for c in frame.columns if c.startswith("I")]
+    torch.cuda.synchronize()
+
+    tmp = tempfile.mkdtemp(prefix="nvt_bench_")
+    wf = build_workflow(cat_names, cont_names, os.path.join(tmp, f"gpu{rank}"))
+    ds = nvt.Dataset(frame)
+
+    def step():
+        wf.fit(ds)
+        out = wf.transform(frame)
+        return out
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as td
+
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    K.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = K.profile_end()
+    del out
+    if world > 1:
+        import torch.distributed as td
+
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = 1e3 * dt / args.steps
+    rows_per_s = world * n * args.steps / dt
+    # algorithmic bytes: fit 4 B/value read; transform 4 B read + 8 B written
+    C, Kc = len(cat_names), len(cont_names)
+    bytes_per_row = (C * 4 + Kc * 4) + (C * 12 + Kc * 12)
+    gbs = rows_per_s * bytes_per_row / 1e9
+
+    # dominant kernel by summed launch time (HIP events around each launch, timed region only)
+    roofline = None
+    if prof:
+        name, (tot_ms, launches, alg_bytes) = max(prof.items(), key=lambda kv: kv[1][0])
+        avg_s = tot_ms / launches / 1e3
+        achieved = alg_bytes / launches / avg_s / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
+            "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
+        }
+
+    result = {
+        "metric": "rows/sec + GB/s (Criteo Categorify+FillMissing+Normalize fit+transform, HBM-resident)",
+        "value": rows_per_s,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32 keys -> int64 labels; fp64 moments/normalize",
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic Criteo-day0: 26 int32 categorical (Criteo-1TB cardinalities, "
+                        "Zipf) + 13 int32 continuous, nulls as Arrow bitmaps; "
+                        "Categorify + FillMissing + Normalize, fit + transform",
+            "rows_per_gpu": n,
+            "algorithmic_bytes_per_row": bytes_per_row,
+            "tie_break": "value (count desc, value asc)",
+            "artifacts": "deferred (no parquet I/O inside the timed region)",
+        },
+        "algorithmic_GBps": gbs,
+        "frac_of_hbm_peak": gbs / (HBM_PEAK_GBS * world),
+        "roofline": roofline,
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(frame, cat_names, cont_names,
+                                              min(args.cpu_sample, n), tmp)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as td
+
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

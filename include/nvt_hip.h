@@ -1,0 +1,213 @@
+/*
+ * nvt_hip.h -- C ABI of the MI355X (gfx950) kernels behind the NVTabular hot path.
+ *
+ * This is the drop-in boundary: every O(rows) step that NVTabular's operators
+ * hand to a dataframe backend (pandas on CPU, libcudf on GPU) for the
+ * Categorify / FillMissing / Normalize / HashBucket / JoinGroupby /
+ * TargetEncoding path has one entry point here.  Signatures use plain device
+ * pointers and sizes only (no torch / Arrow types).  Conventions:
+ *
+ *   - every function returns 0 on success, a negative NVT_E* code on failure;
+ *     nvt_last_error() returns a thread-local message for the last failure;
+ *   - all data pointers are DEVICE pointers (HBM); the caller owns every buffer
+ *     (nvt_gb_table objects own their slot arrays);
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous;
+ *   - `valid` is an Arrow validity bitmap (LSB-first, 1 = valid, bit i = row i)
+ *     or NULL when the column has no nulls.  Float columns additionally treat
+ *     NaN as null (pandas isna() semantics);
+ *   - re-entrant: no global mutable state.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   nvtabular/ops/categorify.py:955-1051   _top_level_groupby   -> nvt_count_*          (size-only)
+ *   nvtabular/ops/categorify.py:1054-1137  _mid/_bottom_level   -> nvt_count_merge_*, nvt_gb_merge
+ *   nvtabular/ops/categorify.py:1149-1337  _write_uniques sorts -> nvt_count_compact_*, nvt_vocab_sort_*
+ *   nvtabular/ops/categorify.py:1558-1807  _encode              -> nvt_encode_build_*, nvt_encode_*
+ *   nvtabular/ops/categorify.py:1837-1852  _hash_bucket         -> nvt_hash_bucket_* / nvt_encode_* (num_buckets)
+ *   nvtabular/ops/hash_bucket.py:86-100    HashBucket.transform -> nvt_hash_bucket_*
+ *   nvtabular/ops/moments.py:64-77         _chunkwise_moments   -> nvt_moments
+ *   nvtabular/ops/fill.py:49-57            FillMissing          -> nvt_fill_normalize (do_norm = 0)
+ *   nvtabular/ops/normalize.py:71-90       Normalize.transform  -> nvt_fill_normalize
+ *   nvtabular/ops/normalize.py:150-186     NormalizeMinMax      -> nvt_minmax, nvt_fill_normalize
+ *   nvtabular/ops/join_groupby.py:175-217  JoinGroupby.transform-> nvt_gb_lookup + nvt_gather_f64
+ *   nvtabular/ops/target_encoding.py:301-384 _op_group_logic    -> nvt_gb_lookup + nvt_te_apply
+ *   cpp/nvtabular/inference/categorify.cc:145-252, fill.cc:91-102 (serving-time
+ *   encode / fill loops) have the same element semantics as nvt_encode_* /
+ *   nvt_fill_normalize.
+ */
+#ifndef NVT_HIP_H
+#define NVT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVT_OK 0
+#define NVT_EINVAL (-1)   /* bad argument */
+#define NVT_EHIP (-2)     /* a HIP runtime call failed */
+#define NVT_ENOMEM (-3)
+
+/* element types of continuous columns */
+#define NVT_F32 0
+#define NVT_F64 1
+#define NVT_I32 2
+#define NVT_I64 3
+#define NVT_U8 4
+
+/* sentinel keys marking an empty hash slot; rows holding this key value are
+ * counted in state[NVT_ST_SENTINEL] instead of the table */
+#define NVT_EMPTY_I32 INT32_MIN
+#define NVT_EMPTY_I64 INT64_MIN
+
+/* layout of the uint64_t state[8] block every count/groupby table carries */
+#define NVT_ST_NULLS 0     /* rows whose key was null                        */
+#define NVT_ST_SENTINEL 1  /* rows whose key equalled the empty sentinel     */
+#define NVT_ST_OCCUPIED 2  /* distinct keys currently in the table           */
+#define NVT_ST_OVERFLOW 3  /* != 0: table too full, result invalid -> regrow */
+#define NVT_ST_ROWS 4      /* rows consumed (nulls included)                 */
+#define NVT_STATE_WORDS 8
+
+int nvt_version(void);
+const char *nvt_last_error(void);
+
+/* ---- Categorify.fit: groupby-size tables (open addressing, linear probe) ----
+ * i32 table slot = {int32 key, uint32 count} (8 B); i64 slot = {int64 key,
+ * uint64 count} (16 B).  capacity must be a power of two. */
+int nvt_count_table_bytes(int key_bytes, uint64_t capacity, uint64_t *bytes);
+int nvt_count_clear(void *table, int key_bytes, uint64_t capacity, uint64_t *state, void *stream);
+int nvt_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, void *table,
+                  uint64_t capacity, uint64_t *state, void *stream);
+int nvt_count_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, void *table,
+                  uint64_t capacity, uint64_t *state, void *stream);
+/* weighted insert of an (key,count) list -- the tree-merge step (_mid_level_groupby)
+ * and the owner-side merge after the multi-GPU exchange */
+int nvt_count_merge_i32(const int32_t *keys, const int64_t *counts, uint64_t n, void *table,
+                        uint64_t capacity, uint64_t *state, void *stream);
+int nvt_count_merge_i64(const int64_t *keys, const int64_t *counts, uint64_t n, void *table,
+                        uint64_t capacity, uint64_t *state, void *stream);
+/* table -> dense (key,count) arrays, arbitrary order; *out_n (device) = rows written.
+ * out arrays must hold state[NVT_ST_OCCUPIED] entries (capacity is always enough) */
+int nvt_count_compact_i32(const void *table, uint64_t capacity, int32_t *out_keys,
+                          int64_t *out_counts, uint64_t *out_n, void *stream);
+int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_keys,
+                          int64_t *out_counts, uint64_t *out_n, void *stream);
+
+/* ---- vocabulary order (_write_uniques): count descending, key ascending ----
+ * LSD radix sort of n (key,count) pairs; tmp must hold nvt_vocab_sort_tmp_bytes(). */
+int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes);
+int nvt_vocab_sort_i32(int32_t *keys, int64_t *counts, uint64_t n, void *tmp, void *stream);
+int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, void *tmp, void *stream);
+
+/* ---- Categorify.transform (_encode) ----
+ * encode table slot: i32 = {int32 key, int32 label}; i64 = {int64 key, int64 label}.
+ * Build assigns label first_label + i to vocab_keys[i]. */
+int nvt_encode_table_bytes(int key_bytes, uint64_t capacity, uint64_t *bytes);
+int nvt_encode_build_i32(const int32_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
+                         void *table, uint64_t capacity, int64_t *sentinel_label, void *stream);
+int nvt_encode_build_i64(const int64_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
+                         void *table, uint64_t capacity, int64_t *sentinel_label, void *stream);
+/* out[i] = null_label            if key i is null
+ *        = table[key]            if present
+ *        = oov_label             if absent and num_buckets <= 1
+ *        = oov_label + h32(key) % num_buckets   otherwise      (out_bytes: 4 or 8) */
+int nvt_encode_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, const void *table,
+                   uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
+                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
+                   void *stream);
+int nvt_encode_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, const void *table,
+                   uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
+                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
+                   void *stream);
+
+/* ---- HashBucket / hashed OOV buckets: out[i] = h32(key) % num_buckets (int32);
+ * xor_in (optional, uint64 per row) is XORed into the 64-bit hash first and
+ * xor_out (optional) receives the 64-bit hash -- the "combo" XOR chain of
+ * categorify.py:1846-1851 */
+int nvt_hash_bucket_i32(const int32_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
+                        const uint64_t *xor_in, uint64_t *xor_out, void *stream);
+int nvt_hash_bucket_i64(const int64_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
+                        const uint64_t *xor_in, uint64_t *xor_out, void *stream);
+
+/* ---- Normalize.fit (_chunkwise_moments): out[3] (double, device) += {count, sum, sum of
+ * squares} over non-null rows; with has_fill, nulls count as fill_val (FillMissing
+ * upstream of Normalize).  partials: device scratch of nvt_moments_scratch_bytes(). */
+uint64_t nvt_moments_scratch_bytes(void);
+int nvt_moments(const void *x, int dtype, const uint8_t *valid, uint64_t n, int has_fill,
+                double fill_val, double *out3, void *partials, void *stream);
+/* NormalizeMinMax.fit: out2 = {min, max} over non-null rows (NaN if none), merged with
+ * the values already in out2 when accumulate != 0 */
+int nvt_minmax(const void *x, int dtype, const uint8_t *valid, uint64_t n, int accumulate,
+               double *out2, void *partials, void *stream);
+
+/* ---- FillMissing + Normalize.transform, fused:
+ *   v      = isnull(x[i]) ? (has_fill ? fill_val : NaN) : x[i]
+ *   out[i] = do_norm ? (scale > 0 ? (v - shift) / scale : v - shift) : v
+ * out dtype NVT_F32 / NVT_F64 (or the input dtype when do_norm == 0 and ints are
+ * filled); filled (optional, uint8 0/1 per row) receives isnull(x[i]) -- the
+ * `<col>_filled` column of FillMissing(add_binary_cols=True). */
+int nvt_fill_normalize(const void *x, int dtype, const uint8_t *valid, uint64_t n, int has_fill,
+                       double fill_val, int do_norm, double shift, double scale, void *out,
+                       int out_dtype, uint8_t *filled, void *stream);
+
+/* ---- JoinGroupby / TargetEncoding / combo-Categorify: multi-key groupby tables ----
+ * A table over nkeys (1..3) key columns (each int64 after widening; null components
+ * allowed and form their own groups, pandas dropna=False) and nvals (0..8) value
+ * columns.  Accumulators per group: size (all rows), count (rows whose FIRST key
+ * component is non-null -- categorify.py:995-999), and per value column
+ * sum / sum of squares / min / max over its non-null entries. */
+typedef struct nvt_gb_table nvt_gb_table;
+#define NVT_GB_SUMSQ 1   /* keep sum of squares (std / var requested)  */
+#define NVT_GB_MINMAX 2  /* keep min / max                             */
+/* The table object owns its device arrays (hipMalloc'ed on the current device). */
+int nvt_gb_create(int nkeys, int nvals, int flags, uint64_t capacity, nvt_gb_table **out);
+void nvt_gb_destroy(nvt_gb_table *t);
+int nvt_gb_clear(nvt_gb_table *t, void *stream);
+/* keys[k]: int64 device column, key_valid[k]: bitmap or NULL; vals[j]: column of vdtype[j] */
+int nvt_gb_update(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *const *key_valid,
+                  const void *const *vals, const int *vdtypes, const uint8_t *const *val_valid,
+                  uint64_t n, void *stream);
+/* merge another table's groups into t (tree reduce / multi-GPU owner merge) given its
+ * compacted columns */
+int nvt_gb_merge(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *key_null_mask,
+                 const int64_t *size, const int64_t *count, const double *const *sum,
+                 const double *const *sumsq, const double *const *vmin,
+                 const double *const *vmax, uint64_t n, void *stream);
+/* host-visible occupancy / overflow: state[NVT_STATE_WORDS] copied to host memory */
+int nvt_gb_state(nvt_gb_table *t, uint64_t *host_state, void *stream);
+/* compact groups: out_keys[k][g], out_null_mask[g] (bit k = component k is null),
+ * out_size/out_count[g], out_sum/sumsq/min/max[j][g]; any out pointer may be NULL.
+ * *out_n (device) = number of groups */
+int nvt_gb_compact(nvt_gb_table *t, int64_t *const *out_keys, uint8_t *out_null_mask,
+                   int64_t *out_size, int64_t *out_count, double *const *out_sum,
+                   double *const *out_sumsq, double *const *out_min, double *const *out_max,
+                   uint64_t *out_n, void *stream);
+/* transform side: build a lookup table over compacted group keys, then map rows to
+ * group ids (row i -> index into the compacted arrays, -1 when unseen) */
+int nvt_gb_index_build(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *key_null_mask,
+                       uint64_t n_groups, void *stream);
+int nvt_gb_lookup(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *const *key_valid,
+                  uint64_t n, int64_t *out_group, void *stream);
+/* out[i] = group[i] >= 0 ? src[group[i]] : miss   (stat columns joined back onto rows) */
+int nvt_gather_f64(const double *src, const int64_t *group, uint64_t n, double miss, void *out,
+                   int out_dtype, void *stream);
+/* TargetEncoding (target_encoding.py:341-363): with g = group_all[i], f = group_fold[i]
+ *   out[i] = g < 0 ? y_mean
+ *          : (sum_all[g] - (f>=0 ? sum_fold[f] : 0) + p*y_mean) /
+ *            (cnt_all[g] - (f>=0 ? cnt_fold[f] : 0) + p)          -> float32/float64
+ * group_fold == NULL means kfold <= 1. */
+int nvt_te_apply(const int64_t *group_all, const int64_t *group_fold, const double *sum_all,
+                 const int64_t *cnt_all, const double *sum_fold, const int64_t *cnt_fold,
+                 uint64_t n, double p_smooth, double y_mean, void *out, int out_dtype,
+                 void *stream);
+
+/* ---- small utilities used by the host layer ---- */
+/* widen an int32/uint8 key column to int64 (multi-key tables take int64 components) */
+int nvt_widen_i64(const void *src, int dtype, uint64_t n, int64_t *out, void *stream);
+/* count set bits of a validity bitmap over n rows (null bookkeeping, meta.*.parquet) */
+int nvt_popcount(const uint8_t *valid, uint64_t n, uint64_t *out_device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVT_HIP_H */

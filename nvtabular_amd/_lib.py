@@ -1,0 +1,133 @@
+"""ctypes binding of the C ABI in ``include/nvt_hip.h`` (``libnvt_hip.so``).
+
+The north star asks for cffi; cffi is not installed in this image, so the thin
+FFI layer is stdlib ``ctypes`` over the same ``extern "C"`` entry points.
+
+There is deliberately NO fallback: if the shared library is missing or a GPU is
+not visible, every compute entry raises.  (The oracle under ``oracle/`` is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnvt_hip.so")
+
+# dtype codes (include/nvt_hip.h)
+NVT_F32, NVT_F64, NVT_I32, NVT_I64, NVT_U8 = 0, 1, 2, 3, 4
+NVT_GB_SUMSQ, NVT_GB_MINMAX = 1, 2
+ST_NULLS, ST_SENTINEL, ST_OCCUPIED, ST_OVERFLOW, ST_ROWS = 0, 1, 2, 3, 4
+STATE_WORDS = 8
+
+_vp, _u64, _i64, _i32, _u32, _dbl = (
+    C.c_void_p,
+    C.c_uint64,
+    C.c_int64,
+    C.c_int,
+    C.c_uint32,
+    C.c_double,
+)
+_pp = C.POINTER(C.c_void_p)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "nvt_version": [],
+    "nvt_last_error": [],
+    "nvt_count_table_bytes": [_i32, _u64, C.POINTER(_u64)],
+    "nvt_count_clear": [_vp, _i32, _u64, _vp, _vp],
+    "nvt_count_i32": [_vp, _vp, _u64, _vp, _u64, _vp, _vp],
+    "nvt_count_i64": [_vp, _vp, _u64, _vp, _u64, _vp, _vp],
+    "nvt_count_merge_i32": [_vp, _vp, _u64, _vp, _u64, _vp, _vp],
+    "nvt_count_merge_i64": [_vp, _vp, _u64, _vp, _u64, _vp, _vp],
+    "nvt_count_compact_i32": [_vp, _u64, _vp, _vp, _vp, _vp],
+    "nvt_count_compact_i64": [_vp, _u64, _vp, _vp, _vp, _vp],
+    "nvt_vocab_sort_tmp_bytes": [_i32, _u64, C.POINTER(_u64)],
+    "nvt_vocab_sort_i32": [_vp, _vp, _u64, _vp, _vp],
+    "nvt_vocab_sort_i64": [_vp, _vp, _u64, _vp, _vp],
+    "nvt_encode_table_bytes": [_i32, _u64, C.POINTER(_u64)],
+    "nvt_encode_build_i32": [_vp, _u64, _i64, _vp, _u64, _vp, _vp],
+    "nvt_encode_build_i64": [_vp, _u64, _i64, _vp, _u64, _vp, _vp],
+    "nvt_encode_i32": [_vp, _vp, _u64, _vp, _u64, _vp, _i64, _i64, _u32, _vp, _i32, _vp],
+    "nvt_encode_i64": [_vp, _vp, _u64, _vp, _u64, _vp, _i64, _i64, _u32, _vp, _i32, _vp],
+    "nvt_hash_bucket_i32": [_vp, _u64, _u32, _vp, _vp, _vp, _vp],
+    "nvt_hash_bucket_i64": [_vp, _u64, _u32, _vp, _vp, _vp, _vp],
+    "nvt_moments_scratch_bytes": [],
+    "nvt_moments": [_vp, _i32, _vp, _u64, _i32, _dbl, _vp, _vp, _vp],
+    "nvt_minmax": [_vp, _i32, _vp, _u64, _i32, _vp, _vp, _vp],
+    "nvt_fill_normalize": [_vp, _i32, _vp, _u64, _i32, _dbl, _i32, _dbl, _dbl, _vp, _i32, _vp, _vp],
+    "nvt_gb_create": [_i32, _i32, _i32, _u64, _pp],
+    "nvt_gb_destroy": [_vp],
+    "nvt_gb_clear": [_vp, _vp],
+    "nvt_gb_update": [_vp, _pp, _pp, _pp, C.POINTER(C.c_int), _pp, _u64, _vp],
+    "nvt_gb_merge": [_vp, _pp, _vp, _vp, _vp, _pp, _pp, _pp, _pp, _u64, _vp],
+    "nvt_gb_state": [_vp, C.POINTER(_u64), _vp],
+    "nvt_gb_compact": [_vp, _pp, _vp, _vp, _vp, _pp, _pp, _pp, _pp, _vp, _vp],
+    "nvt_gb_index_build": [_vp, _pp, _vp, _u64, _vp],
+    "nvt_gb_lookup": [_vp, _pp, _pp, _u64, _vp, _vp],
+    "nvt_gather_f64": [_vp, _vp, _u64, _dbl, _vp, _i32, _vp],
+    "nvt_te_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _dbl, _dbl, _vp, _i32, _vp],
+    "nvt_widen_i64": [_vp, _i32, _u64, _vp, _vp],
+    "nvt_popcount": [_vp, _u64, _vp, _vp],
+}
+_RESTYPES = {
+    "nvt_last_error": C.c_char_p,
+    "nvt_moments_scratch_bytes": C.c_uint64,
+    "nvt_gb_destroy": None,
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NvtHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libnvt_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NvtHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "nvtabular_amd/csrc`). There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().nvt_last_error()
+        raise NvtHipError(f"{what or 'nvt call'} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise NvtHipError(
+            "no MI355X visible (torch.cuda.is_available() is False); the NVTabular hot path "
+            "has no CPU fallback in this engine"
+        )
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers (void*[n]); None -> NULL."""
+    arr = (C.c_void_p * max(len(ptrs), 1))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr

@@ -1,0 +1,514 @@
+// Continuous-column kernels: Normalize.fit moments, NormalizeMinMax.fit,
+// fused FillMissing + Normalize.transform, and the row-wise joins of
+// JoinGroupby / TargetEncoding.  All are pure streaming passes (HBM-bound):
+// 16-byte loads per lane, fp64 arithmetic, 16/32-byte stores.
+//
+// Reference: moments.py:64-116, normalize.py:71-90,150-186, fill.py:49-57,
+// join_groupby.py:175-217, target_encoding.py:340-374.
+#include <limits>
+#include <type_traits>
+
+#include "nvt_common.hpp"
+
+namespace nvt {
+
+constexpr unsigned kReduceGrid = 1024;  // fixed so partial sums combine in a fixed order
+
+template <typename T>
+struct VecOf {
+  static constexpr int n = 16 / sizeof(T);
+};
+
+template <typename T>
+__device__ __forceinline__ void load_vec(const T *p, T (&v)[VecOf<T>::n]) {
+  int4 raw = *reinterpret_cast<const int4 *>(p);
+  memcpy(v, &raw, 16);
+}
+
+// ---------------------------------------------------------------------------
+// moments: per-block partial {count, sum, sumsq} -> deterministic final reduce
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void moments_kernel(const T *__restrict__ x,
+                                                         const uint8_t *__restrict__ valid,
+                                                         uint64_t n, int has_fill, double fill_val,
+                                                         double *__restrict__ partials) {
+  constexpr int VEC = VecOf<T>::n;
+  double cnt = 0, sum = 0, sq = 0;
+  auto acc = [&](T raw, bool ok) {
+    double v = (double)raw;
+    if (!ok || is_nan(raw)) {
+      if (!has_fill) return;
+      v = fill_val;
+    }
+    cnt += 1.0;
+    sum += v;
+    sq += v * v;
+  };
+  const uint64_t nvec = n / VEC;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    T v[VEC];
+    load_vec<T>(x + i * VEC, v);
+    unsigned vbits = 0xF;
+    if (valid != nullptr) {
+      uint64_t row = i * VEC;
+      vbits = valid[row >> 3] >> (row & 7);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc(v[j], (vbits >> j) & 1);
+  }
+  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    acc(x[i], bit_valid(valid, i));
+
+  __shared__ double red[3][kBlock / kWave];
+  cnt = wave_sum(cnt);
+  sum = wave_sum(sum);
+  sq = wave_sum(sq);
+  const unsigned w = threadIdx.x / kWave;
+  if (lane_id() == 0) {
+    red[0][w] = cnt;
+    red[1][w] = sum;
+    red[2][w] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0;
+    for (int k = 0; k < kBlock / kWave; ++k) t += red[threadIdx.x][k];
+    partials[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void moments_final_kernel(const double *__restrict__ partials,
+                                                               unsigned nblocks, double *out3) {
+  __shared__ double red[kBlock / kWave];
+  for (int q = 0; q < 3; ++q) {
+    double t = 0;
+    for (unsigned i = threadIdx.x; i < nblocks; i += kBlock) t += partials[(uint64_t)q * nblocks + i];
+    t = wave_sum(t);
+    if (lane_id() == 0) red[threadIdx.x / kWave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = 0;
+      for (int k = 0; k < kBlock / kWave; ++k) s += red[k];
+      out3[q] += s;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// min / max
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const T *__restrict__ x,
+                                                        const uint8_t *__restrict__ valid,
+                                                        uint64_t n, double *__restrict__ partials) {
+  constexpr int VEC = VecOf<T>::n;
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  double mn = qnan, mx = qnan;
+  auto acc = [&](T raw, bool ok) {
+    if (!ok || is_nan(raw)) return;
+    double v = (double)raw;
+    mn = (v < mn || mn != mn) ? v : mn;
+    mx = (v > mx || mx != mx) ? v : mx;
+  };
+  const uint64_t nvec = n / VEC;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    T v[VEC];
+    load_vec<T>(x + i * VEC, v);
+    unsigned vbits = 0xF;
+    if (valid != nullptr) {
+      uint64_t row = i * VEC;
+      vbits = valid[row >> 3] >> (row & 7);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc(v[j], (vbits >> j) & 1);
+  }
+  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    acc(x[i], bit_valid(valid, i));
+  __shared__ double red[2][kBlock / kWave];
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  const unsigned w = threadIdx.x / kWave;
+  if (lane_id() == 0) {
+    red[0][w] = mn;
+    red[1][w] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = qnan, b = qnan;
+    for (int k = 0; k < kBlock / kWave; ++k) {
+      double p = red[0][k], q = red[1][k];
+      a = (p < a || a != a) ? p : a;
+      b = (q > b || b != b) ? q : b;
+    }
+    partials[blockIdx.x] = a;
+    partials[gridDim.x + blockIdx.x] = b;
+  }
+}
+__global__ void minmax_final_kernel(const double *__restrict__ partials, unsigned nblocks,
+                                    int accumulate, double *out2) {
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  double mn = qnan, mx = qnan;
+  for (unsigned i = threadIdx.x; i < nblocks; i += kWave) {
+    double p = partials[i], q = partials[nblocks + i];
+    mn = (p < mn || mn != mn) ? p : mn;
+    mx = (q > mx || mx != mx) ? q : mx;
+  }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  if (threadIdx.x == 0) {
+    if (accumulate) {
+      double p = out2[0], q = out2[1];
+      mn = (p < mn || mn != mn) ? p : mn;
+      mx = (q > mx || mx != mx) ? q : mx;
+    }
+    out2[0] = mn;
+    out2[1] = mx;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fused FillMissing + Normalize
+// ---------------------------------------------------------------------------
+template <typename T, typename OUT>
+__global__ __launch_bounds__(kBlock) void fill_norm_kernel(
+    const T *__restrict__ x, const uint8_t *__restrict__ valid, uint64_t n, int has_fill,
+    double fill_val, int do_norm, double shift, double scale, OUT *__restrict__ out,
+    uint8_t *__restrict__ filled) {
+  constexpr int VEC = VecOf<T>::n;
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  const double inv_is_div = scale > 0 ? 1.0 : 0.0;
+  auto f = [&](T raw, bool ok, uint8_t &was_null) -> OUT {
+    bool isnull = !ok || is_nan(raw);
+    was_null = isnull ? 1 : 0;
+    if (!do_norm) {
+      // pure fill: stay in the output type (exact for integers)
+      if (isnull) {
+        if (has_fill) return (OUT)fill_val;
+        if constexpr (std::is_floating_point<OUT>::value) return (OUT)qnan;
+        return (OUT)0;
+      }
+      return (OUT)raw;
+    }
+    double v = isnull ? (has_fill ? fill_val : qnan) : (double)raw;
+    v -= shift;
+    if (inv_is_div != 0.0) v /= scale;
+    return (OUT)v;
+  };
+  const uint64_t nvec = n / VEC;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    T v[VEC];
+    load_vec<T>(x + i * VEC, v);
+    unsigned vbits = 0xF;
+    if (valid != nullptr) {
+      uint64_t row = i * VEC;
+      vbits = valid[row >> 3] >> (row & 7);
+    }
+    OUT r[VEC];
+    uint8_t m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) r[j] = f(v[j], (vbits >> j) & 1, m[j]);
+    OUT *dst = out + i * VEC;
+    constexpr int OB = VEC * (int)sizeof(OUT);
+    if constexpr (OB == 32) {
+      int4 a, b;
+      memcpy(&a, &r[0], 16);
+      memcpy(&b, &r[VEC / 2], 16);
+      reinterpret_cast<int4 *>(dst)[0] = a;
+      reinterpret_cast<int4 *>(dst)[1] = b;
+    } else if constexpr (OB == 16) {
+      int4 a;
+      memcpy(&a, &r[0], 16);
+      reinterpret_cast<int4 *>(dst)[0] = a;
+    } else {
+      int2 a;
+      memcpy(&a, &r[0], 8);
+      reinterpret_cast<int2 *>(dst)[0] = a;
+    }
+    if (filled != nullptr) {
+      if constexpr (VEC == 4) {
+        uint32_t pk;
+        memcpy(&pk, m, 4);
+        reinterpret_cast<uint32_t *>(filled)[i] = pk;
+      } else {
+        uint16_t pk;
+        memcpy(&pk, m, 2);
+        reinterpret_cast<uint16_t *>(filled)[i] = pk;
+      }
+    }
+  }
+  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    uint8_t m;
+    out[i] = f(x[i], bit_valid(valid, i), m);
+    if (filled != nullptr) filled[i] = m;
+  }
+}
+
+template <typename OUT>
+__global__ __launch_bounds__(kBlock) void gather_kernel(const double *__restrict__ src,
+                                                        const int64_t *__restrict__ group,
+                                                        uint64_t n, double miss,
+                                                        OUT *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int64_t g = group[i];
+    double v = g >= 0 ? src[g] : miss;
+    out[i] = (OUT)v;
+  }
+}
+
+template <typename OUT>
+__global__ __launch_bounds__(kBlock) void te_kernel(
+    const int64_t *__restrict__ group_all, const int64_t *__restrict__ group_fold,
+    const double *__restrict__ sum_all, const int64_t *__restrict__ cnt_all,
+    const double *__restrict__ sum_fold, const int64_t *__restrict__ cnt_fold, uint64_t n,
+    double p, double y_mean, OUT *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int64_t g = group_all[i];
+    double v = y_mean;
+    if (group_fold != nullptr) {
+      // with folds the reference merges on [fold, key]: an unseen (fold,key) pair -> y_mean
+      int64_t f = group_fold[i];
+      if (g >= 0 && f >= 0) {
+        double s = sum_all[g] - sum_fold[f];
+        double c = (double)(cnt_all[g] - cnt_fold[f]);
+        v = (s + p * y_mean) / (c + p);
+      }
+    } else if (g >= 0) {
+      v = (sum_all[g] + p * y_mean) / ((double)cnt_all[g] + p);
+    }
+    out[i] = (OUT)v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void widen_kernel(const T *__restrict__ src, uint64_t n,
+                                                       int64_t *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    out[i] = (int64_t)src[i];
+}
+
+__global__ __launch_bounds__(kBlock) void popcount_kernel(const uint8_t *__restrict__ valid,
+                                                          uint64_t n, uint64_t *out) {
+  const uint64_t nbytes = n >> 3;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  unsigned long long c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nbytes; i += stride)
+    c += __popc((unsigned)valid[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 7))
+    c += __popc((unsigned)valid[nbytes] & ((1u << (n & 7)) - 1u));
+  double d = wave_sum((double)c);
+  if (lane_id() == 0 && d > 0) atomicAdd((unsigned long long *)out, (unsigned long long)d);
+}
+
+template <typename T>
+int moments_launch(const T *x, const uint8_t *valid, uint64_t n, int has_fill, double fill_val,
+                   double *out3, double *partials, hipStream_t s) {
+  unsigned grid = stream_grid(n / VecOf<T>::n + 1, kBlock * 4, 4);
+  moments_kernel<T><<<grid, kBlock, 0, s>>>(x, valid, n, has_fill, fill_val, partials);
+  NVT_CHECK_LAUNCH();
+  moments_final_kernel<<<1, kBlock, 0, s>>>(partials, grid, out3);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+template <typename T>
+int minmax_launch(const T *x, const uint8_t *valid, uint64_t n, int accumulate, double *out2,
+                  double *partials, hipStream_t s) {
+  unsigned grid = stream_grid(n / VecOf<T>::n + 1, kBlock * 4, 4);
+  minmax_kernel<T><<<grid, kBlock, 0, s>>>(x, valid, n, partials);
+  NVT_CHECK_LAUNCH();
+  minmax_final_kernel<<<1, kWave, 0, s>>>(partials, grid, accumulate, out2);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+template <typename T, typename OUT>
+int fill_norm_launch(const void *x, const uint8_t *valid, uint64_t n, int has_fill, double fill_val,
+                     int do_norm, double shift, double scale, void *out, uint8_t *filled,
+                     hipStream_t s) {
+  unsigned grid = stream_grid(n / VecOf<T>::n + 1, kBlock * 2, 8);
+  fill_norm_kernel<T, OUT><<<grid, kBlock, 0, s>>>(reinterpret_cast<const T *>(x), valid, n,
+                                                   has_fill, fill_val, do_norm, shift, scale,
+                                                   reinterpret_cast<OUT *>(out), filled);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+}  // namespace nvt
+
+using namespace nvt;
+
+extern "C" {
+
+uint64_t nvt_moments_scratch_bytes(void) { return (uint64_t)kReduceGrid * 3 * sizeof(double); }
+
+int nvt_moments(const void *x, int dtype, const uint8_t *valid, uint64_t n, int has_fill,
+                double fill_val, double *out3, void *partials, void *stream) {
+  NVT_CHECK_ARG(out3 && partials, "null out/partials");
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(x && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  double *p = reinterpret_cast<double *>(partials);
+  switch (dtype) {
+    case NVT_F32:
+      return moments_launch<float>((const float *)x, valid, n, has_fill, fill_val, out3, p, s);
+    case NVT_F64:
+      return moments_launch<double>((const double *)x, valid, n, has_fill, fill_val, out3, p, s);
+    case NVT_I32:
+      return moments_launch<int32_t>((const int32_t *)x, valid, n, has_fill, fill_val, out3, p, s);
+    case NVT_I64:
+      return moments_launch<int64_t>((const int64_t *)x, valid, n, has_fill, fill_val, out3, p, s);
+  }
+  set_error("nvt_moments: unsupported dtype %d", dtype);
+  return NVT_EINVAL;
+}
+
+int nvt_minmax(const void *x, int dtype, const uint8_t *valid, uint64_t n, int accumulate,
+               double *out2, void *partials, void *stream) {
+  NVT_CHECK_ARG(out2 && partials, "null out/partials");
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(x && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  double *p = reinterpret_cast<double *>(partials);
+  switch (dtype) {
+    case NVT_F32:
+      return minmax_launch<float>((const float *)x, valid, n, accumulate, out2, p, s);
+    case NVT_F64:
+      return minmax_launch<double>((const double *)x, valid, n, accumulate, out2, p, s);
+    case NVT_I32:
+      return minmax_launch<int32_t>((const int32_t *)x, valid, n, accumulate, out2, p, s);
+    case NVT_I64:
+      return minmax_launch<int64_t>((const int64_t *)x, valid, n, accumulate, out2, p, s);
+  }
+  set_error("nvt_minmax: unsupported dtype %d", dtype);
+  return NVT_EINVAL;
+}
+
+int nvt_fill_normalize(const void *x, int dtype, const uint8_t *valid, uint64_t n, int has_fill,
+                       double fill_val, int do_norm, double shift, double scale, void *out,
+                       int out_dtype, uint8_t *filled, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(x && out, "null x/out");
+  NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                "x/out must be 16-byte aligned");
+  NVT_CHECK_ARG(!filled || (reinterpret_cast<uintptr_t>(filled) & 3) == 0,
+                "filled must be 4-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+#define NVT_FN(T, O) \
+  return fill_norm_launch<T, O>(x, valid, n, has_fill, fill_val, do_norm, shift, scale, out, filled, s)
+  if (out_dtype == NVT_F64) {
+    switch (dtype) {
+      case NVT_F32: NVT_FN(float, double);
+      case NVT_F64: NVT_FN(double, double);
+      case NVT_I32: NVT_FN(int32_t, double);
+      case NVT_I64: NVT_FN(int64_t, double);
+    }
+  } else if (out_dtype == NVT_F32) {
+    switch (dtype) {
+      case NVT_F32: NVT_FN(float, float);
+      case NVT_F64: NVT_FN(double, float);
+      case NVT_I32: NVT_FN(int32_t, float);
+      case NVT_I64: NVT_FN(int64_t, float);
+    }
+  } else if (!do_norm && out_dtype == dtype) {
+    switch (dtype) {
+      case NVT_I32: NVT_FN(int32_t, int32_t);
+      case NVT_I64: NVT_FN(int64_t, int64_t);
+    }
+  }
+#undef NVT_FN
+  set_error("nvt_fill_normalize: unsupported dtype combination in=%d out=%d norm=%d", dtype,
+            out_dtype, do_norm);
+  return NVT_EINVAL;
+}
+
+int nvt_gather_f64(const double *src, const int64_t *group, uint64_t n, double miss, void *out,
+                   int out_dtype, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(src && group && out, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned grid = stream_grid(n, kBlock * 4);
+  switch (out_dtype) {
+    case NVT_F64:
+      gather_kernel<double><<<grid, kBlock, 0, s>>>(src, group, n, miss, (double *)out);
+      break;
+    case NVT_F32:
+      gather_kernel<float><<<grid, kBlock, 0, s>>>(src, group, n, miss, (float *)out);
+      break;
+    case NVT_I32:
+      gather_kernel<int32_t><<<grid, kBlock, 0, s>>>(src, group, n, miss, (int32_t *)out);
+      break;
+    case NVT_I64:
+      gather_kernel<int64_t><<<grid, kBlock, 0, s>>>(src, group, n, miss, (int64_t *)out);
+      break;
+    default:
+      set_error("nvt_gather_f64: unsupported out dtype %d", out_dtype);
+      return NVT_EINVAL;
+  }
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_te_apply(const int64_t *group_all, const int64_t *group_fold, const double *sum_all,
+                 const int64_t *cnt_all, const double *sum_fold, const int64_t *cnt_fold,
+                 uint64_t n, double p_smooth, double y_mean, void *out, int out_dtype,
+                 void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(group_all && sum_all && cnt_all && out, "null pointer");
+  NVT_CHECK_ARG(!group_fold || (sum_fold && cnt_fold), "fold stats missing");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned grid = stream_grid(n, kBlock * 4);
+  if (out_dtype == NVT_F32)
+    te_kernel<float><<<grid, kBlock, 0, s>>>(group_all, group_fold, sum_all, cnt_all, sum_fold,
+                                             cnt_fold, n, p_smooth, y_mean, (float *)out);
+  else if (out_dtype == NVT_F64)
+    te_kernel<double><<<grid, kBlock, 0, s>>>(group_all, group_fold, sum_all, cnt_all, sum_fold,
+                                              cnt_fold, n, p_smooth, y_mean, (double *)out);
+  else {
+    set_error("nvt_te_apply: out dtype must be f32/f64");
+    return NVT_EINVAL;
+  }
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_widen_i64(const void *src, int dtype, uint64_t n, int64_t *out, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(src && out, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned grid = stream_grid(n, kBlock * 4);
+  switch (dtype) {
+    case NVT_I32:
+      widen_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)src, n, out);
+      break;
+    case NVT_U8:
+      widen_kernel<uint8_t><<<grid, kBlock, 0, s>>>((const uint8_t *)src, n, out);
+      break;
+    case NVT_I64:
+      NVT_CHECK_HIP(hipMemcpyAsync(out, src, n * 8, hipMemcpyDeviceToDevice, s));
+      return NVT_OK;
+    default:
+      set_error("nvt_widen_i64: unsupported dtype %d", dtype);
+      return NVT_EINVAL;
+  }
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_popcount(const uint8_t *valid, uint64_t n, uint64_t *out_device, void *stream) {
+  NVT_CHECK_ARG(out_device, "null out");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_CHECK_HIP(hipMemsetAsync(out_device, 0, sizeof(uint64_t), s));
+  if (n == 0 || valid == nullptr) return NVT_OK;
+  popcount_kernel<<<stream_grid(n / 8 + 1, kBlock * 16), kBlock, 0, s>>>(valid, n, out_device);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+}  // extern "C"

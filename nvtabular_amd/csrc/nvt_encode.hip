@@ -1,0 +1,324 @@
+// Categorify.transform / HashBucket on MI355X.
+//
+// Replaces the pandas `codes.merge(vocab, how="left").sort_values("order")`
+// hash join + re-sort of categorify.py:1774-1776 (_encode) with one streaming
+// pass: each lane loads 16 B of keys, probes a {key,label} open-addressing
+// table and writes the labels with 16/32-byte stores.  Row order is preserved by
+// construction, so the reference's O(n log n) re-sort disappears.
+//
+// Bytes per row (int32 keys, int64 labels): 4 read + 8 written = 12; the table
+// probe is extra traffic that stays in L2 / Infinity Cache for all but the
+// ~4e7-key columns.
+#include <limits>
+#include <type_traits>
+
+#include "nvt_common.hpp"
+
+namespace nvt {
+
+template <typename K>
+struct EncSlot;
+template <>
+struct EncSlot<int32_t> {
+  int32_t key;
+  int32_t label;
+};
+template <>
+struct EncSlot<int64_t> {
+  int64_t key;
+  int64_t label;
+};
+template <typename K>
+struct EncTraits;
+template <>
+struct EncTraits<int32_t> {
+  static constexpr int32_t empty = INT32_MIN;
+  static constexpr int vec = 4;
+  using cas_t = int;
+};
+template <>
+struct EncTraits<int64_t> {
+  static constexpr int64_t empty = INT64_MIN;
+  static constexpr int vec = 2;
+  using cas_t = unsigned long long;
+};
+
+template <typename K>
+__global__ __launch_bounds__(kBlock) void enc_clear_kernel(EncSlot<K> *table, uint64_t capacity,
+                                                           int64_t *sentinel_label) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  EncSlot<K> e;
+  e.key = EncTraits<K>::empty;
+  e.label = std::numeric_limits<decltype(e.label)>::max();  // atomicMin target
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < capacity; i += stride)
+    table[i] = e;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sentinel_label = -1;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kBlock) void enc_build_kernel(const K *__restrict__ vocab, uint64_t n,
+                                                           int64_t first_label, EncSlot<K> *table,
+                                                           uint64_t mask, int64_t *sentinel_label) {
+  constexpr K EMPTY = EncTraits<K>::empty;
+  using C = typename EncTraits<K>::cas_t;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    K key = vocab[i];
+    int64_t label = first_label + (int64_t)i;
+    if (key == EMPTY) {
+      *sentinel_label = label;
+      continue;
+    }
+    uint64_t slot = (uint64_t)slot_hash(key) & mask;
+    while (true) {
+      K prev = (K)atomicCAS(reinterpret_cast<C *>(&table[slot].key), (C)EMPTY, (C)key);
+      if (prev == EMPTY || prev == key) {
+        // duplicate vocabulary keys (user-supplied vocabs): first (lowest) label wins,
+        // so every writer goes through atomicMin against the cleared max value
+        using L = decltype(table[slot].label);
+        if constexpr (sizeof(L) == 4)
+          atomicMin(reinterpret_cast<int *>(&table[slot].label), (int)label);
+        else
+          atomicMin(reinterpret_cast<long long *>(&table[slot].label), (long long)label);
+        break;
+      }
+      slot = (slot + 1) & mask;
+    }
+  }
+}
+
+template <typename K>
+__device__ __forceinline__ int64_t probe(const EncSlot<K> *__restrict__ table, uint64_t mask,
+                                         K key) {
+  constexpr K EMPTY = EncTraits<K>::empty;
+  uint64_t slot = (uint64_t)slot_hash(key) & mask;
+  while (true) {
+    EncSlot<K> s = table[slot];
+    if (s.key == key) return (int64_t)s.label;
+    if (s.key == EMPTY) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+template <typename K, typename OUT>
+__global__ __launch_bounds__(kBlock) void encode_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
+    int64_t null_label, int64_t oov_label, uint32_t num_buckets, OUT *__restrict__ out) {
+  constexpr K EMPTY = EncTraits<K>::empty;
+  constexpr int VEC = EncTraits<K>::vec;
+  const int64_t sent = *sentinel_label;
+
+  auto label_of = [&](K key, bool ok) -> OUT {
+    if (!ok) return (OUT)null_label;
+    int64_t lab = (key == EMPTY) ? sent : probe<K>(table, mask, key);
+    if (lab < 0) {
+      lab = oov_label;
+      if (num_buckets > 1) lab += (int64_t)(key_hash32((int64_t)key) % num_buckets);
+    }
+    return (OUT)lab;
+  };
+
+  const uint64_t nvec = n / VEC;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
+  const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
+  for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+    VecT pack = vkeys[v];
+    unsigned vbits = 0xF;
+    if (valid != nullptr) {
+      uint64_t row = v * VEC;
+      vbits = (valid[row >> 3] >> (row & 7));
+    }
+    K k[VEC];
+    if constexpr (sizeof(K) == 4) {
+      k[0] = pack.x;
+      k[1] = pack.y;
+      k[2] = pack.z;
+      k[3] = pack.w;
+    } else {
+      k[0] = pack.x;
+      k[1] = pack.y;
+    }
+    OUT r[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) r[j] = label_of(k[j], (vbits >> j) & 1);
+    // VEC * sizeof(OUT) is 8, 16 or 32 bytes: store as 1-2 wide vectors
+    OUT *dst = out + v * VEC;
+    if constexpr (VEC * sizeof(OUT) == 32) {
+      int4 a, b;
+      memcpy(&a, &r[0], 16);
+      memcpy(&b, &r[2], 16);
+      reinterpret_cast<int4 *>(dst)[0] = a;
+      reinterpret_cast<int4 *>(dst)[1] = b;
+    } else if constexpr (VEC * sizeof(OUT) == 16) {
+      int4 a;
+      memcpy(&a, &r[0], 16);
+      reinterpret_cast<int4 *>(dst)[0] = a;
+    } else {
+      int2 a;
+      memcpy(&a, &r[0], 8);
+      reinterpret_cast<int2 *>(dst)[0] = a;
+    }
+  }
+  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    out[i] = label_of(keys[i], bit_valid(valid, i));
+}
+
+template <typename K>
+__global__ __launch_bounds__(kBlock) void hash_bucket_kernel(const K *__restrict__ keys, uint64_t n,
+                                                             uint32_t nb, int32_t *__restrict__ out,
+                                                             const uint64_t *__restrict__ xor_in,
+                                                             uint64_t *__restrict__ xor_out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    uint64_t h = key_hash64((int64_t)keys[i]);
+    if (xor_in) h ^= xor_in[i];
+    if (xor_out) xor_out[i] = h;
+    if (out) out[i] = (int32_t)((uint32_t)(h >> 32) % nb);
+  }
+}
+
+// fast path: no XOR chain, vectorised
+template <typename K>
+__global__ __launch_bounds__(kBlock) void hash_bucket_vec_kernel(const K *__restrict__ keys,
+                                                                 uint64_t n, uint32_t nb,
+                                                                 int32_t *__restrict__ out) {
+  constexpr int VEC = EncTraits<K>::vec;
+  const uint64_t nvec = n / VEC;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
+  const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
+  for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+    VecT pack = vkeys[v];
+    if constexpr (sizeof(K) == 4) {
+      int4 r;
+      r.x = (int32_t)(key_hash32(pack.x) % nb);
+      r.y = (int32_t)(key_hash32(pack.y) % nb);
+      r.z = (int32_t)(key_hash32(pack.z) % nb);
+      r.w = (int32_t)(key_hash32(pack.w) % nb);
+      reinterpret_cast<int4 *>(out)[v] = r;
+    } else {
+      int2 r;
+      r.x = (int32_t)(key_hash32(pack.x) % nb);
+      r.y = (int32_t)(key_hash32(pack.y) % nb);
+      reinterpret_cast<int2 *>(out)[v] = r;
+    }
+  }
+  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    out[i] = (int32_t)(key_hash32((int64_t)keys[i]) % nb);
+}
+
+template <typename K>
+int build_launch(const K *vocab, uint64_t n, int64_t first_label, void *table, uint64_t capacity,
+                 int64_t *sentinel_label, hipStream_t s) {
+  NVT_CHECK_ARG(table && sentinel_label, "null table");
+  NVT_CHECK_ARG(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be 2^k >= 64");
+  NVT_CHECK_ARG(capacity > n, "capacity must exceed the vocabulary size");
+  NVT_CHECK_ARG(sizeof(K) == 8 || first_label + (int64_t)n < INT32_MAX, "labels overflow int32");
+  auto *t = reinterpret_cast<EncSlot<K> *>(table);
+  enc_clear_kernel<K><<<stream_grid(capacity, kBlock * 4), kBlock, 0, s>>>(t, capacity,
+                                                                           sentinel_label);
+  NVT_CHECK_LAUNCH();
+  if (n) {
+    NVT_CHECK_ARG(vocab, "null vocabulary");
+    enc_build_kernel<K><<<stream_grid(n, kBlock), kBlock, 0, s>>>(vocab, n, first_label, t,
+                                                                  capacity - 1, sentinel_label);
+    NVT_CHECK_LAUNCH();
+  }
+  return NVT_OK;
+}
+
+template <typename K>
+int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *table,
+                  uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
+                  int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
+                  hipStream_t s) {
+  NVT_CHECK_ARG(table && sentinel_label, "null table");
+  NVT_CHECK_ARG(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be 2^k >= 64");
+  NVT_CHECK_ARG(out_bytes == 4 || out_bytes == 8, "out_bytes must be 4 or 8");
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(keys && out, "null keys/out");
+  NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                "keys/out must be 16-byte aligned");
+  constexpr int VEC = EncTraits<K>::vec;
+  unsigned grid = stream_grid(n / VEC + 1, kBlock * 2, 8);
+  auto *t = reinterpret_cast<const EncSlot<K> *>(table);
+  if (out_bytes == 8)
+    encode_kernel<K, int64_t><<<grid, kBlock, 0, s>>>(keys, valid, n, t, capacity - 1,
+                                                      sentinel_label, null_label, oov_label,
+                                                      num_buckets, reinterpret_cast<int64_t *>(out));
+  else
+    encode_kernel<K, int32_t><<<grid, kBlock, 0, s>>>(keys, valid, n, t, capacity - 1,
+                                                      sentinel_label, null_label, oov_label,
+                                                      num_buckets, reinterpret_cast<int32_t *>(out));
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+template <typename K>
+int hash_bucket_launch(const K *keys, uint64_t n, uint32_t nb, int32_t *out, const uint64_t *xor_in,
+                       uint64_t *xor_out, hipStream_t s) {
+  NVT_CHECK_ARG(nb >= 1 && nb < (1u << 31), "num_buckets must be in [1, 2^31)");
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(keys && (out || xor_out), "null keys/out");
+  bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (!xor_in && !xor_out && aligned)
+    hash_bucket_vec_kernel<K><<<stream_grid(n / EncTraits<K>::vec + 1, kBlock * 2), kBlock, 0, s>>>(
+        keys, n, nb, out);
+  else
+    hash_bucket_kernel<K><<<stream_grid(n, kBlock * 4), kBlock, 0, s>>>(keys, n, nb, out, xor_in,
+                                                                       xor_out);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+}  // namespace nvt
+
+using namespace nvt;
+
+extern "C" {
+
+int nvt_encode_table_bytes(int key_bytes, uint64_t capacity, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
+  *bytes = capacity * (key_bytes == 4 ? sizeof(EncSlot<int32_t>) : sizeof(EncSlot<int64_t>));
+  return NVT_OK;
+}
+int nvt_encode_build_i32(const int32_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
+                         void *table, uint64_t capacity, int64_t *sentinel_label, void *stream) {
+  return build_launch<int32_t>(vocab_keys, n_vocab, first_label, table, capacity, sentinel_label,
+                               (hipStream_t)stream);
+}
+int nvt_encode_build_i64(const int64_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
+                         void *table, uint64_t capacity, int64_t *sentinel_label, void *stream) {
+  return build_launch<int64_t>(vocab_keys, n_vocab, first_label, table, capacity, sentinel_label,
+                               (hipStream_t)stream);
+}
+int nvt_encode_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, const void *table,
+                   uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
+                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
+                   void *stream) {
+  return encode_launch<int32_t>(keys, valid, n, table, capacity, sentinel_label, null_label,
+                                oov_label, num_buckets, out, out_bytes, (hipStream_t)stream);
+}
+int nvt_encode_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, const void *table,
+                   uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
+                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
+                   void *stream) {
+  return encode_launch<int64_t>(keys, valid, n, table, capacity, sentinel_label, null_label,
+                                oov_label, num_buckets, out, out_bytes, (hipStream_t)stream);
+}
+int nvt_hash_bucket_i32(const int32_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
+                        const uint64_t *xor_in, uint64_t *xor_out, void *stream) {
+  return hash_bucket_launch<int32_t>(keys, n, num_buckets, out, xor_in, xor_out,
+                                     (hipStream_t)stream);
+}
+int nvt_hash_bucket_i64(const int64_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
+                        const uint64_t *xor_in, uint64_t *xor_out, void *stream) {
+  return hash_bucket_launch<int64_t>(keys, n, num_buckets, out, xor_in, xor_out,
+                                     (hipStream_t)stream);
+}
+
+}  // extern "C"

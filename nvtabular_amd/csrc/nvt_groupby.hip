@@ -1,0 +1,530 @@
+// Multi-key groupby-aggregate tables: JoinGroupby / TargetEncoding fit and
+// "combo" Categorify (categorify.py:955-1137 with agg columns), plus the
+// row -> group lookup their transforms need (join_groupby.py:198-203,
+// target_encoding.py:350-371: a left merge on the key columns followed by a
+// re-sort; here a read-only probe that keeps row order).
+//
+// Slot protocol (keys are 1..3 int64 words + a null mask, too wide for one CAS):
+//   state word 0 = empty, 1 = being written, 2 = ready.
+//   writer: CAS 0->1, write-through (sc1) stores of the key words, drain
+//           (s_waitcnt vmcnt(0)), write-through store of state = 2;
+//   reader: L1-bypassing (sc1) load of state, then of the key words.
+// Per-CU L1s are never refreshed by other CUs' stores and the per-XCD L2s are
+// not coherent, so every protocol word goes through agent-scope atomics;
+// accumulators are only ever touched by atomic RMWs, which execute at the
+// memory side.  (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility".)
+#include <limits>
+
+#include "nvt_common.hpp"
+
+struct nvt_gb_table {
+  int nkeys;
+  int nvals;
+  int flags;
+  uint64_t capacity;
+  unsigned *slot_state;        // [cap]
+  long long *keys;             // [nkeys][cap]
+  unsigned *nullmask;          // [cap]
+  unsigned long long *size;    // [cap]
+  unsigned long long *count;   // [cap]
+  double *sum;                 // [nvals][cap]
+  double *sumsq;               // [nvals][cap] or null
+  double *vmin;                // [nvals][cap] or null
+  double *vmax;                // [nvals][cap] or null
+  long long *index;            // [cap] slot -> compact group id (lookup tables)
+  uint64_t *state;             // [NVT_STATE_WORDS]
+  void *ptr_scratch;           // device copy of per-call pointer tables
+};
+
+namespace nvt {
+
+constexpr int kMaxKeys = 3;
+constexpr int kMaxVals = 8;
+constexpr unsigned ST_EMPTY = 0, ST_LOCKED = 1, ST_READY = 2;
+constexpr int kGbMaxProbe = 1024;
+
+struct GbView {
+  int nkeys, nvals, flags;
+  uint64_t mask, cap;
+  unsigned *slot_state;
+  long long *keys;
+  unsigned *nullmask;
+  unsigned long long *size, *count;
+  double *sum, *sumsq, *vmin, *vmax;
+  long long *index;
+  uint64_t *state;
+};
+
+struct GbRowArgs {
+  const int64_t *keys[kMaxKeys];
+  const uint8_t *key_valid[kMaxKeys];
+  const void *vals[kMaxVals];
+  const uint8_t *val_valid[kMaxVals];
+  int vdtype[kMaxVals];
+};
+
+struct GbMergeArgs {
+  const int64_t *keys[kMaxKeys];
+  const uint8_t *null_mask;
+  const int64_t *size, *count;
+  const double *sum[kMaxVals], *sumsq[kMaxVals], *vmin[kMaxVals], *vmax[kMaxVals];
+};
+
+struct GbOutArgs {
+  int64_t *keys[kMaxKeys];
+  uint8_t *null_mask;
+  int64_t *size, *count;
+  double *sum[kMaxVals], *sumsq[kMaxVals], *vmin[kMaxVals], *vmax[kMaxVals];
+};
+
+__device__ __forceinline__ uint64_t tuple_hash(const long long (&k)[kMaxKeys], unsigned nm,
+                                               int nkeys) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ nm;
+  for (int j = 0; j < nkeys; ++j) h = fmix64(h ^ (uint64_t)k[j]) + 0x9E3779B97F4A7C15ull * (j + 1);
+  return fmix64(h);
+}
+
+// Find (or, when `insert`, create) the slot of a key tuple.  Returns the slot
+// index or -1 (absent / overflow).
+__device__ __forceinline__ int64_t find_slot(const GbView &t, const long long (&k)[kMaxKeys],
+                                             unsigned nm, bool insert, unsigned *n_new,
+                                             unsigned *ovf) {
+  uint64_t slot = tuple_hash(k, nm, t.nkeys) & t.mask;
+  int probe = 0;
+  while (probe < kGbMaxProbe) {
+    unsigned st = __hip_atomic_load(&t.slot_state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st == ST_EMPTY) {
+      if (!insert) return -1;
+      unsigned prev = atomicCAS(&t.slot_state[slot], ST_EMPTY, ST_LOCKED);
+      if (prev == ST_EMPTY) {
+        for (int j = 0; j < t.nkeys; ++j)
+          __hip_atomic_store(&t.keys[(uint64_t)j * t.cap + slot], k[j], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&t.nullmask[slot], nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&t.slot_state[slot], ST_READY, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        *n_new += 1;
+        return (int64_t)slot;
+      }
+      st = prev;  // somebody else got it: fall through with its state
+    }
+    if (st == ST_LOCKED) continue;  // writer is a few instructions from READY: re-read
+    // READY: compare
+    bool same = __hip_atomic_load(&t.nullmask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nm;
+    for (int j = 0; same && j < t.nkeys; ++j)
+      same = __hip_atomic_load(&t.keys[(uint64_t)j * t.cap + slot], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT) == k[j];
+    if (same) return (int64_t)slot;
+    slot = (slot + 1) & t.mask;
+    ++probe;
+  }
+  *ovf = 1;
+  return -1;
+}
+
+__device__ __forceinline__ void atomic_min_f64(double *addr, double v) {
+  unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);
+  unsigned long long old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (v < __longlong_as_double((long long)old)) {
+    unsigned long long prev = atomicCAS(a, old, (unsigned long long)__double_as_longlong(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+__device__ __forceinline__ void atomic_max_f64(double *addr, double v) {
+  unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);
+  unsigned long long old = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (v > __longlong_as_double((long long)old)) {
+    unsigned long long prev = atomicCAS(a, old, (unsigned long long)__double_as_longlong(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
+__device__ __forceinline__ bool load_val(const void *p, int dtype, uint64_t i, double *out) {
+  switch (dtype) {
+    case NVT_F32: {
+      float v = reinterpret_cast<const float *>(p)[i];
+      *out = (double)v;
+      return v == v;
+    }
+    case NVT_F64: {
+      double v = reinterpret_cast<const double *>(p)[i];
+      *out = v;
+      return v == v;
+    }
+    case NVT_I32:
+      *out = (double)reinterpret_cast<const int32_t *>(p)[i];
+      return true;
+    case NVT_I64:
+      *out = (double)reinterpret_cast<const int64_t *>(p)[i];
+      return true;
+    case NVT_U8:
+      *out = (double)reinterpret_cast<const uint8_t *>(p)[i];
+      return true;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(kBlock) void gb_clear_kernel(GbView t) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const double inf = std::numeric_limits<double>::infinity();
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < t.cap; i += stride) {
+    t.slot_state[i] = ST_EMPTY;
+    t.nullmask[i] = 0;
+    t.size[i] = 0;
+    t.count[i] = 0;
+    t.index[i] = -1;
+    for (int j = 0; j < t.nkeys; ++j) t.keys[(uint64_t)j * t.cap + i] = 0;
+    for (int j = 0; j < t.nvals; ++j) {
+      t.sum[(uint64_t)j * t.cap + i] = 0.0;
+      if (t.sumsq) t.sumsq[(uint64_t)j * t.cap + i] = 0.0;
+      if (t.vmin) {
+        t.vmin[(uint64_t)j * t.cap + i] = inf;
+        t.vmax[(uint64_t)j * t.cap + i] = -inf;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < NVT_STATE_WORDS) t.state[threadIdx.x] = 0;
+}
+
+__device__ __forceinline__ unsigned read_tuple(const GbRowArgs &a, int nkeys, uint64_t i,
+                                               long long (&k)[kMaxKeys]) {
+  unsigned nm = 0;
+  for (int j = 0; j < kMaxKeys; ++j) k[j] = 0;
+  for (int j = 0; j < nkeys; ++j) {
+    if (bit_valid(a.key_valid[j], i))
+      k[j] = a.keys[j][i];
+    else
+      nm |= 1u << j;
+  }
+  return nm;
+}
+
+__global__ __launch_bounds__(kBlock) void gb_update_kernel(GbView t, GbRowArgs a, uint64_t n) {
+  unsigned n_new = 0, ovf = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    long long k[kMaxKeys];
+    unsigned nm = read_tuple(a, t.nkeys, i, k);
+    int64_t slot = find_slot(t, k, nm, true, &n_new, &ovf);
+    if (slot < 0) continue;
+    atomicAdd(&t.size[slot], 1ull);
+    if (!(nm & 1u)) atomicAdd(&t.count[slot], 1ull);
+    for (int j = 0; j < t.nvals; ++j) {
+      double v;
+      bool ok = load_val(a.vals[j], a.vdtype[j], i, &v) && bit_valid(a.val_valid[j], i);
+      if (!ok) continue;
+      uint64_t o = (uint64_t)j * t.cap + slot;
+      atomicAdd(&t.sum[o], v);
+      if (t.sumsq) atomicAdd(&t.sumsq[o], v * v);
+      if (t.vmin) {
+        atomic_min_f64(&t.vmin[o], v);
+        atomic_max_f64(&t.vmax[o], v);
+      }
+    }
+  }
+  if (n_new) atomicAdd((unsigned long long *)&t.state[NVT_ST_OCCUPIED], (unsigned long long)n_new);
+  if (ovf) atomicOr((unsigned long long *)&t.state[NVT_ST_OVERFLOW], 1ull);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd((unsigned long long *)&t.state[NVT_ST_ROWS], (unsigned long long)n);
+}
+
+__global__ __launch_bounds__(kBlock) void gb_merge_kernel(GbView t, GbMergeArgs a, uint64_t n) {
+  unsigned n_new = 0, ovf = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    long long k[kMaxKeys] = {0, 0, 0};
+    unsigned nm = a.null_mask ? a.null_mask[i] : 0;
+    for (int j = 0; j < t.nkeys; ++j) k[j] = ((nm >> j) & 1) ? 0 : a.keys[j][i];
+    int64_t slot = find_slot(t, k, nm, true, &n_new, &ovf);
+    if (slot < 0) continue;
+    if (a.size) atomicAdd(&t.size[slot], (unsigned long long)a.size[i]);
+    if (a.count) atomicAdd(&t.count[slot], (unsigned long long)a.count[i]);
+    for (int j = 0; j < t.nvals; ++j) {
+      uint64_t o = (uint64_t)j * t.cap + slot;
+      if (a.sum[j]) atomicAdd(&t.sum[o], a.sum[j][i]);
+      if (t.sumsq && a.sumsq[j]) atomicAdd(&t.sumsq[o], a.sumsq[j][i]);
+      if (t.vmin && a.vmin[j]) {
+        double lo = a.vmin[j][i], hi = a.vmax[j][i];
+        if (lo == lo) atomic_min_f64(&t.vmin[o], lo);
+        if (hi == hi) atomic_max_f64(&t.vmax[o], hi);
+      }
+    }
+  }
+  if (n_new) atomicAdd((unsigned long long *)&t.state[NVT_ST_OCCUPIED], (unsigned long long)n_new);
+  if (ovf) atomicOr((unsigned long long *)&t.state[NVT_ST_OVERFLOW], 1ull);
+}
+
+__global__ __launch_bounds__(kBlock) void gb_compact_kernel(GbView t, GbOutArgs o,
+                                                            uint64_t *out_n) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const uint64_t rounds = (t.cap + stride - 1) / stride;
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  for (uint64_t r = 0; r < rounds; ++r, i += stride) {
+    bool occ = i < t.cap && t.slot_state[i] == ST_READY;
+    unsigned long long m = __ballot(occ);
+    if (m == 0) continue;
+    unsigned lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd((unsigned long long *)out_n, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (!occ) continue;
+    uint64_t g = base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int j = 0; j < t.nkeys; ++j)
+      if (o.keys[j]) o.keys[j][g] = t.keys[(uint64_t)j * t.cap + i];
+    if (o.null_mask) o.null_mask[g] = (uint8_t)t.nullmask[i];
+    if (o.size) o.size[g] = (int64_t)t.size[i];
+    if (o.count) o.count[g] = (int64_t)t.count[i];
+    for (int j = 0; j < t.nvals; ++j) {
+      uint64_t s = (uint64_t)j * t.cap + i;
+      if (o.sum[j]) o.sum[j][g] = t.sum[s];
+      if (o.sumsq[j]) o.sumsq[j][g] = t.sumsq ? t.sumsq[s] : qnan;
+      if (o.vmin[j]) {
+        double v = t.vmin ? t.vmin[s] : qnan;
+        o.vmin[j][g] = (v == std::numeric_limits<double>::infinity()) ? qnan : v;
+      }
+      if (o.vmax[j]) {
+        double v = t.vmax ? t.vmax[s] : qnan;
+        o.vmax[j][g] = (v == -std::numeric_limits<double>::infinity()) ? qnan : v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gb_index_build_kernel(GbView t, GbMergeArgs a,
+                                                                uint64_t n) {
+  unsigned n_new = 0, ovf = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    long long k[kMaxKeys] = {0, 0, 0};
+    unsigned nm = a.null_mask ? a.null_mask[i] : 0;
+    for (int j = 0; j < t.nkeys; ++j) k[j] = ((nm >> j) & 1) ? 0 : a.keys[j][i];
+    int64_t slot = find_slot(t, k, nm, true, &n_new, &ovf);
+    if (slot >= 0) t.index[slot] = (long long)i;
+  }
+  if (n_new) atomicAdd((unsigned long long *)&t.state[NVT_ST_OCCUPIED], (unsigned long long)n_new);
+  if (ovf) atomicOr((unsigned long long *)&t.state[NVT_ST_OVERFLOW], 1ull);
+}
+
+__global__ __launch_bounds__(kBlock) void gb_lookup_kernel(GbView t, GbRowArgs a, uint64_t n,
+                                                           int64_t *__restrict__ out) {
+  unsigned n_new = 0, ovf = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    long long k[kMaxKeys];
+    unsigned nm = read_tuple(a, t.nkeys, i, k);
+    int64_t slot = find_slot(t, k, nm, false, &n_new, &ovf);
+    out[i] = slot >= 0 ? (int64_t)t.index[slot] : -1;
+  }
+}
+
+inline GbView view_of(nvt_gb_table *t) {
+  GbView v;
+  v.nkeys = t->nkeys;
+  v.nvals = t->nvals;
+  v.flags = t->flags;
+  v.cap = t->capacity;
+  v.mask = t->capacity - 1;
+  v.slot_state = t->slot_state;
+  v.keys = t->keys;
+  v.nullmask = t->nullmask;
+  v.size = t->size;
+  v.count = t->count;
+  v.sum = t->sum;
+  v.sumsq = t->sumsq;
+  v.vmin = t->vmin;
+  v.vmax = t->vmax;
+  v.index = t->index;
+  v.state = t->state;
+  return v;
+}
+
+}  // namespace nvt
+
+using namespace nvt;
+
+extern "C" {
+
+void nvt_gb_destroy(nvt_gb_table *t) {
+  if (!t) return;
+  void *ptrs[] = {t->slot_state, t->keys, t->nullmask, t->size, t->count, t->sum,
+                  t->sumsq,      t->vmin, t->vmax,     t->index, t->state};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  delete t;
+}
+
+int nvt_gb_create(int nkeys, int nvals, int flags, uint64_t capacity, nvt_gb_table **out) {
+  NVT_CHECK_ARG(out, "null out");
+  NVT_CHECK_ARG(nkeys >= 1 && nkeys <= kMaxKeys, "nkeys must be 1..3");
+  NVT_CHECK_ARG(nvals >= 0 && nvals <= kMaxVals, "nvals must be 0..8");
+  NVT_CHECK_ARG(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be 2^k >= 64");
+  nvt_gb_table *t = new nvt_gb_table();
+  memset(t, 0, sizeof(*t));
+  t->nkeys = nkeys;
+  t->nvals = nvals;
+  t->flags = flags;
+  t->capacity = capacity;
+  auto alloc = [&](void **p, uint64_t bytes) -> bool {
+    if (bytes == 0) return true;
+    return hipMalloc(p, bytes) == hipSuccess;
+  };
+  bool ok = alloc((void **)&t->slot_state, capacity * 4) &&
+            alloc((void **)&t->keys, capacity * 8 * nkeys) &&
+            alloc((void **)&t->nullmask, capacity * 4) && alloc((void **)&t->size, capacity * 8) &&
+            alloc((void **)&t->count, capacity * 8) &&
+            alloc((void **)&t->sum, capacity * 8 * nvals) &&
+            alloc((void **)&t->index, capacity * 8) &&
+            alloc((void **)&t->state, NVT_STATE_WORDS * 8);
+  if (ok && nvals && (flags & NVT_GB_SUMSQ)) ok = alloc((void **)&t->sumsq, capacity * 8 * nvals);
+  if (ok && nvals && (flags & NVT_GB_MINMAX))
+    ok = alloc((void **)&t->vmin, capacity * 8 * nvals) &&
+         alloc((void **)&t->vmax, capacity * 8 * nvals);
+  if (!ok) {
+    nvt_gb_destroy(t);
+    set_error("nvt_gb_create: hipMalloc failed for capacity %llu", (unsigned long long)capacity);
+    return NVT_ENOMEM;
+  }
+  *out = t;
+  return NVT_OK;
+}
+
+int nvt_gb_clear(nvt_gb_table *t, void *stream) {
+  NVT_CHECK_ARG(t, "null table");
+  gb_clear_kernel<<<stream_grid(t->capacity, kBlock * 2), kBlock, 0, (hipStream_t)stream>>>(
+      view_of(t));
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_gb_update(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *const *key_valid,
+                  const void *const *vals, const int *vdtypes, const uint8_t *const *val_valid,
+                  uint64_t n, void *stream) {
+  NVT_CHECK_ARG(t && keys, "null table/keys");
+  NVT_CHECK_ARG(t->nvals == 0 || (vals && vdtypes), "null vals");
+  if (n == 0) return NVT_OK;
+  GbRowArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int j = 0; j < t->nkeys; ++j) {
+    NVT_CHECK_ARG(keys[j], "null key column");
+    a.keys[j] = keys[j];
+    a.key_valid[j] = key_valid ? key_valid[j] : nullptr;
+  }
+  for (int j = 0; j < t->nvals; ++j) {
+    NVT_CHECK_ARG(vals[j], "null value column");
+    a.vals[j] = vals[j];
+    a.vdtype[j] = vdtypes[j];
+    a.val_valid[j] = val_valid ? val_valid[j] : nullptr;
+  }
+  gb_update_kernel<<<stream_grid(n, kBlock * 2), kBlock, 0, (hipStream_t)stream>>>(view_of(t), a,
+                                                                                    n);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+static int fill_merge_args(nvt_gb_table *t, GbMergeArgs &a, const int64_t *const *keys,
+                           const uint8_t *null_mask, const int64_t *size, const int64_t *count,
+                           const double *const *sum, const double *const *sumsq,
+                           const double *const *vmin, const double *const *vmax) {
+  memset(&a, 0, sizeof(a));
+  for (int j = 0; j < t->nkeys; ++j) {
+    NVT_CHECK_ARG(keys && keys[j], "null key column");
+    a.keys[j] = keys[j];
+  }
+  a.null_mask = null_mask;
+  a.size = size;
+  a.count = count;
+  for (int j = 0; j < t->nvals; ++j) {
+    a.sum[j] = sum ? sum[j] : nullptr;
+    a.sumsq[j] = sumsq ? sumsq[j] : nullptr;
+    a.vmin[j] = vmin ? vmin[j] : nullptr;
+    a.vmax[j] = vmax ? vmax[j] : nullptr;
+    NVT_CHECK_ARG((a.vmin[j] == nullptr) == (a.vmax[j] == nullptr), "min/max come in pairs");
+  }
+  return NVT_OK;
+}
+
+int nvt_gb_merge(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *key_null_mask,
+                 const int64_t *size, const int64_t *count, const double *const *sum,
+                 const double *const *sumsq, const double *const *vmin,
+                 const double *const *vmax, uint64_t n, void *stream) {
+  NVT_CHECK_ARG(t, "null table");
+  if (n == 0) return NVT_OK;
+  GbMergeArgs a;
+  int rc = fill_merge_args(t, a, keys, key_null_mask, size, count, sum, sumsq, vmin, vmax);
+  if (rc) return rc;
+  gb_merge_kernel<<<stream_grid(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(view_of(t), a, n);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_gb_state(nvt_gb_table *t, uint64_t *host_state, void *stream) {
+  NVT_CHECK_ARG(t && host_state, "null pointer");
+  NVT_CHECK_HIP(hipMemcpyAsync(host_state, t->state, NVT_STATE_WORDS * 8, hipMemcpyDeviceToHost,
+                               (hipStream_t)stream));
+  NVT_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return NVT_OK;
+}
+
+int nvt_gb_compact(nvt_gb_table *t, int64_t *const *out_keys, uint8_t *out_null_mask,
+                   int64_t *out_size, int64_t *out_count, double *const *out_sum,
+                   double *const *out_sumsq, double *const *out_min, double *const *out_max,
+                   uint64_t *out_n, void *stream) {
+  NVT_CHECK_ARG(t && out_n, "null pointer");
+  GbOutArgs o;
+  memset(&o, 0, sizeof(o));
+  for (int j = 0; j < t->nkeys; ++j) o.keys[j] = out_keys ? out_keys[j] : nullptr;
+  o.null_mask = out_null_mask;
+  o.size = out_size;
+  o.count = out_count;
+  for (int j = 0; j < t->nvals; ++j) {
+    o.sum[j] = out_sum ? out_sum[j] : nullptr;
+    o.sumsq[j] = out_sumsq ? out_sumsq[j] : nullptr;
+    o.vmin[j] = out_min ? out_min[j] : nullptr;
+    o.vmax[j] = out_max ? out_max[j] : nullptr;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  NVT_CHECK_HIP(hipMemsetAsync(out_n, 0, sizeof(uint64_t), s));
+  gb_compact_kernel<<<stream_grid(t->capacity, kBlock), kBlock, 0, s>>>(view_of(t), o, out_n);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_gb_index_build(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *key_null_mask,
+                       uint64_t n_groups, void *stream) {
+  NVT_CHECK_ARG(t, "null table");
+  NVT_CHECK_ARG(n_groups < t->capacity, "capacity must exceed the number of groups");
+  int rc = nvt_gb_clear(t, stream);
+  if (rc) return rc;
+  if (n_groups == 0) return NVT_OK;
+  GbMergeArgs a;
+  rc = fill_merge_args(t, a, keys, key_null_mask, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr);
+  if (rc) return rc;
+  gb_index_build_kernel<<<stream_grid(n_groups, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+      view_of(t), a, n_groups);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_gb_lookup(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *const *key_valid,
+                  uint64_t n, int64_t *out_group, void *stream) {
+  NVT_CHECK_ARG(t && keys && out_group, "null pointer");
+  if (n == 0) return NVT_OK;
+  GbRowArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int j = 0; j < t->nkeys; ++j) {
+    NVT_CHECK_ARG(keys[j], "null key column");
+    a.keys[j] = keys[j];
+    a.key_valid[j] = key_valid ? key_valid[j] : nullptr;
+  }
+  gb_lookup_kernel<<<stream_grid(n, kBlock * 2), kBlock, 0, (hipStream_t)stream>>>(view_of(t), a,
+                                                                                    n, out_group);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+}  // extern "C"

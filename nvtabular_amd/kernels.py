@@ -1,0 +1,542 @@
+"""Thin, typed wrappers over the C ABI: torch tensors in, torch tensors out.
+
+torch is used here only as the device allocator / stream provider ("plumbing");
+every O(rows) computation below is a hand-written gfx950 kernel reached through
+``libnvt_hip.so``.  Nothing in this module has a CPU code path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+INT32_MIN = -(2**31)
+INT64_MIN = -(2**63)
+
+_DTYPE_CODE = {
+    torch.float32: _lib.NVT_F32,
+    torch.float64: _lib.NVT_F64,
+    torch.int32: _lib.NVT_I32,
+    torch.int64: _lib.NVT_I64,
+    torch.uint8: _lib.NVT_U8,
+    torch.bool: _lib.NVT_U8,
+}
+
+
+# --------------------------------------------------------------------------
+# optional per-launch timing (bench.py): HIP events on the launch stream
+# --------------------------------------------------------------------------
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = {}
+
+
+def profile_end():
+    """{kernel: (total_ms, launches, algorithmic_bytes)} for the profiled region."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, evs in (rec or {}).items():
+        tot = sum(a.elapsed_time(b) for a, b, _ in evs)
+        out[name] = (tot, len(evs), sum(nb for _, _, nb in evs))
+    return out
+
+
+class _timed:
+    """Record start/stop events around one kernel launch when profiling is on."""
+
+    def __init__(self, name, alg_bytes):
+        self.name, self.alg_bytes = name, alg_bytes
+
+    def __enter__(self):
+        if _prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.b.record()
+            _prof.setdefault(self.name, []).append((self.a, self.b, self.alg_bytes))
+        return False
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODE[dt]
+    except KeyError:
+        raise TypeError(f"unsupported column dtype {dt}") from None
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def aligned(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Contiguous and 16-byte aligned (views with a storage offset get copied)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def next_pow2(x: int) -> int:
+    return 1 << max(6, (int(x) - 1).bit_length())
+
+
+def _key_suffix(keys: torch.Tensor) -> str:
+    if keys.dtype == torch.int32:
+        return "i32"
+    if keys.dtype == torch.int64:
+        return "i64"
+    raise TypeError(f"categorical keys must be int32/int64 on device, got {keys.dtype}")
+
+
+# --------------------------------------------------------------------------
+# Categorify.fit: count tables
+# --------------------------------------------------------------------------
+class CountTable:
+    """Open-addressing (key -> count) table in HBM for one column (group)."""
+
+    def __init__(self, key_dtype: torch.dtype, capacity: int, device=None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.key_dtype = key_dtype
+        self.key_bytes = 4 if key_dtype == torch.int32 else 8
+        self.suffix = "i32" if self.key_bytes == 4 else "i64"
+        self.capacity = next_pow2(capacity)
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        nbytes = C.c_uint64()
+        check(self.lib.nvt_count_table_bytes(self.key_bytes, self.capacity, C.byref(nbytes)))
+        self.table = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        self.state = torch.zeros(_lib.STATE_WORDS, dtype=torch.int64, device=self.device)
+        self.clear()
+
+    def clear(self):
+        with _timed("count_clear", 0):
+            check(
+                self.lib.nvt_count_clear(
+                    self.table.data_ptr(), self.key_bytes, self.capacity, self.state.data_ptr(),
+                    stream_ptr(),
+                ),
+                "nvt_count_clear",
+            )
+
+    def update(self, keys: torch.Tensor, valid: Optional[torch.Tensor]):
+        assert keys.dtype == self.key_dtype
+        keys = aligned(keys)
+        fn = getattr(self.lib, f"nvt_count_{self.suffix}")
+        with _timed(f"count_{self.suffix}", keys.numel() * self.key_bytes):
+            check(
+                fn(keys.data_ptr(), ptr(valid), keys.numel(), self.table.data_ptr(),
+                   self.capacity, self.state.data_ptr(), stream_ptr()),
+                f"nvt_count_{self.suffix}",
+            )
+
+    def merge(self, keys: torch.Tensor, counts: torch.Tensor):
+        assert keys.dtype == self.key_dtype and counts.dtype == torch.int64
+        fn = getattr(self.lib, f"nvt_count_merge_{self.suffix}")
+        check(
+            fn(keys.contiguous().data_ptr(), counts.contiguous().data_ptr(), keys.numel(),
+               self.table.data_ptr(), self.capacity, self.state.data_ptr(), stream_ptr()),
+            f"nvt_count_merge_{self.suffix}",
+        )
+
+    def read_state(self) -> List[int]:
+        return self.state.cpu().tolist()  # synchronises the stream
+
+    def compact(self, occupied: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Dense (keys, counts[int64]) in arbitrary order, sentinel-key rows included."""
+        st = self.read_state()
+        occ = st[_lib.ST_OCCUPIED] if occupied is None else occupied
+        out_k = torch.empty(occ + 1, dtype=self.key_dtype, device=self.device)
+        out_c = torch.empty(occ + 1, dtype=torch.int64, device=self.device)
+        out_n = torch.zeros(1, dtype=torch.int64, device=self.device)
+        fn = getattr(self.lib, f"nvt_count_compact_{self.suffix}")
+        with _timed("count_compact", 0):
+            check(
+                fn(self.table.data_ptr(), self.capacity, out_k.data_ptr(), out_c.data_ptr(),
+                   out_n.data_ptr(), stream_ptr()),
+                f"nvt_count_compact_{self.suffix}",
+            )
+        n = occ
+        if st[_lib.ST_SENTINEL] > 0:
+            # rows whose key equals the empty-slot sentinel are counted on the side
+            out_k[n] = INT32_MIN if self.key_bytes == 4 else INT64_MIN
+            out_c[n] = st[_lib.ST_SENTINEL]
+            n += 1
+        return out_k[:n], out_c[:n]
+
+
+def count_into_new_table(
+    keys_list: Sequence[torch.Tensor],
+    valid_list: Sequence[Optional[torch.Tensor]],
+    hint: int,
+    max_tries: int = 8,
+) -> Tuple[CountTable, List[int]]:
+    """Groupby-size of one partition's column(s) into a fresh table sized from
+    ``hint`` (expected distinct keys); regrows and recounts on overflow, which
+    is safe because the table only holds this partition."""
+    total = sum(int(k.numel()) for k in keys_list)
+    cap = next_pow2(max(64, 2 * min(max(hint, 32), max(total, 32))))
+    for _ in range(max_tries):
+        tab = CountTable(keys_list[0].dtype, cap)
+        for k, v in zip(keys_list, valid_list):
+            tab.update(k, v)
+        st = tab.read_state()
+        if not st[_lib.ST_OVERFLOW] and st[_lib.ST_OCCUPIED] * 10 <= tab.capacity * 7:
+            return tab, st
+        cap = next_pow2(max(4 * cap, 3 * st[_lib.ST_OCCUPIED]))
+    raise _lib.NvtHipError("count table kept overflowing; cardinality estimate diverged")
+
+
+def vocab_sort(keys: torch.Tensor, counts: torch.Tensor):
+    """In place: (count desc, key asc) -- categorify.py:1300,1316 with the stable tie rule."""
+    lib = _lib.load()
+    n = keys.numel()
+    if n <= 1:
+        return
+    suffix = _key_suffix(keys)
+    nbytes = C.c_uint64()
+    check(lib.nvt_vocab_sort_tmp_bytes(4 if suffix == "i32" else 8, n, C.byref(nbytes)))
+    tmp = torch.empty(nbytes.value + 16, dtype=torch.uint8, device=keys.device)
+    assert keys.is_contiguous() and counts.is_contiguous()
+    with _timed("vocab_sort", 0):
+        check(
+            getattr(lib, f"nvt_vocab_sort_{suffix}")(
+                keys.data_ptr(), counts.data_ptr(), n, tmp.data_ptr(), stream_ptr()
+            ),
+            "nvt_vocab_sort",
+        )
+
+
+# --------------------------------------------------------------------------
+# Categorify.transform: encode tables
+# --------------------------------------------------------------------------
+class EncodeTable:
+    """key -> label probe table built from an ordered vocabulary."""
+
+    def __init__(self, vocab_keys: torch.Tensor, first_label: int):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.suffix = _key_suffix(vocab_keys)
+        self.key_dtype = vocab_keys.dtype
+        self.key_bytes = 4 if self.suffix == "i32" else 8
+        self.n_vocab = int(vocab_keys.numel())
+        self.first_label = int(first_label)
+        self.capacity = next_pow2(max(64, 2 * self.n_vocab + 1))
+        dev = vocab_keys.device
+        nbytes = C.c_uint64()
+        check(self.lib.nvt_encode_table_bytes(self.key_bytes, self.capacity, C.byref(nbytes)))
+        self.table = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        self.sentinel_label = torch.empty(1, dtype=torch.int64, device=dev)
+        vk = vocab_keys.contiguous()
+        with _timed("encode_build", 0):
+            check(
+                getattr(self.lib, f"nvt_encode_build_{self.suffix}")(
+                    vk.data_ptr() if self.n_vocab else None, self.n_vocab, self.first_label,
+                    self.table.data_ptr(), self.capacity, self.sentinel_label.data_ptr(),
+                    stream_ptr(),
+                ),
+                "nvt_encode_build",
+            )
+
+    def encode(
+        self,
+        keys: torch.Tensor,
+        valid: Optional[torch.Tensor],
+        null_label: int,
+        oov_label: int,
+        num_buckets: int = 0,
+        out_dtype: torch.dtype = torch.int64,
+    ) -> torch.Tensor:
+        if keys.dtype != self.key_dtype:
+            keys = keys.to(self.key_dtype)
+        keys = aligned(keys)
+        if out_dtype not in (torch.int32, torch.int64):
+            raise TypeError("Categorify output dtype must be int32 or int64")
+        out = torch.empty(keys.numel(), dtype=out_dtype, device=keys.device)
+        with _timed(f"encode_{self.suffix}", keys.numel() * (self.key_bytes + out.element_size())):
+            check(
+                getattr(self.lib, f"nvt_encode_{self.suffix}")(
+                    keys.data_ptr(), ptr(valid), keys.numel(), self.table.data_ptr(),
+                    self.capacity, self.sentinel_label.data_ptr(), int(null_label),
+                    int(oov_label), int(num_buckets or 0), out.data_ptr(), out.element_size(),
+                    stream_ptr(),
+                ),
+                "nvt_encode",
+            )
+        return out
+
+
+def hash_bucket(
+    keys: torch.Tensor,
+    num_buckets: int,
+    xor_in: Optional[torch.Tensor] = None,
+    want_hash: bool = False,
+    want_bucket: bool = True,
+):
+    """(bucket int32 or None, hash64 or None).  hash64 is carried as int64 bits."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    keys = aligned(keys)
+    n = keys.numel()
+    out = torch.empty(n, dtype=torch.int32, device=keys.device) if want_bucket else None
+    xo = torch.empty(n, dtype=torch.int64, device=keys.device) if want_hash else None
+    check(
+        getattr(lib, f"nvt_hash_bucket_{_key_suffix(keys)}")(
+            keys.data_ptr(), n, int(num_buckets), ptr(out), ptr(xor_in), ptr(xo), stream_ptr()
+        ),
+        "nvt_hash_bucket",
+    )
+    return out, xo
+
+
+# --------------------------------------------------------------------------
+# continuous columns
+# --------------------------------------------------------------------------
+_scratch = {}
+
+
+def _partials(device) -> torch.Tensor:
+    key = (device.type, device.index)
+    if key not in _scratch:
+        nbytes = _lib.load().nvt_moments_scratch_bytes()
+        _scratch[key] = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+    return _scratch[key]
+
+
+def moments_accumulate(
+    x: torch.Tensor, valid: Optional[torch.Tensor], out3: torch.Tensor, fill: Optional[float] = None
+):
+    """out3 (float64[3] on device) += {count, sum, sum of squares}."""
+    _lib.require_gpu()
+    x = aligned(x.view(torch.uint8) if x.dtype == torch.bool else x)
+    with _timed("moments", x.numel() * x.element_size()):
+        check(
+            _lib.load().nvt_moments(
+                x.data_ptr(), dtype_code(x.dtype), ptr(valid), x.numel(),
+                0 if fill is None else 1, 0.0 if fill is None else float(fill), out3.data_ptr(),
+                _partials(x.device).data_ptr(), stream_ptr(),
+            ),
+            "nvt_moments",
+        )
+
+
+def minmax_accumulate(x: torch.Tensor, valid: Optional[torch.Tensor], out2: torch.Tensor, first: bool):
+    _lib.require_gpu()
+    x = aligned(x)
+    check(
+        _lib.load().nvt_minmax(
+            x.data_ptr(), dtype_code(x.dtype), ptr(valid), x.numel(), 0 if first else 1,
+            out2.data_ptr(), _partials(x.device).data_ptr(), stream_ptr(),
+        ),
+        "nvt_minmax",
+    )
+
+
+def fill_normalize(
+    x: torch.Tensor,
+    valid: Optional[torch.Tensor],
+    fill: Optional[float],
+    do_norm: bool,
+    shift: float,
+    scale: float,
+    out_dtype: torch.dtype,
+    want_filled_mask: bool = False,
+):
+    _lib.require_gpu()
+    x = aligned(x)
+    n = x.numel()
+    out = torch.empty(n, dtype=out_dtype, device=x.device)
+    filled = torch.empty(n, dtype=torch.uint8, device=x.device) if want_filled_mask else None
+    with _timed("fill_normalize", n * (x.element_size() + out.element_size())):
+        check(
+            _lib.load().nvt_fill_normalize(
+                x.data_ptr(), dtype_code(x.dtype), ptr(valid), n, 0 if fill is None else 1,
+                0.0 if fill is None else float(fill), 1 if do_norm else 0, float(shift),
+                float(scale), out.data_ptr(), dtype_code(out_dtype), ptr(filled), stream_ptr(),
+            ),
+            "nvt_fill_normalize",
+        )
+    return out, (filled.view(torch.bool) if filled is not None else None)
+
+
+def widen_i64(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == torch.int64:
+        return x
+    _lib.require_gpu()
+    if x.dtype == torch.bool:
+        x = x.view(torch.uint8)
+    x = x.contiguous()
+    out = torch.empty(x.numel(), dtype=torch.int64, device=x.device)
+    check(
+        _lib.load().nvt_widen_i64(x.data_ptr(), dtype_code(x.dtype), x.numel(), out.data_ptr(),
+                                  stream_ptr()),
+        "nvt_widen_i64",
+    )
+    return out
+
+
+def popcount(valid: Optional[torch.Tensor], n: int) -> int:
+    if valid is None:
+        return n
+    _lib.require_gpu()
+    out = torch.zeros(1, dtype=torch.int64, device=valid.device)
+    check(_lib.load().nvt_popcount(valid.data_ptr(), n, out.data_ptr(), stream_ptr()), "nvt_popcount")
+    return int(out.item())
+
+
+# --------------------------------------------------------------------------
+# multi-key groupby tables
+# --------------------------------------------------------------------------
+class GroupbyTable:
+    """nkeys-column groupby-aggregate table (JoinGroupby / TargetEncoding / combo)."""
+
+    def __init__(self, nkeys: int, nvals: int, capacity: int, sumsq=False, minmax=False):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.nkeys, self.nvals = nkeys, nvals
+        self.flags = (_lib.NVT_GB_SUMSQ if sumsq else 0) | (_lib.NVT_GB_MINMAX if minmax else 0)
+        self.capacity = next_pow2(capacity)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        h = C.c_void_p()
+        check(self.lib.nvt_gb_create(nkeys, nvals, self.flags, self.capacity, C.byref(h)),
+              "nvt_gb_create")
+        self.handle = h
+        self.clear()
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                self.lib.nvt_gb_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    def clear(self):
+        check(self.lib.nvt_gb_clear(self.handle, stream_ptr()), "nvt_gb_clear")
+
+    def state(self) -> List[int]:
+        buf = (C.c_uint64 * _lib.STATE_WORDS)()
+        check(self.lib.nvt_gb_state(self.handle, buf, stream_ptr()), "nvt_gb_state")
+        return list(buf)
+
+    def update(self, keys, key_valid, vals, val_valid):
+        keys = [widen_i64(k) for k in keys]
+        vals = [aligned(v.view(torch.uint8) if v.dtype == torch.bool else v) for v in vals]
+        n = keys[0].numel()
+        kp = _lib.ptr_array([k.data_ptr() for k in keys])
+        kv = _lib.ptr_array([ptr(v) for v in key_valid])
+        vp = _lib.ptr_array([v.data_ptr() for v in vals])
+        vv = _lib.ptr_array([ptr(v) for v in val_valid])
+        vd = (C.c_int * max(1, len(vals)))(*[dtype_code(v.dtype) for v in vals])
+        check(self.lib.nvt_gb_update(self.handle, kp, kv, vp, vd, vv, n, stream_ptr()),
+              "nvt_gb_update")
+
+    def merge(self, keys, null_mask, size, count, sums, sumsqs, mins, maxs):
+        n = keys[0].numel()
+        f = lambda lst: _lib.ptr_array([ptr(t) for t in lst]) if lst else None  # noqa: E731
+        check(
+            self.lib.nvt_gb_merge(
+                self.handle, _lib.ptr_array([k.data_ptr() for k in keys]), ptr(null_mask),
+                ptr(size), ptr(count), f(sums), f(sumsqs), f(mins), f(maxs), n, stream_ptr(),
+            ),
+            "nvt_gb_merge",
+        )
+
+    def compact(self):
+        """dict(keys=[...], null_mask, size, count, sum=[...], sumsq=[...], min=[...], max=[...])"""
+        st = self.state()
+        g = st[_lib.ST_OCCUPIED]
+        dev = self.device
+        keys = [torch.empty(g, dtype=torch.int64, device=dev) for _ in range(self.nkeys)]
+        nm = torch.empty(g, dtype=torch.uint8, device=dev)
+        size = torch.empty(g, dtype=torch.int64, device=dev)
+        count = torch.empty(g, dtype=torch.int64, device=dev)
+        mk = lambda on: (  # noqa: E731
+            [torch.empty(g, dtype=torch.float64, device=dev) for _ in range(self.nvals)] if on else []
+        )
+        sums = mk(True)
+        sumsqs = mk(self.flags & _lib.NVT_GB_SUMSQ)
+        mins = mk(self.flags & _lib.NVT_GB_MINMAX)
+        maxs = mk(self.flags & _lib.NVT_GB_MINMAX)
+        out_n = torch.zeros(1, dtype=torch.int64, device=dev)
+        f = lambda lst: _lib.ptr_array([t.data_ptr() for t in lst]) if lst else None  # noqa: E731
+        check(
+            self.lib.nvt_gb_compact(
+                self.handle, f(keys), nm.data_ptr(), size.data_ptr(), count.data_ptr(), f(sums),
+                f(sumsqs), f(mins), f(maxs), out_n.data_ptr(), stream_ptr(),
+            ),
+            "nvt_gb_compact",
+        )
+        return dict(keys=keys, null_mask=nm, size=size, count=count, sum=sums, sumsq=sumsqs,
+                    min=mins, max=maxs, n=g)
+
+    def index_build(self, keys, null_mask):
+        n = keys[0].numel() if keys else 0
+        check(
+            self.lib.nvt_gb_index_build(
+                self.handle, _lib.ptr_array([k.data_ptr() for k in keys]), ptr(null_mask), n,
+                stream_ptr(),
+            ),
+            "nvt_gb_index_build",
+        )
+
+    def lookup(self, keys, key_valid) -> torch.Tensor:
+        keys = [widen_i64(k) for k in keys]
+        n = keys[0].numel()
+        out = torch.empty(n, dtype=torch.int64, device=keys[0].device)
+        check(
+            self.lib.nvt_gb_lookup(
+                self.handle, _lib.ptr_array([k.data_ptr() for k in keys]),
+                _lib.ptr_array([ptr(v) for v in key_valid]), n, out.data_ptr(), stream_ptr(),
+            ),
+            "nvt_gb_lookup",
+        )
+        return out
+
+
+def gather(src: torch.Tensor, group: torch.Tensor, miss: float, out_dtype: torch.dtype):
+    _lib.require_gpu()
+    src = src.to(torch.float64).contiguous()
+    out = torch.empty(group.numel(), dtype=out_dtype, device=group.device)
+    check(
+        _lib.load().nvt_gather_f64(src.data_ptr(), group.data_ptr(), group.numel(), float(miss),
+                                   out.data_ptr(), dtype_code(out_dtype), stream_ptr()),
+        "nvt_gather_f64",
+    )
+    return out
+
+
+def te_apply(group_all, group_fold, sum_all, cnt_all, sum_fold, cnt_fold, p_smooth, y_mean,
+             out_dtype=torch.float32):
+    _lib.require_gpu()
+    n = group_all.numel()
+    out = torch.empty(n, dtype=out_dtype, device=group_all.device)
+    check(
+        _lib.load().nvt_te_apply(
+            group_all.data_ptr(), ptr(group_fold), sum_all.data_ptr(), cnt_all.data_ptr(),
+            ptr(sum_fold), ptr(cnt_fold), n, float(p_smooth), float(y_mean), out.data_ptr(),
+            dtype_code(out_dtype), stream_ptr(),
+        ),
+        "nvt_te_apply",
+    )
+    return out

@@ -1,0 +1,144 @@
+"""Shared driver for multi-key groupby-aggregate fits (JoinGroupby, TargetEncoding).
+
+Mirrors the reference's tree (categorify.py:1344-1540): a fresh table per
+partition (_top_level_groupby), folded into the accumulated table
+(_mid_level_groupby), finalised once (_bottom_level_groupby) -- with the tables
+living in HBM and every level being an ``nvt_gb_*`` kernel.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+import pandas as pd
+import torch
+
+from .. import kernels as K
+from ..device import DeviceFrame, key_view
+
+
+class GroupAgg:
+    def __init__(self, name: str, key_cols: List[str], val_cols: List[str], sumsq=False,
+                 minmax=False):
+        self.name = name
+        self.key_cols = list(key_cols)
+        self.val_cols = list(val_cols)
+        self.sumsq, self.minmax = sumsq, minmax
+        self.table = None
+        self.hint = 1 << 12
+        self.strings: Dict[str, dict] = {}
+        self.key_dtypes: Dict[str, object] = {}
+
+    def _inputs(self, frame: DeviceFrame):
+        keys, kvalid = [], []
+        for c in self.key_cols:
+            col = frame[c]
+            if col.fill is not None:
+                col = col.materialize()
+            k, v = key_view(col)
+            keys.append(k)
+            kvalid.append(v)
+            self.key_dtypes.setdefault(c, "str" if col.strings is not None else col.data.dtype)
+            if col.strings is not None:
+                self.strings.setdefault(c, {}).update(col.strings)
+        vals, vvalid = [], []
+        for c in self.val_cols:
+            col = frame[c].materialize()
+            vals.append(col.data)
+            vvalid.append(col.valid)
+        return keys, kvalid, vals, vvalid
+
+    def update(self, frame: DeviceFrame):
+        keys, kvalid, vals, vvalid = self._inputs(frame)
+        n = int(keys[0].numel())
+        cap = K.next_pow2(2 * min(max(self.hint, 32), max(n, 32)))
+        while True:
+            part = K.GroupbyTable(len(keys), len(vals), cap, sumsq=self.sumsq, minmax=self.minmax)
+            part.update(keys, kvalid, vals, vvalid)
+            st = part.state()
+            if not st[K._lib.ST_OVERFLOW] and st[K._lib.ST_OCCUPIED] * 10 <= part.capacity * 7:
+                break
+            cap *= 4
+        self.hint = max(self.hint, st[K._lib.ST_OCCUPIED])
+        if self.table is None:
+            self.table = part
+        else:
+            from .categorify import _merge_groups
+
+            self.table = _merge_groups(self.table, part.compact())
+
+    def finalize(self):
+        """Compacted groups (after the cross-rank merge), ordered by key for determinism."""
+        from .. import dist
+
+        if self.table is None:
+            self.table = K.GroupbyTable(len(self.key_cols), len(self.val_cols), 64,
+                                        sumsq=self.sumsq, minmax=self.minmax)
+        comp = self.table.compact()
+        if dist.world_size() > 1:
+            comp = dist.merge_groups(comp, len(self.key_cols), len(self.val_cols),
+                                     sumsq=self.sumsq, minmax=self.minmax)
+            for c in list(self.strings):
+                self.strings[c] = dist.merge_string_luts(self.strings[c])
+        return comp
+
+
+def stats_frame(agg: GroupAgg, comp, stats, name_sep="_", count_name=None) -> pd.DataFrame:
+    """Host frame in the reference's cat_stats layout (categorify.py:1079-1137): key
+    columns, <name>_count, <name>_<cont>_{sum,mean,min,max,var,std} as requested."""
+    keys = [k.cpu().numpy() for k in comp["keys"]]
+    nm = comp["null_mask"].cpu().numpy()
+    data = {}
+    for j, c in enumerate(agg.key_cols):
+        col = keys[j]
+        isnull = ((nm >> j) & 1).astype(bool)
+        lut = agg.strings.get(c)
+        if lut is not None:
+            col = np.array([lut.get(int(k)) for k in col], dtype=object)
+            col[isnull] = None
+        else:
+            src = agg.key_dtypes.get(c)
+            if isinstance(src, torch.dtype) and src in (torch.int32, torch.uint8, torch.bool):
+                col = col.astype({torch.int32: np.int32, torch.uint8: np.uint8,
+                                  torch.bool: np.uint8}[src])
+            if isnull.any():
+                col = col.astype(np.float64)
+                col[isnull] = np.nan
+        data[c] = col
+    base = name_sep.join(agg.key_cols)
+    count = comp["count"].cpu().numpy()
+    derived = derive_stats(comp, stats)
+    if "count" in stats:
+        data[f"{base}{name_sep}count"] = count
+    if "size" in stats:
+        data[f"{base}{name_sep}size"] = comp["size"].cpu().numpy()
+    for j, cont in enumerate(agg.val_cols):
+        for stat in ("sum", "mean", "min", "max", "var", "std"):
+            if stat in stats:
+                data[f"{base}{name_sep}{cont}{name_sep}{stat}"] = derived[(j, stat)].cpu().numpy()
+    df = pd.DataFrame(data)
+    return df
+
+
+def derive_stats(comp, stats):
+    """(value index, stat) -> float64 tensor [groups]  (categorify.py:1087-1131)."""
+    out = {}
+    n = comp["count"].to(torch.float64)
+    for j in range(len(comp["sum"])):
+        x = comp["sum"][j]
+        out[(j, "sum")] = x
+        if "mean" in stats:
+            out[(j, "mean")] = x / n
+        if "min" in stats:
+            out[(j, "min")] = comp["min"][j]
+        if "max" in stats:
+            out[(j, "max")] = comp["max"][j]
+        if "var" in stats or "std" in stats:
+            x2 = comp["sumsq"][j]
+            res = x2 - x * x / n
+            div = torch.clamp(n - 1, min=1)
+            res = res / div
+            res = torch.where((n - 1) == 0, torch.full_like(res, float("nan")), res)
+            out[(j, "var")] = res
+            out[(j, "std")] = torch.sqrt(res)
+    return out

@@ -1,0 +1,781 @@
+"""Categorify on MI355X.
+
+Same constructor, semantics and on-disk artefacts as
+/root/reference/nvtabular/ops/categorify.py (file:line cited inline); the
+groupby-size, vocabulary sort and encode steps run as HIP kernels
+(``nvt_count_*``, ``nvt_vocab_sort_*``, ``nvt_encode_*``; multi-column "combo"
+groups through ``nvt_gb_*``).
+
+Index layout (categorify.py:53-71): 0 pad, 1 null, [2, 2+nb) OOV / hash buckets,
+[2+nb, ...) vocabulary in (count desc, value asc) order.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from copy import deepcopy
+from typing import Dict, List, Optional
+
+import numpy as np
+import pandas as pd
+import torch
+
+from .. import kernels as K
+from ..device import DeviceColumn, DeviceFrame, as_device_frame, key_view
+from ..schema import Tags
+from ..selector import ColumnSelector
+from .base import StatOperator
+
+PAD_OFFSET = 0
+NULL_OFFSET = 1
+OOV_OFFSET = 2
+
+
+def _make_name(*args, sep="_"):
+    return sep.join(args)
+
+
+def _emb_sz_rule(n_cat: int, minimum_size=16, maximum_size=512):
+    """categorify.py:687-688"""
+    return n_cat, min(max(minimum_size, round(1.6 * n_cat**0.56)), maximum_size)
+
+
+def _pick(opt, name, default=None):
+    if isinstance(opt, dict):
+        return opt.get(name, default)
+    return opt
+
+
+class _GroupFit:
+    """Accumulated groupby-size state of one column group on this GPU."""
+
+    def __init__(self, name: str, cols: List[str], combo: bool):
+        self.name = name
+        self.cols = cols
+        self.combo = combo  # multi-column key tuple (nvt_gb_*) vs single key column
+        self.table = None  # K.CountTable | K.GroupbyTable
+        self.nulls = 0
+        self.hint = 1 << 12  # expected distinct keys per partition, learned as we go
+        self.key_dtype = None
+        self.src_dtypes: Dict[str, object] = {}
+        self.strings: Dict[str, dict] = {}  # col -> {surrogate: str}
+
+
+class Categorify(StatOperator):
+    """Encode categorical columns as contiguous integers (categorify.py:59-343)."""
+
+    def __init__(
+        self,
+        freq_threshold=0,
+        out_path=None,
+        cat_cache="host",
+        dtype=None,
+        on_host=True,
+        encode_type="joint",
+        name_sep="_",
+        search_sorted=False,
+        num_buckets=None,
+        vocabs=None,
+        max_size=0,
+        single_table=False,
+        cardinality_memory_limit=None,
+        tree_width=None,
+        split_out=1,
+        split_every=8,
+        defer_artifacts=False,
+        **kwargs,
+    ):
+        # categorify.py:226-241
+        if "start_index" in kwargs:
+            raise ValueError(
+                "start_index is now deprecated. `Categorify` will always reserve index `0` for "
+                "user-specific purposes, and will use index `1` for null values."
+            )
+        if "na_sentinel" in kwargs:
+            raise ValueError(
+                "na_sentinel is now deprecated. `Categorify` will always reserve index `1` for "
+                "null values, and the following `num_buckets` indices for out-of-vocabulary values."
+            )
+        if kwargs:
+            raise ValueError(f"Unrecognized key-word arguments: {kwargs}")
+        if num_buckets and not (max_size or freq_threshold):
+            warnings.warn(
+                "You are setting num_buckets without using max_size or freq_threshold to restrict "
+                "the number of distinct categories. Are you sure this is what you want?"
+            )
+        self.storage_name: Dict[str, str] = {}
+        if encode_type not in ("joint", "combo"):
+            raise ValueError(f"encode_type={encode_type} not supported.")
+        if encode_type == "combo" and vocabs is not None:
+            raise ValueError("Passing in vocabs is not supported with a combo encoding.")
+        super().__init__()
+        self.single_table = single_table
+        self.freq_threshold = freq_threshold or 0
+        self.out_path = out_path or "./"
+        self.dtype = dtype
+        self.on_host = on_host  # accepted, no effect (categorify.py:164-173: placement only)
+        self.cat_cache = cat_cache
+        self.encode_type = encode_type
+        self.name_sep = name_sep
+        self.search_sorted = search_sorted
+        self.cardinality_memory_limit = cardinality_memory_limit
+        self.split_every = split_every
+        self.split_out = split_out
+        if tree_width is not None:
+            warnings.warn("tree_width is deprecated; use split_out/split_every", FutureWarning)
+        if self.search_sorted and self.freq_threshold:
+            raise ValueError(
+                "cannot use search_sorted=True with anything else than the default freq_threshold"
+            )
+        if num_buckets == 0:
+            raise ValueError(
+                "For hashing num_buckets should be an int > 1, otherwise set num_buckets=None."
+            )
+        if isinstance(num_buckets, (dict, int)) or num_buckets is None:
+            self.num_buckets = num_buckets
+        else:
+            raise ValueError(f"`num_buckets` must be dict or int, got type {type(num_buckets)}")
+        if isinstance(max_size, (dict, int)) or max_size is None:
+            self.max_size = max_size
+        else:
+            raise ValueError(f"max_size must be dict or int, got type {type(max_size)}")
+        if freq_threshold and max_size:
+            raise ValueError("cannot use freq_threshold param together with max_size param")
+        if self.num_buckets is not None:
+            warnings.warn(
+                "Performing a hash-based transformation. Do not expect Categorify to be "
+                "consistent on GPU and CPU with this num_buckets setting!"
+            )
+        # device-side state: storage_name -> encoder (built at fit_end or lazily from parquet)
+        self._encoders: Dict[str, object] = {}
+        self._cap_hints: Dict[str, int] = {}
+        # Engine extension (not in the reference): with defer_artifacts=True the
+        # unique.*/meta.*.parquet files are written by flush_artifacts() /
+        # Workflow.save() instead of inside fit, so a device-resident fit does no
+        # host I/O.  Default False = reference behaviour (files exist after fit).
+        self.defer_artifacts = defer_artifacts
+        self._pending: Dict[str, dict] = {}
+        self.vocabs = {}
+        if vocabs is not None:
+            self.vocabs = self.process_vocabs(vocabs)
+        self.categories = deepcopy(self.vocabs)
+
+    # ------------------------------------------------------------------ fit --
+    def _groups(self, col_selector: ColumnSelector):
+        """[(storage_name, [cols], combo?)] for the groups that still need fitting."""
+        flat = []
+        for g in col_selector.grouped_names:
+            flat += list(g) if isinstance(g, tuple) else [g]
+        if sorted(flat) != sorted(set(flat)) and self.encode_type == "joint":
+            raise ValueError("Same column name included in multiple groups.")
+        for group in col_selector.subgroups:
+            if len(group.names) > 1:
+                name = _make_name(*group.names, sep=self.name_sep)
+                for col in group.names:
+                    self.storage_name[col] = name
+        out = []
+        for g in col_selector.grouped_names:
+            cols = list(g) if isinstance(g, tuple) else [g]
+            name = _make_name(*cols, sep=self.name_sep)
+            if name in self.categories and name in self.vocabs:
+                continue  # user supplied vocabulary (categorify.py:382-390)
+            combo = self.encode_type == "combo" and len(cols) > 1
+            out.append((name, cols, combo))
+        return out
+
+    def fit_begin(self, col_selector: ColumnSelector):
+        return {name: _GroupFit(name, cols, combo) for name, cols, combo in self._groups(col_selector)}
+
+    def _group_keys(self, g: _GroupFit, frame: DeviceFrame):
+        keys, valids = [], []
+        for c in g.cols:
+            col = frame[c]
+            if col.fill is not None:
+                col = col.materialize()
+            k, v = key_view(col)
+            keys.append(k)
+            valids.append(v)
+            g.src_dtypes.setdefault(c, "str" if col.strings is not None else col.dtype)
+            if col.strings is not None:
+                g.strings.setdefault(c, {}).update(col.strings)
+        return keys, valids
+
+    def fit_partition(self, state, col_selector, frame):
+        frame, _ = as_device_frame(frame)
+        for g in state.values():
+            keys, valids = self._group_keys(g, frame)
+            if g.combo:
+                self._fit_partition_combo(g, keys, valids)
+                continue
+            # joint groups: every column of the group feeds one table (categorify.py:972-981)
+            if len({k.dtype for k in keys}) > 1:
+                keys = [K.widen_i64(k) for k in keys]
+            g.key_dtype = keys[0].dtype
+            hint = self._cap_hints.get(g.name, g.hint)
+            part, st = K.count_into_new_table(keys, valids, hint)
+            g.nulls += st[K._lib.ST_NULLS]
+            g.hint = max(g.hint, st[K._lib.ST_OCCUPIED])
+            self._cap_hints[g.name] = max(64, st[K._lib.ST_OCCUPIED])
+            if g.table is None:
+                g.table = part
+            else:
+                pk, pc = part.compact(st[K._lib.ST_OCCUPIED])
+                g.table = _merge_counts(g.table, pk, pc)
+
+    def _fit_partition_combo(self, g: _GroupFit, keys, valids):
+        hint = self._cap_hints.get(g.name, g.hint)
+        n = int(keys[0].numel())
+        cap = K.next_pow2(2 * min(max(hint, 32), max(n, 32)))
+        while True:
+            part = K.GroupbyTable(len(keys), 0, cap)
+            part.update(keys, valids, [], [])
+            st = part.state()
+            if not st[K._lib.ST_OVERFLOW] and st[K._lib.ST_OCCUPIED] * 10 <= part.capacity * 7:
+                break
+            cap *= 4
+        self._cap_hints[g.name] = max(64, st[K._lib.ST_OCCUPIED])
+        if g.table is None:
+            g.table = part
+        else:
+            g.table = _merge_groups(g.table, part.compact())
+
+    def fit_end(self, state, col_selector):
+        from .. import dist
+
+        base = os.path.join(self.out_path, "categories")
+        os.makedirs(base, exist_ok=True)
+        paths = {}
+        for g in state.values():
+            nb = _pick(self.num_buckets, g.name) if self.num_buckets else None
+            oov_count = nb or 1
+            max_emb = _pick(self.max_size, g.name) if self.max_size else 0
+            freq = _pick(self.freq_threshold, g.name, 0) if self.freq_threshold else 0
+            if max_emb and max_emb < oov_count + 2:
+                raise ValueError(
+                    "`max_size` can never be less than the maximum of `num_buckets + 2` and `3`, "
+                    "because we must always reserve pad, null and at least 1 oov-bucket index."
+                )
+            if g.combo:
+                vocab = self._finalize_combo(g, dist)
+            else:
+                vocab = self._finalize_single(g, dist)
+            paths[g.name] = self._save_encodings(
+                g, vocab, base, first_n=max_emb, freq_threshold=freq, oov_count=oov_count
+            )
+        return paths
+
+    # -- vocabulary finalisation ------------------------------------------------
+    def _finalize_single(self, g: _GroupFit, dist):
+        if g.table is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            keys = torch.empty(0, dtype=torch.int64, device=dev)
+            counts = torch.empty(0, dtype=torch.int64, device=dev)
+        else:
+            keys, counts = g.table.compact()
+        nulls = g.nulls
+        if dist.world_size() > 1:
+            keys, counts, nulls = dist.merge_counts(keys, counts, nulls)
+        strings = None
+        for c in g.cols:
+            if c in g.strings:
+                strings = {**(strings or {}), **g.strings[c]}
+        if strings is not None:
+            strings = dist.merge_string_luts(strings)
+            # string columns: order ties by the string value on the host (O(#uniques))
+            hk, hc = keys.cpu().numpy(), counts.cpu().numpy()
+            vals = np.array([strings[int(k)] for k in hk], dtype=object)
+            order = np.lexsort((vals, -hc))
+            keys = torch.from_numpy(hk[order]).to(keys.device)
+            counts = torch.from_numpy(hc[order]).to(counts.device)
+        else:
+            keys, counts = keys.contiguous(), counts.contiguous()
+            K.vocab_sort(keys, counts)
+        return dict(keys=[keys], null_mask=None, counts=counts, null_size=nulls, strings=strings)
+
+    def _finalize_combo(self, g: _GroupFit, dist):
+        comp = g.table.compact()
+        if dist.world_size() > 1:
+            comp = dist.merge_groups(comp, len(g.cols), 0)
+        keys, nm, size = comp["keys"], comp["null_mask"], comp["size"]
+        all_null = (1 << len(g.cols)) - 1
+        is_all_null = nm == all_null
+        null_size = int(size[is_all_null].sum().item())
+        keep = ~is_all_null
+        keys = [k[keep] for k in keys]
+        nm, size = nm[keep], size[keep]
+        # order: size desc, then key columns ascending with nulls first (categorify.py:1300,1316)
+        hk = [k.cpu().numpy() for k in keys]
+        hnm, hs = nm.cpu().numpy(), size.cpu().numpy()
+        sort_cols = []
+        for j, c in enumerate(g.cols):
+            isnull = (hnm >> j) & 1
+            if c in g.strings:
+                lut = g.strings[c]
+                vals = np.array([lut.get(int(k), "") for k in hk[j]], dtype=object)
+            else:
+                vals = hk[j]
+            sort_cols.append((isnull, vals))
+        lex = []
+        for isnull, vals in reversed(sort_cols):
+            lex += [vals, 1 - isnull]
+        lex.append(-hs)
+        order = np.lexsort(tuple(lex)) if len(hs) else np.array([], dtype=np.int64)
+        dev = size.device
+        keys = [torch.from_numpy(k[order]).to(dev) for k in hk]
+        nm = torch.from_numpy(hnm[order]).to(dev)
+        size = torch.from_numpy(hs[order]).to(dev)
+        strings = {c: g.strings[c] for c in g.cols if c in g.strings} or None
+        return dict(keys=keys, null_mask=nm, counts=size, null_size=null_size, strings=strings,
+                    combo=True)
+
+    def _save_encodings(self, g: _GroupFit, vocab, base, first_n, freq_threshold, oov_count):
+        """categorify.py:719-822 on the finalised (ordered) vocabulary."""
+        counts = vocab["counts"]
+        keys = vocab["keys"]
+        nm = vocab["null_mask"]
+        start = oov_count + OOV_OFFSET
+        oov_size = 0
+        if freq_threshold:
+            keep = (counts >= freq_threshold) | (counts == 0)
+            oov_size += int(counts[~keep].sum().item())
+            counts = counts[keep]
+            keys = [k[keep] for k in keys]
+            nm = nm[keep] if nm is not None else None
+        if first_n:
+            limit = max(first_n - start, 0)
+            if counts.numel() > limit:
+                oov_size += int(counts[limit:].sum().item())
+                counts = counts[:limit]
+                keys = [k[:limit] for k in keys]
+                nm = nm[:limit] if nm is not None else None
+        unique_count = int(counts.numel())
+        unique_size = int(counts.sum().item()) if unique_count else 0
+        # device-side encoder, cached for transform (cat_cache="device" behaviour)
+        combo = bool(vocab.get("combo"))
+        self._encoders[g.name] = _build_encoder(keys, nm, start, combo)
+        final = dict(
+            name=g.name, cols=list(g.cols), combo=combo, keys=keys, null_mask=nm, counts=counts,
+            strings=vocab["strings"], start=start, oov_count=oov_count, oov_size=oov_size,
+            unique_count=unique_count, unique_size=unique_size, null_size=vocab["null_size"],
+            empty_input=g.table is None, base=str(base),
+        )
+        unique_path = "/".join([str(base), f"unique.{g.name}.parquet"])
+        if self.defer_artifacts:
+            self._pending[g.name] = final
+        else:
+            _write_artifacts(final)
+        return unique_path
+
+    def flush_artifacts(self):
+        """Write any deferred unique.*/meta.*.parquet files (defer_artifacts=True)."""
+        for final in self._pending.values():
+            _write_artifacts(final)
+        self._pending = {}
+
+    def fit_finalize(self, categories):
+        """categorify.py:404-415"""
+        idx_count = 0
+        if self.single_table:
+            self.flush_artifacts()
+        for cat in categories:
+            self.categories[cat] = categories[cat]
+            if self.single_table:
+                path = self.categories[cat]
+                df = pd.read_parquet(path)
+                df.index = df.index + idx_count
+                idx_count += df.shape[0]
+                df.to_parquet(path, compression=None)
+                self._encoders.pop(cat, None)  # rebuilt lazily with the shifted labels
+
+    def clear(self):
+        self.categories = deepcopy(self.vocabs)
+        self._encoders = {}
+        self._pending = {}
+
+    def process_vocabs(self, vocabs):
+        """categorify.py:421-454"""
+        categories = {}
+        if isinstance(vocabs, dict) and all(isinstance(v, pd.Series) for v in vocabs.values()):
+            base = os.path.join(self.out_path, "categories")
+            os.makedirs(base, exist_ok=True)
+            for col, vocab in vocabs.items():
+                col_name = _make_name(*col, sep=self.name_sep) if isinstance(col, tuple) else col
+                nb = self.num_buckets
+                oov_count = 1
+                if nb:
+                    oov_count = (nb if isinstance(nb, int) else nb[col_name]) or 1
+                col_df = pd.DataFrame({col_name: vocab}).dropna()
+                col_df.index += NULL_OFFSET + oov_count
+                # the reference writes through _save_encodings with its default oov_count=1
+                # (categorify.py:439), so the file index restarts at 3
+                col_df = col_df.copy()
+                col_df.index = pd.RangeIndex(start=3, stop=3 + len(col_df))
+                path = "/".join([base, f"unique.{col_name}.parquet"])
+                col_df.to_parquet(path, compression=None)
+                pd.DataFrame(
+                    {
+                        "kind": ["pad", "null", "oov", "unique"],
+                        "offset": [0, 1, 2, 3],
+                        "num_indices": [1, 1, 1, len(col_df)],
+                    }
+                ).to_parquet("/".join([base, f"meta.{col_name}.parquet"]))
+                categories[col_name] = path
+        elif isinstance(vocabs, dict) and all(isinstance(v, str) for v in vocabs.values()):
+            categories = {
+                (_make_name(*col, sep=self.name_sep) if isinstance(col, tuple) else col): path
+                for col, path in vocabs.items()
+            }
+        else:
+            raise ValueError(
+                "Unrecognized vocab type, please provide either a dictionary with paths to "
+                "parquet files or a dictionary with pandas Series objects."
+            )
+        return categories
+
+    def set_storage_path(self, new_path, copy=False):
+        import shutil
+
+        self.flush_artifacts()
+        new = {}
+        for col, old in self.categories.items():
+            target = old.replace(str(self.out_path), str(new_path))
+            if copy and target != old:
+                os.makedirs(os.path.dirname(target), exist_ok=True)
+                shutil.copy(old, target)
+                meta_old = old.replace("unique.", "meta.")
+                if os.path.exists(meta_old):
+                    shutil.copy(meta_old, target.replace("unique.", "meta."))
+            new[col] = target
+        self.categories = new
+        self.out_path = new_path
+
+    # ------------------------------------------------------------ transform --
+    def _encoder_for(self, storage_name: str, cols: List[str], frame: DeviceFrame):
+        enc = self._encoders.get(storage_name)
+        if enc is not None:
+            return enc
+        path = self.categories[storage_name]
+        nb = _pick(self.num_buckets, storage_name) if self.num_buckets else None
+        n_oov = nb or 1
+        value = pd.read_parquet(path)
+        labels = value.index.to_numpy()
+        start = int(labels[0]) if len(labels) else OOV_OFFSET + n_oov
+        if len(labels) and start < OOV_OFFSET + n_oov and not self.single_table:
+            start += OOV_OFFSET + n_oov  # categorify.py:1641-1643 re-base guard
+        dev = torch.device("cuda", torch.cuda.current_device())
+        combo = self.encode_type == "combo" and len(cols) > 1
+        key_names = cols if combo else [storage_name]
+        keys, nm = [], np.zeros(len(value), dtype=np.uint8)
+        for j, kn in enumerate(key_names):
+            s = value[kn]
+            isnull = s.isna().to_numpy()
+            if s.dtype == object or pd.api.types.is_string_dtype(s.dtype):
+                from ..strings import string_key64
+
+                hk = np.zeros(len(s), dtype=np.int64)
+                if (~isnull).any():
+                    hk[~isnull] = string_key64(s.to_numpy(dtype=object)[~isnull])
+            else:
+                hk = s.fillna(0).to_numpy().astype(np.int64)
+            nm |= (isnull.astype(np.uint8) << j)
+            keys.append(hk)
+        if not combo:
+            keep = ~(nm.astype(bool))
+            if not keep.all():
+                if keep.any():
+                    raise ValueError(f"vocabulary file {path} mixes null and non-null rows")
+                keys = [keys[0][:0]]  # the reference's "empty" file: nothing is ever matched
+            src = frame[cols[0]].data.dtype if cols[0] in frame else torch.int64
+            i32 = src == torch.int32 and all(
+                c not in frame or frame[c].data.dtype == torch.int32 for c in self._group_cols(storage_name, cols)
+            )
+            kt = torch.from_numpy(keys[0].astype(np.int32 if i32 else np.int64)).to(dev)
+            enc = _build_encoder([kt], None, start, False)
+        else:
+            enc = _build_encoder(
+                [torch.from_numpy(k).to(dev) for k in keys], torch.from_numpy(nm).to(dev), start, True
+            )
+        self._encoders[storage_name] = enc
+        return enc
+
+    def _group_cols(self, storage_name, cols):
+        members = [c for c, sn in self.storage_name.items() if sn == storage_name]
+        return members or cols
+
+    def transform(self, col_selector: ColumnSelector, df):
+        """categorify.py:477-537"""
+        frame, was_pandas = as_device_frame(df)
+        new = frame.copy(deep=False)
+        if isinstance(self.freq_threshold, dict):
+            assert all(x in self.freq_threshold for x in col_selector.names)
+        column_mapping = self.column_mapping(col_selector)
+        out_dtype = torch.int32 if np.dtype(self.output_dtype) == np.dtype("int32") else torch.int64
+        for name in column_mapping:
+            try:
+                use_name = column_mapping.get(name, name)
+                if isinstance(use_name, (list, tuple)) and len(use_name) == 1:
+                    use_name = use_name[0]
+                if use_name != name or self.encode_type == "joint":
+                    storage_name = self.storage_name.get(name, name)
+                else:
+                    storage_name = name
+                cols = list(use_name) if isinstance(use_name, (list, tuple)) else [use_name]
+                nb = _pick(self.num_buckets, storage_name) if self.num_buckets else None
+                enc = self._encoder_for(storage_name, cols, frame)
+                null_off = enc.first_label_in_file if self.single_table else NULL_OFFSET
+                new[name] = enc.encode(frame, cols, null_off, null_off + 1, nb or 0, out_dtype)
+            except Exception as e:
+                raise RuntimeError(f"Failed to categorical encode column {name}") from e
+        return new.to_pandas() if was_pandas else new
+
+    # --------------------------------------------------------------- schema --
+    def column_mapping(self, col_selector):
+        """categorify.py:539-553"""
+        if self.encode_type == "combo":
+            mapping = {}
+            for group in col_selector.grouped_names:
+                if isinstance(group, (tuple, list)):
+                    name = _make_name(*group, sep=self.name_sep)
+                    group = [*group]
+                else:
+                    name = group
+                    group = [group]
+                mapping[name] = group
+            return mapping
+        return super().column_mapping(col_selector)
+
+    def compute_selector(self, input_schema, selector, parents_selector=None,
+                         dependencies_selector=None):
+        self._validate_matching_cols(input_schema, parents_selector, "computing input selector")
+        return parents_selector
+
+    def _compute_properties(self, col_schema, input_schema):
+        """categorify.py:555-579"""
+        new_schema = super()._compute_properties(col_schema, input_schema)
+        col_name = col_schema.name
+        category_name = self.storage_name.get(col_name, col_name)
+        path = self.categories.get(category_name, None)
+        cardinality, dimensions = self.get_embedding_sizes([category_name])[category_name]
+        to_add = {
+            "num_buckets": _pick(self.num_buckets, col_name),
+            "freq_threshold": _pick(self.freq_threshold, col_name),
+            "max_size": _pick(self.max_size, col_name),
+            "cat_path": path,
+            "domain": {"min": 0, "max": cardinality - 1, "name": category_name},
+            "embedding_sizes": {"cardinality": cardinality, "dimension": dimensions},
+        }
+        return col_schema.with_properties({**new_schema.properties, **to_add})
+
+    @property
+    def output_tags(self):
+        return [Tags.CATEGORICAL]
+
+    @property
+    def output_dtype(self):
+        return self.dtype or np.int64
+
+    def get_embedding_sizes(self, columns):
+        pending = {n: f["unique_count"] for n, f in self._pending.items()}
+        return _get_embeddings(self.categories, columns, self.num_buckets, pending)
+
+
+# ------------------------------------------------------------------ helpers --
+def _write_artifacts(final):
+    """Host side of categorify.py:719-822: unique.<name>.parquet (columns <name>,
+    <name>_size; RangeIndex = label) and meta.<name>.parquet."""
+    name, base, start = final["name"], final["base"], final["start"]
+    keys, nm, counts = final["keys"], final["null_mask"], final["counts"]
+    unique_path = "/".join([base, f"unique.{name}.parquet"])
+    meta_path = "/".join([base, f"meta.{name}.parquet"])
+    combo = final["combo"]
+    key_names = final["cols"] if combo else [name]
+    unique_count = final["unique_count"]
+    hnm = nm.cpu().numpy() if nm is not None else None
+    data = {}
+    for j, kn in enumerate(key_names):
+        col = keys[j].cpu().numpy()
+        lut = None
+        if final["strings"] is not None:
+            lut = final["strings"].get(kn) if combo else final["strings"]
+        if lut is not None:
+            col = np.array([lut.get(int(k)) for k in col], dtype=object)
+        if hnm is not None:
+            isnull = ((hnm >> j) & 1).astype(bool)
+            if isnull.any():
+                if col.dtype == object:
+                    col[isnull] = None
+                else:
+                    col = col.astype(np.float64)
+                    col[isnull] = np.nan
+        data[kn] = col
+    if final["empty_input"]:
+        # categorify.py:1318-1324: empty input -> one all-null row
+        df = pd.DataFrame({kn: pd.Series([None], dtype=object) for kn in key_names})
+        df.index = pd.RangeIndex(start=start, stop=start + 1)
+        unique_count = 1
+    else:
+        df = pd.DataFrame(data)
+        df[f"{name}_size"] = counts.cpu().numpy()
+        df.index = pd.RangeIndex(start=start, stop=start + len(df))
+    os.makedirs(base, exist_ok=True)
+    if os.path.exists(unique_path):
+        os.remove(unique_path)
+    df.to_parquet(unique_path, compression=None)
+    meta = {
+        "kind": ["pad", "null", "oov", "unique"],
+        "offset": [PAD_OFFSET, NULL_OFFSET, OOV_OFFSET, OOV_OFFSET + final["oov_count"]],
+        "num_indices": [1, 1, final["oov_count"], unique_count],
+        "num_observed": [0, final["null_size"], final["oov_size"], final["unique_size"]],
+    }
+    pd.DataFrame(meta).to_parquet(meta_path)
+    return unique_path
+
+
+def _merge_counts(acc: "K.CountTable", keys, counts) -> "K.CountTable":
+    """Tree-merge step (_mid_level_groupby, categorify.py:1054-1070): fold one
+    partition's (key,count) list into the accumulated table, regrowing it first
+    when the load factor would exceed 0.5."""
+    st = acc.read_state()
+    need = st[K._lib.ST_OCCUPIED] + int(keys.numel())
+    if keys.dtype != acc.key_dtype:
+        if acc.key_dtype == torch.int32:  # widen the accumulator
+            ak, ac = acc.compact(st[K._lib.ST_OCCUPIED])
+            new = K.CountTable(torch.int64, 2 * need)
+            new.merge(K.widen_i64(ak), ac)
+            new.state[K._lib.ST_NULLS] = st[K._lib.ST_NULLS]
+            acc = new
+        else:
+            keys = K.widen_i64(keys)
+    if 2 * need > acc.capacity:
+        ak, ac = acc.compact(st[K._lib.ST_OCCUPIED])
+        new = K.CountTable(acc.key_dtype, 4 * need)
+        new.merge(ak, ac)
+        acc = new
+    acc.merge(keys, counts)
+    if acc.read_state()[K._lib.ST_OVERFLOW]:
+        raise K._lib.NvtHipError("count table overflow during merge")
+    return acc
+
+
+def _merge_groups(acc: "K.GroupbyTable", comp) -> "K.GroupbyTable":
+    st = acc.state()
+    need = st[K._lib.ST_OCCUPIED] + comp["n"]
+    if 2 * need > acc.capacity:
+        old = acc.compact()
+        new = K.GroupbyTable(acc.nkeys, acc.nvals, 4 * need,
+                             sumsq=bool(acc.flags & K._lib.NVT_GB_SUMSQ),
+                             minmax=bool(acc.flags & K._lib.NVT_GB_MINMAX))
+        new.merge(old["keys"], old["null_mask"], old["size"], old["count"], old["sum"],
+                  old["sumsq"], old["min"], old["max"])
+        acc = new
+    acc.merge(comp["keys"], comp["null_mask"], comp["size"], comp["count"], comp["sum"],
+              comp["sumsq"], comp["min"], comp["max"])
+    if acc.state()[K._lib.ST_OVERFLOW]:
+        raise K._lib.NvtHipError("groupby table overflow during merge")
+    return acc
+
+
+class _SingleEncoder:
+    """One key column (or a joint group sharing one vocabulary)."""
+
+    def __init__(self, table: "K.EncodeTable", first_label: int):
+        self.table = table
+        self.first_label_in_file = first_label
+
+    def encode(self, frame, cols, null_label, oov_label, num_buckets, out_dtype):
+        col = frame[cols[0]]
+        if col.fill is not None:
+            col = col.materialize()
+        keys, valid = key_view(col)
+        out = self.table.encode(keys, valid, null_label, oov_label, num_buckets, out_dtype)
+        return DeviceColumn(out, None, col.offsets, None, None)
+
+
+class _ComboEncoder:
+    """Multi-column key tuples: index table over the vocabulary groups."""
+
+    def __init__(self, keys, null_mask, first_label: int):
+        self.n = int(keys[0].numel())
+        self.first_label_in_file = first_label
+        self.index = K.GroupbyTable(len(keys), 0, max(64, 2 * self.n + 1))
+        self.index.index_build([k.contiguous() for k in keys], null_mask)
+
+    def encode(self, frame, cols, null_label, oov_label, num_buckets, out_dtype):
+        keys, valids = [], []
+        for c in cols:
+            k, v = key_view(frame[c])
+            keys.append(k)
+            valids.append(v)
+        grp = self.index.lookup(keys, valids)
+        labels = grp + self.first_label_in_file
+        if num_buckets and num_buckets > 1:
+            acc = None
+            for k in keys:  # XOR chain of categorify.py:1846-1851
+                _, acc = K.hash_bucket(k, num_buckets, xor_in=acc, want_hash=True, want_bucket=False)
+            h32 = (acc >> 32) & 0xFFFFFFFF
+            oov = oov_label + (h32 % num_buckets)
+        else:
+            oov = torch.full_like(labels, oov_label)
+        labels = torch.where(grp >= 0, labels, oov)
+        # a row is null only when every component is null (categorify.py:1689-1692)
+        all_null = None
+        for c in cols:
+            col = frame[c]
+            host = col.valid_mask_host()
+            isnull = torch.zeros(len(col), dtype=torch.bool, device=labels.device) if host is None \
+                else torch.from_numpy(~host).to(labels.device)
+            all_null = isnull if all_null is None else (all_null & isnull)
+        labels = torch.where(all_null, torch.full_like(labels, null_label), labels)
+        return DeviceColumn(labels.to(out_dtype))
+
+
+def _build_encoder(keys, null_mask, first_label, combo):
+    if combo:
+        return _ComboEncoder(keys, null_mask, first_label)
+    return _SingleEncoder(K.EncodeTable(keys[0].contiguous(), first_label), first_label)
+
+
+def _get_embeddings(paths, cat_names, buckets=0, pending=None):
+    """categorify.py:663-684"""
+    import pyarrow.dataset as pa_ds
+
+    embeddings = {}
+    if isinstance(buckets, int):
+        buckets = {name: buckets for name in cat_names}
+    for col in cat_names:
+        path = paths.get(col)
+        num_rows = OOV_OFFSET
+        if pending and col in pending:
+            num_rows += pending[col]
+        elif path:
+            for frag in pa_ds.dataset(path, format="parquet").get_fragments():
+                num_rows += frag.metadata.num_rows
+        if isinstance(buckets, dict):
+            bucket_size = buckets.get(col, 0)
+        elif isinstance(buckets, int):
+            bucket_size = buckets
+        else:
+            bucket_size = 1
+        num_rows += bucket_size
+        embeddings[col] = _emb_sz_rule(num_rows)
+    return embeddings
+
+
+def get_embedding_sizes(source, output_dtypes=None):
+    """categorify.py:616-660: {col: (cardinality, dimension)} from a Workflow or node."""
+    from ..workflow import Workflow
+
+    output_node = source.output_node if isinstance(source, Workflow) else source
+    output = {}
+    multihot = set()
+    cats_schema = output_node.output_schema.select_by_tag(Tags.CATEGORICAL)
+    for col_name, col_schema in cats_schema.column_schemas.items():
+        if col_schema.dtype is not None and col_schema.is_list and col_schema.is_ragged:
+            multihot.add(col_name)
+        sizes = col_schema.properties.get("embedding_sizes", {})
+        output[col_name] = (sizes["cardinality"], sizes["dimension"])
+    if not multihot:
+        return output
+    single = {k: v for k, v in output.items() if k not in multihot}
+    multi = {k: v for k, v in output.items() if k in multihot}
+    return single, multi

@@ -1,0 +1,237 @@
+"""JoinGroupby (reference: nvtabular/ops/join_groupby.py:37-283)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pandas as pd
+import torch
+
+from .. import kernels as K
+from ..device import DeviceColumn, DeviceFrame, as_device_frame, key_view
+from ..node import Node
+from ..selector import ColumnSelector
+from .base import StatOperator
+from ._groupby import GroupAgg, derive_stats, stats_frame
+from .categorify import _make_name
+
+AGG_DTYPES = {"count": np.int32, "std": np.float32, "var": np.float32, "mean": np.float32}
+
+
+class _Stats:
+    """Device-resident stat table of one group: lookup index + stat columns."""
+
+    def __init__(self, key_cols, keys, null_mask, columns):
+        self.key_cols = key_cols
+        self.n = int(keys[0].numel()) if keys else 0
+        self.index = K.GroupbyTable(len(key_cols), 0, max(64, 2 * self.n + 1))
+        self.index.index_build([k.contiguous() for k in keys], null_mask)
+        self.columns = columns  # name -> float64/int64 tensor [groups]
+
+
+class JoinGroupby(StatOperator):
+    def __init__(self, cont_cols=None, stats=("count",), split_out=None, split_every=None,
+                 cat_cache="host", out_path=None, on_host=True, name_sep="_", tree_width=None):
+        super().__init__()
+        self.storage_name = {}
+        self.name_sep = name_sep
+        self.stats = stats
+        self.split_out = split_out
+        self.split_every = split_every
+        self.out_path = out_path or "./"
+        self.on_host = on_host
+        self.cat_cache = cat_cache
+        self.categories = {}
+        self._device_stats = {}
+        self._cont_names = None
+        if isinstance(cont_cols, Node):
+            self.cont_cols = cont_cols
+        elif isinstance(cont_cols, ColumnSelector):
+            self.cont_cols = self._cont_names = cont_cols
+        else:
+            self.cont_cols = self._cont_names = ColumnSelector(cont_cols)
+        supported = ["count", "sum", "mean", "std", "var", "min", "max"]
+        for op in self.stats:
+            if op not in supported:
+                raise ValueError(op + " operation is not supported.")
+
+    @property
+    def cont_names(self):
+        if self._cont_names:
+            return self._cont_names
+        if isinstance(self.cont_cols, Node) and self.cont_cols.output_schema:
+            return self.cont_cols.output_columns
+        if self._cont_names is not None:
+            return self._cont_names
+        raise RuntimeError(
+            "Can't compute continuous columns used by `JoinGroupby` until `Workflow` is fit to "
+            "dataset or schema."
+        )
+
+    def _group_list(self, col_selector):
+        out = []
+        for g in col_selector.grouped_names:
+            cols = list(g) if isinstance(g, (tuple, list)) else [g]
+            out.append((_make_name(*cols, sep=self.name_sep), cols))
+        return out
+
+    def fit_begin(self, col_selector):
+        for group in col_selector.subgroups:
+            if len(group.names) > 1:
+                name = _make_name(*group.names, sep=self.name_sep)
+                for col in group.names:
+                    self.storage_name[col] = name
+        sumsq = "std" in self.stats or "var" in self.stats
+        minmax = "min" in self.stats or "max" in self.stats
+        conts = list(self.cont_names.names)
+        return {name: GroupAgg(name, cols, conts, sumsq=sumsq, minmax=minmax)
+                for name, cols in self._group_list(col_selector)}
+
+    def fit_partition(self, state, col_selector, df):
+        frame, _ = as_device_frame(df)
+        for agg in state.values():
+            agg.update(frame)
+
+    def fit_end(self, state, col_selector):
+        base = os.path.join(self.out_path, "categories")
+        os.makedirs(base, exist_ok=True)
+        out = {}
+        for name, agg in state.items():
+            comp = agg.finalize()
+            df = stats_frame(agg, comp, list(self.stats), self.name_sep)
+            d = os.path.join(base, f"cat_stats.{name}.parquet")
+            os.makedirs(d, exist_ok=True)
+            df.to_parquet(os.path.join(d, "part.0.parquet"), index=False)
+            out[name] = d
+            # device cache for transform
+            derived = derive_stats(comp, self.stats)
+            cols = {}
+            if "count" in self.stats:
+                cols[f"{name}{self.name_sep}count"] = comp["count"].to(torch.float64)
+            for j, cont in enumerate(agg.val_cols):
+                for stat in self.stats:
+                    if stat != "count":
+                        cols[f"{name}{self.name_sep}{cont}{self.name_sep}{stat}"] = derived[(j, stat)]
+            self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols)
+        return out
+
+    def fit_finalize(self, dask_stats):
+        for col in dask_stats:
+            self.categories[col] = dask_stats[col]
+
+    def _stats_for(self, name, cols):
+        st = self._device_stats.get(name)
+        if st is not None:
+            return st
+        df = pd.read_parquet(self.categories[name])
+        st = _stats_from_frame(df, cols)
+        self._device_stats[name] = st
+        return st
+
+    def transform(self, col_selector, df):
+        frame, was_pandas = as_device_frame(df)
+        new = DeviceFrame()
+        for name, cols in self._group_list(col_selector):
+            if not all(c in frame for c in cols):
+                continue
+            storage = self.storage_name.get(name, name) if len(cols) == 1 else name
+            st = self._stats_for(storage, cols)
+            keys, valids = [], []
+            for c in cols:
+                k, v = key_view(frame[c].materialize())
+                keys.append(k)
+                valids.append(v)
+            grp = st.index.lookup(keys, valids)
+            for cname, src in st.columns.items():
+                if cname in new:
+                    continue
+                out_dt, miss = torch.float64, float("nan")
+                for agg, npdt in AGG_DTYPES.items():
+                    if cname.endswith(f"{self.name_sep}{agg}"):
+                        out_dt = torch.int32 if npdt == np.int32 else torch.float32
+                if out_dt == torch.int32:
+                    if bool((grp < 0).any()):
+                        # join_groupby.py:214 astype(int32) on NaN raises in the reference too
+                        raise ValueError(
+                            f"Cannot convert non-finite values (NA or inf) to integer: column "
+                            f"{cname} has unseen categories"
+                        )
+                    miss = 0.0
+                new[cname] = DeviceColumn(K.gather(src, grp, miss, out_dt))
+        return new.to_pandas() if was_pandas else new
+
+    @property
+    def dependencies(self):
+        return self.cont_cols if isinstance(self.cont_cols, Node) else None
+
+    def compute_selector(self, input_schema, selector, parents_selector=None,
+                         dependencies_selector=None):
+        self._validate_matching_cols(input_schema, parents_selector, "computing input selector")
+        return parents_selector
+
+    def column_mapping(self, col_selector):
+        mapping = {}
+        for group in col_selector.grouped_names:
+            if isinstance(group, (tuple, list)):
+                name = _make_name(*group, sep=self.name_sep)
+                group = [*group]
+            else:
+                name = group
+                group = [group]
+            for cont in self.cont_names.names:
+                for stat in self.stats:
+                    if stat == "count":
+                        mapping[f"{name}_{stat}"] = [*group]
+                    else:
+                        mapping[f"{name}_{cont}_{stat}"] = [cont, *group]
+        return mapping
+
+    def _compute_dtype(self, col_schema, input_schema):
+        new_schema = super()._compute_dtype(col_schema, input_schema)
+        dtype = new_schema.dtype
+        for agg in AGG_DTYPES:
+            if new_schema.name.endswith(f"{self.name_sep}{agg}"):
+                dtype = AGG_DTYPES[agg]
+                break
+        return new_schema.with_dtype(dtype, is_list=False, is_ragged=False)
+
+    def set_storage_path(self, new_path, copy=False):
+        import shutil
+
+        new = {}
+        for col, old in self.categories.items():
+            target = old.replace(str(self.out_path), str(new_path))
+            if copy and target != old:
+                shutil.copytree(old, target, dirs_exist_ok=True)
+            new[col] = target
+        self.categories = new
+        self.out_path = new_path
+
+    def clear(self):
+        self.categories = {}
+        self.storage_name = {}
+        self._device_stats = {}
+
+
+def _stats_from_frame(df: pd.DataFrame, key_cols) -> _Stats:
+    """Rebuild the device stat table from a cat_stats parquet frame."""
+    from ..strings import string_key64
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    keys, nm = [], np.zeros(len(df), dtype=np.uint8)
+    for j, c in enumerate(key_cols):
+        s = df[c]
+        isnull = s.isna().to_numpy()
+        if s.dtype == object or pd.api.types.is_string_dtype(s.dtype):
+            hk = np.zeros(len(s), dtype=np.int64)
+            if (~isnull).any():
+                hk[~isnull] = string_key64(s.to_numpy(dtype=object)[~isnull])
+        else:
+            hk = s.fillna(0).to_numpy().astype(np.int64)
+        nm |= isnull.astype(np.uint8) << j
+        keys.append(torch.from_numpy(hk).to(dev))
+    cols = {
+        c: torch.from_numpy(df[c].to_numpy().astype(np.float64)).to(dev)
+        for c in df.columns if c not in key_cols
+    }
+    return _Stats(list(key_cols), keys, torch.from_numpy(nm).to(dev), cols)

@@ -1,0 +1,258 @@
+"""TargetEncoding (reference: nvtabular/ops/target_encoding.py:30-439)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pandas as pd
+import torch
+
+from .. import kernels as K
+from ..device import DeviceColumn, DeviceFrame, as_device_frame, key_view
+from ..node import Node
+from ..schema import Tags
+from ..selector import ColumnSelector
+from .base import StatOperator
+from ._groupby import GroupAgg, stats_frame
+from .categorify import _make_name
+from .join_groupby import _Stats, _stats_from_frame
+from .normalize import moments_begin, moments_end, moments_partition
+
+
+def _add_fold(n, kfold, fold_seed=None) -> np.ndarray:
+    """target_encoding.py:427-439: per-partition fold ids (host RNG so that the
+    sequence is numpy's MT19937 stream, bit-identical to the reference; 1 B/row)."""
+    typ = np.min_scalar_type(kfold * 2)
+    if fold_seed is None:
+        fold = np.arange(n, dtype=typ)
+        np.mod(fold, kfold, out=fold)
+        return fold
+    state = np.random.RandomState(fold_seed)
+    return state.choice(np.arange(kfold, dtype=typ), n)
+
+
+def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
+    f = _add_fold(n, kfold, fold_seed).astype(np.uint8)
+    return DeviceColumn(torch.from_numpy(f).to(device))
+
+
+class TargetEncoding(StatOperator):
+    def __init__(self, target, target_mean=None, kfold=None, fold_seed=42, p_smooth=20,
+                 out_col=None, out_dtype=None, split_out=None, split_every=None,
+                 cat_cache="host", out_path=None, on_host=True, name_sep="_", drop_folds=True,
+                 tree_width=None):
+        super().__init__()
+        target = Node.construct_from(target)
+        self.dependency = target
+        self.target = target
+        self.target_mean = target_mean
+        self.kfold = kfold or 3
+        self.fold_seed = fold_seed
+        self.p_smooth = p_smooth
+        self.out_col = [out_col] if isinstance(out_col, str) else out_col
+        self.out_dtype = out_dtype
+        self.split_out = split_out
+        self.split_every = split_every
+        self.out_path = out_path or "./"
+        self.on_host = on_host
+        self.cat_cache = cat_cache
+        self.name_sep = name_sep
+        self.drop_folds = drop_folds
+        self.fold_name = "__fold__"
+        self.stats = {}
+        self.means = {}
+        self._device_stats = {}
+
+    # ------------------------------------------------------------------ fit --
+    def _groups(self, col_selector):
+        out = []
+        for g in col_selector.grouped_names:
+            out.append(list(g) if isinstance(g, (tuple, list)) else [g])
+        return out
+
+    def fit_begin(self, col_selector):
+        targets = list(self.target_columns)
+        state = {"moments": None, "aggs": {}}
+        if self.target_mean is None:
+            state["moments"] = moments_begin(targets)
+        for cols in self._groups(col_selector):
+            name = _make_name(*cols, sep=self.name_sep)
+            state["aggs"][name] = GroupAgg(name, cols, targets)
+            if self.kfold > 1:
+                fcols = [self.fold_name] + cols
+                fname = _make_name(*fcols, sep=self.name_sep)
+                state["aggs"][fname] = GroupAgg(fname, fcols, targets)
+        return state
+
+    def fit_partition(self, state, col_selector, df):
+        frame, _ = as_device_frame(df)
+        if state["moments"] is not None:
+            moments_partition(state["moments"], frame)
+        if self.kfold > 1 and self.fold_name not in frame:
+            frame = frame.copy()
+            dev = next(iter(frame.items()))[1].data.device
+            frame[self.fold_name] = _fold_column(len(frame), self.kfold, self.fold_seed, dev)
+        for agg in state["aggs"].values():
+            agg.update(frame)
+
+    def fit_end(self, state, col_selector):
+        base = os.path.join(self.out_path, "categories")
+        os.makedirs(base, exist_ok=True)
+        paths = {}
+        for name, agg in state["aggs"].items():
+            comp = agg.finalize()
+            df = stats_frame(agg, comp, ["count", "sum"], self.name_sep)
+            d = os.path.join(base, f"cat_stats.{name}.parquet")
+            os.makedirs(d, exist_ok=True)
+            df.to_parquet(os.path.join(d, "part.0.parquet"), index=False)
+            paths[name] = d
+            cols = {"count": comp["count"]}
+            for j, t in enumerate(agg.val_cols):
+                cols[f"sum:{t}"] = comp["sum"][j]
+            self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols)
+        moments = moments_end(state["moments"]) if state["moments"] is not None else None
+        return paths, moments
+
+    def fit_finalize(self, dask_stats):
+        for col, value in dask_stats[0].items():
+            self.stats[col] = value
+        if dask_stats[1] is not None:
+            for col, m in dask_stats[1].items():
+                self.means[col] = float(m["mean"])
+
+    # ------------------------------------------------------------ transform --
+    def _stats_for(self, name, key_cols):
+        st = self._device_stats.get(name)
+        if st is not None:
+            return st
+        df = pd.read_parquet(self.stats[name])
+        targets = list(self.target_columns)
+        # file layout (categorify.py:1079-1137): keys, <name>_count, <name>_<t>_sum...
+        ren = {f"{name}{self.name_sep}count": "count"}
+        for t in targets:
+            ren[f"{name}{self.name_sep}{t}{self.name_sep}sum"] = f"sum:{t}"
+        st = _stats_from_frame(df.rename(columns=ren), key_cols)
+        st.columns["count"] = st.columns["count"].to(torch.int64)
+        self._device_stats[name] = st
+        return st
+
+    def transform(self, col_selector, df):
+        frame, was_pandas = as_device_frame(df)
+        fit_folds = self.kfold > 1
+        dev = next(iter(frame.items()))[1].data.device
+        work = frame
+        if fit_folds:
+            work = frame.copy()
+            work[self.fold_name] = _fold_column(len(frame), self.kfold, self.fold_seed, dev)
+        y_mean = self.target_mean or self.means
+        targets = list(self.target_columns)
+        out_dt = torch.float64 if np.dtype(self.output_dtype) == np.dtype("float64") else torch.float32
+        new = DeviceFrame()
+        for ind, cat_group in enumerate(self._groups(col_selector)):
+            if isinstance(self.out_col, list):
+                if ind >= len(self.out_col):
+                    raise ValueError("out_col and cat_groups are different sizes.")
+                out_col = self.out_col[ind]
+                out_col = [out_col] if isinstance(out_col, str) else out_col
+                if len(out_col) != len(targets):
+                    raise ValueError("out_col and target are different sizes.")
+            else:
+                tag = _make_name(*cat_group, sep=self.name_sep)
+                out_col = [f"TE_{tag}_{x}" for x in targets]
+            name_all = _make_name(*cat_group, sep=self.name_sep)
+            st_all = self._stats_for(name_all, cat_group)
+
+            def lookup(st, cols):
+                keys, valids = [], []
+                for c in cols:
+                    k, v = key_view(work[c].materialize())
+                    keys.append(k)
+                    valids.append(v)
+                return st.index.lookup(keys, valids)
+
+            g_all = lookup(st_all, cat_group)
+            g_fold, st_fold = None, None
+            if fit_folds:
+                fcols = [self.fold_name] + cat_group
+                st_fold = self._stats_for(_make_name(*fcols, sep=self.name_sep), fcols)
+                g_fold = lookup(st_fold, fcols)
+            for i, t in enumerate(targets):
+                ym = y_mean[t] if isinstance(y_mean, dict) else y_mean
+                out = K.te_apply(
+                    g_all, g_fold,
+                    st_all.columns[f"sum:{t}"].to(torch.float64).contiguous(),
+                    st_all.columns["count"].to(torch.int64).contiguous(),
+                    st_fold.columns[f"sum:{t}"].to(torch.float64).contiguous() if fit_folds else None,
+                    st_fold.columns["count"].to(torch.int64).contiguous() if fit_folds else None,
+                    self.p_smooth, ym, out_dt,
+                )
+                new[out_col[i]] = DeviceColumn(out)
+        if fit_folds and not self.drop_folds:
+            new[self.fold_name] = work[self.fold_name]
+        return new.to_pandas() if was_pandas else new
+
+    # --------------------------------------------------------------- schema --
+    @property
+    def dependencies(self):
+        return self.dependency
+
+    def compute_selector(self, input_schema, selector, parents_selector=None,
+                         dependencies_selector=None):
+        self._validate_matching_cols(input_schema, parents_selector, "computing input selector")
+        return parents_selector
+
+    def column_mapping(self, col_selector):
+        mapping = {}
+        for group in col_selector.grouped_names:
+            group = ColumnSelector(group if isinstance(group, str) else list(group))
+            tag = _make_name(*group.names, sep=self.name_sep)
+            for target_name in self.target_columns:
+                mapping[f"TE_{tag}_{target_name}"] = [target_name, *group.names]
+        if self.kfold > 1 and not self.drop_folds:
+            mapping[self.fold_name] = []
+        return mapping
+
+    def _compute_dtype(self, col_schema, input_schema):
+        if input_schema.column_schemas:
+            return super()._compute_dtype(col_schema, input_schema).with_dtype(
+                self.output_dtype, is_list=False, is_ragged=False)
+        return col_schema.with_dtype(np.uint8)
+
+    def _compute_tags(self, col_schema, input_schema):
+        if input_schema.column_schemas:
+            src = input_schema.column_names[0]
+            return col_schema.with_tags(list(input_schema[src].tags) + self.output_tags)
+        return col_schema
+
+    @property
+    def output_dtype(self):
+        return self.out_dtype or np.float32
+
+    @property
+    def output_tags(self):
+        return [Tags.CONTINUOUS]
+
+    @property
+    def target_columns(self):
+        if self.target.output_schema is not None:
+            return self.target.output_schema.column_names
+        if self.target.selector is not None:
+            return self.target.selector.names
+        return []
+
+    def set_storage_path(self, new_path, copy=False):
+        import shutil
+
+        new = {}
+        for col, old in self.stats.items():
+            target = old.replace(str(self.out_path), str(new_path))
+            if copy and target != old:
+                shutil.copytree(old, target, dirs_exist_ok=True)
+            new[col] = target
+        self.stats = new
+        self.out_path = new_path
+
+    def clear(self):
+        self.stats = {}
+        self.means = {}
+        self._device_stats = {}

@@ -1,0 +1,213 @@
+"""Workflow: fit / transform orchestration (reference:
+nvtabular/workflow/workflow.py:45-358; executor semantics from merlin-core's
+DaskExecutor / LocalExecutor).
+
+fit runs the StatOperators in *phases* (a StatOperator is ready once every
+StatOperator upstream of it has been fitted); all operators of a phase consume
+each partition once, so e.g. Categorify and FillMissing>>Normalize of the Criteo
+workflow are fitted in a single pass over the data.  With torch.distributed
+initialised, each rank fits its shard of the partitions and the per-op
+``fit_end`` merges over RCCL (dist.py).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import pickle
+import time
+from typing import Dict, List, Optional
+
+import pandas as pd
+
+from . import dist
+from .device import DeviceFrame, as_device_frame
+from .io import Dataset
+from .node import Node, iter_nodes
+from .ops.base import StatOperator
+from .schema import Schema
+
+LOG = logging.getLogger("nvtabular_amd")
+
+
+class Workflow:
+    def __init__(self, output_node, client=None):
+        self.output_node = Node.construct_from(output_node)
+        self.client = client  # accepted for API compatibility (no dask here)
+        self.input_schema: Optional[Schema] = None
+        self.output_schema: Optional[Schema] = None
+        self.output_dtypes = None
+
+    # ---- schema ----------------------------------------------------------------
+    def fit_schema(self, input_schema: Schema) -> "Workflow":
+        for node in iter_nodes(self.output_node):
+            node.compute_schemas(input_schema)
+        roots = self._root_columns()
+        self.input_schema = input_schema.select_by_name(roots)
+        self.output_schema = self.output_node.output_schema
+        self.output_dtypes = {c.name: c.dtype for c in self.output_schema}
+        return self
+
+    def _root_columns(self) -> List[str]:
+        cols = []
+        for node in iter_nodes(self.output_node):
+            if node.op is None and node.input_schema is not None:
+                for n in node.input_schema.column_names:
+                    if n not in cols:
+                        cols.append(n)
+        return cols
+
+    def _input_columns(self):
+        return self._root_columns()
+
+    # ---- execution of the graph on one partition ----------------------------------
+    def _run(self, node: Node, root: DeviceFrame, cache: Dict[int, DeviceFrame]) -> DeviceFrame:
+        key = id(node)
+        if key in cache:
+            return cache[key]
+        if node.op is None:
+            out = root[node.output_schema.column_names]
+        else:
+            inp = self._node_input(node, root, cache)
+            out = node.op.transform(node.input_columns, inp)
+            out, _ = as_device_frame(out)
+            names = node.output_schema.column_names
+            if all(n in out for n in names):
+                out = out[names]
+        cache[key] = out
+        return out
+
+    def _node_input(self, node: Node, root: DeviceFrame, cache) -> DeviceFrame:
+        ups = [self._run(u, root, cache) for u in node.parents_with_dependencies]
+        # shallow copies: ops such as FillMissing mutate the frame they are given
+        return DeviceFrame.concat_columns(ups).copy()
+
+    # ---- fit ------------------------------------------------------------------------
+    def fit(self, dataset: Dataset) -> "Workflow":
+        self.clear_stats()
+        self.fit_schema(dataset.schema)
+        nodes = iter_nodes(self.output_node)
+        stat_nodes = [n for n in nodes if isinstance(n.op, StatOperator)]
+        fitted: set = set()
+        shard = (dist.rank(), dist.world_size()) if dist.world_size() > 1 else None
+        roots = self._root_columns()
+        while len(fitted) < len(stat_nodes):
+            phase = [
+                n for n in stat_nodes
+                if id(n) not in fitted
+                and all(id(a) in fitted for a in _stat_ancestors(n))
+            ]
+            if not phase:
+                raise RuntimeError("failed to schedule StatOperators (dependency cycle?)")
+            states = {id(n): n.op.fit_begin(n.input_columns) for n in phase}
+            for part in dataset.to_iter(columns=roots, shard=shard):
+                cache: Dict[int, DeviceFrame] = {}
+                for n in phase:
+                    inp = self._node_input(n, part, cache)
+                    n.op.fit_partition(states[id(n)], n.input_columns, inp)
+            for n in phase:
+                n.op.fit_finalize(n.op.fit_end(states[id(n)], n.input_columns))
+                fitted.add(id(n))
+        # properties such as embedding sizes depend on the fitted state
+        self.fit_schema(dataset.schema)
+        if any(getattr(n.op, "dynamic_dtypes", False) for n in nodes if n.op is not None):
+            self._capture_dtypes(dataset)
+        return self
+
+    def _capture_dtypes(self, dataset):
+        for part in dataset.to_iter(columns=self._root_columns()):
+            out = self._run(self.output_node, part, {})
+            sample = Schema.from_frame(out)
+            cols = []
+            for c in self.output_schema:
+                s = sample.get(c.name)
+                cols.append(c.with_dtype(s.dtype, s.is_list, s.is_ragged) if s is not None else c)
+            self.output_schema = Schema(cols)
+            self.output_node.output_schema = self.output_schema
+            self.output_dtypes = {c.name: c.dtype for c in self.output_schema}
+            break
+
+    # ---- transform ---------------------------------------------------------------------
+    def transform(self, data):
+        if isinstance(data, Dataset):
+            if self.output_schema is None:
+                self.fit_schema(data.schema)
+            roots = self._root_columns()
+
+            def gen(columns=None):
+                for part in data.to_iter(columns=roots):
+                    yield self._run(self.output_node, part, {})
+
+            return Dataset(gen, schema=self.output_schema, npartitions=data.npartitions)
+        if isinstance(data, pd.DataFrame):
+            if self.output_schema is None:
+                self.fit_schema(Schema.from_frame(data))
+            frame, _ = as_device_frame(data[self._root_columns()])
+            return self._run(self.output_node, frame, {}).to_pandas()
+        if isinstance(data, DeviceFrame):
+            if self.output_schema is None:
+                self.fit_schema(Schema.from_frame(data))
+            return self._run(self.output_node, data, {})
+        raise TypeError(f"Workflow.transform: unsupported input {type(data)}")
+
+    def fit_transform(self, dataset: Dataset) -> Dataset:
+        self.fit(dataset)
+        return self.transform(dataset)
+
+    # ---- persistence (minimal, artefact-compatible layout) --
+    def save(self, path):
+        os.makedirs(path, exist_ok=True)
+        for i, node in enumerate(iter_nodes(self.output_node)):
+            if isinstance(node.op, StatOperator):
+                node.op.set_storage_path(os.path.join(path, "artifacts", f"node_{i}"), copy=True)
+        meta = {"generated_timestamp": int(time.time()), "engine": "nvtabular_amd"}
+        with open(os.path.join(path, "metadata.json"), "w") as f:
+            json.dump(meta, f)
+        dev = _strip_device_state(self)
+        try:
+            with open(os.path.join(path, "workflow.pkl"), "wb") as f:
+                pickle.dump(self, f)
+        finally:
+            _restore_device_state(dev)
+
+    @classmethod
+    def load(cls, path, client=None) -> "Workflow":
+        with open(os.path.join(path, "workflow.pkl"), "rb") as f:
+            wf = pickle.load(f)
+        wf.client = client
+        for i, node in enumerate(iter_nodes(wf.output_node)):
+            if isinstance(node.op, StatOperator):
+                node.op.set_storage_path(os.path.join(path, "artifacts", f"node_{i}"), copy=False)
+        return wf
+
+    def clear_stats(self):
+        for node in iter_nodes(self.output_node):
+            if isinstance(node.op, StatOperator):
+                node.op.clear()
+
+
+def _stat_ancestors(node: Node) -> List[Node]:
+    out = []
+    for u in node.parents_with_dependencies:
+        for a in iter_nodes(u):
+            if isinstance(a.op, StatOperator):
+                out.append(a)
+    return out
+
+
+_DEVICE_ATTRS = ("_encoders", "_device_stats")
+
+
+def _strip_device_state(wf):
+    saved = []
+    for node in iter_nodes(wf.output_node):
+        for attr in _DEVICE_ATTRS:
+            if node.op is not None and getattr(node.op, attr, None):
+                saved.append((node.op, attr, getattr(node.op, attr)))
+                setattr(node.op, attr, {})
+    return saved
+
+
+def _restore_device_state(saved):
+    for op, attr, val in saved:
+        setattr(op, attr, val)
