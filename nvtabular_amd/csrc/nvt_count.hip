@@ -47,7 +47,7 @@ struct KeyTraits<int64_t> {
   using cas_t = unsigned long long;
 };
 
-constexpr int kMaxProbe = 512;  // longer chains mean the table is too full -> overflow
+constexpr int kMaxProbe = 128;  // longer chains mean the table is too full -> overflow
 
 template <typename K>
 __device__ __forceinline__ K cas_key(K *addr, K expect, K val) {
@@ -134,6 +134,10 @@ __global__ __launch_bounds__(kBlock) void count_kernel(const K *__restrict__ key
   using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
   const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
   for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+    // a table that already overflowed is going to be thrown away: stop early
+    if (my_ovf || __hip_atomic_load(&state[NVT_ST_OVERFLOW], __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT))
+      break;
     VecT pack = vkeys[v];
     unsigned vbits = 0xF;
     if (valid != nullptr) {
@@ -223,33 +227,61 @@ __global__ __launch_bounds__(kBlock) void clear_kernel(CountSlot<K> *table, uint
     table[i] = e;
 }
 
-// table -> dense arrays.  One ballot + one atomic per wave; order is arbitrary
-// (the vocabulary sort fixes it afterwards).
+// table -> dense arrays, arbitrary order (the vocabulary sort fixes it afterwards).
+// Each block takes tiles of kBlock * kCompactItems slots, ranks the occupied ones with
+// a wave scan + LDS, and reserves its output range with ONE atomic per tile -- a
+// per-wave atomic on the single cursor serialises at ~90 atomics/us and was 16 ms
+// per step in the first profile (profiles/r01_baseline_kernel_stats.csv).
+constexpr int kCompactItems = 8;
 template <typename K>
 __global__ __launch_bounds__(kBlock) void compact_kernel(const CountSlot<K> *__restrict__ table,
                                                          uint64_t capacity, K *out_keys,
                                                          int64_t *out_counts, uint64_t *out_n) {
   constexpr K EMPTY = KeyTraits<K>::empty;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  const uint64_t rounds = (capacity + stride - 1) / stride;
-  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  for (uint64_t r = 0; r < rounds; ++r, i += stride) {
-    CountSlot<K> s;
-    s.key = EMPTY;
-    s.cnt = 0;
-    if (i < capacity) s = table[i];
-    bool occ = s.key != EMPTY;
-    unsigned long long m = __ballot(occ);
-    if (m == 0) continue;
-    unsigned lane = lane_id();
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd((unsigned long long *)out_n, (unsigned long long)__popcll(m));
-    base = __shfl(base, 0, 64);
-    if (occ) {
-      unsigned rank = __popcll(m & ((1ull << lane) - 1ull));
-      out_keys[base + rank] = s.key;
-      out_counts[base + rank] = (int64_t)s.cnt;
+  constexpr uint64_t TILE = (uint64_t)kBlock * kCompactItems;
+  __shared__ unsigned wsum[kBlock / kWave];
+  __shared__ unsigned long long tile_base;
+  const unsigned lane = lane_id();
+  const unsigned w = threadIdx.x / kWave;
+  const uint64_t ntiles = (capacity + TILE - 1) / TILE;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // thread owns kCompactItems consecutive slots (coalesced enough: 64-128 B per lane)
+    const uint64_t first = t * TILE + (uint64_t)threadIdx.x * kCompactItems;
+    CountSlot<K> s[kCompactItems];
+    unsigned mine = 0;
+#pragma unroll
+    for (int j = 0; j < kCompactItems; ++j) {
+      s[j].key = EMPTY;
+      s[j].cnt = 0;
+      if (first + j < capacity) s[j] = table[first + j];
+      mine += (s[j].key != EMPTY);
     }
+    unsigned inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned o = __shfl_up(inc, off, 64);
+      if (lane >= (unsigned)off) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned wbase = 0, total = 0;
+    for (unsigned i = 0; i < kBlock / kWave; ++i) {
+      if (i < w) wbase += wsum[i];
+      total += wsum[i];
+    }
+    if (threadIdx.x == 0)
+      tile_base = total ? atomicAdd((unsigned long long *)out_n, (unsigned long long)total) : 0;
+    __syncthreads();
+    uint64_t pos = tile_base + wbase + inc - mine;
+#pragma unroll
+    for (int j = 0; j < kCompactItems; ++j) {
+      if (s[j].key != EMPTY) {
+        out_keys[pos] = s[j].key;
+        out_counts[pos] = (int64_t)s[j].cnt;
+        ++pos;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -522,7 +554,7 @@ int compact_launch(const void *table, uint64_t capacity, K *out_keys, int64_t *o
                    uint64_t *out_n, hipStream_t stream) {
   NVT_CHECK_ARG(table && out_keys && out_counts && out_n, "null pointer");
   NVT_CHECK_HIP(hipMemsetAsync(out_n, 0, sizeof(uint64_t), stream));
-  compact_kernel<K><<<stream_grid(capacity, kBlock), kBlock, 0, stream>>>(
+  compact_kernel<K><<<stream_grid(capacity, kBlock * kCompactItems), kBlock, 0, stream>>>(
       reinterpret_cast<const CountSlot<K> *>(table), capacity, out_keys, out_counts, out_n);
   NVT_CHECK_LAUNCH();
   return NVT_OK;

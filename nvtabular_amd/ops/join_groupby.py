@@ -109,8 +109,9 @@ class JoinGroupby(StatOperator):
             if "count" in self.stats:
                 cols[f"{name}{self.name_sep}count"] = comp["count"].to(torch.float64)
             for j, cont in enumerate(agg.val_cols):
-                for stat in self.stats:
-                    if stat != "count":
+                # column order of _bottom_level_groupby's `required` list (categorify.py:1087-1131)
+                for stat in ("sum", "mean", "min", "max", "var", "std"):
+                    if stat in self.stats:
                         cols[f"{name}{self.name_sep}{cont}{self.name_sep}{stat}"] = derived[(j, stat)]
             self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols)
         return out
@@ -134,8 +135,7 @@ class JoinGroupby(StatOperator):
         for name, cols in self._group_list(col_selector):
             if not all(c in frame for c in cols):
                 continue
-            storage = self.storage_name.get(name, name) if len(cols) == 1 else name
-            st = self._stats_for(storage, cols)
+            st = self._stats_for(name, cols)  # stat tables are stored under the group name
             keys, valids = [], []
             for c in cols:
                 k, v = key_view(frame[c].materialize())
@@ -162,7 +162,7 @@ class JoinGroupby(StatOperator):
 
     @property
     def dependencies(self):
-        return self.cont_cols if isinstance(self.cont_cols, Node) else None
+        return self.cont_cols  # selector or node: either way an upstream dependency
 
     def compute_selector(self, input_schema, selector, parents_selector=None,
                          dependencies_selector=None):
