@@ -93,6 +93,23 @@ int nvt_count_compact_i32(const void *table, uint64_t capacity, int32_t *out_key
 int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_keys,
                           int64_t *out_counts, uint64_t *out_n, void *stream);
 
+/* ---- Categorify.fit, atomic-free: key column -> dense (key,count) list ----
+ * path 0: <= ~6000 distinct keys, three LDS-table stages (512 -> 16 -> 1 workgroups);
+ * path 1 / 2: hash-partition the rows into 64 x 64 / 64 x 256 buckets, then one LDS
+ * table per bucket.  weights (optional, int64 per row) turns the count into a weighted
+ * sum -- the tree-merge of (key,count) lists (_mid_level_groupby).  ws: device scratch
+ * of nvt_dense_count_ws_bytes().  state (device uint64[NVT_STATE_WORDS], written):
+ * [NVT_ST_NULLS] null rows (weighted), [NVT_ST_SENTINEL] rows whose key is the empty
+ * sentinel (NOT in the list), [NVT_ST_OCCUPIED] entries written, [NVT_ST_OVERFLOW]
+ * bit0: an LDS table filled up (rerun on a larger path), bit1: out_capacity too small. */
+int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes);
+int nvt_dense_count_i32(const int32_t *keys, const uint8_t *valid, const int64_t *weights,
+                        uint64_t n, int path, void *ws, int32_t *out_keys, int64_t *out_counts,
+                        uint64_t out_capacity, uint64_t *state, void *stream);
+int nvt_dense_count_i64(const int64_t *keys, const uint8_t *valid, const int64_t *weights,
+                        uint64_t n, int path, void *ws, int64_t *out_keys, int64_t *out_counts,
+                        uint64_t out_capacity, uint64_t *state, void *stream);
+
 /* ---- vocabulary order (_write_uniques): count descending, key ascending ----
  * LSD radix sort of n (key,count) pairs; tmp must hold nvt_vocab_sort_tmp_bytes(). */
 int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes);

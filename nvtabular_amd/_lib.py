@@ -44,6 +44,9 @@ SIGNATURES = {
     "nvt_count_merge_i64": [_vp, _vp, _u64, _vp, _u64, _vp, _vp],
     "nvt_count_compact_i32": [_vp, _u64, _vp, _vp, _vp, _vp],
     "nvt_count_compact_i64": [_vp, _u64, _vp, _vp, _vp, _vp],
+    "nvt_dense_count_ws_bytes": [_i32, _u64, _i32, _i32, C.POINTER(_u64)],
+    "nvt_dense_count_i32": [_vp, _vp, _vp, _u64, _i32, _vp, _vp, _vp, _u64, _vp, _vp],
+    "nvt_dense_count_i64": [_vp, _vp, _vp, _u64, _i32, _vp, _vp, _vp, _u64, _vp, _vp],
     "nvt_vocab_sort_tmp_bytes": [_i32, _u64, C.POINTER(_u64)],
     "nvt_vocab_sort_i32": [_vp, _vp, _u64, _vp, _vp],
     "nvt_vocab_sort_i64": [_vp, _vp, _u64, _vp, _vp],

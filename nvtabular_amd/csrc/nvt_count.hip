@@ -528,8 +528,10 @@ int count_launch(const K *keys, const uint8_t *valid, uint64_t n, void *table, u
   NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
   if (n == 0) return NVT_OK;
   constexpr int VEC = KeyTraits<K>::vec;
-  unsigned grid = stream_grid(n / VEC + 1, kBlock * 4, sizeof(K) == 4 ? 4 : 3);
-  count_kernel<K, 4096><<<grid, kBlock, 0, stream>>>(keys, valid, n,
+  // 2 resident blocks per CU, each with an 8192-slot LDS table (64/96 KiB): fewer,
+  // larger private tables halve the number of end-of-kernel flushes into the global table
+  unsigned grid = stream_grid(n / VEC + 1, kBlock * 4, 2);
+  count_kernel<K, 8192><<<grid, kBlock, 0, stream>>>(keys, valid, n,
                                                      reinterpret_cast<CountSlot<K> *>(table),
                                                      capacity - 1, state);
   NVT_CHECK_LAUNCH();

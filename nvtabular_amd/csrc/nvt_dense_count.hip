@@ -1,0 +1,884 @@
+// Categorify.fit groupby-size WITHOUT global atomics: key column -> dense
+// (key, count) list.  Replaces categorify.py:955-1051 (_top_level_groupby,
+// size only) and, with weights, the concat + re-groupby of :1054-1070.
+//
+// Why: the first version (nvt_count.hip: LDS front table + one global
+// open-addressing table) spends its time in device-scope atomics -- 512-1024
+// workgroups flushing the same hot keys serialise at the memory-side atomic unit
+// (36 distinct keys: 290 us; 1000 keys: 1 ms for a 45 M-row column whose stream
+// takes 35 us), and every row of a high-cardinality column is 2 random atomics.
+// LDS atomics, by contrast, run at near stream speed (micro-benchmark
+// tools/micro/lds_count_probe.hip: 45 M keys, 36 distinct: 58 us = 3.1 TB/s).
+//
+// Path S ("small", <= ~6000 distinct keys)
+//   stage 1  512 workgroups, each counts its grid-stride share into a private
+//            8192-slot LDS table and appends its occupied slots to a partials
+//            list (ONE reservation atomic per workgroup);
+//   stage 2  16 workgroups re-count the (key, weight) partials the same way;
+//   stage 3  1 workgroup produces the final dense list.
+//   No global hash table, no contended atomics.  A workgroup whose table fills
+//   up raises OVERFLOW and the caller reruns the column on path P.
+//
+// Path P ("partitioned", anything larger)
+//   P0  per-workgroup LDS histogram of the top hash bits  -> bucket sizes
+//   P0b scan -> exact bucket starts (no over-allocation, no overflow)
+//   P1  scatter rows to 64 coarse buckets   (LDS-staged, 512 B contiguous runs)
+//   P2  scatter each coarse bucket to 64/256 fine buckets
+//   P3  one workgroup per fine bucket: LDS table count -> dense output
+//   All occurrences of a key land in one fine bucket, so counts are exact and the
+//   only atomics left are LDS ones plus one reservation per tile / workgroup.
+//   HBM traffic: 6 x 4 B per row (3 reads + 2 writes + hist read) against 4 B
+//   algorithmic -- the price of removing 90 M random device atomics.
+#include <type_traits>
+
+#include "nvt_common.hpp"
+
+namespace nvt {
+
+template <typename K>
+struct DKey;
+template <>
+struct DKey<int32_t> {
+  static constexpr int32_t empty = INT32_MIN;
+  static constexpr int vec = 4;
+  using cas_t = int;
+};
+template <>
+struct DKey<int64_t> {
+  static constexpr int64_t empty = INT64_MIN;
+  static constexpr int vec = 2;
+  using cas_t = unsigned long long;
+};
+
+// state words (uint64) written by these kernels
+constexpr int DS_NULLS = NVT_ST_NULLS, DS_SENT = NVT_ST_SENTINEL, DS_OUT = NVT_ST_OCCUPIED,
+              DS_OVF = NVT_ST_OVERFLOW, DS_ROWS = NVT_ST_ROWS;
+
+constexpr int kLdsSlots = 8192;
+constexpr int kLdsProbe = 24;
+constexpr int kLdsMaxFill = 6144;  // 75 %: beyond this the LDS table is declared full
+
+template <typename K>
+__device__ __forceinline__ K lds_cas(K *addr, K expect, K val) {
+  using C = typename DKey<K>::cas_t;
+  return (K)atomicCAS(reinterpret_cast<C *>(addr), (C)expect, (C)val);
+}
+
+// Insert into a workgroup-private LDS table.  Returns false when no slot was found.
+template <typename K, typename C>
+__device__ __forceinline__ bool lds_add(K *lkeys, C *lcnt, unsigned *lfill, K key, C w,
+                                        unsigned hash_shift) {
+  constexpr K EMPTY = DKey<K>::empty;
+  uint32_t h = (uint32_t)(slot_hash(key) >> hash_shift);
+  for (int p = 0; p < kLdsProbe; ++p) {
+    uint32_t s = (h + p) & (kLdsSlots - 1);
+    K cur = lkeys[s];
+    if (cur == EMPTY) {
+      cur = lds_cas<K>(&lkeys[s], EMPTY, key);
+      if (cur == EMPTY) {
+        cur = key;
+        atomicAdd(lfill, 1u);
+      }
+    }
+    if (cur == key) {
+      atomicAdd(&lcnt[s], w);
+      return true;
+    }
+  }
+  return false;
+}
+
+// Append the occupied LDS slots to (out_keys, out_cnt) at a range reserved with one
+// atomic on *cursor.  All threads of the block must call this.
+template <typename K, typename C>
+__device__ __forceinline__ void lds_flush(const K *lkeys, const C *lcnt, K *out_keys,
+                                          int64_t *out_cnt, uint64_t out_cap,
+                                          unsigned long long *cursor, uint64_t *state) {
+  constexpr K EMPTY = DKey<K>::empty;
+  __shared__ unsigned wsum[kBlock / kWave];
+  __shared__ unsigned long long base_s;
+  constexpr int PER = kLdsSlots / kBlock;
+  const unsigned lane = lane_id(), w = threadIdx.x / kWave;
+  unsigned mine = 0;
+  const int first = threadIdx.x * PER;
+#pragma unroll 8
+  for (int j = 0; j < PER; ++j) mine += (lkeys[first + j] != EMPTY);
+  unsigned inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned o = __shfl_up(inc, off, 64);
+    if (lane >= (unsigned)off) inc += o;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  unsigned wbase = 0, total = 0;
+  for (unsigned i = 0; i < kBlock / kWave; ++i) {
+    if (i < w) wbase += wsum[i];
+    total += wsum[i];
+  }
+  if (threadIdx.x == 0) base_s = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+  __syncthreads();
+  uint64_t pos = base_s + wbase + inc - mine;
+  if (base_s + total > out_cap) {
+    if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 2ull);
+    return;
+  }
+#pragma unroll 8
+  for (int j = 0; j < PER; ++j) {
+    K k = lkeys[first + j];
+    if (k != EMPTY) {
+      out_keys[pos] = k;
+      out_cnt[pos] = (int64_t)lcnt[first + j];
+      ++pos;
+    }
+  }
+}
+
+// Same, but into a caller-assigned region [out_keys, out_keys + kLdsMaxFill) -- used for
+// the per-chunk partial lists of split (skewed) buckets.  *out_len receives the count.
+template <typename K, typename C>
+__device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, K *out_keys,
+                                                 int64_t *out_cnt, unsigned *out_len) {
+  constexpr K EMPTY = DKey<K>::empty;
+  __shared__ unsigned wsum2[kBlock / kWave];
+  constexpr int PER = kLdsSlots / kBlock;
+  const unsigned lane = lane_id(), w = threadIdx.x / kWave;
+  unsigned mine = 0;
+  const int first = threadIdx.x * PER;
+#pragma unroll 8
+  for (int j = 0; j < PER; ++j) mine += (lkeys[first + j] != EMPTY);
+  unsigned inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned o = __shfl_up(inc, off, 64);
+    if (lane >= (unsigned)off) inc += o;
+  }
+  if (lane == 63) wsum2[w] = inc;
+  __syncthreads();
+  unsigned wbase = 0, total = 0;
+  for (unsigned i = 0; i < kBlock / kWave; ++i) {
+    if (i < w) wbase += wsum2[i];
+    total += wsum2[i];
+  }
+  if (threadIdx.x == 0) *out_len = total;
+  unsigned pos = wbase + inc - mine;
+#pragma unroll 8
+  for (int j = 0; j < PER; ++j) {
+    K k = lkeys[first + j];
+    if (k != EMPTY) {
+      out_keys[pos] = k;
+      out_cnt[pos] = (int64_t)lcnt[first + j];
+      ++pos;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Path S, stage kernel.  FIRST: input is the key column (+validity, optional
+// weights); otherwise input is a (key, weight) partials list whose length is read
+// from *in_len on the device.
+// ---------------------------------------------------------------------------
+template <typename K, bool FIRST, typename C>
+__global__ __launch_bounds__(kBlock) void lds_stage_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid,
+    const int64_t *__restrict__ weights, uint64_t n, const unsigned long long *in_len,
+    K *out_keys, int64_t *out_cnt, uint64_t out_cap, unsigned long long *cursor, uint64_t *state,
+    int final_stage) {
+  constexpr K EMPTY = DKey<K>::empty;
+  constexpr int VEC = DKey<K>::vec;
+  __shared__ K lkeys[kLdsSlots];
+  __shared__ C lcnt[kLdsSlots];
+  __shared__ unsigned lfill, lovf;
+  __shared__ unsigned long long s_nulls, s_sent;
+  for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
+    lkeys[i] = EMPTY;
+    lcnt[i] = 0;
+  }
+  if (threadIdx.x == 0) {
+    lfill = 0;
+    lovf = 0;
+    s_nulls = 0;
+    s_sent = 0;
+  }
+  __syncthreads();
+  if (!FIRST) n = (uint64_t)*in_len;
+  unsigned long long my_nulls = 0, my_sent = 0;
+  bool failed = false;
+  auto add = [&](K key, unsigned long long w) {
+    if (key == EMPTY) {
+      my_sent += w;
+      return;
+    }
+    if (!lds_add<K, C>(lkeys, lcnt, &lfill, key, (C)w, 17)) failed = true;
+  };
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  if (FIRST && weights == nullptr) {
+    const uint64_t nvec = n / VEC;
+    using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
+    const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
+    // 8 independent 16-byte loads in flight per lane before any LDS work: with only
+    // 2 workgroups (8 waves) per CU the HBM latency has to be covered by ILP
+    constexpr int U = 8;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v0 < nvec; v0 += stride * U) {
+      if (lfill > kLdsMaxFill) break;  // table is filling up: this column belongs on path P
+      VecT pack[U];
+      unsigned vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint64_t v = v0 + (uint64_t)u * stride;
+        vb[u] = 0;
+        if (v < nvec) {
+          pack[u] = vkeys[v];
+          vb[u] = 0xF;
+          if (valid != nullptr) {
+            uint64_t row = v * VEC;
+            vb[u] = (valid[row >> 3] >> (row & 7)) & ((1u << VEC) - 1u);
+          }
+          vb[u] |= 0x100;  // in range
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!(vb[u] & 0x100)) continue;
+        K k[VEC];
+        if constexpr (sizeof(K) == 4) {
+          k[0] = pack[u].x;
+          k[1] = pack[u].y;
+          k[2] = pack[u].z;
+          k[3] = pack[u].w;
+        } else {
+          k[0] = pack[u].x;
+          k[1] = pack[u].y;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if ((vb[u] >> j) & 1)
+            add(k[j], 1ull);
+          else
+            ++my_nulls;
+        }
+      }
+    }
+    for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+      if (bit_valid(valid, i))
+        add(keys[i], 1ull);
+      else
+        ++my_nulls;
+    }
+  } else {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+      if (lfill > kLdsMaxFill) break;
+      if (FIRST && !bit_valid(valid, i)) {
+        my_nulls += (unsigned long long)weights[i];
+        continue;
+      }
+      add(keys[i], (unsigned long long)weights[i]);
+    }
+  }
+  if (failed) atomicOr(&lovf, 1u);
+  if (my_nulls) atomicAdd(&s_nulls, my_nulls);
+  if (my_sent) atomicAdd(&s_sent, my_sent);
+  __syncthreads();
+  if (lovf || lfill > kLdsMaxFill) {
+    if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
+    return;
+  }
+  if (threadIdx.x == 0) {
+    if (s_nulls) atomicAdd((unsigned long long *)&state[DS_NULLS], s_nulls);
+    if (s_sent) atomicAdd((unsigned long long *)&state[DS_SENT], s_sent);
+    if (FIRST && blockIdx.x == 0) atomicAdd((unsigned long long *)&state[DS_ROWS], (unsigned long long)n);
+  }
+  lds_flush<K, C>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+  (void)final_stage;
+}
+
+// ---------------------------------------------------------------------------
+// Path P
+// ---------------------------------------------------------------------------
+constexpr int kTile = 8192;        // rows per scatter tile (32 rows per thread)
+constexpr int kChunk = 65536;      // rows one P3 workgroup counts
+constexpr int kMaxFine = 1 << 14;  // up to 6 + 8 hash bits
+constexpr int kHistBlocks = 512;
+
+template <typename K>
+__device__ __forceinline__ uint32_t part_hash(K key) {
+  // independent of the LDS-table hash (which uses bits >= 17 of slot_hash)
+  return fmix32((uint32_t)slot_hash(key) * 0x9E3779B1u + 0x7F4A7C15u);
+}
+
+// P0: per-block histogram over the fine bucket id = top (b1+b2) bits of part_hash
+template <typename K>
+__global__ __launch_bounds__(kBlock) void part_hist_kernel(const K *__restrict__ keys,
+                                                           const uint8_t *__restrict__ valid,
+                                                           const int64_t *__restrict__ weights,
+                                                           uint64_t n, int bits, unsigned *block_hist,
+                                                           uint64_t *state) {
+  __shared__ unsigned h[kMaxFine];
+  const int nb = 1 << bits;
+  for (int i = threadIdx.x; i < nb; i += kBlock) h[i] = 0;
+  __syncthreads();
+  unsigned long long nulls = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  constexpr int U = 16;  // independent loads in flight per lane
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += stride * U) {
+    K k[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint64_t i = i0 + (uint64_t)u * stride;
+      ok[u] = false;
+      if (i < n) {
+        if (bit_valid(valid, i)) {
+          k[u] = keys[i];
+          ok[u] = true;
+        } else {
+          nulls += weights ? (unsigned long long)weights[i] : 1ull;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (ok[u]) atomicAdd(&h[part_hash<K>(k[u]) >> (32 - bits)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += kBlock) block_hist[(uint64_t)blockIdx.x * nb + i] = h[i];
+  double dn = wave_sum((double)nulls);
+  if (lane_id() == 0 && dn > 0)
+    atomicAdd((unsigned long long *)&state[DS_NULLS], (unsigned long long)dn);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd((unsigned long long *)&state[DS_ROWS], (unsigned long long)n);
+}
+
+// P0b-1: bucket totals = column sums of the per-block histograms.  64 bins x 4 row groups
+// per workgroup; loads are coalesced across bins and 16 are kept in flight per lane.
+__global__ __launch_bounds__(kBlock) void part_reduce_kernel(const unsigned *__restrict__ block_hist,
+                                                             int nblocks, int nb,
+                                                             unsigned long long *totals) {
+  __shared__ unsigned long long part[4][64];
+  const int f = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  unsigned long long t = 0;
+  if (f < nb) {
+#pragma unroll 16
+    for (int b = g; b < nblocks; b += 4) t += block_hist[(uint64_t)b * nb + f];
+  }
+  part[g][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (g == 0 && f < nb) totals[f] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+                                    part[3][threadIdx.x];
+}
+
+// P0b-2: exclusive scan -> exact bucket starts, cursors, per-coarse tile starts. One block.
+__global__ __launch_bounds__(1024) void part_scan_kernel(const unsigned long long *__restrict__ totals,
+                                                         int bits, int b1,
+                                                         unsigned long long *fine_start,
+                                                         unsigned long long *fine_cursor,
+                                                         unsigned long long *coarse_cursor,
+                                                         unsigned *tile_start,
+                                                         unsigned *chunk_start,
+                                                         unsigned *pchunk_start) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry;
+  const int nb = 1 << bits;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    int f = base + threadIdx.x;
+    unsigned long long v = f < nb ? totals[f] : 0, inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned long long o = __shfl_up(inc, off, 64);
+      if (lane_id() >= (unsigned)off) inc += o;
+    }
+    const unsigned w = threadIdx.x / kWave;
+    if (lane_id() == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned long long wb = carry;
+    for (unsigned k = 0; k < w; ++k) wb += wsum[k];
+    if (f < nb) {
+      fine_start[f] = wb + inc - v;
+      fine_cursor[f] = wb + inc - v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = wb + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fine_start[nb] = carry;
+  __syncthreads();
+  const int nc = 1 << b1, sub = nb >> b1;
+  if ((int)threadIdx.x < nc) coarse_cursor[threadIdx.x] = fine_start[threadIdx.x * sub];
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int c = 0; c < nc; ++c) {
+      tile_start[c] = t;
+      unsigned long long sz = fine_start[(c + 1) * sub] - fine_start[c * sub];
+      t += (unsigned)((sz + kTile - 1) / kTile);
+    }
+    tile_start[nc] = t;
+  }
+  // P3 work list: a fine bucket is processed in chunks of kChunk rows; buckets that need
+  // more than one chunk (skew: a hot key drags its whole bucket) are "split" and get one
+  // partial-list region per chunk, merged per bucket by P4.  Two more block scans.
+  __syncthreads();
+  __shared__ unsigned long long wsum2[16][2];
+  __shared__ unsigned long long carry2[2];
+  if (threadIdx.x == 0) carry2[0] = carry2[1] = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    int f = base + threadIdx.x;
+    unsigned long long sz = f < nb ? fine_start[f + 1] - fine_start[f] : 0;
+    unsigned long long k = (sz + kChunk - 1) / kChunk;
+    unsigned long long v0 = k, v1 = (k > 1) ? k : 0, i0 = v0, i1 = v1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned long long o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64);
+      if (lane_id() >= (unsigned)off) {
+        i0 += o0;
+        i1 += o1;
+      }
+    }
+    const unsigned w = threadIdx.x / kWave;
+    if (lane_id() == 63) {
+      wsum2[w][0] = i0;
+      wsum2[w][1] = i1;
+    }
+    __syncthreads();
+    unsigned long long b0 = carry2[0], b1c = carry2[1];
+    for (unsigned q = 0; q < w; ++q) {
+      b0 += wsum2[q][0];
+      b1c += wsum2[q][1];
+    }
+    if (f < nb) {
+      chunk_start[f] = (unsigned)(b0 + i0 - v0);
+      pchunk_start[f] = (unsigned)(b1c + i1 - v1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) {
+      carry2[0] = b0 + i0;
+      carry2[1] = b1c + i1;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    chunk_start[nb] = (unsigned)carry2[0];
+    pchunk_start[nb] = (unsigned)carry2[1];
+  }
+}
+
+// P1 / P2: LDS-staged scatter of one tile of rows into 2^nbits buckets.
+//   LEVEL 1: tile t covers input rows [t*kTile, ...); bucket = top b1 bits of the hash.
+//   LEVEL 2: tiles are laid out per coarse bucket (tile_start); bucket = the next nbits.
+template <typename K, int LEVEL, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void part_scatter_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid,
+    const int64_t *__restrict__ weights, uint64_t n, int b1, int nbits,
+    const unsigned long long *__restrict__ fine_start, unsigned long long *cursor,
+    const unsigned *__restrict__ tile_start, K *__restrict__ out_keys,
+    int64_t *__restrict__ out_w) {
+  constexpr int ROWS = kTile / kBlock;
+  __shared__ K stage[kTile];
+  __shared__ unsigned lcnt[256], loff[256];
+  __shared__ unsigned long long gbase[256];
+  __shared__ uint64_t seg_lo, seg_hi;
+  __shared__ int coarse_s;
+  const int nbk = 1 << nbits;
+  if (LEVEL == 1) {
+    if (threadIdx.x == 0) {
+      seg_lo = (uint64_t)blockIdx.x * kTile;
+      seg_hi = seg_lo + kTile < n ? seg_lo + kTile : n;
+      coarse_s = 0;
+    }
+  } else {
+    if (threadIdx.x == 0) {
+      const int nc = 1 << b1;
+      int c = -1;
+      if (blockIdx.x < tile_start[nc]) {
+        int lo = 0, hi = nc - 1;  // last c with tile_start[c] <= blockIdx.x
+        while (lo < hi) {
+          int mid = (lo + hi + 1) >> 1;
+          if (tile_start[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        c = lo;
+      }
+      coarse_s = c;
+      if (c >= 0) {
+        const int sub = nbk;
+        uint64_t cs = fine_start[(uint64_t)c * sub], ce = fine_start[(uint64_t)(c + 1) * sub];
+        seg_lo = cs + (uint64_t)(blockIdx.x - tile_start[c]) * kTile;
+        seg_hi = seg_lo + kTile < ce ? seg_lo + kTile : ce;
+      }
+    }
+  }
+  if (threadIdx.x < 256) lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  if (LEVEL == 2 && coarse_s < 0) return;
+  const uint64_t lo = seg_lo, hi = seg_hi;
+  const int shift = (LEVEL == 1) ? (32 - b1) : (32 - b1 - nbits);
+  const uint32_t mask = (uint32_t)nbk - 1;
+
+  K k[ROWS];
+  unsigned pos[ROWS];
+  unsigned short bk[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    uint64_t i = lo + (uint64_t)r * kBlock + threadIdx.x;
+    bool ok = i < hi && (LEVEL == 2 || bit_valid(valid, i));
+    bk[r] = 0xFFFF;
+    if (ok) {
+      k[r] = keys[i];
+      unsigned b = (part_hash<K>(k[r]) >> shift) & mask;
+      bk[r] = (unsigned short)b;
+      pos[r] = atomicAdd(&lcnt[b], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of lcnt over the block (kBlock == 256 >= buckets) + global reservation
+  {
+    __shared__ unsigned ws4[kBlock / kWave];
+    const unsigned v = (int)threadIdx.x < nbk ? lcnt[threadIdx.x] : 0;
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned o = __shfl_up(inc, off, 64);
+      if (lane_id() >= (unsigned)off) inc += o;
+    }
+    const unsigned w = threadIdx.x / kWave;
+    if (lane_id() == 63) ws4[w] = inc;
+    __syncthreads();
+    unsigned add = 0;
+    for (unsigned q = 0; q < w; ++q) add += ws4[q];
+    loff[threadIdx.x] = add + inc - v;
+    if ((int)threadIdx.x < nbk && v) {
+      unsigned long long *cur = cursor + (LEVEL == 1 ? 0 : (uint64_t)coarse_s * nbk);
+      gbase[threadIdx.x] = atomicAdd(&cur[threadIdx.x], (unsigned long long)v);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+    if (bk[r] != 0xFFFF) stage[loff[bk[r]] + pos[r]] = k[r];
+  __syncthreads();
+  const unsigned total = loff[nbk - 1] + lcnt[nbk - 1];
+  for (unsigned i = threadIdx.x; i < total; i += kBlock) {
+    K key = stage[i];
+    unsigned b = (part_hash<K>(key) >> shift) & mask;
+    out_keys[gbase[b] + (i - loff[b])] = key;
+  }
+  if (WEIGHTED) {
+    // weights ride along: same destination, recomputed from (bucket, pos)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      if (bk[r] != 0xFFFF) {
+        uint64_t i = lo + (uint64_t)r * kBlock + threadIdx.x;
+        out_w[gbase[bk[r]] + pos[r]] = weights[i];
+      }
+    }
+  }
+}
+
+// P3: one workgroup per (fine bucket, chunk of kChunk rows).  Single-chunk buckets go
+// straight to the output list; chunks of split buckets write partial lists for P4.
+template <typename K, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void part_count_kernel(
+    const K *__restrict__ keys, const int64_t *__restrict__ weights,
+    const unsigned long long *__restrict__ fine_start, const unsigned *__restrict__ chunk_start,
+    const unsigned *__restrict__ pchunk_start, int nb, K *part_keys, int64_t *part_cnt,
+    unsigned *part_len, K *out_keys, int64_t *out_cnt, uint64_t out_cap, unsigned long long *cursor,
+    uint64_t *state) {
+  constexpr K EMPTY = DKey<K>::empty;
+  using C = typename std::conditional<WEIGHTED, unsigned long long, unsigned>::type;
+  __shared__ K lkeys[kLdsSlots];
+  __shared__ C lcnt[kLdsSlots];
+  __shared__ unsigned lfill, lovf;
+  __shared__ unsigned long long s_sent;
+  __shared__ int s_f;
+  if (threadIdx.x == 0) {
+    int f = -1;
+    if (blockIdx.x < chunk_start[nb]) {
+      int lo = 0, hi = nb - 1;  // last f with chunk_start[f] <= blockIdx.x (skips empty buckets)
+      while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (chunk_start[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+      }
+      f = lo;
+    }
+    s_f = f;
+    lfill = 0;
+    lovf = 0;
+    s_sent = 0;
+  }
+  for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
+    lkeys[i] = EMPTY;
+    lcnt[i] = 0;
+  }
+  __syncthreads();
+  const int f = s_f;
+  if (f < 0) return;
+  const unsigned j = blockIdx.x - chunk_start[f];
+  const unsigned nchunks = chunk_start[f + 1] - chunk_start[f];
+  const uint64_t lo = fine_start[f] + (uint64_t)j * kChunk;
+  const uint64_t end = fine_start[f + 1];
+  const uint64_t hi = lo + kChunk < end ? lo + kChunk : end;
+  bool failed = false;
+  unsigned long long my_sent = 0;
+  constexpr int U = 8;
+  for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (uint64_t)kBlock * U) {
+    if (lfill > kLdsMaxFill) break;
+    K kk[U];
+    unsigned long long ww[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint64_t i = i0 + (uint64_t)u * kBlock;
+      ww[u] = 0;
+      if (i < hi) {
+        kk[u] = keys[i];
+        ww[u] = WEIGHTED ? (unsigned long long)weights[i] : 1ull;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + (uint64_t)u * kBlock >= hi) continue;
+      if (kk[u] == EMPTY) {
+        my_sent += ww[u];
+        continue;
+      }
+      if (!lds_add<K, C>(lkeys, lcnt, &lfill, kk[u], (C)ww[u], 17)) failed = true;
+    }
+  }
+  if (failed) atomicOr(&lovf, 1u);
+  if (my_sent) atomicAdd(&s_sent, my_sent);
+  __syncthreads();
+  if (lovf || lfill > kLdsMaxFill) {
+    if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
+    return;
+  }
+  if (threadIdx.x == 0 && s_sent) atomicAdd((unsigned long long *)&state[DS_SENT], s_sent);
+  if (nchunks == 1) {
+    lds_flush<K, C>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+  } else {
+    const uint64_t region = (uint64_t)(pchunk_start[f] + j);
+    lds_flush_region<K, C>(lkeys, lcnt, part_keys + region * kLdsMaxFill,
+                           part_cnt + region * kLdsMaxFill, &part_len[region]);
+  }
+}
+
+// P4: one workgroup per split bucket merges that bucket's per-chunk partial lists.
+template <typename K>
+__global__ __launch_bounds__(kBlock) void part_merge_kernel(
+    const unsigned *__restrict__ chunk_start, const unsigned *__restrict__ pchunk_start,
+    const K *__restrict__ part_keys, const int64_t *__restrict__ part_cnt,
+    const unsigned *__restrict__ part_len, K *out_keys, int64_t *out_cnt, uint64_t out_cap,
+    unsigned long long *cursor, uint64_t *state) {
+  constexpr K EMPTY = DKey<K>::empty;
+  using C = unsigned long long;
+  const int f = blockIdx.x;
+  const unsigned nchunks = chunk_start[f + 1] - chunk_start[f];
+  if (nchunks <= 1) return;
+  __shared__ K lkeys[kLdsSlots];
+  __shared__ C lcnt[kLdsSlots];
+  __shared__ unsigned lfill, lovf;
+  for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
+    lkeys[i] = EMPTY;
+    lcnt[i] = 0;
+  }
+  if (threadIdx.x == 0) {
+    lfill = 0;
+    lovf = 0;
+  }
+  __syncthreads();
+  bool failed = false;
+  for (unsigned j = 0; j < nchunks; ++j) {
+    const uint64_t region = (uint64_t)(pchunk_start[f] + j);
+    const unsigned len = part_len[region];
+    const K *pk = part_keys + region * kLdsMaxFill;
+    const int64_t *pc = part_cnt + region * kLdsMaxFill;
+    for (unsigned i = threadIdx.x; i < len; i += kBlock)
+      if (!lds_add<K, C>(lkeys, lcnt, &lfill, pk[i], (C)pc[i], 17)) failed = true;
+  }
+  if (failed) atomicOr(&lovf, 1u);
+  __syncthreads();
+  if (lovf || lfill > kLdsMaxFill) {
+    if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
+    return;
+  }
+  lds_flush<K, C>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+}
+
+__global__ void finish_kernel(uint64_t *state, const unsigned long long *cursor) {
+  state[DS_OUT] = *cursor;
+}
+
+inline uint64_t align16(uint64_t x) { return (x + 15) & ~15ull; }
+
+struct DenseWs {
+  // path S
+  char *p1_keys, *p2_keys;
+  int64_t *p1_cnt, *p2_cnt;
+  // path P
+  char *bufA, *bufB;
+  int64_t *wA, *wB;
+  unsigned *block_hist, *tile_start;
+  unsigned long long *fine_start, *fine_cursor, *coarse_cursor, *totals;
+  unsigned *chunk_start, *pchunk_start, *part_len;
+  char *part_keys;
+  int64_t *part_cnt;
+  uint64_t max_regions;
+  unsigned long long *cursors;  // [0]=stage1, [1]=stage2, [2]=final
+};
+
+constexpr uint64_t kStage1Blocks = 512, kStage2Blocks = 16;
+constexpr uint64_t kP1Cap = kStage1Blocks * kLdsMaxFill, kP2Cap = kStage2Blocks * kLdsMaxFill;
+
+inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighted, char *base,
+                                DenseWs *ws) {
+  uint64_t off = 0;
+  auto take = [&](uint64_t bytes) {
+    char *p = base ? base + off : nullptr;
+    off += align16(bytes);
+    return p;
+  };
+  DenseWs w;
+  memset(&w, 0, sizeof(w));
+  w.cursors = (unsigned long long *)take(8 * 8);
+  if (path == 0) {
+    w.p1_keys = take(kP1Cap * key_bytes);
+    w.p1_cnt = (int64_t *)take(kP1Cap * 8);
+    w.p2_keys = take(kP2Cap * key_bytes);
+    w.p2_cnt = (int64_t *)take(kP2Cap * 8);
+  } else {
+    w.bufA = take(n * key_bytes);
+    w.bufB = take(n * key_bytes);
+    if (weighted) {
+      w.wA = (int64_t *)take(n * 8);
+      w.wB = (int64_t *)take(n * 8);
+    }
+    w.block_hist = (unsigned *)take((uint64_t)kHistBlocks * kMaxFine * 4);
+    w.tile_start = (unsigned *)take(260 * 4);
+    w.fine_start = (unsigned long long *)take((kMaxFine + 1) * 8);
+    w.fine_cursor = (unsigned long long *)take((kMaxFine + 1) * 8);
+    w.coarse_cursor = (unsigned long long *)take(256 * 8);
+    w.totals = (unsigned long long *)take((uint64_t)kMaxFine * 8);
+    w.chunk_start = (unsigned *)take((kMaxFine + 1) * 4);
+    w.pchunk_start = (unsigned *)take((kMaxFine + 1) * 4);
+    // split buckets have >= 2 chunks, all but the last full: at most 2n / kChunk regions
+    w.max_regions = 2 * (n / kChunk) + 2;
+    w.part_len = (unsigned *)take(w.max_regions * 4);
+    w.part_keys = take(w.max_regions * kLdsMaxFill * key_bytes);
+    w.part_cnt = (int64_t *)take(w.max_regions * kLdsMaxFill * 8);
+  }
+  if (ws) *ws = w;
+  return off;
+}
+
+template <typename K>
+int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uint64_t n, int path,
+                void *wsp, K *out_keys, int64_t *out_cnt, uint64_t out_cap, uint64_t *state,
+                hipStream_t s) {
+  NVT_CHECK_ARG(state && wsp, "null state/workspace");
+  NVT_CHECK_ARG(path >= 0 && path <= 2, "path must be 0 (LDS), 1 (64 x 64 buckets) or 2 (64 x 256)");
+  NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
+  NVT_CHECK_ARG(n == 0 || (keys && out_keys && out_cnt), "null keys/out");
+  NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 rows per call (32-bit LDS counters)");
+  NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
+  DenseWs w;
+  dense_ws_layout((int)sizeof(K), n, path, weights != nullptr, (char *)wsp, &w);
+  NVT_CHECK_HIP(hipMemsetAsync(w.cursors, 0, 64, s));
+  if (n == 0) return NVT_OK;
+  if (path == 0) {
+    if (weights)
+      lds_stage_kernel<K, true, unsigned long long><<<(unsigned)kStage1Blocks, kBlock, 0, s>>>(
+          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &w.cursors[0], state,
+          0);
+    else
+      lds_stage_kernel<K, true, unsigned><<<(unsigned)kStage1Blocks, kBlock, 0, s>>>(
+          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &w.cursors[0], state,
+          0);
+    NVT_CHECK_LAUNCH();
+    lds_stage_kernel<K, false, unsigned long long><<<(unsigned)kStage2Blocks, kBlock, 0, s>>>(
+        (const K *)w.p1_keys, nullptr, w.p1_cnt, 0, &w.cursors[0], (K *)w.p2_keys, w.p2_cnt, kP2Cap,
+        &w.cursors[1], state, 0);
+    NVT_CHECK_LAUNCH();
+    lds_stage_kernel<K, false, unsigned long long><<<1, kBlock, 0, s>>>(
+        (const K *)w.p2_keys, nullptr, w.p2_cnt, 0, &w.cursors[1], out_keys, out_cnt, out_cap,
+        &w.cursors[2], state, 1);
+    NVT_CHECK_LAUNCH();
+  } else {
+    const int b1 = 6, b2 = (path == 1) ? 6 : 8, bits = b1 + b2;
+    part_hist_kernel<K><<<kHistBlocks, kBlock, 0, s>>>(keys, valid, weights, n, bits, w.block_hist,
+                                                       state);
+    NVT_CHECK_LAUNCH();
+    part_reduce_kernel<<<(1 << bits) / 64, kBlock, 0, s>>>(w.block_hist, kHistBlocks, 1 << bits,
+                                                               w.totals);
+    NVT_CHECK_LAUNCH();
+    part_scan_kernel<<<1, 1024, 0, s>>>(w.totals, bits, b1, w.fine_start, w.fine_cursor,
+                                        w.coarse_cursor, w.tile_start, w.chunk_start,
+                                        w.pchunk_start);
+    NVT_CHECK_LAUNCH();
+    const unsigned t1 = (unsigned)((n + kTile - 1) / kTile);
+    const unsigned t2 = t1 + (1u << b1);  // upper bound: every coarse bucket rounds up once
+    const unsigned t3 = (unsigned)(n / kChunk) + (1u << bits);  // upper bound on P3 chunks
+    if (weights) {
+      part_scatter_kernel<K, 1, true><<<t1, kBlock, 0, s>>>(keys, valid, weights, n, b1, b1,
+                                                            w.fine_start, w.coarse_cursor,
+                                                            w.tile_start, (K *)w.bufA, w.wA);
+      NVT_CHECK_LAUNCH();
+      part_scatter_kernel<K, 2, true><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, w.wA, n, b1,
+                                                            b2, w.fine_start, w.fine_cursor,
+                                                            w.tile_start, (K *)w.bufB, w.wB);
+      NVT_CHECK_LAUNCH();
+      part_count_kernel<K, true><<<t3, kBlock, 0, s>>>(
+          (const K *)w.bufB, w.wB, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
+          (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &w.cursors[2],
+          state);
+    } else {
+      part_scatter_kernel<K, 1, false><<<t1, kBlock, 0, s>>>(keys, valid, nullptr, n, b1, b1,
+                                                             w.fine_start, w.coarse_cursor,
+                                                             w.tile_start, (K *)w.bufA, nullptr);
+      NVT_CHECK_LAUNCH();
+      part_scatter_kernel<K, 2, false><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, nullptr, n,
+                                                             b1, b2, w.fine_start, w.fine_cursor,
+                                                             w.tile_start, (K *)w.bufB, nullptr);
+      NVT_CHECK_LAUNCH();
+      part_count_kernel<K, false><<<t3, kBlock, 0, s>>>(
+          (const K *)w.bufB, nullptr, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
+          (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &w.cursors[2],
+          state);
+    }
+    NVT_CHECK_LAUNCH();
+    part_merge_kernel<K><<<1u << bits, kBlock, 0, s>>>(w.chunk_start, w.pchunk_start,
+                                                       (const K *)w.part_keys, w.part_cnt,
+                                                       w.part_len, out_keys, out_cnt, out_cap,
+                                                       &w.cursors[2], state);
+    NVT_CHECK_LAUNCH();
+  }
+  finish_kernel<<<1, 1, 0, s>>>(state, &w.cursors[2]);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+}  // namespace nvt
+
+using namespace nvt;
+
+extern "C" {
+
+int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
+  NVT_CHECK_ARG(path >= 0 && path <= 2, "path must be 0, 1 or 2");
+  *bytes = dense_ws_layout(key_bytes, n, path, weighted, nullptr, nullptr) + 64;
+  return NVT_OK;
+}
+int nvt_dense_count_i32(const int32_t *keys, const uint8_t *valid, const int64_t *weights,
+                        uint64_t n, int path, void *ws, int32_t *out_keys, int64_t *out_counts,
+                        uint64_t out_capacity, uint64_t *state, void *stream) {
+  return dense_count<int32_t>(keys, valid, weights, n, path, ws, out_keys, out_counts, out_capacity,
+                              state, (hipStream_t)stream);
+}
+int nvt_dense_count_i64(const int64_t *keys, const uint8_t *valid, const int64_t *weights,
+                        uint64_t n, int path, void *ws, int64_t *out_keys, int64_t *out_counts,
+                        uint64_t out_capacity, uint64_t *state, void *stream) {
+  return dense_count<int64_t>(keys, valid, weights, n, path, ws, out_keys, out_counts, out_capacity,
+                              state, (hipStream_t)stream);
+}
+
+}  // extern "C"

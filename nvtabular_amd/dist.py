@@ -155,9 +155,8 @@ def _hip_owner(keys_list: Sequence[torch.Tensor], G: int) -> torch.Tensor:
 def _hip_merge_counts(keys: torch.Tensor, counts: torch.Tensor):
     from . import kernels as K
 
-    tab = K.CountTable(keys.dtype, max(64, 2 * int(keys.numel())))
-    tab.merge(keys, counts)
-    return tab.compact()
+    k, c, _, _ = K.dense_count(keys, None, counts, hint=int(keys.numel()))
+    return k, c
 
 
 _owner_fn: Callable = _hip_owner

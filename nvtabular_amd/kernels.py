@@ -96,6 +96,9 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+MIN_COUNT_CAPACITY = 1 << 16
+
+
 def next_pow2(x: int) -> int:
     return 1 << max(6, (int(x) - 1).bit_length())
 
@@ -194,7 +197,10 @@ def count_into_new_table(
     ``hint`` (expected distinct keys); regrows and recounts on overflow, which
     is safe because the table only holds this partition."""
     total = sum(int(k.numel()) for k in keys_list)
-    cap = next_pow2(max(64, 2 * min(max(hint, 32), max(total, 32))))
+    # never below 2^16 slots: a tiny table puts every block's end-of-kernel flush on the
+    # same few memory channels (measured: 36 keys in a 128-slot table cost 340 us of
+    # serialised atomics; spread over 512 KiB they cost ~10 us)
+    cap = next_pow2(max(MIN_COUNT_CAPACITY, 2 * min(max(hint, 32), max(total, 32))))
     for _ in range(max_tries):
         tab = CountTable(keys_list[0].dtype, cap)
         for k, v in zip(keys_list, valid_list):
@@ -202,8 +208,124 @@ def count_into_new_table(
         st = tab.read_state()
         if not st[_lib.ST_OVERFLOW] and st[_lib.ST_OCCUPIED] * 10 <= tab.capacity * 7:
             return tab, st
-        cap = next_pow2(max(4 * cap, 3 * st[_lib.ST_OCCUPIED]))
+        cap = next_pow2(max(16 * cap, 3 * st[_lib.ST_OCCUPIED]))
     raise _lib.NvtHipError("count table kept overflowing; cardinality estimate diverged")
+
+
+# --------------------------------------------------------------------------
+# Categorify.fit, atomic-free: dense (key, count) lists
+# --------------------------------------------------------------------------
+PATH_S_MAX_DISTINCT = 4096          # path 0: three LDS-table stages
+PATH_P1_MAX_DISTINCT = 10_000_000   # path 1: 64 x 64 buckets, <= ~2.4k distinct per bucket
+PATH_P2_MAX_DISTINCT = 45_000_000   # path 2: 64 x 256 buckets
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _ws_cache.pop(key, None)
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _path_for(hint: int) -> int:
+    if hint <= PATH_S_MAX_DISTINCT:
+        return 0
+    if hint <= PATH_P1_MAX_DISTINCT:
+        return 1
+    if hint <= PATH_P2_MAX_DISTINCT:
+        return 2
+    return 3  # global-table fallback
+
+
+def dense_count(
+    keys: torch.Tensor,
+    valid: Optional[torch.Tensor],
+    weights: Optional[torch.Tensor] = None,
+    hint: int = 0,
+):
+    """Groupby-size (or weighted sum) of a key column -> (keys, counts[int64], nulls, info).
+
+    ``hint`` = expected number of distinct keys (0 = unknown).  Picks the LDS /
+    partitioned path from it and escalates when a kernel reports that its LDS
+    tables filled up; the last resort is the global-table kernel of nvt_count_*.
+    info = dict(path=..., distinct=...) so callers can remember the hint."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    keys = aligned(keys)
+    n = int(keys.numel())
+    dev = keys.device
+    suffix = _key_suffix(keys)
+    kb = 4 if suffix == "i32" else 8
+    if weights is not None:
+        weights = weights.contiguous()
+    sentinel = INT32_MIN if kb == 4 else INT64_MIN
+    if n == 0:
+        return (torch.empty(0, dtype=keys.dtype, device=dev),
+                torch.empty(0, dtype=torch.int64, device=dev), 0, dict(path=0, distinct=0))
+    path = _path_for(hint if hint > 0 else 1)
+    cap_guess = max(1 << 16, 2 * max(hint, 1))
+    state = torch.zeros(_lib.STATE_WORDS, dtype=torch.int64, device=dev)
+    while path <= 2:
+        out_cap = min(cap_guess, n) + 1
+        if path == 0:
+            out_cap = min(out_cap, 8192)
+        out_k = torch.empty(out_cap + 1, dtype=keys.dtype, device=dev)
+        out_c = torch.empty(out_cap + 1, dtype=torch.int64, device=dev)
+        nbytes = C.c_uint64()
+        check(lib.nvt_dense_count_ws_bytes(kb, n, path, 0 if weights is None else 1, C.byref(nbytes)))
+        ws = _workspace(nbytes.value, dev)
+        with _timed(f"dense_count_p{path}", n * kb):
+            check(
+                getattr(lib, f"nvt_dense_count_{suffix}")(
+                    keys.data_ptr(), ptr(valid), ptr(weights), n, path, ws.data_ptr(),
+                    out_k.data_ptr(), out_c.data_ptr(), out_cap, state.data_ptr(), stream_ptr(),
+                ),
+                "nvt_dense_count",
+            )
+        st = state.cpu().tolist()
+        ovf = st[_lib.ST_OVERFLOW]
+        if ovf & 1:
+            path += 1
+            continue
+        if ovf & 2:
+            cap_guess = max(4 * cap_guess, 1 << 20)
+            continue
+        m = st[_lib.ST_OCCUPIED]
+        if st[_lib.ST_SENTINEL] > 0:
+            out_k[m] = sentinel
+            out_c[m] = st[_lib.ST_SENTINEL]
+            m += 1
+        return out_k[:m], out_c[:m], st[_lib.ST_NULLS], dict(path=path, distinct=m)
+    # last resort: one global open-addressing table (device atomics)
+    tab, st = count_into_new_table([keys], [valid], max(hint, 1 << 20)) if weights is None \
+        else (None, None)
+    if tab is None:
+        tab = CountTable(keys.dtype, 2 * n)
+        tab.merge(keys, weights)
+        st = tab.read_state()
+    k, c = tab.compact()
+    return k, c, st[_lib.ST_NULLS], dict(path=3, distinct=int(k.numel()))
+
+
+def merge_dense(lists, hint: int = 0):
+    """Tree-merge step (_mid_level_groupby): sum the counts of equal keys across
+    several dense (keys, counts) lists."""
+    lists = [(k, c) for k, c in lists if k.numel()]
+    if not lists:
+        return None
+    if len(lists) == 1:
+        return lists[0]
+    dt = torch.int64 if any(k.dtype == torch.int64 for k, _ in lists) else torch.int32
+    keys = torch.cat([k.to(dt) for k, _ in lists])
+    counts = torch.cat([c for _, c in lists])
+    k, c, _, _ = dense_count(keys, None, counts, hint=hint or max(int(x[0].numel()) for x in lists))
+    return k, c
 
 
 def vocab_sort(keys: torch.Tensor, counts: torch.Tensor):

@@ -207,20 +207,21 @@ class Categorify(StatOperator):
             if g.combo:
                 self._fit_partition_combo(g, keys, valids)
                 continue
-            # joint groups: every column of the group feeds one table (categorify.py:972-981)
+            # joint groups: every column of the group feeds one vocabulary (categorify.py:972-981)
             if len({k.dtype for k in keys}) > 1:
                 keys = [K.widen_i64(k) for k in keys]
             g.key_dtype = keys[0].dtype
-            hint = self._cap_hints.get(g.name, g.hint)
-            part, st = K.count_into_new_table(keys, valids, hint)
-            g.nulls += st[K._lib.ST_NULLS]
-            g.hint = max(g.hint, st[K._lib.ST_OCCUPIED])
-            self._cap_hints[g.name] = max(64, st[K._lib.ST_OCCUPIED])
-            if g.table is None:
-                g.table = part
-            else:
-                pk, pc = part.compact(st[K._lib.ST_OCCUPIED])
-                g.table = _merge_counts(g.table, pk, pc)
+            lists = [] if g.table is None else [g.table]
+            for ci, (k, v) in enumerate(zip(keys, valids)):
+                hkey = f"{g.name}#{ci}"
+                dk, dc, nulls, info = K.dense_count(k, v, None, hint=self._cap_hints.get(hkey, 0))
+                self._cap_hints[hkey] = max(64, info["distinct"])
+                g.nulls += nulls
+                lists.append((dk, dc))
+            # tree merge (_mid_level_groupby): weighted re-count of the concatenated lists
+            g.table = K.merge_dense(lists, hint=self._cap_hints.get(g.name, 0))
+            if g.table is not None:
+                self._cap_hints[g.name] = max(64, int(g.table[0].numel()))
 
     def _fit_partition_combo(self, g: _GroupFit, keys, valids):
         hint = self._cap_hints.get(g.name, g.hint)
@@ -271,7 +272,7 @@ class Categorify(StatOperator):
             keys = torch.empty(0, dtype=torch.int64, device=dev)
             counts = torch.empty(0, dtype=torch.int64, device=dev)
         else:
-            keys, counts = g.table.compact()
+            keys, counts = g.table
         nulls = g.nulls
         if dist.world_size() > 1:
             keys, counts, nulls = dist.merge_counts(keys, counts, nulls)

@@ -1,0 +1,86 @@
+"""Multi-GPU fit-statistics merge, exercised with world_size=2 over gloo on CPU.
+
+The choreography in nvtabular_amd/dist.py (owner hashing -> all-to-all(v) ->
+owner merge -> all-gather; all-reduce for moments) is backend-agnostic; the two
+device steps are injected here with host implementations (test infrastructure)
+so the N>1 path is covered without GPUs.  Results must equal a single-process
+groupby over the union of both ranks' data.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _host_owner(keys_list, G):
+    import oracle as O
+
+    acc = np.zeros(keys_list[0].numel(), dtype=np.uint64)
+    for k in keys_list:
+        acc ^= O.nvt_hash64(k.numpy())
+    return torch.from_numpy(((acc >> np.uint64(32)) % np.uint64(G)).astype(np.int32))
+
+
+def _host_merge(keys, counts):
+    import pandas as pd
+
+    s = pd.Series(counts.numpy()).groupby(keys.numpy()).sum()
+    return torch.from_numpy(s.index.to_numpy()), torch.from_numpy(s.to_numpy())
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as td
+
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from nvtabular_amd import dist
+
+    dist.set_backend_fns(_host_owner, _host_merge)
+    rng = np.random.default_rng(100 + rank)
+    keys = rng.integers(-50, 300, 5000)
+    import pandas as pd
+
+    local = pd.Series(1, index=keys).groupby(level=0).sum()
+    k = torch.from_numpy(local.index.to_numpy())
+    c = torch.from_numpy(local.to_numpy())
+    gk, gc, nulls = dist.merge_counts(k, c, nulls=rank + 3)
+    mom = dist.all_reduce_sum(torch.tensor([[1.0 + rank, 2.0, 3.0]], dtype=torch.float64))
+    mn = dist.all_reduce_min(torch.tensor([float("nan") if rank == 0 else 4.0, 2.0 + rank]))
+    lut = dist.merge_string_luts({rank: f"s{rank}"})
+    got = pd.Series(gc.numpy(), index=gk.numpy()).sort_index()
+    q.put((rank, got.index.to_numpy(), got.to_numpy(), nulls, mom.tolist(), mn.tolist(), lut, keys))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_merge_counts_world2_gloo():
+    import pandas as pd
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    allkeys = np.concatenate([r[7] for r in res])
+    exp = pd.Series(1, index=allkeys).groupby(level=0).sum().sort_index()
+    for r in res:
+        # every rank ends with the same, complete table
+        np.testing.assert_array_equal(r[1], exp.index.to_numpy())
+        np.testing.assert_array_equal(r[2], exp.to_numpy())
+        assert r[3] == 3 + 4
+        assert r[4] == [[3.0, 4.0, 6.0]]
+        assert r[5] == [4.0, 2.0]
+        assert r[6] == {0: "s0", 1: "s1"}

@@ -464,3 +464,34 @@ def test_count_roundtrip_large():
     labels = enc.encode(keys, None, 1, 2)
     assert int(labels.min().item()) == 3 and int(labels.max().item()) == 2 + vk.numel()
     assert torch.equal(vk[(labels - 3)], keys)
+
+
+# ---- atomic-free dense counting (nvt_dense_count_*): every path, exact ----------------
+@pytest.mark.parametrize("dtype", ["int32", "int64"])
+@pytest.mark.parametrize("card,n", [(5, 1000), (3000, 200_000), (50_000, 400_000),
+                                    (10**9, 1_500_000)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_dense_count_paths_vs_numpy(dtype, card, n, weighted):
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.device import pack_bitmap
+
+    rng = np.random.default_rng(card % 1000 + n)
+    ids, mask = _nullable_int_frame(rng, n, card, 0.1, dtype)
+    ids[5] = np.iinfo(dtype).min
+    mask[5] = False
+    w = rng.integers(1, 1000, n).astype("int64") if weighted else None
+    keys = torch.from_numpy(ids).cuda()
+    valid = torch.from_numpy(pack_bitmap(~mask)).cuda()
+    wt = torch.from_numpy(w).cuda() if weighted else None
+    seen_paths = set()
+    for hint in (0, 5000, 2_000_000, 20_000_000):
+        k, c, nulls, info = K.dense_count(keys, valid, wt, hint=hint)
+        seen_paths.add(info["path"])
+        ww = w if weighted else np.ones(n, dtype="int64")
+        exp = pd.Series(ww[~mask]).groupby(ids[~mask]).sum()
+        got = pd.Series(c.cpu().numpy(), index=k.cpu().numpy()).sort_index()
+        assert got.index.is_unique
+        np.testing.assert_array_equal(got.index.to_numpy(), exp.index.to_numpy())
+        np.testing.assert_array_equal(got.to_numpy(), exp.to_numpy())
+        assert nulls == int(ww[mask].sum())
+    assert seen_paths >= ({1, 2} if card > 5000 else {0, 1, 2})
