@@ -33,6 +33,10 @@
 
 #include "nvt_common.hpp"
 
+#ifndef NVT_STAGE_U
+#define NVT_STAGE_U 4
+#endif
+
 namespace nvt {
 
 template <typename K>
@@ -90,14 +94,14 @@ __device__ __forceinline__ bool lds_add(K *lkeys, C *lcnt, unsigned *lfill, K ke
 
 // Append the occupied LDS slots to (out_keys, out_cnt) at a range reserved with one
 // atomic on *cursor.  All threads of the block must call this.
-template <typename K, typename C>
+template <typename K, typename C, int BS>
 __device__ __forceinline__ void lds_flush(const K *lkeys, const C *lcnt, K *out_keys,
                                           int64_t *out_cnt, uint64_t out_cap,
                                           unsigned long long *cursor, uint64_t *state) {
   constexpr K EMPTY = DKey<K>::empty;
-  __shared__ unsigned wsum[kBlock / kWave];
+  __shared__ unsigned wsum[BS / kWave];
   __shared__ unsigned long long base_s;
-  constexpr int PER = kLdsSlots / kBlock;
+  constexpr int PER = kLdsSlots / BS;
   const unsigned lane = lane_id(), w = threadIdx.x / kWave;
   unsigned mine = 0;
   const int first = threadIdx.x * PER;
@@ -112,7 +116,7 @@ __device__ __forceinline__ void lds_flush(const K *lkeys, const C *lcnt, K *out_
   if (lane == 63) wsum[w] = inc;
   __syncthreads();
   unsigned wbase = 0, total = 0;
-  for (unsigned i = 0; i < kBlock / kWave; ++i) {
+  for (unsigned i = 0; i < BS / kWave; ++i) {
     if (i < w) wbase += wsum[i];
     total += wsum[i];
   }
@@ -136,12 +140,12 @@ __device__ __forceinline__ void lds_flush(const K *lkeys, const C *lcnt, K *out_
 
 // Same, but into a caller-assigned region [out_keys, out_keys + kLdsMaxFill) -- used for
 // the per-chunk partial lists of split (skewed) buckets.  *out_len receives the count.
-template <typename K, typename C>
+template <typename K, typename C, int BS>
 __device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, K *out_keys,
                                                  int64_t *out_cnt, unsigned *out_len) {
   constexpr K EMPTY = DKey<K>::empty;
-  __shared__ unsigned wsum2[kBlock / kWave];
-  constexpr int PER = kLdsSlots / kBlock;
+  __shared__ unsigned wsum2[BS / kWave];
+  constexpr int PER = kLdsSlots / BS;
   const unsigned lane = lane_id(), w = threadIdx.x / kWave;
   unsigned mine = 0;
   const int first = threadIdx.x * PER;
@@ -156,7 +160,7 @@ __device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, 
   if (lane == 63) wsum2[w] = inc;
   __syncthreads();
   unsigned wbase = 0, total = 0;
-  for (unsigned i = 0; i < kBlock / kWave; ++i) {
+  for (unsigned i = 0; i < BS / kWave; ++i) {
     if (i < w) wbase += wsum2[i];
     total += wsum2[i];
   }
@@ -178,8 +182,9 @@ __device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, 
 // weights); otherwise input is a (key, weight) partials list whose length is read
 // from *in_len on the device.
 // ---------------------------------------------------------------------------
+constexpr int kStageBS = 1024;  // 16 waves per workgroup, one 64-96 KiB LDS table per CU
 template <typename K, bool FIRST, typename C>
-__global__ __launch_bounds__(kBlock) void lds_stage_kernel(
+__global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid,
     const int64_t *__restrict__ weights, uint64_t n, const unsigned long long *in_len,
     K *out_keys, int64_t *out_cnt, uint64_t out_cap, unsigned long long *cursor, uint64_t *state,
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void lds_stage_kernel(
   __shared__ C lcnt[kLdsSlots];
   __shared__ unsigned lfill, lovf;
   __shared__ unsigned long long s_nulls, s_sent;
-  for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
+  for (int i = threadIdx.x; i < kLdsSlots; i += kStageBS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
   }
@@ -211,15 +216,15 @@ __global__ __launch_bounds__(kBlock) void lds_stage_kernel(
     }
     if (!lds_add<K, C>(lkeys, lcnt, &lfill, key, (C)w, 17)) failed = true;
   };
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const uint64_t stride = (uint64_t)gridDim.x * kStageBS;
   if (FIRST && weights == nullptr) {
     const uint64_t nvec = n / VEC;
     using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
     const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
     // 8 independent 16-byte loads in flight per lane before any LDS work: with only
     // 2 workgroups (8 waves) per CU the HBM latency has to be covered by ILP
-    constexpr int U = 8;
-    for (uint64_t v0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v0 < nvec; v0 += stride * U) {
+    constexpr int U = NVT_STAGE_U;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * kStageBS + threadIdx.x; v0 < nvec; v0 += stride * U) {
       if (lfill > kLdsMaxFill) break;  // table is filling up: this column belongs on path P
       VecT pack[U];
       unsigned vb[U];
@@ -259,20 +264,36 @@ __global__ __launch_bounds__(kBlock) void lds_stage_kernel(
         }
       }
     }
-    for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kStageBS + threadIdx.x; i < n; i += stride) {
       if (bit_valid(valid, i))
         add(keys[i], 1ull);
       else
         ++my_nulls;
     }
   } else {
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    constexpr int UW = 4;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * kStageBS + threadIdx.x; i0 < n; i0 += stride * UW) {
       if (lfill > kLdsMaxFill) break;
-      if (FIRST && !bit_valid(valid, i)) {
-        my_nulls += (unsigned long long)weights[i];
-        continue;
+      K kk[UW];
+      unsigned long long ww[UW];
+      int st[UW];  // 0 = out of range, 1 = key, 2 = null row
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        uint64_t i = i0 + (uint64_t)u * stride;
+        st[u] = 0;
+        if (i < n) {
+          ww[u] = (unsigned long long)weights[i];
+          st[u] = (FIRST && !bit_valid(valid, i)) ? 2 : 1;
+          if (st[u] == 1) kk[u] = keys[i];
+        }
       }
-      add(keys[i], (unsigned long long)weights[i]);
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        if (st[u] == 1)
+          add(kk[u], ww[u]);
+        else if (st[u] == 2)
+          my_nulls += ww[u];
+      }
     }
   }
   if (failed) atomicOr(&lovf, 1u);
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void lds_stage_kernel(
     if (s_sent) atomicAdd((unsigned long long *)&state[DS_SENT], s_sent);
     if (FIRST && blockIdx.x == 0) atomicAdd((unsigned long long *)&state[DS_ROWS], (unsigned long long)n);
   }
-  lds_flush<K, C>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+  lds_flush<K, C, kStageBS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
   (void)final_stage;
 }
 
@@ -308,19 +329,19 @@ __device__ __forceinline__ uint32_t part_hash(K key) {
 
 // P0: per-block histogram over the fine bucket id = top (b1+b2) bits of part_hash
 template <typename K>
-__global__ __launch_bounds__(kBlock) void part_hist_kernel(const K *__restrict__ keys,
+__global__ __launch_bounds__(1024) void part_hist_kernel(const K *__restrict__ keys,
                                                            const uint8_t *__restrict__ valid,
                                                            const int64_t *__restrict__ weights,
                                                            uint64_t n, int bits, unsigned *block_hist,
                                                            uint64_t *state) {
   __shared__ unsigned h[kMaxFine];
   const int nb = 1 << bits;
-  for (int i = threadIdx.x; i < nb; i += kBlock) h[i] = 0;
+  for (int i = threadIdx.x; i < nb; i += 1024) h[i] = 0;
   __syncthreads();
   unsigned long long nulls = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  constexpr int U = 16;  // independent loads in flight per lane
-  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n; i0 += stride * U) {
+  const uint64_t stride = (uint64_t)gridDim.x * 1024;
+  constexpr int U = 8;  // independent loads in flight per lane
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += stride * U) {
     K k[U];
     bool ok[U];
 #pragma unroll
@@ -341,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void part_hist_kernel(const K *__restrict__
       if (ok[u]) atomicAdd(&h[part_hash<K>(k[u]) >> (32 - bits)], 1u);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nb; i += kBlock) block_hist[(uint64_t)blockIdx.x * nb + i] = h[i];
+  for (int i = threadIdx.x; i < nb; i += 1024) block_hist[(uint64_t)blockIdx.x * nb + i] = h[i];
   double dn = wave_sum((double)nulls);
   if (lane_id() == 0 && dn > 0)
     atomicAdd((unsigned long long *)&state[DS_NULLS], (unsigned long long)dn);
@@ -579,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
 // P3: one workgroup per (fine bucket, chunk of kChunk rows).  Single-chunk buckets go
 // straight to the output list; chunks of split buckets write partial lists for P4.
 template <typename K, bool WEIGHTED>
-__global__ __launch_bounds__(kBlock) void part_count_kernel(
+__global__ __launch_bounds__(kStageBS) void part_count_kernel(
     const K *__restrict__ keys, const int64_t *__restrict__ weights,
     const unsigned long long *__restrict__ fine_start, const unsigned *__restrict__ chunk_start,
     const unsigned *__restrict__ pchunk_start, int nb, K *part_keys, int64_t *part_cnt,
@@ -607,7 +628,7 @@ __global__ __launch_bounds__(kBlock) void part_count_kernel(
     lovf = 0;
     s_sent = 0;
   }
-  for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
+  for (int i = threadIdx.x; i < kLdsSlots; i += kStageBS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
   }
@@ -622,13 +643,13 @@ __global__ __launch_bounds__(kBlock) void part_count_kernel(
   bool failed = false;
   unsigned long long my_sent = 0;
   constexpr int U = 8;
-  for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (uint64_t)kBlock * U) {
+  for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (uint64_t)kStageBS * U) {
     if (lfill > kLdsMaxFill) break;
     K kk[U];
     unsigned long long ww[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      uint64_t i = i0 + (uint64_t)u * kBlock;
+      uint64_t i = i0 + (uint64_t)u * kStageBS;
       ww[u] = 0;
       if (i < hi) {
         kk[u] = keys[i];
@@ -637,7 +658,7 @@ __global__ __launch_bounds__(kBlock) void part_count_kernel(
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (i0 + (uint64_t)u * kBlock >= hi) continue;
+      if (i0 + (uint64_t)u * kStageBS >= hi) continue;
       if (kk[u] == EMPTY) {
         my_sent += ww[u];
         continue;
@@ -654,17 +675,17 @@ __global__ __launch_bounds__(kBlock) void part_count_kernel(
   }
   if (threadIdx.x == 0 && s_sent) atomicAdd((unsigned long long *)&state[DS_SENT], s_sent);
   if (nchunks == 1) {
-    lds_flush<K, C>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+    lds_flush<K, C, kStageBS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
   } else {
     const uint64_t region = (uint64_t)(pchunk_start[f] + j);
-    lds_flush_region<K, C>(lkeys, lcnt, part_keys + region * kLdsMaxFill,
+    lds_flush_region<K, C, kStageBS>(lkeys, lcnt, part_keys + region * kLdsMaxFill,
                            part_cnt + region * kLdsMaxFill, &part_len[region]);
   }
 }
 
 // P4: one workgroup per split bucket merges that bucket's per-chunk partial lists.
 template <typename K>
-__global__ __launch_bounds__(kBlock) void part_merge_kernel(
+__global__ __launch_bounds__(kStageBS) void part_merge_kernel(
     const unsigned *__restrict__ chunk_start, const unsigned *__restrict__ pchunk_start,
     const K *__restrict__ part_keys, const int64_t *__restrict__ part_cnt,
     const unsigned *__restrict__ part_len, K *out_keys, int64_t *out_cnt, uint64_t out_cap,
@@ -677,7 +698,7 @@ __global__ __launch_bounds__(kBlock) void part_merge_kernel(
   __shared__ K lkeys[kLdsSlots];
   __shared__ C lcnt[kLdsSlots];
   __shared__ unsigned lfill, lovf;
-  for (int i = threadIdx.x; i < kLdsSlots; i += kBlock) {
+  for (int i = threadIdx.x; i < kLdsSlots; i += kStageBS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
   }
@@ -692,7 +713,7 @@ __global__ __launch_bounds__(kBlock) void part_merge_kernel(
     const unsigned len = part_len[region];
     const K *pk = part_keys + region * kLdsMaxFill;
     const int64_t *pc = part_cnt + region * kLdsMaxFill;
-    for (unsigned i = threadIdx.x; i < len; i += kBlock)
+    for (unsigned i = threadIdx.x; i < len; i += kStageBS)
       if (!lds_add<K, C>(lkeys, lcnt, &lfill, pk[i], (C)pc[i], 17)) failed = true;
   }
   if (failed) atomicOr(&lovf, 1u);
@@ -701,19 +722,15 @@ __global__ __launch_bounds__(kBlock) void part_merge_kernel(
     if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
     return;
   }
-  lds_flush<K, C>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
-}
-
-__global__ void finish_kernel(uint64_t *state, const unsigned long long *cursor) {
-  state[DS_OUT] = *cursor;
+  lds_flush<K, C, kStageBS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
 }
 
 inline uint64_t align16(uint64_t x) { return (x + 15) & ~15ull; }
 
 struct DenseWs {
   // path S
-  char *p1_keys, *p2_keys;
-  int64_t *p1_cnt, *p2_cnt;
+  char *p1_keys, *p2_keys, *p3_keys;
+  int64_t *p1_cnt, *p2_cnt, *p3_cnt;
   // path P
   char *bufA, *bufB;
   int64_t *wA, *wB;
@@ -723,11 +740,15 @@ struct DenseWs {
   char *part_keys;
   int64_t *part_cnt;
   uint64_t max_regions;
-  unsigned long long *cursors;  // [0]=stage1, [1]=stage2, [2]=final
 };
 
-constexpr uint64_t kStage1Blocks = 512, kStage2Blocks = 16;
-constexpr uint64_t kP1Cap = kStage1Blocks * kLdsMaxFill, kP2Cap = kStage2Blocks * kLdsMaxFill;
+// Path S reduction tree: 256 -> 32 -> 4 -> 1 workgroups (fan-in 8 per level)
+constexpr uint64_t kStage1Blocks = 256, kStage2Blocks = 32, kStage3Blocks = 4;
+constexpr uint64_t kP1Cap = kStage1Blocks * kLdsMaxFill, kP2Cap = kStage2Blocks * kLdsMaxFill,
+                   kP3Cap = kStage3Blocks * kLdsMaxFill;
+// intermediate list cursors live in the spare words of the caller's state block, the final
+// list length IS state[NVT_ST_OCCUPIED]: one memset, no finish kernel
+constexpr int DS_CUR1 = 5, DS_CUR2 = 6, DS_CUR3 = 7;
 
 inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighted, char *base,
                                 DenseWs *ws) {
@@ -739,12 +760,13 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
   };
   DenseWs w;
   memset(&w, 0, sizeof(w));
-  w.cursors = (unsigned long long *)take(8 * 8);
   if (path == 0) {
     w.p1_keys = take(kP1Cap * key_bytes);
     w.p1_cnt = (int64_t *)take(kP1Cap * 8);
     w.p2_keys = take(kP2Cap * key_bytes);
     w.p2_cnt = (int64_t *)take(kP2Cap * 8);
+    w.p3_keys = take(kP3Cap * key_bytes);
+    w.p3_cnt = (int64_t *)take(kP3Cap * 8);
   } else {
     w.bufA = take(n * key_bytes);
     w.bufB = take(n * key_bytes);
@@ -782,29 +804,33 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
   NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
   DenseWs w;
   dense_ws_layout((int)sizeof(K), n, path, weights != nullptr, (char *)wsp, &w);
-  NVT_CHECK_HIP(hipMemsetAsync(w.cursors, 0, 64, s));
+  unsigned long long *cur = reinterpret_cast<unsigned long long *>(state);
   if (n == 0) return NVT_OK;
   if (path == 0) {
     if (weights)
-      lds_stage_kernel<K, true, unsigned long long><<<(unsigned)kStage1Blocks, kBlock, 0, s>>>(
-          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &w.cursors[0], state,
+      lds_stage_kernel<K, true, unsigned long long><<<(unsigned)kStage1Blocks, kStageBS, 0, s>>>(
+          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &cur[DS_CUR1], state,
           0);
     else
-      lds_stage_kernel<K, true, unsigned><<<(unsigned)kStage1Blocks, kBlock, 0, s>>>(
-          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &w.cursors[0], state,
+      lds_stage_kernel<K, true, unsigned><<<(unsigned)kStage1Blocks, kStageBS, 0, s>>>(
+          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &cur[DS_CUR1], state,
           0);
     NVT_CHECK_LAUNCH();
-    lds_stage_kernel<K, false, unsigned long long><<<(unsigned)kStage2Blocks, kBlock, 0, s>>>(
-        (const K *)w.p1_keys, nullptr, w.p1_cnt, 0, &w.cursors[0], (K *)w.p2_keys, w.p2_cnt, kP2Cap,
-        &w.cursors[1], state, 0);
+    lds_stage_kernel<K, false, unsigned long long><<<(unsigned)kStage2Blocks, kStageBS, 0, s>>>(
+        (const K *)w.p1_keys, nullptr, w.p1_cnt, 0, &cur[DS_CUR1], (K *)w.p2_keys, w.p2_cnt, kP2Cap,
+        &cur[DS_CUR2], state, 0);
     NVT_CHECK_LAUNCH();
-    lds_stage_kernel<K, false, unsigned long long><<<1, kBlock, 0, s>>>(
-        (const K *)w.p2_keys, nullptr, w.p2_cnt, 0, &w.cursors[1], out_keys, out_cnt, out_cap,
-        &w.cursors[2], state, 1);
+    lds_stage_kernel<K, false, unsigned long long><<<(unsigned)kStage3Blocks, kStageBS, 0, s>>>(
+        (const K *)w.p2_keys, nullptr, w.p2_cnt, 0, &cur[DS_CUR2], (K *)w.p3_keys, w.p3_cnt, kP3Cap,
+        &cur[DS_CUR3], state, 0);
+    NVT_CHECK_LAUNCH();
+    lds_stage_kernel<K, false, unsigned long long><<<1, kStageBS, 0, s>>>(
+        (const K *)w.p3_keys, nullptr, w.p3_cnt, 0, &cur[DS_CUR3], out_keys, out_cnt, out_cap,
+        &cur[DS_OUT], state, 1);
     NVT_CHECK_LAUNCH();
   } else {
     const int b1 = 6, b2 = (path == 1) ? 6 : 8, bits = b1 + b2;
-    part_hist_kernel<K><<<kHistBlocks, kBlock, 0, s>>>(keys, valid, weights, n, bits, w.block_hist,
+    part_hist_kernel<K><<<kHistBlocks, 1024, 0, s>>>(keys, valid, weights, n, bits, w.block_hist,
                                                        state);
     NVT_CHECK_LAUNCH();
     part_reduce_kernel<<<(1 << bits) / 64, kBlock, 0, s>>>(w.block_hist, kHistBlocks, 1 << bits,
@@ -826,9 +852,9 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                                                             b2, w.fine_start, w.fine_cursor,
                                                             w.tile_start, (K *)w.bufB, w.wB);
       NVT_CHECK_LAUNCH();
-      part_count_kernel<K, true><<<t3, kBlock, 0, s>>>(
+      part_count_kernel<K, true><<<t3, kStageBS, 0, s>>>(
           (const K *)w.bufB, w.wB, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
-          (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &w.cursors[2],
+          (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
           state);
     } else {
       part_scatter_kernel<K, 1, false><<<t1, kBlock, 0, s>>>(keys, valid, nullptr, n, b1, b1,
@@ -839,20 +865,18 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                                                              b1, b2, w.fine_start, w.fine_cursor,
                                                              w.tile_start, (K *)w.bufB, nullptr);
       NVT_CHECK_LAUNCH();
-      part_count_kernel<K, false><<<t3, kBlock, 0, s>>>(
+      part_count_kernel<K, false><<<t3, kStageBS, 0, s>>>(
           (const K *)w.bufB, nullptr, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
-          (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &w.cursors[2],
+          (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
           state);
     }
     NVT_CHECK_LAUNCH();
-    part_merge_kernel<K><<<1u << bits, kBlock, 0, s>>>(w.chunk_start, w.pchunk_start,
+    part_merge_kernel<K><<<1u << bits, kStageBS, 0, s>>>(w.chunk_start, w.pchunk_start,
                                                        (const K *)w.part_keys, w.part_cnt,
                                                        w.part_len, out_keys, out_cnt, out_cap,
-                                                       &w.cursors[2], state);
+                                                       &cur[DS_OUT], state);
     NVT_CHECK_LAUNCH();
   }
-  finish_kernel<<<1, 1, 0, s>>>(state, &w.cursors[2]);
-  NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
 
