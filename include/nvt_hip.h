@@ -60,13 +60,15 @@ extern "C" {
 #define NVT_EMPTY_I32 INT32_MIN
 #define NVT_EMPTY_I64 INT64_MIN
 
-/* layout of the uint64_t state[8] block every count/groupby table carries */
+/* layout of the uint64_t state[NVT_STATE_WORDS] block every count/groupby table carries */
 #define NVT_ST_NULLS 0     /* rows whose key was null                        */
 #define NVT_ST_SENTINEL 1  /* rows whose key equalled the empty sentinel     */
 #define NVT_ST_OCCUPIED 2  /* distinct keys currently in the table           */
 #define NVT_ST_OVERFLOW 3  /* != 0: table too full, result invalid -> regrow */
 #define NVT_ST_ROWS 4      /* rows consumed (nulls included)                 */
-#define NVT_STATE_WORDS 8
+/* words 5..7: scratch cursors of nvt_dense_count_*                                  */
+#define NVT_ST_MAXCOUNT 8  /* nvt_dense_count_*: largest count in the output list    */
+#define NVT_STATE_WORDS 16
 
 int nvt_version(void);
 const char *nvt_last_error(void);
@@ -113,8 +115,13 @@ int nvt_dense_count_i64(const int64_t *keys, const uint8_t *valid, const int64_t
 /* ---- vocabulary order (_write_uniques): count descending, key ascending ----
  * LSD radix sort of n (key,count) pairs; tmp must hold nvt_vocab_sort_tmp_bytes(). */
 int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes);
-int nvt_vocab_sort_i32(int32_t *keys, int64_t *counts, uint64_t n, void *tmp, void *stream);
-int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, void *tmp, void *stream);
+/* max_count: an upper bound on counts[] (e.g. state[NVT_ST_MAXCOUNT]) lets the sort pick
+ * its count passes without reading anything back; <= 0 = unknown (the sort then builds
+ * per-pass histograms and synchronises the stream once). */
+int nvt_vocab_sort_i32(int32_t *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tmp,
+                       void *stream);
+int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tmp,
+                       void *stream);
 
 /* ---- Categorify.transform (_encode) ----
  * encode table slot: i32 = {int32 key, int32 label}; i64 = {int64 key, int64 label}.

@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(_HERE, "libnvt_hip.so")
 NVT_F32, NVT_F64, NVT_I32, NVT_I64, NVT_U8 = 0, 1, 2, 3, 4
 NVT_GB_SUMSQ, NVT_GB_MINMAX = 1, 2
 ST_NULLS, ST_SENTINEL, ST_OCCUPIED, ST_OVERFLOW, ST_ROWS = 0, 1, 2, 3, 4
-STATE_WORDS = 8
+ST_MAXCOUNT = 8
+STATE_WORDS = 16
 
 _vp, _u64, _i64, _i32, _u32, _dbl = (
     C.c_void_p,
@@ -48,8 +49,8 @@ SIGNATURES = {
     "nvt_dense_count_i32": [_vp, _vp, _vp, _u64, _i32, _vp, _vp, _vp, _u64, _vp, _vp],
     "nvt_dense_count_i64": [_vp, _vp, _vp, _u64, _i32, _vp, _vp, _vp, _u64, _vp, _vp],
     "nvt_vocab_sort_tmp_bytes": [_i32, _u64, C.POINTER(_u64)],
-    "nvt_vocab_sort_i32": [_vp, _vp, _u64, _vp, _vp],
-    "nvt_vocab_sort_i64": [_vp, _vp, _u64, _vp, _vp],
+    "nvt_vocab_sort_i32": [_vp, _vp, _u64, _i64, _vp, _vp],
+    "nvt_vocab_sort_i64": [_vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_encode_table_bytes": [_i32, _u64, C.POINTER(_u64)],
     "nvt_encode_build_i32": [_vp, _u64, _i64, _vp, _u64, _vp, _vp],
     "nvt_encode_build_i64": [_vp, _u64, _i64, _vp, _u64, _vp, _vp],

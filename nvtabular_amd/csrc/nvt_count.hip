@@ -285,240 +285,6 @@ __global__ __launch_bounds__(kBlock) void compact_kernel(const CountSlot<K> *__r
   }
 }
 
-// ---------------------------------------------------------------------------
-// Vocabulary order: (count descending, key ascending) -- the two sort_values
-// calls of categorify.py:1300,1316 with the stable tie rule.
-// LSD radix sort, 8-bit digits, one wave per 1024-element tile; stability
-// inside a tile comes from ballot-matching equal digits in lane order.
-// Passes whose digit is constant over the whole array are skipped.
-// ---------------------------------------------------------------------------
-constexpr int kSortRows = 16;
-constexpr int kSortTile = kWave * kSortRows;
-
-template <typename K>
-__device__ __forceinline__ unsigned sort_digit(K key, int64_t cnt, int pass) {
-  constexpr int KB = (int)sizeof(K);
-  if (pass < KB) {
-    using U = typename std::make_unsigned<K>::type;
-    U u = (U)key ^ ((U)1 << (8 * KB - 1));  // signed order
-    return (unsigned)((u >> (8 * pass)) & 0xFF);
-  }
-  uint64_t inv = ~(uint64_t)cnt;  // descending counts
-  return (unsigned)((inv >> (8 * (pass - KB))) & 0xFF);
-}
-
-template <typename K>
-__global__ __launch_bounds__(kBlock) void sort_pass_hist_kernel(const K *__restrict__ keys,
-                                                                const int64_t *__restrict__ cnts,
-                                                                uint64_t n,
-                                                                unsigned long long *pass_hist) {
-  constexpr int NP = (int)sizeof(K) + 8;
-  __shared__ unsigned h[NP * 256];
-  for (int i = threadIdx.x; i < NP * 256; i += kBlock) h[i] = 0;
-  __syncthreads();
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    K k = keys[i];
-    int64_t c = cnts[i];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) atomicAdd(&h[p * 256 + sort_digit<K>(k, c, p)], 1u);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < NP * 256; i += kBlock)
-    if (h[i]) atomicAdd(&pass_hist[i], (unsigned long long)h[i]);
-}
-
-// peers = lanes of this wave holding the same digit (inactive lanes excluded)
-__device__ __forceinline__ unsigned long long match_digit(unsigned digit, bool active) {
-  unsigned long long peers = __ballot(active);
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    unsigned long long m = __ballot((digit >> b) & 1);
-    peers &= ((digit >> b) & 1) ? m : ~m;
-  }
-  return peers;
-}
-
-template <typename K>
-__global__ __launch_bounds__(kWave) void sort_tile_hist_kernel(const K *__restrict__ keys,
-                                                               const int64_t *__restrict__ cnts,
-                                                               uint64_t n, int pass,
-                                                               unsigned *tile_hist,
-                                                               uint64_t ntiles) {
-  __shared__ unsigned h[256];
-  const unsigned lane = threadIdx.x;
-  for (int i = lane; i < 256; i += kWave) h[i] = 0;
-  __syncthreads();
-  const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
-#pragma unroll 4
-  for (int r = 0; r < kSortRows; ++r) {
-    uint64_t i = base + (uint64_t)r * kWave + lane;
-    if (i < n) atomicAdd(&h[sort_digit<K>(keys[i], cnts[i], pass)], 1u);
-  }
-  __syncthreads();
-  for (int d = lane; d < 256; d += kWave) tile_hist[(uint64_t)d * ntiles + blockIdx.x] = h[d];
-}
-
-// Exclusive scan of `len` uint32 in three steps (chunk scan, chunk-total scan, add).
-constexpr int kScanChunk = 2048;  // 256 threads x 8
-__global__ __launch_bounds__(kBlock) void scan_chunk_kernel(unsigned *data, uint64_t len,
-                                                            unsigned long long *chunk_tot) {
-  __shared__ unsigned wsum[kBlock / kWave];
-  const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * 8;
-  unsigned v[8];
-  unsigned tot = 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    v[j] = (base + j < len) ? data[base + j] : 0;
-    tot += v[j];
-  }
-  // wave inclusive scan of tot
-  unsigned inc = tot;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    unsigned o = __shfl_up(inc, off, 64);
-    if (lane_id() >= (unsigned)off) inc += o;
-  }
-  const unsigned w = threadIdx.x / kWave;
-  if (lane_id() == 63) wsum[w] = inc;
-  __syncthreads();
-  unsigned wbase = 0;
-  for (unsigned i = 0; i < w; ++i) wbase += wsum[i];
-  unsigned run = wbase + inc - tot;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (base + j < len) data[base + j] = run;
-    run += v[j];
-  }
-  if (threadIdx.x == kBlock - 1) chunk_tot[blockIdx.x] = (unsigned long long)(wbase + inc);
-}
-__global__ void scan_totals_kernel(unsigned long long *chunk_tot, uint64_t nchunks) {
-  // single block; sequential over tiles of 256 with a wave/block scan
-  __shared__ unsigned long long carry;
-  __shared__ unsigned long long wsum[kBlock / kWave];
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint64_t b = 0; b < nchunks; b += kBlock) {
-    uint64_t i = b + threadIdx.x;
-    unsigned long long v = i < nchunks ? chunk_tot[i] : 0;
-    unsigned long long inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      unsigned long long o = __shfl_up(inc, off, 64);
-      if (lane_id() >= (unsigned)off) inc += o;
-    }
-    const unsigned w = threadIdx.x / kWave;
-    if (lane_id() == 63) wsum[w] = inc;
-    __syncthreads();
-    unsigned long long wbase = carry;
-    for (unsigned k = 0; k < w; ++k) wbase += wsum[k];
-    if (i < nchunks) chunk_tot[i] = wbase + inc - v;
-    __syncthreads();
-    if (threadIdx.x == kBlock - 1) carry = wbase + inc;
-    __syncthreads();
-  }
-}
-__global__ __launch_bounds__(kBlock) void scan_add_kernel(unsigned *data, uint64_t len,
-                                                          const unsigned long long *chunk_tot) {
-  const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * 8;
-  const unsigned add = (unsigned)chunk_tot[blockIdx.x];
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (base + j < len) data[base + j] += add;
-}
-
-template <typename K>
-__global__ __launch_bounds__(kWave) void sort_scatter_kernel(
-    const K *__restrict__ keys, const int64_t *__restrict__ cnts, uint64_t n, int pass,
-    const unsigned *__restrict__ tile_off, uint64_t ntiles, K *out_keys, int64_t *out_cnts) {
-  __shared__ unsigned run[256];
-  const unsigned lane = threadIdx.x;
-  for (int d = lane; d < 256; d += kWave) run[d] = tile_off[(uint64_t)d * ntiles + blockIdx.x];
-  __syncthreads();
-  const uint64_t base = (uint64_t)blockIdx.x * kSortTile;
-  for (int r = 0; r < kSortRows; ++r) {
-    uint64_t i = base + (uint64_t)r * kWave + lane;
-    bool active = i < n;
-    K k = active ? keys[i] : (K)0;
-    int64_t c = active ? cnts[i] : 0;
-    unsigned d = sort_digit<K>(k, c, pass);
-    unsigned long long peers = match_digit(d, active);
-    unsigned rank = __popcll(peers & ((1ull << lane) - 1ull));
-    unsigned dst = 0;
-    if (active) dst = run[d] + rank;
-    __syncthreads();  // all lanes read run[] before leaders bump it
-    if (active && rank == 0) run[d] += (unsigned)__popcll(peers);
-    __syncthreads();
-    if (active) {
-      out_keys[dst] = k;
-      out_cnts[dst] = c;
-    }
-  }
-}
-
-template <typename K>
-int vocab_sort(K *keys, int64_t *counts, uint64_t n, void *tmp, hipStream_t stream) {
-  constexpr int NP = (int)sizeof(K) + 8;
-  if (n <= 1) return NVT_OK;
-  NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 vocabulary entries");
-  const uint64_t ntiles = (n + kSortTile - 1) / kSortTile;
-  // tmp layout: keys2 | counts2 | tile_hist | chunk_tot | pass_hist
-  char *p = reinterpret_cast<char *>(tmp);
-  int64_t *counts2 = reinterpret_cast<int64_t *>(p);
-  p += n * sizeof(int64_t);
-  K *keys2 = reinterpret_cast<K *>(p);
-  p += ((n * sizeof(K) + 15) / 16) * 16;
-  unsigned *tile_hist = reinterpret_cast<unsigned *>(p);
-  const uint64_t hist_len = 256 * ntiles;
-  p += ((hist_len * sizeof(unsigned) + 15) / 16) * 16;
-  const uint64_t nchunks = (hist_len + kScanChunk - 1) / kScanChunk;
-  unsigned long long *chunk_tot = reinterpret_cast<unsigned long long *>(p);
-  p += nchunks * sizeof(unsigned long long);
-  unsigned long long *pass_hist = reinterpret_cast<unsigned long long *>(p);
-
-  NVT_CHECK_HIP(hipMemsetAsync(pass_hist, 0, NP * 256 * sizeof(unsigned long long), stream));
-  sort_pass_hist_kernel<K><<<stream_grid(n, kBlock * 8, 4), kBlock, 0, stream>>>(keys, counts, n,
-                                                                                   pass_hist);
-  NVT_CHECK_LAUNCH();
-  unsigned long long host_hist[NP * 256];
-  NVT_CHECK_HIP(hipMemcpyAsync(host_hist, pass_hist, sizeof(host_hist), hipMemcpyDeviceToHost,
-                               stream));
-  NVT_CHECK_HIP(hipStreamSynchronize(stream));
-
-  K *src_k = keys, *dst_k = keys2;
-  int64_t *src_c = counts, *dst_c = counts2;
-  for (int pass = 0; pass < NP; ++pass) {
-    bool trivial = false;
-    for (int d = 0; d < 256; ++d)
-      if (host_hist[pass * 256 + d] == n) trivial = true;
-    if (trivial) continue;
-    sort_tile_hist_kernel<K><<<(unsigned)ntiles, kWave, 0, stream>>>(src_k, src_c, n, pass,
-                                                                     tile_hist, ntiles);
-    NVT_CHECK_LAUNCH();
-    scan_chunk_kernel<<<(unsigned)nchunks, kBlock, 0, stream>>>(tile_hist, hist_len, chunk_tot);
-    NVT_CHECK_LAUNCH();
-    scan_totals_kernel<<<1, kBlock, 0, stream>>>(chunk_tot, nchunks);
-    NVT_CHECK_LAUNCH();
-    scan_add_kernel<<<(unsigned)nchunks, kBlock, 0, stream>>>(tile_hist, hist_len, chunk_tot);
-    NVT_CHECK_LAUNCH();
-    sort_scatter_kernel<K><<<(unsigned)ntiles, kWave, 0, stream>>>(src_k, src_c, n, pass,
-                                                                   tile_hist, ntiles, dst_k, dst_c);
-    NVT_CHECK_LAUNCH();
-    K *tk = src_k;
-    src_k = dst_k;
-    dst_k = tk;
-    int64_t *tc = src_c;
-    src_c = dst_c;
-    dst_c = tc;
-  }
-  if (src_k != keys) {
-    NVT_CHECK_HIP(hipMemcpyAsync(keys, src_k, n * sizeof(K), hipMemcpyDeviceToDevice, stream));
-    NVT_CHECK_HIP(
-        hipMemcpyAsync(counts, src_c, n * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
-  }
-  return NVT_OK;
-}
-
 template <typename K>
 int count_launch(const K *keys, const uint8_t *valid, uint64_t n, void *table, uint64_t capacity,
                  uint64_t *state, hipStream_t stream) {
@@ -613,25 +379,6 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
                           int64_t *out_counts, uint64_t *out_n, void *stream) {
   return compact_launch<int64_t>(table, capacity, out_keys, out_counts, out_n,
                                  (hipStream_t)stream);
-}
-
-int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes) {
-  NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
-  const uint64_t ntiles = (n + kSortTile - 1) / kSortTile;
-  const uint64_t hist_len = 256 * ntiles;
-  const uint64_t nchunks = (hist_len + kScanChunk - 1) / kScanChunk;
-  uint64_t b = n * 8 + ((n * key_bytes + 15) / 16) * 16 + ((hist_len * 4 + 15) / 16) * 16 +
-               nchunks * 8 + (uint64_t)(key_bytes + 8) * 256 * 8 + 64;
-  *bytes = b;
-  return NVT_OK;
-}
-int nvt_vocab_sort_i32(int32_t *keys, int64_t *counts, uint64_t n, void *tmp, void *stream) {
-  NVT_CHECK_ARG(n <= 1 || (keys && counts && tmp), "null pointer");
-  return vocab_sort<int32_t>(keys, counts, n, tmp, (hipStream_t)stream);
-}
-int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, void *tmp, void *stream) {
-  NVT_CHECK_ARG(n <= 1 || (keys && counts && tmp), "null pointer");
-  return vocab_sort<int64_t>(keys, counts, n, tmp, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -58,9 +58,11 @@ struct DKey<int64_t> {
 constexpr int DS_NULLS = NVT_ST_NULLS, DS_SENT = NVT_ST_SENTINEL, DS_OUT = NVT_ST_OCCUPIED,
               DS_OVF = NVT_ST_OVERFLOW, DS_ROWS = NVT_ST_ROWS;
 
-constexpr int kLdsSlots = 8192;
+constexpr int kLdsSlots = 8192;     // weighted stages / per-bucket tables (u64 or u32 counts)
+constexpr int kLdsSlotsBig = 16384; // unweighted path S: int32 key + u32 count = 128 KiB, 1 WG / CU
 constexpr int kLdsProbe = 24;
-constexpr int kLdsMaxFill = 6144;  // 75 %: beyond this the LDS table is declared full
+constexpr int kLdsMaxFill = 6144;   // 75 % of kLdsSlots: beyond this the table is declared full
+__host__ __device__ constexpr int max_fill(int slots) { return slots / 4 * 3; }
 
 template <typename K>
 __device__ __forceinline__ K lds_cas(K *addr, K expect, K val) {
@@ -69,13 +71,13 @@ __device__ __forceinline__ K lds_cas(K *addr, K expect, K val) {
 }
 
 // Insert into a workgroup-private LDS table.  Returns false when no slot was found.
-template <typename K, typename C>
+template <typename K, typename C, int SLOTS = kLdsSlots>
 __device__ __forceinline__ bool lds_add(K *lkeys, C *lcnt, unsigned *lfill, K key, C w,
                                         unsigned hash_shift) {
   constexpr K EMPTY = DKey<K>::empty;
   uint32_t h = (uint32_t)(slot_hash(key) >> hash_shift);
   for (int p = 0; p < kLdsProbe; ++p) {
-    uint32_t s = (h + p) & (kLdsSlots - 1);
+    uint32_t s = (h + p) & (SLOTS - 1);
     K cur = lkeys[s];
     if (cur == EMPTY) {
       cur = lds_cas<K>(&lkeys[s], EMPTY, key);
@@ -94,14 +96,14 @@ __device__ __forceinline__ bool lds_add(K *lkeys, C *lcnt, unsigned *lfill, K ke
 
 // Append the occupied LDS slots to (out_keys, out_cnt) at a range reserved with one
 // atomic on *cursor.  All threads of the block must call this.
-template <typename K, typename C, int BS>
+template <typename K, typename C, int BS, int SLOTS = kLdsSlots>
 __device__ __forceinline__ void lds_flush(const K *lkeys, const C *lcnt, K *out_keys,
                                           int64_t *out_cnt, uint64_t out_cap,
                                           unsigned long long *cursor, uint64_t *state) {
   constexpr K EMPTY = DKey<K>::empty;
   __shared__ unsigned wsum[BS / kWave];
   __shared__ unsigned long long base_s;
-  constexpr int PER = kLdsSlots / BS;
+  constexpr int PER = SLOTS / BS;
   const unsigned lane = lane_id(), w = threadIdx.x / kWave;
   unsigned mine = 0;
   const int first = threadIdx.x * PER;
@@ -127,13 +129,29 @@ __device__ __forceinline__ void lds_flush(const K *lkeys, const C *lcnt, K *out_
     if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 2ull);
     return;
   }
+  unsigned long long mx = 0;
 #pragma unroll 8
   for (int j = 0; j < PER; ++j) {
     K k = lkeys[first + j];
     if (k != EMPTY) {
+      unsigned long long c = (unsigned long long)lcnt[first + j];
       out_keys[pos] = k;
-      out_cnt[pos] = (int64_t)lcnt[first + j];
+      out_cnt[pos] = (int64_t)c;
+      mx = c > mx ? c : mx;
       ++pos;
+    }
+  }
+  // final list only: largest count, so the host can size the vocabulary sort without a
+  // second round trip (one relaxed read, an atomic only when this block raises the max)
+  if (cursor == reinterpret_cast<unsigned long long *>(&state[DS_OUT])) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      unsigned long long o = __shfl_down(mx, off, 64);
+      mx = o > mx ? o : mx;
+    }
+    if (lane == 0 && mx > 0) {
+      unsigned long long *gm = reinterpret_cast<unsigned long long *>(&state[NVT_ST_MAXCOUNT]);
+      if (mx > __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gm, mx);
     }
   }
 }
@@ -183,7 +201,7 @@ __device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, 
 // from *in_len on the device.
 // ---------------------------------------------------------------------------
 constexpr int kStageBS = 1024;  // 16 waves per workgroup, one 64-96 KiB LDS table per CU
-template <typename K, bool FIRST, typename C>
+template <typename K, bool FIRST, typename C, int SLOTS>
 __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid,
     const int64_t *__restrict__ weights, uint64_t n, const unsigned long long *in_len,
@@ -191,11 +209,11 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     int final_stage) {
   constexpr K EMPTY = DKey<K>::empty;
   constexpr int VEC = DKey<K>::vec;
-  __shared__ K lkeys[kLdsSlots];
-  __shared__ C lcnt[kLdsSlots];
+  __shared__ K lkeys[SLOTS];
+  __shared__ C lcnt[SLOTS];
   __shared__ unsigned lfill, lovf;
   __shared__ unsigned long long s_nulls, s_sent;
-  for (int i = threadIdx.x; i < kLdsSlots; i += kStageBS) {
+  for (int i = threadIdx.x; i < SLOTS; i += kStageBS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
   }
@@ -214,7 +232,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
       my_sent += w;
       return;
     }
-    if (!lds_add<K, C>(lkeys, lcnt, &lfill, key, (C)w, 17)) failed = true;
+    if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, key, (C)w, 17)) failed = true;
   };
   const uint64_t stride = (uint64_t)gridDim.x * kStageBS;
   if (FIRST && weights == nullptr) {
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     // 2 workgroups (8 waves) per CU the HBM latency has to be covered by ILP
     constexpr int U = NVT_STAGE_U;
     for (uint64_t v0 = (uint64_t)blockIdx.x * kStageBS + threadIdx.x; v0 < nvec; v0 += stride * U) {
-      if (lfill > kLdsMaxFill) break;  // table is filling up: this column belongs on path P
+      if (lfill > (unsigned)max_fill(SLOTS)) break;  // table is filling up: this column belongs on path P
       VecT pack[U];
       unsigned vb[U];
 #pragma unroll
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
   } else {
     constexpr int UW = 4;
     for (uint64_t i0 = (uint64_t)blockIdx.x * kStageBS + threadIdx.x; i0 < n; i0 += stride * UW) {
-      if (lfill > kLdsMaxFill) break;
+      if (lfill > (unsigned)max_fill(SLOTS)) break;
       K kk[UW];
       unsigned long long ww[UW];
       int st[UW];  // 0 = out of range, 1 = key, 2 = null row
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
   if (my_nulls) atomicAdd(&s_nulls, my_nulls);
   if (my_sent) atomicAdd(&s_sent, my_sent);
   __syncthreads();
-  if (lovf || lfill > kLdsMaxFill) {
+  if (lovf || lfill > (unsigned)max_fill(SLOTS)) {
     if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
     return;
   }
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     if (s_sent) atomicAdd((unsigned long long *)&state[DS_SENT], s_sent);
     if (FIRST && blockIdx.x == 0) atomicAdd((unsigned long long *)&state[DS_ROWS], (unsigned long long)n);
   }
-  lds_flush<K, C, kStageBS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+  lds_flush<K, C, kStageBS, SLOTS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
   (void)final_stage;
 }
 
@@ -744,8 +762,9 @@ struct DenseWs {
 
 // Path S reduction tree: 256 -> 32 -> 4 -> 1 workgroups (fan-in 8 per level)
 constexpr uint64_t kStage1Blocks = 256, kStage2Blocks = 32, kStage3Blocks = 4;
-constexpr uint64_t kP1Cap = kStage1Blocks * kLdsMaxFill, kP2Cap = kStage2Blocks * kLdsMaxFill,
-                   kP3Cap = kStage3Blocks * kLdsMaxFill;
+constexpr uint64_t kP1Cap = kStage1Blocks * max_fill(kLdsSlotsBig),
+                   kP2Cap = kStage2Blocks * max_fill(kLdsSlotsBig),
+                   kP3Cap = kStage3Blocks * max_fill(kLdsSlotsBig);
 // intermediate list cursors live in the spare words of the caller's state block, the final
 // list length IS state[NVT_ST_OCCUPIED]: one memset, no finish kernel
 constexpr int DS_CUR1 = 5, DS_CUR2 = 6, DS_CUR3 = 7;
@@ -807,27 +826,45 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
   unsigned long long *cur = reinterpret_cast<unsigned long long *>(state);
   if (n == 0) return NVT_OK;
   if (path == 0) {
-    if (weights)
-      lds_stage_kernel<K, true, unsigned long long><<<(unsigned)kStage1Blocks, kStageBS, 0, s>>>(
-          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &cur[DS_CUR1], state,
-          0);
-    else
-      lds_stage_kernel<K, true, unsigned><<<(unsigned)kStage1Blocks, kStageBS, 0, s>>>(
-          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &cur[DS_CUR1], state,
-          0);
-    NVT_CHECK_LAUNCH();
-    lds_stage_kernel<K, false, unsigned long long><<<(unsigned)kStage2Blocks, kStageBS, 0, s>>>(
-        (const K *)w.p1_keys, nullptr, w.p1_cnt, 0, &cur[DS_CUR1], (K *)w.p2_keys, w.p2_cnt, kP2Cap,
-        &cur[DS_CUR2], state, 0);
-    NVT_CHECK_LAUNCH();
-    lds_stage_kernel<K, false, unsigned long long><<<(unsigned)kStage3Blocks, kStageBS, 0, s>>>(
-        (const K *)w.p2_keys, nullptr, w.p2_cnt, 0, &cur[DS_CUR2], (K *)w.p3_keys, w.p3_cnt, kP3Cap,
-        &cur[DS_CUR3], state, 0);
-    NVT_CHECK_LAUNCH();
-    lds_stage_kernel<K, false, unsigned long long><<<1, kStageBS, 0, s>>>(
-        (const K *)w.p3_keys, nullptr, w.p3_cnt, 0, &cur[DS_CUR3], out_keys, out_cnt, out_cap,
-        &cur[DS_OUT], state, 1);
-    NVT_CHECK_LAUNCH();
+    // unweighted: every partial sum is < 2^32 (n is), so u32 counts and 16384-slot tables
+    // all the way down the tree; weighted merges need u64 counts and use 8192 slots
+    if (weights) {
+      using C = unsigned long long;
+      constexpr int S = kLdsSlots;
+      lds_stage_kernel<K, true, C, S><<<(unsigned)kStage1Blocks, kStageBS, 0, s>>>(
+          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &cur[DS_CUR1], state, 0);
+      NVT_CHECK_LAUNCH();
+      lds_stage_kernel<K, false, C, S><<<(unsigned)kStage2Blocks, kStageBS, 0, s>>>(
+          (const K *)w.p1_keys, nullptr, w.p1_cnt, 0, &cur[DS_CUR1], (K *)w.p2_keys, w.p2_cnt,
+          kP2Cap, &cur[DS_CUR2], state, 0);
+      NVT_CHECK_LAUNCH();
+      lds_stage_kernel<K, false, C, S><<<(unsigned)kStage3Blocks, kStageBS, 0, s>>>(
+          (const K *)w.p2_keys, nullptr, w.p2_cnt, 0, &cur[DS_CUR2], (K *)w.p3_keys, w.p3_cnt,
+          kP3Cap, &cur[DS_CUR3], state, 0);
+      NVT_CHECK_LAUNCH();
+      lds_stage_kernel<K, false, C, S><<<1, kStageBS, 0, s>>>(
+          (const K *)w.p3_keys, nullptr, w.p3_cnt, 0, &cur[DS_CUR3], out_keys, out_cnt, out_cap,
+          &cur[DS_OUT], state, 1);
+      NVT_CHECK_LAUNCH();
+    } else {
+      using C = unsigned;
+      constexpr int S = sizeof(K) == 4 ? kLdsSlotsBig : kLdsSlots;  // 128 KiB / 96 KiB of LDS
+      lds_stage_kernel<K, true, C, S><<<(unsigned)kStage1Blocks, kStageBS, 0, s>>>(
+          keys, valid, nullptr, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &cur[DS_CUR1], state, 0);
+      NVT_CHECK_LAUNCH();
+      lds_stage_kernel<K, false, C, S><<<(unsigned)kStage2Blocks, kStageBS, 0, s>>>(
+          (const K *)w.p1_keys, nullptr, w.p1_cnt, 0, &cur[DS_CUR1], (K *)w.p2_keys, w.p2_cnt,
+          kP2Cap, &cur[DS_CUR2], state, 0);
+      NVT_CHECK_LAUNCH();
+      lds_stage_kernel<K, false, C, S><<<(unsigned)kStage3Blocks, kStageBS, 0, s>>>(
+          (const K *)w.p2_keys, nullptr, w.p2_cnt, 0, &cur[DS_CUR2], (K *)w.p3_keys, w.p3_cnt,
+          kP3Cap, &cur[DS_CUR3], state, 0);
+      NVT_CHECK_LAUNCH();
+      lds_stage_kernel<K, false, C, S><<<1, kStageBS, 0, s>>>(
+          (const K *)w.p3_keys, nullptr, w.p3_cnt, 0, &cur[DS_CUR3], out_keys, out_cnt, out_cap,
+          &cur[DS_OUT], state, 1);
+      NVT_CHECK_LAUNCH();
+    }
   } else {
     const int b1 = 6, b2 = (path == 1) ? 6 : 8, bits = b1 + b2;
     part_hist_kernel<K><<<kHistBlocks, 1024, 0, s>>>(keys, valid, weights, n, bits, w.block_hist,

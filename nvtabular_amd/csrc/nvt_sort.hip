@@ -1,0 +1,373 @@
+// Vocabulary order: (count descending, key ascending) -- the two sort_values calls of
+// categorify.py:1300,1316 with the deterministic tie rule.
+//
+//  * n <= 8192: one workgroup, bitonic network in LDS over the composite
+//    (inverted count, key) -- most Criteo vocabularies are this small and a
+//    multi-pass radix sort would be pure launch latency.
+//  * larger: LSD radix sort, 8-bit digits over (key bytes, then inverted-count bytes);
+//    passes whose digit is constant over the whole array are skipped (the high count
+//    bytes almost always are).  Per pass: tile histogram -> scan -> stable scatter.
+//    A tile is 2048 elements = 4 waves x 8 rows x 64 lanes; stability inside a tile
+//    comes from ballot-matching equal digits in lane order (rank within a row), a
+//    per-wave running digit counter in LDS (rows), and a 4-entry prefix over the waves.
+#include <type_traits>
+
+#include "nvt_common.hpp"
+
+namespace nvt {
+
+template <typename K>
+__device__ __forceinline__ unsigned sort_digit(K key, int64_t cnt, int pass) {
+  constexpr int KB = (int)sizeof(K);
+  if (pass < KB) {
+    using U = typename std::make_unsigned<K>::type;
+    U u = (U)key ^ ((U)1 << (8 * KB - 1));  // signed order
+    return (unsigned)((u >> (8 * pass)) & 0xFF);
+  }
+  uint64_t inv = ~(uint64_t)cnt;  // descending counts
+  return (unsigned)((inv >> (8 * (pass - KB))) & 0xFF);
+}
+
+// ---- small: single-workgroup bitonic sort -------------------------------------
+constexpr int kSmallMax = 8192;
+constexpr int kSmallBS = 1024;
+
+template <typename K>
+__device__ __forceinline__ bool vocab_before(int64_t ca, K ka, int64_t cb, K kb) {
+  return ca > cb || (ca == cb && ka < kb);
+}
+
+template <typename K>
+__global__ __launch_bounds__(kSmallBS) void sort_small_kernel(K *keys, int64_t *counts, unsigned n) {
+  __shared__ K sk[kSmallMax];
+  __shared__ int64_t sc[kSmallMax];
+  unsigned m = 1;
+  while (m < n) m <<= 1;
+  for (unsigned i = threadIdx.x; i < m; i += kSmallBS) {
+    if (i < n) {
+      sk[i] = keys[i];
+      sc[i] = counts[i];
+    } else {  // padding sorts last: count = INT64_MIN
+      sk[i] = std::numeric_limits<K>::max();
+      sc[i] = INT64_MIN;
+    }
+  }
+  __syncthreads();
+  for (unsigned size = 2; size <= m; size <<= 1) {
+    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+      for (unsigned t = threadIdx.x; t < m / 2; t += kSmallBS) {
+        unsigned lo = 2 * t - (t & (stride - 1));
+        unsigned hi = lo + stride;
+        bool up = (lo & size) == 0;
+        K ka = sk[lo], kb = sk[hi];
+        int64_t ca = sc[lo], cb = sc[hi];
+        bool swap = up ? vocab_before<K>(cb, kb, ca, ka) : vocab_before<K>(ca, ka, cb, kb);
+        if (swap) {
+          sk[lo] = kb;
+          sk[hi] = ka;
+          sc[lo] = cb;
+          sc[hi] = ca;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (unsigned i = threadIdx.x; i < n; i += kSmallBS) {
+    keys[i] = sk[i];
+    counts[i] = sc[i];
+  }
+}
+
+// ---- large: LSD radix ------------------------------------------------------------
+constexpr int kRows = 8;
+constexpr int kTileSort = kBlock * kRows;  // 2048 elements
+
+template <typename K>
+__global__ __launch_bounds__(kBlock) void sort_pass_hist_kernel(const K *__restrict__ keys,
+                                                                const int64_t *__restrict__ cnts,
+                                                                uint64_t n,
+                                                                unsigned long long *pass_hist) {
+  constexpr int NP = (int)sizeof(K) + 8;
+  __shared__ unsigned h[NP * 256];
+  for (int i = threadIdx.x; i < NP * 256; i += kBlock) h[i] = 0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    K k = keys[i];
+    int64_t c = cnts[i];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) atomicAdd(&h[p * 256 + sort_digit<K>(k, c, p)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NP * 256; i += kBlock)
+    if (h[i]) atomicAdd(&pass_hist[i], (unsigned long long)h[i]);
+}
+
+// element index of (wave w, row r, lane l) inside a tile: waves own contiguous 512-element runs
+__device__ __forceinline__ uint64_t tile_elem(uint64_t tile, unsigned w, unsigned r, unsigned l) {
+  return tile * kTileSort + (uint64_t)w * (kRows * kWave) + (uint64_t)r * kWave + l;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kBlock) void sort_tile_hist_kernel(const K *__restrict__ keys,
+                                                                const int64_t *__restrict__ cnts,
+                                                                uint64_t n, int pass,
+                                                                unsigned *tile_hist,
+                                                                uint64_t ntiles) {
+  constexpr int KB = (int)sizeof(K);
+  __shared__ unsigned h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned w = threadIdx.x / kWave, l = lane_id();
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    uint64_t i = tile_elem(blockIdx.x, w, r, l);
+    if (i < n) {
+      // only the array that holds this pass's digit is read
+      unsigned d = pass < KB ? sort_digit<K>(keys[i], 0, pass) : sort_digit<K>((K)0, cnts[i], pass);
+      atomicAdd(&h[d], 1u);
+    }
+  }
+  __syncthreads();
+  tile_hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// peers = lanes of this wave holding the same digit (inactive lanes excluded)
+__device__ __forceinline__ unsigned long long match_digit(unsigned digit, bool active) {
+  unsigned long long peers = __ballot(active);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    unsigned long long m = __ballot((digit >> b) & 1);
+    peers &= ((digit >> b) & 1) ? m : ~m;
+  }
+  return peers;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kBlock) void sort_scatter_kernel(
+    const K *__restrict__ keys, const int64_t *__restrict__ cnts, uint64_t n, int pass,
+    const unsigned *__restrict__ tile_off, uint64_t ntiles, K *out_keys, int64_t *out_cnts) {
+  __shared__ unsigned wcnt[kBlock / kWave][256];
+  const unsigned w = threadIdx.x / kWave, l = lane_id();
+  for (int i = threadIdx.x; i < (kBlock / kWave) * 256; i += kBlock) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  K k[kRows];
+  int64_t c[kRows];
+  unsigned dig[kRows], local[kRows];
+  bool act[kRows];
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    uint64_t i = tile_elem(blockIdx.x, w, r, l);
+    act[r] = i < n;
+    k[r] = act[r] ? keys[i] : (K)0;
+    c[r] = act[r] ? cnts[i] : 0;
+    dig[r] = sort_digit<K>(k[r], c[r], pass);
+  }
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    unsigned long long peers = match_digit(dig[r], act[r]);
+    unsigned rank = __popcll(peers & ((1ull << l) - 1ull));
+    unsigned before = act[r] ? wcnt[w][dig[r]] : 0;  // digits seen in earlier rows of this wave
+    __builtin_amdgcn_wave_barrier();
+    if (act[r] && rank == 0) wcnt[w][dig[r]] = before + (unsigned)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    local[r] = before + rank;
+  }
+  __syncthreads();
+  {  // per digit: exclusive prefix over the 4 waves, seeded with the tile's global offset
+    const unsigned d = threadIdx.x;
+    unsigned run = tile_off[(uint64_t)d * ntiles + blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < kBlock / kWave; ++q) {
+      unsigned t = wcnt[q][d];
+      wcnt[q][d] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    if (act[r]) {
+      unsigned dst = wcnt[w][dig[r]] + local[r];
+      out_keys[dst] = k[r];
+      out_cnts[dst] = c[r];
+    }
+  }
+}
+
+// Exclusive scan of `len` uint32 in three steps (chunk scan, chunk-total scan, add).
+constexpr int kScanChunk = 2048;  // 256 threads x 8
+__global__ __launch_bounds__(kBlock) void scan_chunk_kernel(unsigned *data, uint64_t len,
+                                                            unsigned long long *chunk_tot) {
+  __shared__ unsigned wsum[kBlock / kWave];
+  const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * 8;
+  unsigned v[8];
+  unsigned tot = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = (base + j < len) ? data[base + j] : 0;
+    tot += v[j];
+  }
+  unsigned inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned o = __shfl_up(inc, off, 64);
+    if (lane_id() >= (unsigned)off) inc += o;
+  }
+  const unsigned w = threadIdx.x / kWave;
+  if (lane_id() == 63) wsum[w] = inc;
+  __syncthreads();
+  unsigned wbase = 0;
+  for (unsigned i = 0; i < w; ++i) wbase += wsum[i];
+  unsigned run = wbase + inc - tot;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (base + j < len) data[base + j] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == kBlock - 1) chunk_tot[blockIdx.x] = (unsigned long long)(wbase + inc);
+}
+__global__ __launch_bounds__(kBlock) void scan_totals_kernel(unsigned long long *chunk_tot,
+                                                             uint64_t nchunks) {
+  __shared__ unsigned long long carry;
+  __shared__ unsigned long long wsum[kBlock / kWave];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint64_t b = 0; b < nchunks; b += kBlock) {
+    uint64_t i = b + threadIdx.x;
+    unsigned long long v = i < nchunks ? chunk_tot[i] : 0;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned long long o = __shfl_up(inc, off, 64);
+      if (lane_id() >= (unsigned)off) inc += o;
+    }
+    const unsigned w = threadIdx.x / kWave;
+    if (lane_id() == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned long long wbase = carry;
+    for (unsigned k = 0; k < w; ++k) wbase += wsum[k];
+    if (i < nchunks) chunk_tot[i] = wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry = wbase + inc;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kBlock) void scan_add_kernel(unsigned *data, uint64_t len,
+                                                          const unsigned long long *chunk_tot) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * 8;
+  const unsigned add = (unsigned)chunk_tot[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (base + j < len) data[base + j] += add;
+}
+
+inline uint64_t pad16(uint64_t x) { return (x + 15) & ~15ull; }
+
+template <typename K>
+int vocab_sort(K *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tmp,
+               hipStream_t stream) {
+  constexpr int NP = (int)sizeof(K) + 8;
+  if (n <= 1) return NVT_OK;
+  NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 vocabulary entries");
+  if (n <= kSmallMax) {
+    sort_small_kernel<K><<<1, kSmallBS, 0, stream>>>(keys, counts, (unsigned)n);
+    NVT_CHECK_LAUNCH();
+    return NVT_OK;
+  }
+  const uint64_t ntiles = (n + kTileSort - 1) / kTileSort;
+  // tmp layout: counts2 | keys2 | tile_hist | chunk_tot | pass_hist
+  char *p = reinterpret_cast<char *>(tmp);
+  int64_t *counts2 = reinterpret_cast<int64_t *>(p);
+  p += n * sizeof(int64_t);
+  K *keys2 = reinterpret_cast<K *>(p);
+  p += pad16(n * sizeof(K));
+  unsigned *tile_hist = reinterpret_cast<unsigned *>(p);
+  const uint64_t hist_len = 256 * ntiles;
+  p += pad16(hist_len * sizeof(unsigned));
+  const uint64_t nchunks = (hist_len + kScanChunk - 1) / kScanChunk;
+  unsigned long long *chunk_tot = reinterpret_cast<unsigned long long *>(p);
+  p += nchunks * sizeof(unsigned long long);
+  unsigned long long *pass_hist = reinterpret_cast<unsigned long long *>(p);
+
+  bool run_pass[NP];
+  if (max_count > 0) {
+    // counts lie in [0, max_count]: the inverted-count bytes above its top byte are all 0xFF
+    constexpr int KB = (int)sizeof(K);
+    int count_bytes = 0;
+    for (uint64_t m = (uint64_t)max_count; m; m >>= 8) ++count_bytes;
+    for (int p = 0; p < NP; ++p) run_pass[p] = p < KB || (p - KB) < count_bytes;
+  } else {
+    NVT_CHECK_HIP(hipMemsetAsync(pass_hist, 0, NP * 256 * sizeof(unsigned long long), stream));
+    sort_pass_hist_kernel<K><<<stream_grid(n, kBlock * 8, 4), kBlock, 0, stream>>>(keys, counts, n,
+                                                                                     pass_hist);
+    NVT_CHECK_LAUNCH();
+    unsigned long long host_hist[NP * 256];
+    NVT_CHECK_HIP(hipMemcpyAsync(host_hist, pass_hist, sizeof(host_hist), hipMemcpyDeviceToHost,
+                                 stream));
+    NVT_CHECK_HIP(hipStreamSynchronize(stream));
+    for (int p = 0; p < NP; ++p) {
+      run_pass[p] = true;
+      for (int d = 0; d < 256; ++d)
+        if (host_hist[p * 256 + d] == n) run_pass[p] = false;
+    }
+  }
+
+  K *src_k = keys, *dst_k = keys2;
+  int64_t *src_c = counts, *dst_c = counts2;
+  for (int pass = 0; pass < NP; ++pass) {
+    if (!run_pass[pass]) continue;
+    sort_tile_hist_kernel<K><<<(unsigned)ntiles, kBlock, 0, stream>>>(src_k, src_c, n, pass,
+                                                                      tile_hist, ntiles);
+    NVT_CHECK_LAUNCH();
+    scan_chunk_kernel<<<(unsigned)nchunks, kBlock, 0, stream>>>(tile_hist, hist_len, chunk_tot);
+    NVT_CHECK_LAUNCH();
+    scan_totals_kernel<<<1, kBlock, 0, stream>>>(chunk_tot, nchunks);
+    NVT_CHECK_LAUNCH();
+    scan_add_kernel<<<(unsigned)nchunks, kBlock, 0, stream>>>(tile_hist, hist_len, chunk_tot);
+    NVT_CHECK_LAUNCH();
+    sort_scatter_kernel<K><<<(unsigned)ntiles, kBlock, 0, stream>>>(src_k, src_c, n, pass,
+                                                                    tile_hist, ntiles, dst_k, dst_c);
+    NVT_CHECK_LAUNCH();
+    K *tk = src_k;
+    src_k = dst_k;
+    dst_k = tk;
+    int64_t *tc = src_c;
+    src_c = dst_c;
+    dst_c = tc;
+  }
+  if (src_k != keys) {
+    NVT_CHECK_HIP(hipMemcpyAsync(keys, src_k, n * sizeof(K), hipMemcpyDeviceToDevice, stream));
+    NVT_CHECK_HIP(
+        hipMemcpyAsync(counts, src_c, n * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+  }
+  return NVT_OK;
+}
+
+}  // namespace nvt
+
+using namespace nvt;
+
+extern "C" {
+
+int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
+  const uint64_t ntiles = (n + kTileSort - 1) / kTileSort;
+  const uint64_t hist_len = 256 * ntiles;
+  const uint64_t nchunks = (hist_len + kScanChunk - 1) / kScanChunk;
+  *bytes = n * 8 + pad16(n * key_bytes) + pad16(hist_len * 4) + nchunks * 8 +
+           (uint64_t)(key_bytes + 8) * 256 * 8 + 64;
+  return NVT_OK;
+}
+int nvt_vocab_sort_i32(int32_t *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tmp,
+                       void *stream) {
+  NVT_CHECK_ARG(n <= 1 || (keys && counts && tmp), "null pointer");
+  return vocab_sort<int32_t>(keys, counts, n, max_count, tmp, (hipStream_t)stream);
+}
+int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tmp,
+                       void *stream) {
+  NVT_CHECK_ARG(n <= 1 || (keys && counts && tmp), "null pointer");
+  return vocab_sort<int64_t>(keys, counts, n, max_count, tmp, (hipStream_t)stream);
+}
+
+}  // extern "C"

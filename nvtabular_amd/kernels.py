@@ -215,7 +215,8 @@ def count_into_new_table(
 # --------------------------------------------------------------------------
 # Categorify.fit, atomic-free: dense (key, count) lists
 # --------------------------------------------------------------------------
-PATH_S_MAX_DISTINCT = 4096          # path 0: three LDS-table stages
+PATH_S_MAX_DISTINCT = 11000         # path 0 (int32 keys, unweighted): 16384-slot LDS tables
+PATH_S_MAX_WEIGHTED = 5000          # path 0 for weighted merges / int64 keys: 8192 slots
 PATH_P1_MAX_DISTINCT = 10_000_000   # path 1: 64 x 64 buckets, <= ~2.4k distinct per bucket
 PATH_P2_MAX_DISTINCT = 45_000_000   # path 2: 64 x 256 buckets
 
@@ -233,14 +234,115 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-def _path_for(hint: int) -> int:
-    if hint <= PATH_S_MAX_DISTINCT:
+def _path_for(hint: int, small_tables: bool = False) -> int:
+    if hint <= (PATH_S_MAX_WEIGHTED if small_tables else PATH_S_MAX_DISTINCT):
         return 0
     if hint <= PATH_P1_MAX_DISTINCT:
         return 1
     if hint <= PATH_P2_MAX_DISTINCT:
         return 2
     return 3  # global-table fallback
+
+
+class DenseCountJob:
+    """One column's groupby-size, launched asynchronously; ``dense_count_many`` reads all
+    jobs' state words back with a single device->host copy."""
+
+    def __init__(self, keys, valid, weights=None, hint: int = 0):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.keys = aligned(keys)
+        self.valid = valid
+        self.weights = weights.contiguous() if weights is not None else None
+        self.n = int(self.keys.numel())
+        self.dev = self.keys.device
+        self.suffix = _key_suffix(self.keys)
+        self.kb = 4 if self.suffix == "i32" else 8
+        self.hint = hint
+        self.path = _path_for(hint if hint > 0 else 1,
+                              small_tables=(weights is not None or self.kb == 8))
+        self.cap_guess = max(1 << 16, 2 * max(hint, 1))
+        self.state = None  # device uint64[STATE_WORDS] view, assigned by dense_count_many
+        self.result = None
+
+    def launch(self):
+        n, path = self.n, self.path
+        out_cap = min(self.cap_guess, n) + 1
+        if path == 0:
+            out_cap = min(out_cap, 16384)
+        self.out_k = torch.empty(out_cap + 1, dtype=self.keys.dtype, device=self.dev)
+        self.out_c = torch.empty(out_cap + 1, dtype=torch.int64, device=self.dev)
+        nbytes = C.c_uint64()
+        check(self.lib.nvt_dense_count_ws_bytes(self.kb, n, path,
+                                                0 if self.weights is None else 1, C.byref(nbytes)))
+        ws = _workspace(nbytes.value, self.dev)  # shared: calls are ordered on one stream
+        with _timed(f"dense_count_p{path}", n * self.kb):
+            check(
+                getattr(self.lib, f"nvt_dense_count_{self.suffix}")(
+                    self.keys.data_ptr(), ptr(self.valid), ptr(self.weights), n, path,
+                    ws.data_ptr(), self.out_k.data_ptr(), self.out_c.data_ptr(), out_cap,
+                    self.state.data_ptr(), stream_ptr(),
+                ),
+                "nvt_dense_count",
+            )
+
+    def resolve(self, st) -> bool:
+        """Inspect the state words read back for this job; False = relaunch needed."""
+        ovf = st[_lib.ST_OVERFLOW]
+        if ovf & 1:
+            self.path += 1
+            if self.path > 2:
+                self._fallback()
+                return True
+            return False
+        if ovf & 2:
+            self.cap_guess = max(4 * self.cap_guess, 1 << 20)
+            return False
+        m = st[_lib.ST_OCCUPIED]
+        max_count = st[_lib.ST_MAXCOUNT]
+        if st[_lib.ST_SENTINEL] > 0:
+            self.out_k[m] = INT32_MIN if self.kb == 4 else INT64_MIN
+            self.out_c[m] = st[_lib.ST_SENTINEL]
+            max_count = max(max_count, st[_lib.ST_SENTINEL])
+            m += 1
+        self.result = (self.out_k[:m], self.out_c[:m], st[_lib.ST_NULLS],
+                       dict(path=self.path, distinct=m, max_count=max_count, rows=st[_lib.ST_ROWS]))
+        return True
+
+    def _fallback(self):
+        """Last resort: one global open-addressing table (device atomics)."""
+        if self.weights is None:
+            tab, st = count_into_new_table([self.keys], [self.valid], max(self.hint, 1 << 20))
+        else:
+            tab = CountTable(self.keys.dtype, 2 * self.n)
+            tab.merge(self.keys, self.weights)
+            st = tab.read_state()
+        k, c = tab.compact()
+        mx = int(c.max().item()) if c.numel() else 0
+        self.result = (k, c, st[_lib.ST_NULLS],
+                       dict(path=3, distinct=int(k.numel()), max_count=mx, rows=self.n))
+
+
+def dense_count_many(jobs):
+    """Launch every job, then ONE readback for all their state words; jobs whose LDS
+    tables or output lists overflowed are relaunched on a larger path (rare once the
+    hints are learned)."""
+    jobs = [j for j in jobs]
+    for j in jobs:
+        if j.n == 0:
+            j.result = (torch.empty(0, dtype=j.keys.dtype, device=j.dev),
+                        torch.empty(0, dtype=torch.int64, device=j.dev), 0,
+                        dict(path=0, distinct=0, max_count=0, rows=0))
+    pending = [j for j in jobs if j.result is None]
+    while pending:
+        states = torch.zeros(len(pending), _lib.STATE_WORDS, dtype=torch.int64,
+                             device=pending[0].dev)
+        for i, j in enumerate(pending):
+            j.state = states[i]
+            j.launch()
+        host = states.cpu().tolist()  # the single synchronisation point
+        pending = [j for i, j in enumerate(pending) if not j.resolve(host[i])]
+    return [j.result for j in jobs]
 
 
 def dense_count(
@@ -254,82 +356,30 @@ def dense_count(
     ``hint`` = expected number of distinct keys (0 = unknown).  Picks the LDS /
     partitioned path from it and escalates when a kernel reports that its LDS
     tables filled up; the last resort is the global-table kernel of nvt_count_*.
-    info = dict(path=..., distinct=...) so callers can remember the hint."""
-    _lib.require_gpu()
-    lib = _lib.load()
-    keys = aligned(keys)
-    n = int(keys.numel())
-    dev = keys.device
-    suffix = _key_suffix(keys)
-    kb = 4 if suffix == "i32" else 8
-    if weights is not None:
-        weights = weights.contiguous()
-    sentinel = INT32_MIN if kb == 4 else INT64_MIN
-    if n == 0:
-        return (torch.empty(0, dtype=keys.dtype, device=dev),
-                torch.empty(0, dtype=torch.int64, device=dev), 0, dict(path=0, distinct=0))
-    path = _path_for(hint if hint > 0 else 1)
-    cap_guess = max(1 << 16, 2 * max(hint, 1))
-    state = torch.zeros(_lib.STATE_WORDS, dtype=torch.int64, device=dev)
-    while path <= 2:
-        out_cap = min(cap_guess, n) + 1
-        if path == 0:
-            out_cap = min(out_cap, 8192)
-        out_k = torch.empty(out_cap + 1, dtype=keys.dtype, device=dev)
-        out_c = torch.empty(out_cap + 1, dtype=torch.int64, device=dev)
-        nbytes = C.c_uint64()
-        check(lib.nvt_dense_count_ws_bytes(kb, n, path, 0 if weights is None else 1, C.byref(nbytes)))
-        ws = _workspace(nbytes.value, dev)
-        with _timed(f"dense_count_p{path}", n * kb):
-            check(
-                getattr(lib, f"nvt_dense_count_{suffix}")(
-                    keys.data_ptr(), ptr(valid), ptr(weights), n, path, ws.data_ptr(),
-                    out_k.data_ptr(), out_c.data_ptr(), out_cap, state.data_ptr(), stream_ptr(),
-                ),
-                "nvt_dense_count",
-            )
-        st = state.cpu().tolist()
-        ovf = st[_lib.ST_OVERFLOW]
-        if ovf & 1:
-            path += 1
-            continue
-        if ovf & 2:
-            cap_guess = max(4 * cap_guess, 1 << 20)
-            continue
-        m = st[_lib.ST_OCCUPIED]
-        if st[_lib.ST_SENTINEL] > 0:
-            out_k[m] = sentinel
-            out_c[m] = st[_lib.ST_SENTINEL]
-            m += 1
-        return out_k[:m], out_c[:m], st[_lib.ST_NULLS], dict(path=path, distinct=m)
-    # last resort: one global open-addressing table (device atomics)
-    tab, st = count_into_new_table([keys], [valid], max(hint, 1 << 20)) if weights is None \
-        else (None, None)
-    if tab is None:
-        tab = CountTable(keys.dtype, 2 * n)
-        tab.merge(keys, weights)
-        st = tab.read_state()
-    k, c = tab.compact()
-    return k, c, st[_lib.ST_NULLS], dict(path=3, distinct=int(k.numel()))
+    info = dict(path, distinct, max_count, rows) so callers can remember the hint."""
+    return dense_count_many([DenseCountJob(keys, valid, weights, hint)])[0]
 
 
 def merge_dense(lists, hint: int = 0):
     """Tree-merge step (_mid_level_groupby): sum the counts of equal keys across
     several dense (keys, counts) lists."""
-    lists = [(k, c) for k, c in lists if k.numel()]
+    lists = [(t[0], t[1]) + tuple(t[2:]) for t in lists if t[0].numel()]
     if not lists:
         return None
     if len(lists) == 1:
-        return lists[0]
+        return lists[0] if len(lists[0]) == 3 else (lists[0][0], lists[0][1], 0)
+    lists = [(t[0], t[1]) for t in lists]
     dt = torch.int64 if any(k.dtype == torch.int64 for k, _ in lists) else torch.int32
     keys = torch.cat([k.to(dt) for k, _ in lists])
     counts = torch.cat([c for _, c in lists])
-    k, c, _, _ = dense_count(keys, None, counts, hint=hint or max(int(x[0].numel()) for x in lists))
-    return k, c
+    k, c, _, info = dense_count(keys, None, counts,
+                                hint=hint or max(int(x[0].numel()) for x in lists))
+    return k, c, info["max_count"]
 
 
-def vocab_sort(keys: torch.Tensor, counts: torch.Tensor):
-    """In place: (count desc, key asc) -- categorify.py:1300,1316 with the stable tie rule."""
+def vocab_sort(keys: torch.Tensor, counts: torch.Tensor, max_count: int = 0):
+    """In place: (count desc, key asc) -- categorify.py:1300,1316 with the stable tie rule.
+    max_count (upper bound on counts, 0 = unknown) avoids a stream synchronisation."""
     lib = _lib.load()
     n = keys.numel()
     if n <= 1:
@@ -342,7 +392,7 @@ def vocab_sort(keys: torch.Tensor, counts: torch.Tensor):
     with _timed("vocab_sort", 0):
         check(
             getattr(lib, f"nvt_vocab_sort_{suffix}")(
-                keys.data_ptr(), counts.data_ptr(), n, tmp.data_ptr(), stream_ptr()
+                keys.data_ptr(), counts.data_ptr(), n, int(max_count), tmp.data_ptr(), stream_ptr()
             ),
             "nvt_vocab_sort",
         )

@@ -53,8 +53,9 @@ class _GroupFit:
         self.name = name
         self.cols = cols
         self.combo = combo  # multi-column key tuple (nvt_gb_*) vs single key column
-        self.table = None  # K.CountTable | K.GroupbyTable
+        self.table = None  # (keys, counts, max_count) dense list | K.GroupbyTable (combo)
         self.nulls = 0
+        self.valid_rows = 0  # non-null key rows seen (== sum of counts)
         self.hint = 1 << 12  # expected distinct keys per partition, learned as we go
         self.key_dtype = None
         self.src_dtypes: Dict[str, object] = {}
@@ -202,6 +203,7 @@ class Categorify(StatOperator):
 
     def fit_partition(self, state, col_selector, frame):
         frame, _ = as_device_frame(frame)
+        jobs, owners = [], []
         for g in state.values():
             keys, valids = self._group_keys(g, frame)
             if g.combo:
@@ -211,15 +213,26 @@ class Categorify(StatOperator):
             if len({k.dtype for k in keys}) > 1:
                 keys = [K.widen_i64(k) for k in keys]
             g.key_dtype = keys[0].dtype
-            lists = [] if g.table is None else [g.table]
             for ci, (k, v) in enumerate(zip(keys, valids)):
                 hkey = f"{g.name}#{ci}"
-                dk, dc, nulls, info = K.dense_count(k, v, None, hint=self._cap_hints.get(hkey, 0))
-                self._cap_hints[hkey] = max(64, info["distinct"])
-                g.nulls += nulls
-                lists.append((dk, dc))
-            # tree merge (_mid_level_groupby): weighted re-count of the concatenated lists
-            g.table = K.merge_dense(lists, hint=self._cap_hints.get(g.name, 0))
+                jobs.append(K.DenseCountJob(k, v, None, hint=self._cap_hints.get(hkey, 0)))
+                owners.append((g, hkey))
+        # every column's count kernels are queued before the one readback of all state words
+        results = K.dense_count_many(jobs)
+        per_group = {}
+        for (g, hkey), (dk, dc, nulls, info) in zip(owners, results):
+            self._cap_hints[hkey] = max(64, info["distinct"])
+            g.nulls += nulls
+            g.valid_rows += info["rows"] - nulls
+            per_group.setdefault(g.name, (g, []))[1].append((dk, dc, info["max_count"]))
+        for g, lists in per_group.values():
+            if g.table is not None:
+                lists = [g.table] + lists
+            if len(lists) == 1:
+                g.table = lists[0]
+            else:
+                # tree merge (_mid_level_groupby): weighted re-count of the concatenated lists
+                g.table = K.merge_dense(lists, hint=self._cap_hints.get(g.name, 0))
             if g.table is not None:
                 self._cap_hints[g.name] = max(64, int(g.table[0].numel()))
 
@@ -271,11 +284,15 @@ class Categorify(StatOperator):
             dev = torch.device("cuda", torch.cuda.current_device())
             keys = torch.empty(0, dtype=torch.int64, device=dev)
             counts = torch.empty(0, dtype=torch.int64, device=dev)
+            max_count = 0
         else:
-            keys, counts = g.table
+            keys, counts, max_count = g.table
         nulls = g.nulls
         if dist.world_size() > 1:
             keys, counts, nulls = dist.merge_counts(keys, counts, nulls)
+            tot = dist.all_reduce_sum(torch.tensor([max_count, g.valid_rows], dtype=torch.int64,
+                                                   device=keys.device)).tolist()
+            max_count, g.valid_rows = int(tot[0]), int(tot[1])  # sum of maxima bounds the max
         strings = None
         for c in g.cols:
             if c in g.strings:
@@ -290,8 +307,9 @@ class Categorify(StatOperator):
             counts = torch.from_numpy(hc[order]).to(counts.device)
         else:
             keys, counts = keys.contiguous(), counts.contiguous()
-            K.vocab_sort(keys, counts)
-        return dict(keys=[keys], null_mask=None, counts=counts, null_size=nulls, strings=strings)
+            K.vocab_sort(keys, counts, max_count)
+        return dict(keys=[keys], null_mask=None, counts=counts, null_size=nulls, strings=strings,
+                    total=g.valid_rows)
 
     def _finalize_combo(self, g: _GroupFit, dist):
         comp = g.table.compact()
@@ -350,7 +368,10 @@ class Categorify(StatOperator):
                 keys = [k[:limit] for k in keys]
                 nm = nm[:limit] if nm is not None else None
         unique_count = int(counts.numel())
-        unique_size = int(counts.sum().item()) if unique_count else 0
+        if not (freq_threshold or first_n) and vocab.get("total") is not None:
+            unique_size = int(vocab["total"])  # nothing dropped: no device readback needed
+        else:
+            unique_size = int(counts.sum().item()) if unique_count else 0
         # device-side encoder, cached for transform (cat_cache="device" behaviour)
         combo = bool(vocab.get("combo"))
         self._encoders[g.name] = _build_encoder(keys, nm, start, combo)
@@ -630,32 +651,6 @@ def _write_artifacts(final):
     }
     pd.DataFrame(meta).to_parquet(meta_path)
     return unique_path
-
-
-def _merge_counts(acc: "K.CountTable", keys, counts) -> "K.CountTable":
-    """Tree-merge step (_mid_level_groupby, categorify.py:1054-1070): fold one
-    partition's (key,count) list into the accumulated table, regrowing it first
-    when the load factor would exceed 0.5."""
-    st = acc.read_state()
-    need = st[K._lib.ST_OCCUPIED] + int(keys.numel())
-    if keys.dtype != acc.key_dtype:
-        if acc.key_dtype == torch.int32:  # widen the accumulator
-            ak, ac = acc.compact(st[K._lib.ST_OCCUPIED])
-            new = K.CountTable(torch.int64, 2 * need)
-            new.merge(K.widen_i64(ak), ac)
-            new.state[K._lib.ST_NULLS] = st[K._lib.ST_NULLS]
-            acc = new
-        else:
-            keys = K.widen_i64(keys)
-    if 2 * need > acc.capacity:
-        ak, ac = acc.compact(st[K._lib.ST_OCCUPIED])
-        new = K.CountTable(acc.key_dtype, 4 * need)
-        new.merge(ak, ac)
-        acc = new
-    acc.merge(keys, counts)
-    if acc.read_state()[K._lib.ST_OVERFLOW]:
-        raise K._lib.NvtHipError("count table overflow during merge")
-    return acc
 
 
 def _merge_groups(acc: "K.GroupbyTable", comp) -> "K.GroupbyTable":

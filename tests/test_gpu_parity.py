@@ -495,3 +495,25 @@ def test_dense_count_paths_vs_numpy(dtype, card, n, weighted):
         np.testing.assert_array_equal(got.to_numpy(), exp.to_numpy())
         assert nulls == int(ww[mask].sum())
     assert seen_paths >= ({1, 2} if card > 5000 else {0, 1, 2})
+
+
+@pytest.mark.parametrize("dtype", ["int32", "int64"])
+@pytest.mark.parametrize("n", [2, 3, 100, 4097, 8192, 8193, 50_000, 300_000])
+def test_vocab_sort_vs_numpy(dtype, n):
+    """(count desc, key asc) on both code paths: LDS bitonic (n <= 8192) and LSD radix."""
+    from nvtabular_amd import kernels as K
+
+    rng = np.random.default_rng(n)
+    info = np.iinfo(dtype)
+    keys = rng.choice(np.arange(-3 * n, 3 * n, dtype=np.int64), size=n, replace=False).astype(dtype)
+    keys[0], keys[1 % n] = info.min, info.max
+    keys = np.unique(keys)
+    m = len(keys)
+    rng.shuffle(keys)
+    counts = rng.integers(1, 6, m).astype("int64")  # lots of ties
+    counts[: min(3, m)] = [2**40, 1, 2**33][: min(3, m)]
+    order = np.lexsort((keys, -counts))
+    tk, tc = torch.from_numpy(keys).cuda(), torch.from_numpy(counts).cuda()
+    K.vocab_sort(tk, tc)
+    np.testing.assert_array_equal(tk.cpu().numpy(), keys[order])
+    np.testing.assert_array_equal(tc.cpu().numpy(), counts[order])
