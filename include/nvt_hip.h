@@ -127,22 +127,30 @@ int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, int64_t max_c
  * encode table slot: i32 = {int32 key, int32 label}; i64 = {int64 key, int64 label}.
  * Build assigns label first_label + i to vocab_keys[i]. */
 int nvt_encode_table_bytes(int key_bytes, uint64_t capacity, uint64_t *bytes);
+/* unique_keys != 0 promises vocab_keys holds no duplicates (true for fitted vocabularies):
+ * int32 slots are then claimed and filled with one 64-bit CAS.  With duplicates (user
+ * vocabs) the lowest label wins. */
 int nvt_encode_build_i32(const int32_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
-                         void *table, uint64_t capacity, int64_t *sentinel_label, void *stream);
+                         void *table, uint64_t capacity, int64_t *sentinel_label, int unique_keys,
+                         void *stream);
 int nvt_encode_build_i64(const int64_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
-                         void *table, uint64_t capacity, int64_t *sentinel_label, void *stream);
+                         void *table, uint64_t capacity, int64_t *sentinel_label, int unique_keys,
+                         void *stream);
 /* out[i] = null_label            if key i is null
  *        = table[key]            if present
  *        = oov_label             if absent and num_buckets <= 1
- *        = oov_label + h32(key) % num_buckets   otherwise      (out_bytes: 4 or 8) */
+ *        = oov_label + h32(key) % num_buckets   otherwise      (out_bytes: 4 or 8)
+ * vocab_keys / n_vocab / first_label (optional: pass NULL, 0, 0): the ordered, duplicate-free
+ * vocabulary the table was built from.  Its head -- the most frequent keys -- is then
+ * staged in LDS by every workgroup and only rows that miss it probe the table in HBM. */
 int nvt_encode_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, const void *table,
                    uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                    int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
-                   void *stream);
+                   const int32_t *vocab_keys, uint64_t n_vocab, int64_t first_label, void *stream);
 int nvt_encode_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, const void *table,
                    uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                    int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
-                   void *stream);
+                   const int64_t *vocab_keys, uint64_t n_vocab, int64_t first_label, void *stream);
 
 /* ---- HashBucket / hashed OOV buckets: out[i] = h32(key) % num_buckets (int32);
  * xor_in (optional, uint64 per row) is XORed into the 64-bit hash first and

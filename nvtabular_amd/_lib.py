@@ -52,10 +52,12 @@ SIGNATURES = {
     "nvt_vocab_sort_i32": [_vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_vocab_sort_i64": [_vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_encode_table_bytes": [_i32, _u64, C.POINTER(_u64)],
-    "nvt_encode_build_i32": [_vp, _u64, _i64, _vp, _u64, _vp, _vp],
-    "nvt_encode_build_i64": [_vp, _u64, _i64, _vp, _u64, _vp, _vp],
-    "nvt_encode_i32": [_vp, _vp, _u64, _vp, _u64, _vp, _i64, _i64, _u32, _vp, _i32, _vp],
-    "nvt_encode_i64": [_vp, _vp, _u64, _vp, _u64, _vp, _i64, _i64, _u32, _vp, _i32, _vp],
+    "nvt_encode_build_i32": [_vp, _u64, _i64, _vp, _u64, _vp, _i32, _vp],
+    "nvt_encode_build_i64": [_vp, _u64, _i64, _vp, _u64, _vp, _i32, _vp],
+    "nvt_encode_i32": [_vp, _vp, _u64, _vp, _u64, _vp, _i64, _i64, _u32, _vp, _i32, _vp, _u64, _i64,
+                       _vp],
+    "nvt_encode_i64": [_vp, _vp, _u64, _vp, _u64, _vp, _i64, _i64, _u32, _vp, _i32, _vp, _u64, _i64,
+                       _vp],
     "nvt_hash_bucket_i32": [_vp, _u64, _u32, _vp, _vp, _vp, _vp],
     "nvt_hash_bucket_i64": [_vp, _u64, _u32, _vp, _vp, _vp, _vp],
     "nvt_moments_scratch_bytes": [],

@@ -60,7 +60,8 @@ constexpr int DS_NULLS = NVT_ST_NULLS, DS_SENT = NVT_ST_SENTINEL, DS_OUT = NVT_S
 
 constexpr int kLdsSlots = 8192;     // weighted stages / per-bucket tables (u64 or u32 counts)
 constexpr int kLdsSlotsBig = 16384; // unweighted path S: int32 key + u32 count = 128 KiB, 1 WG / CU
-constexpr int kLdsProbe = 24;
+constexpr int kLdsProbe = 512;  // linear-probing clusters reach ~25 slots at 37 % load; the real
+                                // "table full" signal is lfill > max_fill, not the chain length
 constexpr int kLdsMaxFill = 6144;   // 75 % of kLdsSlots: beyond this the table is declared full
 __host__ __device__ constexpr int max_fill(int slots) { return slots / 4 * 3; }
 
@@ -70,12 +71,21 @@ __device__ __forceinline__ K lds_cas(K *addr, K expect, K val) {
   return (K)atomicCAS(reinterpret_cast<C *>(addr), (C)expect, (C)val);
 }
 
+// (A wave-level "aggregate the lanes that share the first lane's key" pre-pass was tried to
+// relieve same-address LDS atomics on hot keys; it cost more issue slots than it saved on
+// every cardinality measured, see profiles/r01_notes.md.)
 // Insert into a workgroup-private LDS table.  Returns false when no slot was found.
+// `h` must be independent of whatever selected the rows that reach this table: path S
+// uses the upper bits of slot_hash, path P the LOW bits of part_hash (its top bits chose
+// the bucket; reusing slot_hash there clustered and overflowed 24-probe chains at 37 % load).
 template <typename K, typename C, int SLOTS = kLdsSlots>
 __device__ __forceinline__ bool lds_add(K *lkeys, C *lcnt, unsigned *lfill, K key, C w,
-                                        unsigned hash_shift) {
+                                        uint32_t h) {
   constexpr K EMPTY = DKey<K>::empty;
-  uint32_t h = (uint32_t)(slot_hash(key) >> hash_shift);
+#ifndef NVT_PROBE_UNROLL
+#define NVT_PROBE_UNROLL 4
+#endif
+#pragma unroll NVT_PROBE_UNROLL
   for (int p = 0; p < kLdsProbe; ++p) {
     uint32_t s = (h + p) & (SLOTS - 1);
     K cur = lkeys[s];
@@ -158,12 +168,12 @@ __device__ __forceinline__ void lds_flush(const K *lkeys, const C *lcnt, K *out_
 
 // Same, but into a caller-assigned region [out_keys, out_keys + kLdsMaxFill) -- used for
 // the per-chunk partial lists of split (skewed) buckets.  *out_len receives the count.
-template <typename K, typename C, int BS>
+template <typename K, typename C, int BS, int SLOTS = kLdsSlots>
 __device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, K *out_keys,
                                                  int64_t *out_cnt, unsigned *out_len) {
   constexpr K EMPTY = DKey<K>::empty;
   __shared__ unsigned wsum2[BS / kWave];
-  constexpr int PER = kLdsSlots / BS;
+  constexpr int PER = SLOTS / BS;
   const unsigned lane = lane_id(), w = threadIdx.x / kWave;
   unsigned mine = 0;
   const int first = threadIdx.x * PER;
@@ -232,7 +242,8 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
       my_sent += w;
       return;
     }
-    if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, key, (C)w, 17)) failed = true;
+    if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, key, (C)w, (uint32_t)(slot_hash(key) >> 17)))
+      failed = true;
   };
   const uint64_t stride = (uint64_t)gridDim.x * kStageBS;
   if (FIRST && weights == nullptr) {
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (!(vb[u] & 0x100)) continue;
+        if (!(vb[u] & 0x100)) vb[u] = 0xF0000;  // out of range: no valid rows, no nulls either
         K k[VEC];
         if constexpr (sizeof(K) == 4) {
           k[0] = pack[u].x;
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
         for (int j = 0; j < VEC; ++j) {
           if ((vb[u] >> j) & 1)
             add(k[j], 1ull);
-          else
+          else if (!(vb[u] & 0xF0000))
             ++my_nulls;
         }
       }
@@ -336,6 +347,13 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kTile = 8192;        // rows per scatter tile (32 rows per thread)
 constexpr int kChunk = 65536;      // rows one P3 workgroup counts
+#ifndef NVT_COUNT_BS
+#define NVT_COUNT_BS 512
+#endif
+#ifndef NVT_P1_SLOTS
+#define NVT_P1_SLOTS 4096
+#endif
+constexpr int kCountBS = NVT_COUNT_BS;      // P3 workgroup size
 constexpr int kMaxFine = 1 << 14;  // up to 6 + 8 hash bits
 constexpr int kHistBlocks = 512;
 
@@ -617,8 +635,8 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
 
 // P3: one workgroup per (fine bucket, chunk of kChunk rows).  Single-chunk buckets go
 // straight to the output list; chunks of split buckets write partial lists for P4.
-template <typename K, bool WEIGHTED>
-__global__ __launch_bounds__(kStageBS) void part_count_kernel(
+template <typename K, bool WEIGHTED, int SLOTS, int BS>
+__global__ __launch_bounds__(BS) void part_count_kernel(
     const K *__restrict__ keys, const int64_t *__restrict__ weights,
     const unsigned long long *__restrict__ fine_start, const unsigned *__restrict__ chunk_start,
     const unsigned *__restrict__ pchunk_start, int nb, K *part_keys, int64_t *part_cnt,
@@ -626,8 +644,8 @@ __global__ __launch_bounds__(kStageBS) void part_count_kernel(
     uint64_t *state) {
   constexpr K EMPTY = DKey<K>::empty;
   using C = typename std::conditional<WEIGHTED, unsigned long long, unsigned>::type;
-  __shared__ K lkeys[kLdsSlots];
-  __shared__ C lcnt[kLdsSlots];
+  __shared__ K lkeys[SLOTS];
+  __shared__ C lcnt[SLOTS];
   __shared__ unsigned lfill, lovf;
   __shared__ unsigned long long s_sent;
   __shared__ int s_f;
@@ -646,7 +664,7 @@ __global__ __launch_bounds__(kStageBS) void part_count_kernel(
     lovf = 0;
     s_sent = 0;
   }
-  for (int i = threadIdx.x; i < kLdsSlots; i += kStageBS) {
+  for (int i = threadIdx.x; i < SLOTS; i += BS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
   }
@@ -661,13 +679,13 @@ __global__ __launch_bounds__(kStageBS) void part_count_kernel(
   bool failed = false;
   unsigned long long my_sent = 0;
   constexpr int U = 8;
-  for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (uint64_t)kStageBS * U) {
-    if (lfill > kLdsMaxFill) break;
+  for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (uint64_t)BS * U) {
+    if (lfill > (unsigned)max_fill(SLOTS)) break;
     K kk[U];
     unsigned long long ww[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      uint64_t i = i0 + (uint64_t)u * kStageBS;
+      uint64_t i = i0 + (uint64_t)u * BS;
       ww[u] = 0;
       if (i < hi) {
         kk[u] = keys[i];
@@ -676,27 +694,30 @@ __global__ __launch_bounds__(kStageBS) void part_count_kernel(
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (i0 + (uint64_t)u * kStageBS >= hi) continue;
+      if (i0 + (uint64_t)u * BS >= hi) continue;
       if (kk[u] == EMPTY) {
         my_sent += ww[u];
         continue;
       }
-      if (!lds_add<K, C>(lkeys, lcnt, &lfill, kk[u], (C)ww[u], 17)) failed = true;
+      if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, kk[u], (C)ww[u], part_hash<K>(kk[u])))
+        failed = true;
     }
   }
   if (failed) atomicOr(&lovf, 1u);
   if (my_sent) atomicAdd(&s_sent, my_sent);
   __syncthreads();
-  if (lovf || lfill > kLdsMaxFill) {
-    if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
+  if (lovf || lfill > (unsigned)max_fill(SLOTS)) {
+    if (threadIdx.x == 0) {
+      atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
+    }
     return;
   }
   if (threadIdx.x == 0 && s_sent) atomicAdd((unsigned long long *)&state[DS_SENT], s_sent);
   if (nchunks == 1) {
-    lds_flush<K, C, kStageBS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+    lds_flush<K, C, BS, SLOTS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
   } else {
     const uint64_t region = (uint64_t)(pchunk_start[f] + j);
-    lds_flush_region<K, C, kStageBS>(lkeys, lcnt, part_keys + region * kLdsMaxFill,
+    lds_flush_region<K, C, BS, SLOTS>(lkeys, lcnt, part_keys + region * kLdsMaxFill,
                            part_cnt + region * kLdsMaxFill, &part_len[region]);
   }
 }
@@ -732,7 +753,7 @@ __global__ __launch_bounds__(kStageBS) void part_merge_kernel(
     const K *pk = part_keys + region * kLdsMaxFill;
     const int64_t *pc = part_cnt + region * kLdsMaxFill;
     for (unsigned i = threadIdx.x; i < len; i += kStageBS)
-      if (!lds_add<K, C>(lkeys, lcnt, &lfill, pk[i], (C)pc[i], 17)) failed = true;
+      if (!lds_add<K, C>(lkeys, lcnt, &lfill, pk[i], (C)pc[i], part_hash<K>(pk[i]))) failed = true;
   }
   if (failed) atomicOr(&lovf, 1u);
   __syncthreads();
@@ -889,7 +910,7 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                                                             b2, w.fine_start, w.fine_cursor,
                                                             w.tile_start, (K *)w.bufB, w.wB);
       NVT_CHECK_LAUNCH();
-      part_count_kernel<K, true><<<t3, kStageBS, 0, s>>>(
+      part_count_kernel<K, true, kLdsSlots, kCountBS><<<t3, kCountBS, 0, s>>>(
           (const K *)w.bufB, w.wB, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
           (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
           state);
@@ -902,10 +923,17 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                                                              b1, b2, w.fine_start, w.fine_cursor,
                                                              w.tile_start, (K *)w.bufB, nullptr);
       NVT_CHECK_LAUNCH();
-      part_count_kernel<K, false><<<t3, kStageBS, 0, s>>>(
-          (const K *)w.bufB, nullptr, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
-          (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
-          state);
+      // path 1 buckets hold <= ~2.4k distinct keys: 4096-slot tables (32 KiB -> 4 WGs / CU)
+      if (path == 1)
+        part_count_kernel<K, false, NVT_P1_SLOTS, kCountBS><<<t3, kCountBS, 0, s>>>(
+            (const K *)w.bufB, nullptr, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
+            (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
+            state);
+      else
+        part_count_kernel<K, false, kLdsSlots, kCountBS><<<t3, kCountBS, 0, s>>>(
+            (const K *)w.bufB, nullptr, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
+            (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
+            state);
     }
     NVT_CHECK_LAUNCH();
     part_merge_kernel<K><<<1u << bits, kStageBS, 0, s>>>(w.chunk_start, w.pchunk_start,

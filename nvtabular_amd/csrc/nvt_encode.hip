@@ -87,6 +87,30 @@ __global__ __launch_bounds__(kBlock) void enc_build_kernel(const K *__restrict__
   }
 }
 
+// Vocabulary produced by fit: keys are unique, so an int32 slot {key,label} is claimed
+// and filled by ONE 64-bit CAS (half the atomics of the general build above).
+__global__ __launch_bounds__(kBlock) void enc_build_unique_i32_kernel(
+    const int32_t *__restrict__ vocab, uint64_t n, int64_t first_label, EncSlot<int32_t> *table,
+    uint64_t mask, int64_t *sentinel_label) {
+  const unsigned long long EMPTY_SLOT =
+      ((unsigned long long)(uint32_t)std::numeric_limits<int32_t>::max() << 32) |
+      (unsigned long long)(uint32_t)INT32_MIN;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int32_t key = vocab[i];
+    int64_t label = first_label + (int64_t)i;
+    if (key == INT32_MIN) {
+      *sentinel_label = label;
+      continue;
+    }
+    unsigned long long want = ((unsigned long long)(uint32_t)label << 32) | (uint32_t)key;
+    uint64_t slot = (uint64_t)slot_hash(key) & mask;
+    while (atomicCAS(reinterpret_cast<unsigned long long *>(&table[slot]), EMPTY_SLOT, want) !=
+           EMPTY_SLOT)
+      slot = (slot + 1) & mask;
+  }
+}
+
 template <typename K>
 __device__ __forceinline__ int64_t probe(const EncSlot<K> *__restrict__ table, uint64_t mask,
                                          K key) {
@@ -165,6 +189,192 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(
     out[i] = label_of(keys[i], bit_valid(valid, i));
 }
 
+// Encode with the head of the vocabulary staged in LDS.  The vocabulary is ordered by
+// frequency (categorify.py:1316), so its first entries are exactly the keys most rows
+// carry: each workgroup copies the first n_hot entries into a private LDS table and only
+// rows that miss it go to the global table in HBM.  A vocabulary that fits entirely
+// (n_vocab <= n_hot) never touches the global table: pure stream + LDS gathers.
+constexpr int kEncBS = 1024;
+template <typename K>
+struct HotCfg;
+template <>
+struct HotCfg<int32_t> {
+  static constexpr int slots = 16384;  // 128 KiB of {key,label} int32 pairs
+};
+template <>
+struct HotCfg<int64_t> {
+  static constexpr int slots = 8192;  // 128 KiB of {key,label} int64 pairs
+};
+
+template <typename K, typename OUT>
+__global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
+    int64_t null_label, int64_t oov_label, uint32_t num_buckets, OUT *__restrict__ out,
+    const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label, int global_needed) {
+  constexpr K EMPTY = EncTraits<K>::empty;
+  constexpr int VEC = EncTraits<K>::vec;
+  constexpr int SLOTS = HotCfg<K>::slots;
+  using L = decltype(EncSlot<K>::label);
+  using C = typename EncTraits<K>::cas_t;
+  __shared__ EncSlot<K> lt[SLOTS];
+  for (int i = threadIdx.x; i < SLOTS; i += kEncBS) {
+    lt[i].key = EMPTY;
+    lt[i].label = 0;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_hot; i += kEncBS) {
+    K key = hot_keys[i];
+    if (key == EMPTY) continue;
+    uint32_t s = (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
+    while (true) {
+      K prev = (K)atomicCAS(reinterpret_cast<C *>(&lt[s].key), (C)EMPTY, (C)key);
+      if (prev == EMPTY || prev == key) {
+        if (prev == EMPTY) lt[s].label = (L)(first_label + (int64_t)i);
+        break;
+      }
+      s = (s + 1) & (SLOTS - 1);
+    }
+  }
+  __syncthreads();
+  const int64_t sent = *sentinel_label;
+
+  // LDS lookup: label, or -1 when the key is not in the staged head of the vocabulary
+  auto hot_lookup = [&](K key) -> int64_t {
+    uint32_t s = (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
+    while (true) {
+      EncSlot<K> e = lt[s];
+      if (e.key == key) return (int64_t)e.label;
+      if (e.key == EMPTY) return -1;
+      s = (s + 1) & (SLOTS - 1);
+    }
+  };
+  auto finish = [&](K key, int64_t lab) -> OUT {
+    if (lab < 0) {
+      lab = oov_label;
+      if (num_buckets > 1) lab += (int64_t)(key_hash32((int64_t)key) % num_buckets);
+    }
+    return (OUT)lab;
+  };
+
+  const uint64_t nvec = n / VEC;
+  const uint64_t stride = (uint64_t)gridDim.x * kEncBS;
+  using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
+  const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
+  constexpr int U = 2;
+  constexpr int NK = U * VEC;
+  for (uint64_t v0 = (uint64_t)blockIdx.x * kEncBS + threadIdx.x; v0 < nvec; v0 += stride * U) {
+    VecT pack[U];
+    unsigned vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint64_t v = v0 + (uint64_t)u * stride;
+      vb[u] = 0;
+      if (v < nvec) {
+        pack[u] = vkeys[v];
+        vb[u] = 0xF;
+        if (valid != nullptr) {
+          uint64_t row = v * VEC;
+          vb[u] = (valid[row >> 3] >> (row & 7)) & ((1u << VEC) - 1u);
+        }
+        vb[u] |= 0x100;
+      }
+    }
+    K k[NK];
+    int64_t lab[NK];
+    bool need[NK];  // still unresolved: must probe the table in HBM
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (sizeof(K) == 4) {
+        k[u * VEC + 0] = pack[u].x;
+        k[u * VEC + 1] = pack[u].y;
+        k[u * VEC + 2] = pack[u].z;
+        k[u * VEC + 3] = pack[u].w;
+      } else {
+        k[u * VEC + 0] = pack[u].x;
+        k[u * VEC + 1] = pack[u].y;
+      }
+    }
+    // phase 1: LDS
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      const bool ok = (vb[q / VEC] & 0x100) && ((vb[q / VEC] >> (q % VEC)) & 1);
+      lab[q] = -1;
+      need[q] = false;
+      if (ok) {
+        if (k[q] == EMPTY) {
+          lab[q] = sent;
+        } else {
+          lab[q] = hot_lookup(k[q]);
+          need[q] = lab[q] < 0 && global_needed;
+        }
+      } else {
+        lab[q] = null_label;
+      }
+    }
+    // phase 2: first probe of every miss issued back to back (independent loads), so the
+    // HBM / Infinity-Cache latency is paid once per batch, not once per key
+    uint64_t slot[NK];
+    EncSlot<K> e[NK];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      slot[q] = (uint64_t)slot_hash(k[q]) & mask;
+      if (need[q]) e[q] = table[slot[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      if (!need[q]) continue;
+      while (true) {  // collisions continue here (load factor <= 0.5: short chains)
+        if (e[q].key == k[q]) {
+          lab[q] = (int64_t)e[q].label;
+          break;
+        }
+        if (e[q].key == EMPTY) break;
+        slot[q] = (slot[q] + 1) & mask;
+        e[q] = table[slot[q]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!(vb[u] & 0x100)) continue;
+      uint64_t v = v0 + (uint64_t)u * stride;
+      OUT r[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int q = u * VEC + j;
+        const bool ok = (vb[u] >> j) & 1;
+        r[j] = ok ? finish(k[q], lab[q]) : (OUT)null_label;
+      }
+      OUT *dst = out + v * VEC;
+      if constexpr (VEC * sizeof(OUT) == 32) {
+        int4 a, b;
+        memcpy(&a, &r[0], 16);
+        memcpy(&b, &r[2], 16);
+        reinterpret_cast<int4 *>(dst)[0] = a;
+        reinterpret_cast<int4 *>(dst)[1] = b;
+      } else if constexpr (VEC * sizeof(OUT) == 16) {
+        int4 a;
+        memcpy(&a, &r[0], 16);
+        reinterpret_cast<int4 *>(dst)[0] = a;
+      } else {
+        int2 a;
+        memcpy(&a, &r[0], 8);
+        reinterpret_cast<int2 *>(dst)[0] = a;
+      }
+    }
+  }
+  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kEncBS + threadIdx.x; i < n; i += stride) {
+    K key = keys[i];
+    OUT r = (OUT)null_label;
+    if (bit_valid(valid, i)) {
+      int64_t lab = key == EMPTY ? sent : hot_lookup(key);
+      if (lab < 0 && key != EMPTY && global_needed) lab = probe<K>(table, mask, key);
+      r = finish(key, lab);
+    }
+    out[i] = r;
+  }
+}
+
 template <typename K>
 __global__ __launch_bounds__(kBlock) void hash_bucket_kernel(const K *__restrict__ keys, uint64_t n,
                                                              uint32_t nb, int32_t *__restrict__ out,
@@ -211,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void hash_bucket_vec_kernel(const K *__rest
 
 template <typename K>
 int build_launch(const K *vocab, uint64_t n, int64_t first_label, void *table, uint64_t capacity,
-                 int64_t *sentinel_label, hipStream_t s) {
+                 int64_t *sentinel_label, int unique_keys, hipStream_t s) {
   NVT_CHECK_ARG(table && sentinel_label, "null table");
   NVT_CHECK_ARG(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be 2^k >= 64");
   NVT_CHECK_ARG(capacity > n, "capacity must exceed the vocabulary size");
@@ -222,6 +432,14 @@ int build_launch(const K *vocab, uint64_t n, int64_t first_label, void *table, u
   NVT_CHECK_LAUNCH();
   if (n) {
     NVT_CHECK_ARG(vocab, "null vocabulary");
+    if constexpr (sizeof(K) == 4) {
+      if (unique_keys) {
+        enc_build_unique_i32_kernel<<<stream_grid(n, kBlock), kBlock, 0, s>>>(
+            vocab, n, first_label, t, capacity - 1, sentinel_label);
+        NVT_CHECK_LAUNCH();
+        return NVT_OK;
+      }
+    }
     enc_build_kernel<K><<<stream_grid(n, kBlock), kBlock, 0, s>>>(vocab, n, first_label, t,
                                                                   capacity - 1, sentinel_label);
     NVT_CHECK_LAUNCH();
@@ -233,7 +451,7 @@ template <typename K>
 int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *table,
                   uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
-                  hipStream_t s) {
+                  const K *hot_keys, uint64_t n_vocab, int64_t first_label, hipStream_t s) {
   NVT_CHECK_ARG(table && sentinel_label, "null table");
   NVT_CHECK_ARG(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be 2^k >= 64");
   NVT_CHECK_ARG(out_bytes == 4 || out_bytes == 8, "out_bytes must be 4 or 8");
@@ -243,8 +461,25 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0,
                 "keys/out must be 16-byte aligned");
   constexpr int VEC = EncTraits<K>::vec;
-  unsigned grid = stream_grid(n / VEC + 1, kBlock * 2, 8);
   auto *t = reinterpret_cast<const EncSlot<K> *>(table);
+  if (hot_keys != nullptr && n_vocab > 0) {
+    // head of the frequency-ordered vocabulary in LDS (load factor <= 0.5)
+    const uint32_t n_hot = (uint32_t)(n_vocab < (uint64_t)HotCfg<K>::slots / 2
+                                          ? n_vocab : (uint64_t)HotCfg<K>::slots / 2);
+    const int global_needed = n_vocab > n_hot;
+    unsigned hgrid = stream_grid(n / VEC + 1, kEncBS * 2, 1);
+    if (out_bytes == 8)
+      encode_hot_kernel<K, int64_t><<<hgrid, kEncBS, 0, s>>>(
+          keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
+          reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label, global_needed);
+    else
+      encode_hot_kernel<K, int32_t><<<hgrid, kEncBS, 0, s>>>(
+          keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
+          reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label, global_needed);
+    NVT_CHECK_LAUNCH();
+    return NVT_OK;
+  }
+  unsigned grid = stream_grid(n / VEC + 1, kBlock * 2, 8);
   if (out_bytes == 8)
     encode_kernel<K, int64_t><<<grid, kBlock, 0, s>>>(keys, valid, n, t, capacity - 1,
                                                       sentinel_label, null_label, oov_label,
@@ -287,28 +522,34 @@ int nvt_encode_table_bytes(int key_bytes, uint64_t capacity, uint64_t *bytes) {
   return NVT_OK;
 }
 int nvt_encode_build_i32(const int32_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
-                         void *table, uint64_t capacity, int64_t *sentinel_label, void *stream) {
+                         void *table, uint64_t capacity, int64_t *sentinel_label, int unique_keys,
+                         void *stream) {
   return build_launch<int32_t>(vocab_keys, n_vocab, first_label, table, capacity, sentinel_label,
-                               (hipStream_t)stream);
+                               unique_keys, (hipStream_t)stream);
 }
 int nvt_encode_build_i64(const int64_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
-                         void *table, uint64_t capacity, int64_t *sentinel_label, void *stream) {
+                         void *table, uint64_t capacity, int64_t *sentinel_label, int unique_keys,
+                         void *stream) {
   return build_launch<int64_t>(vocab_keys, n_vocab, first_label, table, capacity, sentinel_label,
-                               (hipStream_t)stream);
+                               unique_keys, (hipStream_t)stream);
 }
 int nvt_encode_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, const void *table,
                    uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                    int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
+                   const int32_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
                    void *stream) {
   return encode_launch<int32_t>(keys, valid, n, table, capacity, sentinel_label, null_label,
-                                oov_label, num_buckets, out, out_bytes, (hipStream_t)stream);
+                                oov_label, num_buckets, out, out_bytes, vocab_keys, n_vocab,
+                                first_label, (hipStream_t)stream);
 }
 int nvt_encode_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, const void *table,
                    uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                    int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
+                   const int64_t *vocab_keys, uint64_t n_vocab, int64_t first_label,
                    void *stream) {
   return encode_launch<int64_t>(keys, valid, n, table, capacity, sentinel_label, null_label,
-                                oov_label, num_buckets, out, out_bytes, (hipStream_t)stream);
+                                oov_label, num_buckets, out, out_bytes, vocab_keys, n_vocab,
+                                first_label, (hipStream_t)stream);
 }
 int nvt_hash_bucket_i32(const int32_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
                         const uint64_t *xor_in, uint64_t *xor_out, void *stream) {

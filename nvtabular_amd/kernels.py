@@ -217,7 +217,7 @@ def count_into_new_table(
 # --------------------------------------------------------------------------
 PATH_S_MAX_DISTINCT = 11000         # path 0 (int32 keys, unweighted): 16384-slot LDS tables
 PATH_S_MAX_WEIGHTED = 5000          # path 0 for weighted merges / int64 keys: 8192 slots
-PATH_P1_MAX_DISTINCT = 10_000_000   # path 1: 64 x 64 buckets, <= ~2.4k distinct per bucket
+PATH_P1_MAX_DISTINCT = 9_000_000    # path 1: 64 x 64 buckets, 4096-slot LDS tables (<= 3072 keys)
 PATH_P2_MAX_DISTINCT = 45_000_000   # path 2: 64 x 256 buckets
 
 _ws_cache = {}
@@ -404,7 +404,7 @@ def vocab_sort(keys: torch.Tensor, counts: torch.Tensor, max_count: int = 0):
 class EncodeTable:
     """key -> label probe table built from an ordered vocabulary."""
 
-    def __init__(self, vocab_keys: torch.Tensor, first_label: int):
+    def __init__(self, vocab_keys: torch.Tensor, first_label: int, unique: bool = False):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.suffix = _key_suffix(vocab_keys)
@@ -419,12 +419,14 @@ class EncodeTable:
         self.table = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         self.sentinel_label = torch.empty(1, dtype=torch.int64, device=dev)
         vk = vocab_keys.contiguous()
+        # kept: the head of the (frequency-ordered, duplicate-free) vocabulary is staged in LDS
+        self.vocab_keys = vk if unique else None
         with _timed("encode_build", 0):
             check(
                 getattr(self.lib, f"nvt_encode_build_{self.suffix}")(
                     vk.data_ptr() if self.n_vocab else None, self.n_vocab, self.first_label,
                     self.table.data_ptr(), self.capacity, self.sentinel_label.data_ptr(),
-                    stream_ptr(),
+                    1 if unique else 0, stream_ptr(),
                 ),
                 "nvt_encode_build",
             )
@@ -450,6 +452,8 @@ class EncodeTable:
                     keys.data_ptr(), ptr(valid), keys.numel(), self.table.data_ptr(),
                     self.capacity, self.sentinel_label.data_ptr(), int(null_label),
                     int(oov_label), int(num_buckets or 0), out.data_ptr(), out.element_size(),
+                    ptr(self.vocab_keys) if self.n_vocab else None,
+                    self.n_vocab if self.vocab_keys is not None else 0, self.first_label,
                     stream_ptr(),
                 ),
                 "nvt_encode",

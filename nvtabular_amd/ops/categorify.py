@@ -512,7 +512,7 @@ class Categorify(StatOperator):
                 c not in frame or frame[c].data.dtype == torch.int32 for c in self._group_cols(storage_name, cols)
             )
             kt = torch.from_numpy(keys[0].astype(np.int32 if i32 else np.int64)).to(dev)
-            enc = _build_encoder([kt], None, start, False)
+            enc = _build_encoder([kt], None, start, False, unique=not pd.Series(keys[0]).duplicated().any())
         else:
             enc = _build_encoder(
                 [torch.from_numpy(k).to(dev) for k in keys], torch.from_numpy(nm).to(dev), start, True
@@ -725,10 +725,11 @@ class _ComboEncoder:
         return DeviceColumn(labels.to(out_dtype))
 
 
-def _build_encoder(keys, null_mask, first_label, combo):
+def _build_encoder(keys, null_mask, first_label, combo, unique=True):
     if combo:
         return _ComboEncoder(keys, null_mask, first_label)
-    return _SingleEncoder(K.EncodeTable(keys[0].contiguous(), first_label), first_label)
+    return _SingleEncoder(K.EncodeTable(keys[0].contiguous(), first_label, unique=unique),
+                          first_label)
 
 
 def _get_embeddings(paths, cat_names, buckets=0, pending=None):
