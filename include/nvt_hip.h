@@ -96,9 +96,9 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
                           int64_t *out_counts, uint64_t *out_n, void *stream);
 
 /* ---- Categorify.fit, atomic-free: key column -> dense (key,count) list ----
- * path 0: <= ~6000 distinct keys, three LDS-table stages (512 -> 16 -> 1 workgroups);
- * path 1 / 2: hash-partition the rows into 64 x 64 / 64 x 256 buckets, then one LDS
- * table per bucket.  weights (optional, int64 per row) turns the count into a weighted
+ * path 0: <= ~11000 distinct keys, LDS-table stages (256 -> 32 -> 4 -> 1 workgroups);
+ * path 1 / 2 / 3: hash-partition the rows into 256 / 64 x 64 / 64 x 256 buckets, then one
+ * LDS table per bucket (chunked + merged when a hot key makes a bucket huge).  weights (optional, int64 per row) turns the count into a weighted
  * sum -- the tree-merge of (key,count) lists (_mid_level_groupby).  ws: device scratch
  * of nvt_dense_count_ws_bytes().  state (device uint64[NVT_STATE_WORDS], written):
  * [NVT_ST_NULLS] null rows (weighted), [NVT_ST_SENTINEL] rows whose key is the empty

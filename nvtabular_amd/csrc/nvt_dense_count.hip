@@ -62,7 +62,7 @@ constexpr int kLdsSlots = 8192;     // weighted stages / per-bucket tables (u64 
 constexpr int kLdsSlotsBig = 16384; // unweighted path S: int32 key + u32 count = 128 KiB, 1 WG / CU
 constexpr int kLdsProbe = 512;  // linear-probing clusters reach ~25 slots at 37 % load; the real
                                 // "table full" signal is lfill > max_fill, not the chain length
-constexpr int kLdsMaxFill = 6144;   // 75 % of kLdsSlots: beyond this the table is declared full
+
 __host__ __device__ constexpr int max_fill(int slots) { return slots / 4 * 3; }
 
 template <typename K>
@@ -376,26 +376,53 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const K *__restrict__ k
   __syncthreads();
   unsigned long long nulls = 0;
   const uint64_t stride = (uint64_t)gridDim.x * 1024;
-  constexpr int U = 8;  // independent loads in flight per lane
-  for (uint64_t i0 = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += stride * U) {
-    K k[U];
-    bool ok[U];
+  constexpr int VEC = DKey<K>::vec;
+  constexpr int U = 4;  // independent 16-byte loads in flight per lane
+  using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
+  const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
+  const uint64_t nvec = n / VEC;
+  for (uint64_t v0 = (uint64_t)blockIdx.x * 1024 + threadIdx.x; v0 < nvec; v0 += stride * U) {
+    VecT pack[U];
+    unsigned vb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      uint64_t i = i0 + (uint64_t)u * stride;
-      ok[u] = false;
-      if (i < n) {
-        if (bit_valid(valid, i)) {
-          k[u] = keys[i];
-          ok[u] = true;
+      const uint64_t v = v0 + (uint64_t)u * stride;
+      vb[u] = 0x100;  // out of range marker
+      if (v < nvec) {
+        pack[u] = vkeys[v];
+        const uint64_t row = v * VEC;
+        vb[u] = valid ? (valid[row >> 3] >> (row & 7)) & ((1u << VEC) - 1u) : (1u << VEC) - 1u;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (vb[u] & 0x100) continue;
+      K kv[VEC];
+      if constexpr (sizeof(K) == 4) {
+        kv[0] = pack[u].x;
+        kv[1] = pack[u].y;
+        kv[2] = pack[u].z;
+        kv[3] = pack[u].w;
+      } else {
+        kv[0] = pack[u].x;
+        kv[1] = pack[u].y;
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if ((vb[u] >> j) & 1) {
+          atomicAdd(&h[part_hash<K>(kv[j]) >> (32 - bits)], 1u);
         } else {
+          const uint64_t i = (v0 + (uint64_t)u * stride) * VEC + j;
           nulls += weights ? (unsigned long long)weights[i] : 1ull;
         }
       }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (ok[u]) atomicAdd(&h[part_hash<K>(k[u]) >> (32 - bits)], 1u);
+  }
+  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) {
+    if (bit_valid(valid, i))
+      atomicAdd(&h[part_hash<K>(keys[i]) >> (32 - bits)], 1u);
+    else
+      nulls += weights ? (unsigned long long)weights[i] : 1ull;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nb; i += 1024) block_hist[(uint64_t)blockIdx.x * nb + i] = h[i];
@@ -433,7 +460,8 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const unsigned long lon
                                                          unsigned long long *coarse_cursor,
                                                          unsigned *tile_start,
                                                          unsigned *chunk_start,
-                                                         unsigned *pchunk_start) {
+                                                         unsigned *pchunk_start,
+                                                         unsigned long long chunk_rows) {
   __shared__ unsigned long long wsum[16];
   __shared__ unsigned long long carry;
   const int nb = 1 << bits;
@@ -484,7 +512,7 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const unsigned long lon
   for (int base = 0; base < nb; base += 1024) {
     int f = base + threadIdx.x;
     unsigned long long sz = f < nb ? fine_start[f + 1] - fine_start[f] : 0;
-    unsigned long long k = (sz + kChunk - 1) / kChunk;
+    unsigned long long k = (sz + chunk_rows - 1) / chunk_rows;
     unsigned long long v0 = k, v1 = (k > 1) ? k : 0, i0 = v0, i1 = v1;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -576,16 +604,67 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
   K k[ROWS];
   unsigned pos[ROWS];
   unsigned short bk[ROWS];
+  // row handled by register slot r.  LEVEL 1 reads the (16-byte aligned) input column with
+  // one 16-byte load per lane and takes the VEC validity bits from a single bitmap byte;
+  // LEVEL 2 segments start anywhere, so they are read element-wise.
+  constexpr int VEC = DKey<K>::vec;
+  auto row_of = [&](int r) -> uint64_t {
+    if (LEVEL == 1) return lo + ((uint64_t)(r / VEC) * kBlock + threadIdx.x) * VEC + (r % VEC);
+    return lo + (uint64_t)r * kBlock + threadIdx.x;
+  };
+  if (LEVEL == 1) {
+    using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    uint64_t i = lo + (uint64_t)r * kBlock + threadIdx.x;
-    bool ok = i < hi && (LEVEL == 2 || bit_valid(valid, i));
-    bk[r] = 0xFFFF;
-    if (ok) {
-      k[r] = keys[i];
-      unsigned b = (part_hash<K>(k[r]) >> shift) & mask;
-      bk[r] = (unsigned short)b;
-      pos[r] = atomicAdd(&lcnt[b], 1u);
+    for (int u = 0; u < ROWS / VEC; ++u) {
+      const uint64_t i0 = row_of(u * VEC);
+      unsigned vb = 0;
+      K kv[VEC];
+      if (i0 + VEC <= hi) {
+        VecT pack = *reinterpret_cast<const VecT *>(keys + i0);
+        if constexpr (sizeof(K) == 4) {
+          kv[0] = pack.x;
+          kv[1] = pack.y;
+          kv[2] = pack.z;
+          kv[3] = pack.w;
+        } else {
+          kv[0] = pack.x;
+          kv[1] = pack.y;
+        }
+        vb = valid ? (valid[i0 >> 3] >> (i0 & 7)) & ((1u << VEC) - 1u) : (1u << VEC) - 1u;
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          kv[j] = 0;
+          if (i0 + j < hi && bit_valid(valid, i0 + j)) {
+            kv[j] = keys[i0 + j];
+            vb |= 1u << j;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int r = u * VEC + j;
+        bk[r] = 0xFFFF;
+        k[r] = kv[j];
+        if ((vb >> j) & 1) {
+          unsigned b = (part_hash<K>(kv[j]) >> shift) & mask;
+          bk[r] = (unsigned short)b;
+          pos[r] = atomicAdd(&lcnt[b], 1u);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      uint64_t i = row_of(r);
+      bool ok = i < hi;
+      bk[r] = 0xFFFF;
+      if (ok) {
+        k[r] = keys[i];
+        unsigned b = (part_hash<K>(k[r]) >> shift) & mask;
+        bk[r] = (unsigned short)b;
+        pos[r] = atomicAdd(&lcnt[b], 1u);
+      }
     }
   }
   __syncthreads();
@@ -625,10 +704,7 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
     // weights ride along: same destination, recomputed from (bucket, pos)
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-      if (bk[r] != 0xFFFF) {
-        uint64_t i = lo + (uint64_t)r * kBlock + threadIdx.x;
-        out_w[gbase[bk[r]] + pos[r]] = weights[i];
-      }
+      if (bk[r] != 0xFFFF) out_w[gbase[bk[r]] + pos[r]] = weights[row_of(r)];
     }
   }
 }
@@ -639,9 +715,9 @@ template <typename K, bool WEIGHTED, int SLOTS, int BS>
 __global__ __launch_bounds__(BS) void part_count_kernel(
     const K *__restrict__ keys, const int64_t *__restrict__ weights,
     const unsigned long long *__restrict__ fine_start, const unsigned *__restrict__ chunk_start,
-    const unsigned *__restrict__ pchunk_start, int nb, K *part_keys, int64_t *part_cnt,
-    unsigned *part_len, K *out_keys, int64_t *out_cnt, uint64_t out_cap, unsigned long long *cursor,
-    uint64_t *state) {
+    const unsigned *__restrict__ pchunk_start, int nb, uint64_t chunk_rows, K *part_keys,
+    int64_t *part_cnt, unsigned *part_len, K *out_keys, int64_t *out_cnt, uint64_t out_cap,
+    unsigned long long *cursor, uint64_t *state) {
   constexpr K EMPTY = DKey<K>::empty;
   using C = typename std::conditional<WEIGHTED, unsigned long long, unsigned>::type;
   __shared__ K lkeys[SLOTS];
@@ -673,9 +749,9 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
   if (f < 0) return;
   const unsigned j = blockIdx.x - chunk_start[f];
   const unsigned nchunks = chunk_start[f + 1] - chunk_start[f];
-  const uint64_t lo = fine_start[f] + (uint64_t)j * kChunk;
+  const uint64_t lo = fine_start[f] + (uint64_t)j * chunk_rows;
   const uint64_t end = fine_start[f + 1];
-  const uint64_t hi = lo + kChunk < end ? lo + kChunk : end;
+  const uint64_t hi = lo + chunk_rows < end ? lo + chunk_rows : end;
   bool failed = false;
   unsigned long long my_sent = 0;
   constexpr int U = 8;
@@ -717,27 +793,27 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
     lds_flush<K, C, BS, SLOTS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
   } else {
     const uint64_t region = (uint64_t)(pchunk_start[f] + j);
-    lds_flush_region<K, C, BS, SLOTS>(lkeys, lcnt, part_keys + region * kLdsMaxFill,
-                           part_cnt + region * kLdsMaxFill, &part_len[region]);
+    lds_flush_region<K, C, BS, SLOTS>(lkeys, lcnt, part_keys + region * max_fill(SLOTS),
+                                      part_cnt + region * max_fill(SLOTS), &part_len[region]);
   }
 }
 
-// P4: one workgroup per split bucket merges that bucket's per-chunk partial lists.
-template <typename K>
+// P4: one workgroup per split bucket merges that bucket's per-chunk partial lists (same
+// table geometry as P3, so whatever fitted there fits here).
+template <typename K, typename C, int SLOTS>
 __global__ __launch_bounds__(kStageBS) void part_merge_kernel(
     const unsigned *__restrict__ chunk_start, const unsigned *__restrict__ pchunk_start,
     const K *__restrict__ part_keys, const int64_t *__restrict__ part_cnt,
     const unsigned *__restrict__ part_len, K *out_keys, int64_t *out_cnt, uint64_t out_cap,
     unsigned long long *cursor, uint64_t *state) {
   constexpr K EMPTY = DKey<K>::empty;
-  using C = unsigned long long;
   const int f = blockIdx.x;
   const unsigned nchunks = chunk_start[f + 1] - chunk_start[f];
   if (nchunks <= 1) return;
-  __shared__ K lkeys[kLdsSlots];
-  __shared__ C lcnt[kLdsSlots];
+  __shared__ K lkeys[SLOTS];
+  __shared__ C lcnt[SLOTS];
   __shared__ unsigned lfill, lovf;
-  for (int i = threadIdx.x; i < kLdsSlots; i += kStageBS) {
+  for (int i = threadIdx.x; i < SLOTS; i += kStageBS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
   }
@@ -750,21 +826,38 @@ __global__ __launch_bounds__(kStageBS) void part_merge_kernel(
   for (unsigned j = 0; j < nchunks; ++j) {
     const uint64_t region = (uint64_t)(pchunk_start[f] + j);
     const unsigned len = part_len[region];
-    const K *pk = part_keys + region * kLdsMaxFill;
-    const int64_t *pc = part_cnt + region * kLdsMaxFill;
+    const K *pk = part_keys + region * max_fill(SLOTS);
+    const int64_t *pc = part_cnt + region * max_fill(SLOTS);
     for (unsigned i = threadIdx.x; i < len; i += kStageBS)
-      if (!lds_add<K, C>(lkeys, lcnt, &lfill, pk[i], (C)pc[i], part_hash<K>(pk[i]))) failed = true;
+      if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, pk[i], (C)pc[i], part_hash<K>(pk[i])))
+        failed = true;
   }
   if (failed) atomicOr(&lovf, 1u);
   __syncthreads();
-  if (lovf || lfill > kLdsMaxFill) {
+  if (lovf || lfill > (unsigned)max_fill(SLOTS)) {
     if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
     return;
   }
-  lds_flush<K, C, kStageBS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+  lds_flush<K, C, kStageBS, SLOTS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
 }
 
 inline uint64_t align16(uint64_t x) { return (x + 15) & ~15ull; }
+
+// Partitioned paths:
+//   1: ONE level, 256 buckets, 16384-slot tables (int32 keys, unweighted; 8192 otherwise):
+//      up to ~2.5 M distinct keys with a single scatter pass;
+//   2: 64 x 64 buckets, 4096-slot tables (8192 when weighted)      up to ~9 M distinct;
+//   3: 64 x 256 buckets, 8192-slot tables                          up to ~32 M distinct.
+struct PathCfg {
+  int b1, b2, slots;
+  uint64_t chunk_rows;
+};
+inline PathCfg path_cfg(int path, int key_bytes, int weighted) {
+  const bool small = weighted || key_bytes == 8;
+  if (path == 1) return {8, 0, small ? kLdsSlots : kLdsSlotsBig, 1ull << 17};
+  if (path == 2) return {6, 6, weighted ? kLdsSlots : 4096, (uint64_t)kChunk};
+  return {6, 8, kLdsSlots, (uint64_t)kChunk};
+}
 
 struct DenseWs {
   // path S
@@ -822,11 +915,12 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
     w.totals = (unsigned long long *)take((uint64_t)kMaxFine * 8);
     w.chunk_start = (unsigned *)take((kMaxFine + 1) * 4);
     w.pchunk_start = (unsigned *)take((kMaxFine + 1) * 4);
-    // split buckets have >= 2 chunks, all but the last full: at most 2n / kChunk regions
-    w.max_regions = 2 * (n / kChunk) + 2;
+    // split buckets have >= 2 chunks, all but the last full: at most 2n / chunk_rows regions
+    const PathCfg cfg = path_cfg(path, key_bytes, weighted);
+    w.max_regions = 2 * (n / cfg.chunk_rows) + 2;
     w.part_len = (unsigned *)take(w.max_regions * 4);
-    w.part_keys = take(w.max_regions * kLdsMaxFill * key_bytes);
-    w.part_cnt = (int64_t *)take(w.max_regions * kLdsMaxFill * 8);
+    w.part_keys = take(w.max_regions * max_fill(cfg.slots) * key_bytes);
+    w.part_cnt = (int64_t *)take(w.max_regions * max_fill(cfg.slots) * 8);
   }
   if (ws) *ws = w;
   return off;
@@ -837,7 +931,7 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                 void *wsp, K *out_keys, int64_t *out_cnt, uint64_t out_cap, uint64_t *state,
                 hipStream_t s) {
   NVT_CHECK_ARG(state && wsp, "null state/workspace");
-  NVT_CHECK_ARG(path >= 0 && path <= 2, "path must be 0 (LDS), 1 (64 x 64 buckets) or 2 (64 x 256)");
+  NVT_CHECK_ARG(path >= 0 && path <= 3, "path must be 0 (LDS), 1 (256 buckets), 2 (64 x 64) or 3 (64 x 256)");
   NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
   NVT_CHECK_ARG(n == 0 || (keys && out_keys && out_cnt), "null keys/out");
   NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 rows per call (32-bit LDS counters)");
@@ -887,60 +981,76 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
       NVT_CHECK_LAUNCH();
     }
   } else {
-    const int b1 = 6, b2 = (path == 1) ? 6 : 8, bits = b1 + b2;
+    const PathCfg cfg = path_cfg(path, (int)sizeof(K), weights != nullptr);
+    const int b1 = cfg.b1, b2 = cfg.b2, bits = b1 + b2;
+    const uint64_t chunk_rows = cfg.chunk_rows;
     part_hist_kernel<K><<<kHistBlocks, 1024, 0, s>>>(keys, valid, weights, n, bits, w.block_hist,
                                                        state);
     NVT_CHECK_LAUNCH();
-    part_reduce_kernel<<<(1 << bits) / 64, kBlock, 0, s>>>(w.block_hist, kHistBlocks, 1 << bits,
-                                                               w.totals);
+    part_reduce_kernel<<<((1 << bits) + 63) / 64, kBlock, 0, s>>>(w.block_hist, kHistBlocks,
+                                                                  1 << bits, w.totals);
     NVT_CHECK_LAUNCH();
     part_scan_kernel<<<1, 1024, 0, s>>>(w.totals, bits, b1, w.fine_start, w.fine_cursor,
                                         w.coarse_cursor, w.tile_start, w.chunk_start,
-                                        w.pchunk_start);
+                                        w.pchunk_start, chunk_rows);
     NVT_CHECK_LAUNCH();
     const unsigned t1 = (unsigned)((n + kTile - 1) / kTile);
     const unsigned t2 = t1 + (1u << b1);  // upper bound: every coarse bucket rounds up once
-    const unsigned t3 = (unsigned)(n / kChunk) + (1u << bits);  // upper bound on P3 chunks
+    const unsigned t3 = (unsigned)(n / chunk_rows) + (1u << bits);  // upper bound on P3 chunks
+    const K *fine_keys;
+    const int64_t *fine_w = nullptr;
     if (weights) {
       part_scatter_kernel<K, 1, true><<<t1, kBlock, 0, s>>>(keys, valid, weights, n, b1, b1,
                                                             w.fine_start, w.coarse_cursor,
                                                             w.tile_start, (K *)w.bufA, w.wA);
       NVT_CHECK_LAUNCH();
-      part_scatter_kernel<K, 2, true><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, w.wA, n, b1,
-                                                            b2, w.fine_start, w.fine_cursor,
-                                                            w.tile_start, (K *)w.bufB, w.wB);
-      NVT_CHECK_LAUNCH();
-      part_count_kernel<K, true, kLdsSlots, kCountBS><<<t3, kCountBS, 0, s>>>(
-          (const K *)w.bufB, w.wB, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
-          (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
-          state);
+      fine_keys = (const K *)w.bufA;
+      fine_w = w.wA;
+      if (b2) {
+        part_scatter_kernel<K, 2, true><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, w.wA, n,
+                                                              b1, b2, w.fine_start, w.fine_cursor,
+                                                              w.tile_start, (K *)w.bufB, w.wB);
+        NVT_CHECK_LAUNCH();
+        fine_keys = (const K *)w.bufB;
+        fine_w = w.wB;
+      }
     } else {
       part_scatter_kernel<K, 1, false><<<t1, kBlock, 0, s>>>(keys, valid, nullptr, n, b1, b1,
                                                              w.fine_start, w.coarse_cursor,
                                                              w.tile_start, (K *)w.bufA, nullptr);
       NVT_CHECK_LAUNCH();
-      part_scatter_kernel<K, 2, false><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, nullptr, n,
-                                                             b1, b2, w.fine_start, w.fine_cursor,
-                                                             w.tile_start, (K *)w.bufB, nullptr);
-      NVT_CHECK_LAUNCH();
-      // path 1 buckets hold <= ~2.4k distinct keys: 4096-slot tables (32 KiB -> 4 WGs / CU)
-      if (path == 1)
-        part_count_kernel<K, false, NVT_P1_SLOTS, kCountBS><<<t3, kCountBS, 0, s>>>(
-            (const K *)w.bufB, nullptr, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
-            (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
-            state);
-      else
-        part_count_kernel<K, false, kLdsSlots, kCountBS><<<t3, kCountBS, 0, s>>>(
-            (const K *)w.bufB, nullptr, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits,
-            (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],
-            state);
+      fine_keys = (const K *)w.bufA;
+      if (b2) {
+        part_scatter_kernel<K, 2, false><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, nullptr,
+                                                               n, b1, b2, w.fine_start,
+                                                               w.fine_cursor, w.tile_start,
+                                                               (K *)w.bufB, nullptr);
+        NVT_CHECK_LAUNCH();
+        fine_keys = (const K *)w.bufB;
+      }
     }
-    NVT_CHECK_LAUNCH();
-    part_merge_kernel<K><<<1u << bits, kStageBS, 0, s>>>(w.chunk_start, w.pchunk_start,
-                                                       (const K *)w.part_keys, w.part_cnt,
-                                                       w.part_len, out_keys, out_cnt, out_cap,
-                                                       &cur[DS_OUT], state);
-    NVT_CHECK_LAUNCH();
+#define NVT_P3P4(WEIGHTED, C, SLOTS, BS)                                                          \
+  do {                                                                                            \
+    part_count_kernel<K, WEIGHTED, SLOTS, BS><<<t3, BS, 0, s>>>(                                  \
+        fine_keys, fine_w, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits, chunk_rows,    \
+        (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],       \
+        state);                                                                                   \
+    NVT_CHECK_LAUNCH();                                                                           \
+    part_merge_kernel<K, C, SLOTS><<<1u << bits, kStageBS, 0, s>>>(                               \
+        w.chunk_start, w.pchunk_start, (const K *)w.part_keys, w.part_cnt, w.part_len, out_keys,  \
+        out_cnt, out_cap, &cur[DS_OUT], state);                                                   \
+    NVT_CHECK_LAUNCH();                                                                           \
+  } while (0)
+    if (weights) {
+      NVT_P3P4(true, unsigned long long, kLdsSlots, kCountBS);
+    } else if (cfg.slots == kLdsSlotsBig) {
+      if constexpr (sizeof(K) == 4) NVT_P3P4(false, unsigned, kLdsSlotsBig, 1024);
+    } else if (cfg.slots == 4096) {
+      NVT_P3P4(false, unsigned, 4096, kCountBS);
+    } else {
+      NVT_P3P4(false, unsigned, kLdsSlots, kCountBS);
+    }
+#undef NVT_P3P4
   }
   return NVT_OK;
 }
@@ -953,7 +1063,7 @@ extern "C" {
 
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
-  NVT_CHECK_ARG(path >= 0 && path <= 2, "path must be 0, 1 or 2");
+  NVT_CHECK_ARG(path >= 0 && path <= 3, "path must be 0..3");
   *bytes = dense_ws_layout(key_bytes, n, path, weighted, nullptr, nullptr) + 64;
   return NVT_OK;
 }

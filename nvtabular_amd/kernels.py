@@ -217,8 +217,11 @@ def count_into_new_table(
 # --------------------------------------------------------------------------
 PATH_S_MAX_DISTINCT = 11000         # path 0 (int32 keys, unweighted): 16384-slot LDS tables
 PATH_S_MAX_WEIGHTED = 5000          # path 0 for weighted merges / int64 keys: 8192 slots
-PATH_P1_MAX_DISTINCT = 9_000_000    # path 1: 64 x 64 buckets, 4096-slot LDS tables (<= 3072 keys)
-PATH_P2_MAX_DISTINCT = 45_000_000   # path 2: 64 x 256 buckets
+PATH_P1_MAX_DISTINCT = 2_400_000    # path 1: ONE level, 256 buckets x 16384-slot tables (int32)
+PATH_P1_MAX_SMALL = 1_100_000       #         ... 8192-slot tables (int64 keys / weighted merges)
+PATH_P2_MAX_DISTINCT = 9_000_000    # path 2: 64 x 64 buckets, 4096-slot tables
+PATH_P2_MAX_WEIGHTED = 18_000_000   #         weighted: 8192-slot tables
+PATH_P3_MAX_DISTINCT = 32_000_000   # path 3: 64 x 256 buckets, 8192-slot tables
 
 _ws_cache = {}
 
@@ -237,11 +240,13 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 def _path_for(hint: int, small_tables: bool = False) -> int:
     if hint <= (PATH_S_MAX_WEIGHTED if small_tables else PATH_S_MAX_DISTINCT):
         return 0
-    if hint <= PATH_P1_MAX_DISTINCT:
+    if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
         return 1
     if hint <= PATH_P2_MAX_DISTINCT:
         return 2
-    return 3  # global-table fallback
+    if hint <= PATH_P3_MAX_DISTINCT:
+        return 3
+    return 4  # global-table fallback
 
 
 class DenseCountJob:
@@ -291,7 +296,7 @@ class DenseCountJob:
         ovf = st[_lib.ST_OVERFLOW]
         if ovf & 1:
             self.path += 1
-            if self.path > 2:
+            if self.path > 3:
                 self._fallback()
                 return True
             return False
@@ -320,7 +325,7 @@ class DenseCountJob:
         k, c = tab.compact()
         mx = int(c.max().item()) if c.numel() else 0
         self.result = (k, c, st[_lib.ST_NULLS],
-                       dict(path=3, distinct=int(k.numel()), max_count=mx, rows=self.n))
+                       dict(path=4, distinct=int(k.numel()), max_count=mx, rows=self.n))
 
 
 def dense_count_many(jobs):

@@ -483,18 +483,20 @@ def test_dense_count_paths_vs_numpy(dtype, card, n, weighted):
     keys = torch.from_numpy(ids).cuda()
     valid = torch.from_numpy(pack_bitmap(~mask)).cuda()
     wt = torch.from_numpy(w).cuda() if weighted else None
-    seen_paths = set()
-    for hint in (0, 5000, 2_000_000, 20_000_000):
-        k, c, nulls, info = K.dense_count(keys, valid, wt, hint=hint)
-        seen_paths.add(info["path"])
-        ww = w if weighted else np.ones(n, dtype="int64")
-        exp = pd.Series(ww[~mask]).groupby(ids[~mask]).sum()
+    ww = w if weighted else np.ones(n, dtype="int64")
+    exp = pd.Series(ww[~mask]).groupby(ids[~mask]).sum()
+    distinct = len(exp)
+    for path in (0, 1, 2, 3):
+        job = K.DenseCountJob(keys, valid, wt, hint=distinct)
+        job.path = path  # force every kernel path (the driver escalates 0 -> 1 on overflow)
+        k, c, nulls, info = K.dense_count_many([job])[0]
+        assert info["path"] >= path and (info["path"] == path or path == 0)
         got = pd.Series(c.cpu().numpy(), index=k.cpu().numpy()).sort_index()
         assert got.index.is_unique
         np.testing.assert_array_equal(got.index.to_numpy(), exp.index.to_numpy())
         np.testing.assert_array_equal(got.to_numpy(), exp.to_numpy())
         assert nulls == int(ww[mask].sum())
-    assert seen_paths >= ({1, 2} if card > 5000 else {0, 1, 2})
+        assert info["max_count"] >= int(exp.max()) and info["rows"] == n
 
 
 @pytest.mark.parametrize("dtype", ["int32", "int64"])
