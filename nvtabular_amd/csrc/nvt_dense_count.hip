@@ -260,20 +260,18 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         uint64_t v = v0 + (uint64_t)u * stride;
-        vb[u] = 0;
+        vb[u] = 0x10000;  // out of range
         if (v < nvec) {
           pack[u] = vkeys[v];
-          vb[u] = 0xF;
-          if (valid != nullptr) {
-            uint64_t row = v * VEC;
-            vb[u] = (valid[row >> 3] >> (row & 7)) & ((1u << VEC) - 1u);
-          }
-          vb[u] |= 0x100;  // in range
+          vb[u] = valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu;  // raw byte, shifted later
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (!(vb[u] & 0x100)) vb[u] = 0xF0000;  // out of range: no valid rows, no nulls either
+        if (vb[u] & 0x10000)
+          vb[u] = 0xF0000;  // out of range: no valid rows, no nulls either
+        else
+          vb[u] = (vb[u] >> (((v0 + (uint64_t)u * stride) * VEC) & 7)) & ((1u << VEC) - 1u);
         K k[VEC];
         if constexpr (sizeof(K) == 4) {
           k[0] = pack[u].x;
@@ -387,16 +385,18 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const K *__restrict__ k
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t v = v0 + (uint64_t)u * stride;
-      vb[u] = 0x100;  // out of range marker
+      vb[u] = 0x10000;  // out of range marker
       if (v < nvec) {
         pack[u] = vkeys[v];
-        const uint64_t row = v * VEC;
-        vb[u] = valid ? (valid[row >> 3] >> (row & 7)) & ((1u << VEC) - 1u) : (1u << VEC) - 1u;
+        // raw bitmap byte only: shifting it here would make the compiler wait for this load
+        // before issuing the next one and serialise the whole batch
+        vb[u] = valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu;
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (vb[u] & 0x100) continue;
+      if (vb[u] & 0x10000) continue;
+      vb[u] = (vb[u] >> (((v0 + (uint64_t)u * stride) * VEC) & 7)) & ((1u << VEC) - 1u);
       K kv[VEC];
       if constexpr (sizeof(K) == 4) {
         kv[0] = pack[u].x;
@@ -408,13 +408,17 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const K *__restrict__ k
         kv[1] = pack[u].y;
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        if ((vb[u] >> j) & 1) {
-          atomicAdd(&h[part_hash<K>(kv[j]) >> (32 - bits)], 1u);
-        } else {
-          const uint64_t i = (v0 + (uint64_t)u * stride) * VEC + j;
-          nulls += weights ? (unsigned long long)weights[i] : 1ull;
-        }
+      for (int j = 0; j < VEC; ++j)
+        if ((vb[u] >> j) & 1) atomicAdd(&h[part_hash<K>(kv[j]) >> (32 - bits)], 1u);
+      // nulls: one popcount per vector (a per-row else-branch here tripled the kernel time
+      // on columns with nulls); the weighted form only occurs in list merges
+      const unsigned nmask = (~vb[u]) & ((1u << VEC) - 1u);
+      if (weights == nullptr) {
+        nulls += __popc(nmask);
+      } else if (nmask) {
+        for (int j = 0; j < VEC; ++j)
+          if ((nmask >> j) & 1)
+            nulls += (unsigned long long)weights[(v0 + (uint64_t)u * stride) * VEC + j];
       }
     }
   }
@@ -426,9 +430,14 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const K *__restrict__ k
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nb; i += 1024) block_hist[(uint64_t)blockIdx.x * nb + i] = h[i];
-  double dn = wave_sum((double)nulls);
-  if (lane_id() == 0 && dn > 0)
-    atomicAdd((unsigned long long *)&state[DS_NULLS], (unsigned long long)dn);
+  // one device atomic per WORKGROUP (an atomic per wave on this single word serialised at the
+  // memory side: +85 us on every column that has nulls)
+  __shared__ unsigned long long s_nulls;
+  if (threadIdx.x == 0) s_nulls = 0;
+  __syncthreads();
+  if (nulls) atomicAdd(&s_nulls, nulls);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_nulls) atomicAdd((unsigned long long *)&state[DS_NULLS], s_nulls);
   if (blockIdx.x == 0 && threadIdx.x == 0)
     atomicAdd((unsigned long long *)&state[DS_ROWS], (unsigned long long)n);
 }
@@ -614,23 +623,36 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
   };
   if (LEVEL == 1) {
     using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
+    constexpr int NV = ROWS / VEC;
+    VecT pack[NV];
+    unsigned vraw[NV];
+    // phase 1: issue every load of the tile (keys + raw bitmap bytes), no dependent math
 #pragma unroll
-    for (int u = 0; u < ROWS / VEC; ++u) {
+    for (int u = 0; u < NV; ++u) {
+      const uint64_t i0 = row_of(u * VEC);
+      vraw[u] = 0x10000;  // not a full in-range vector
+      if (i0 + VEC <= hi) {
+        pack[u] = *reinterpret_cast<const VecT *>(keys + i0);
+        vraw[u] = valid ? (unsigned)valid[i0 >> 3] : 0xFFu;
+      }
+    }
+    // phase 2: bucket + rank
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
       const uint64_t i0 = row_of(u * VEC);
       unsigned vb = 0;
       K kv[VEC];
-      if (i0 + VEC <= hi) {
-        VecT pack = *reinterpret_cast<const VecT *>(keys + i0);
+      if (!(vraw[u] & 0x10000)) {
         if constexpr (sizeof(K) == 4) {
-          kv[0] = pack.x;
-          kv[1] = pack.y;
-          kv[2] = pack.z;
-          kv[3] = pack.w;
+          kv[0] = pack[u].x;
+          kv[1] = pack[u].y;
+          kv[2] = pack[u].z;
+          kv[3] = pack[u].w;
         } else {
-          kv[0] = pack.x;
-          kv[1] = pack.y;
+          kv[0] = pack[u].x;
+          kv[1] = pack[u].y;
         }
-        vb = valid ? (valid[i0 >> 3] >> (i0 & 7)) & ((1u << VEC) - 1u) : (1u << VEC) - 1u;
+        vb = (vraw[u] >> (i0 & 7)) & ((1u << VEC) - 1u);
       } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {

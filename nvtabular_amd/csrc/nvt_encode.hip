@@ -272,14 +272,14 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
       vb[u] = 0;
       if (v < nvec) {
         pack[u] = vkeys[v];
-        vb[u] = 0xF;
-        if (valid != nullptr) {
-          uint64_t row = v * VEC;
-          vb[u] = (valid[row >> 3] >> (row & 7)) & ((1u << VEC) - 1u);
-        }
-        vb[u] |= 0x100;
+        vb[u] = 0x10000u | (valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu);  // raw byte
       }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)  // shift after ALL loads are in flight (no early s_waitcnt)
+      if (vb[u])
+        vb[u] = 0x100u | (((vb[u] & 0xFFu) >> (((v0 + (uint64_t)u * stride) * VEC) & 7)) &
+                          ((1u << VEC) - 1u));
     K k[NK];
     int64_t lab[NK];
     bool need[NK];  // still unresolved: must probe the table in HBM
