@@ -125,13 +125,35 @@ def cpu_baseline(frame, cat_names, cont_names, sample_rows, tmp):
     }
 
 
+_PMC_KERNEL = {"encode_i32": "nvt::encode_hot_kernel<int, long>",
+               "dense_count_p1": "nvt::part_scatter_kernel<int, 1, false>",
+               "dense_count_p2": "nvt::part_scatter_kernel<int, 1, false>",
+               "dense_count_p0": "nvt::lds_stage_kernel<int, true, unsigned int, 16384>",
+               "fill_normalize": "nvt::fill_norm_kernel<int, double>",
+               "moments": "nvt::moments_kernel<int>"}
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected separately with
+    rocprofv3 --pmc and corrected per MI355X_MICROARCH.md).  PMC cannot be sampled from
+    inside the timed run, so this is the figure of the same command at the same size."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"][_PMC_KERNEL[name]]
+        return k["hbm_bytes_corrected"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=45_000_000, help="rows per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -206,7 +228,8 @@ def main():
         achieved = alg_bytes / launches / avg_s / 1e9
         roofline = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic(name),
             "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
             "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
         }
