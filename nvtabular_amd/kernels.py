@@ -97,7 +97,6 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 MIN_COUNT_CAPACITY = 1 << 16
-ENCODE_MAX_LOAD = 0.75  # encode tables: smaller footprint (Infinity-Cache hits) beats shorter chains
 
 
 def next_pow2(x: int) -> int:
@@ -418,7 +417,7 @@ class EncodeTable:
         self.key_bytes = 4 if self.suffix == "i32" else 8
         self.n_vocab = int(vocab_keys.numel())
         self.first_label = int(first_label)
-        self.capacity = next_pow2(max(64, int(self.n_vocab / ENCODE_MAX_LOAD) + 1))
+        self.capacity = next_pow2(max(64, (4 if self.n_vocab <= (1 << 20) else 2) * self.n_vocab + 1))
         dev = vocab_keys.device
         nbytes = C.c_uint64()
         check(self.lib.nvt_encode_table_bytes(self.key_bytes, self.capacity, C.byref(nbytes)))
