@@ -162,8 +162,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; NVT_BENCH_SHARE_GPU=1 folds ranks onto the visible devices (debug only)
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("NVT_BENCH_SHARE_GPU") \
+        else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as td
 

@@ -874,9 +874,15 @@ struct PathCfg {
   int b1, b2, slots;
   uint64_t chunk_rows;
 };
-inline PathCfg path_cfg(int path, int key_bytes, int weighted) {
+inline PathCfg path_cfg(int path, int key_bytes, int weighted, uint64_t n) {
   const bool small = weighted || key_bytes == 8;
-  if (path == 1) return {8, 0, small ? kLdsSlots : kLdsSlotsBig, 1ull << 17};
+  if (path == 1) {
+    // one workgroup per bucket in the common case: chunk = average bucket + 15 %, so only
+    // buckets inflated by a hot key are split (and merged by P4)
+    uint64_t chunk = (n / 256) + (n / 256) / 7 + 1;
+    chunk = chunk < 65536 ? 65536 : (chunk > (1ull << 20) ? (1ull << 20) : chunk);
+    return {8, 0, small ? kLdsSlots : kLdsSlotsBig, chunk};
+  }
   if (path == 2) return {6, 6, weighted ? kLdsSlots : 4096, (uint64_t)kChunk};
   return {6, 8, kLdsSlots, (uint64_t)kChunk};
 }
@@ -938,7 +944,7 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
     w.chunk_start = (unsigned *)take((kMaxFine + 1) * 4);
     w.pchunk_start = (unsigned *)take((kMaxFine + 1) * 4);
     // split buckets have >= 2 chunks, all but the last full: at most 2n / chunk_rows regions
-    const PathCfg cfg = path_cfg(path, key_bytes, weighted);
+    const PathCfg cfg = path_cfg(path, key_bytes, weighted, n);
     w.max_regions = 2 * (n / cfg.chunk_rows) + 2;
     w.part_len = (unsigned *)take(w.max_regions * 4);
     w.part_keys = take(w.max_regions * max_fill(cfg.slots) * key_bytes);
@@ -1003,7 +1009,7 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
       NVT_CHECK_LAUNCH();
     }
   } else {
-    const PathCfg cfg = path_cfg(path, (int)sizeof(K), weights != nullptr);
+    const PathCfg cfg = path_cfg(path, (int)sizeof(K), weights != nullptr, n);
     const int b1 = cfg.b1, b2 = cfg.b2, bits = b1 + b2;
     const uint64_t chunk_rows = cfg.chunk_rows;
     part_hist_kernel<K><<<kHistBlocks, 1024, 0, s>>>(keys, valid, weights, n, bits, w.block_hist,

@@ -519,3 +519,47 @@ def test_vocab_sort_vs_numpy(dtype, n):
     K.vocab_sort(tk, tc)
     np.testing.assert_array_equal(tk.cpu().numpy(), keys[order])
     np.testing.assert_array_equal(tc.cpu().numpy(), counts[order])
+
+
+def test_virtual_shard_vocab_merge_matches_single_shot():
+    """the multi-GPU vocabulary merge with G virtual shards on ONE GPU.
+    Same device steps as nvtabular_amd.dist.merge_counts (owner = h32(key) % G via the HIP
+    hash kernel, owner-side weighted dense count), with the all-to-all / all-gather replaced
+    by in-process routing -- the RCCL choreography itself is covered by test_dist_gloo.py."""
+    from nvtabular_amd import dist, kernels as K
+
+    G = 4
+    rng = np.random.default_rng(42)
+    n = 400_000
+    ids, _ = _nullable_int_frame(rng, n, 50_000, 0.0, "int32")
+    shards = np.array_split(ids, G)
+    per_rank = []
+    for part in shards:
+        k, c, _, _ = K.dense_count(torch.from_numpy(part).cuda(), None, None, hint=0)
+        per_rank.append((k, c))
+    # route every (key, count) row to its owner, merge there, gather
+    inbox = [[] for _ in range(G)]
+    for k, c in per_rank:
+        owner = dist._hip_owner([k], G).to(torch.int64)
+        assert int(owner.min()) >= 0 and int(owner.max()) < G
+        for g in range(G):
+            m = owner == g
+            inbox[g].append((k[m], c[m]))
+    merged = []
+    for g in range(G):
+        mk, mc = dist._hip_merge_counts(torch.cat([x[0] for x in inbox[g]]),
+                                        torch.cat([x[1] for x in inbox[g]]))
+        merged.append((mk, mc))
+    gk = torch.cat([m[0] for m in merged]).cpu().numpy()
+    gc = torch.cat([m[1] for m in merged]).cpu().numpy()
+    got = pd.Series(gc, index=gk).sort_index()
+    exp = pd.Series(1, index=ids).groupby(level=0).sum().sort_index()
+    assert got.index.is_unique  # a key has exactly one owner
+    np.testing.assert_array_equal(got.index.to_numpy(), exp.index.to_numpy())
+    np.testing.assert_array_equal(got.to_numpy(), exp.to_numpy())
+    # owners agree with the oracle's hash definition
+    import oracle as O
+
+    k0 = per_rank[0][0]
+    np.testing.assert_array_equal(dist._hip_owner([k0], G).cpu().numpy(),
+                                  (O.nvt_hash32(k0.cpu().numpy()) % G).astype("int32"))
