@@ -1,0 +1,200 @@
+"""Workflow-level parity on the GPU: parquet datasets, list columns, joint groups of mixed
+dtypes, user vocabularies, single_table, save / load -- against the oracle or the
+reference's own expectations (file:line cited)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _criteo_like(n, seed=0):
+    rng = np.random.default_rng(seed)
+    df = pd.DataFrame({
+        "C1": pd.array(rng.zipf(1.2, n) % 5000, dtype="Int32"),
+        "C2": pd.array(rng.integers(0, 40, n), dtype="Int32"),
+        "C3": rng.integers(-2**40, 2**40, n) // 2**28,  # int64, ~8k distinct, negative too
+        "I1": pd.array(np.floor(rng.lognormal(2, 2, n)).astype("int64"), dtype="Int32"),
+        "I2": rng.normal(size=n).astype("float32"),
+        "label": rng.integers(0, 2, n).astype("int32"),
+    })
+    for c, f in (("C1", 0.1), ("C2", 0.02), ("I1", 0.3)):
+        df.loc[rng.random(n) < f, c] = pd.NA
+    df.loc[rng.random(n) < 0.05, "I2"] = np.nan
+    return df
+
+
+def _oracle_view(df):
+    """What pandas' default parquet reader hands the reference: nullable ints -> float64."""
+    out = df.copy()
+    for c in out.columns:
+        if isinstance(out[c].dtype, pd.api.extensions.ExtensionDtype):
+            out[c] = out[c].astype("float64")
+    return out
+
+
+def test_parquet_dataset_fit_transform_vs_oracle(tmp_path):
+    """cfg1/cfg2 shape end to end: parquet row groups -> Arrow buffers -> HBM -> ops -> pandas;
+    3 files x 2 row groups = 6 partitions (tree merge + per-partition transform)."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    df = _criteo_like(60_000, seed=1)
+    paths = []
+    for i, part in enumerate(np.array_split(np.arange(len(df)), 3)):
+        p = str(tmp_path / f"day_{i}.parquet")
+        pq.write_table(pa.Table.from_pandas(df.iloc[part], preserve_index=False), p,
+                       row_group_size=10_000)
+        paths.append(p)
+    cats = ["C1", "C2", "C3"] >> ops.Categorify(out_path=str(tmp_path / "gpu"))
+    conts = ["I1", "I2"] >> ops.FillMissing() >> ops.Normalize()
+    wf = nvt.Workflow(cats + conts + ["label"])
+    ds = nvt.Dataset(paths, engine="parquet")
+    assert ds.npartitions == 6
+    wf.fit(ds)
+    got = wf.transform(ds).to_ddf().compute()
+
+    odf = _oracle_view(df)
+    parts = [odf.iloc[i : i + 10_000].reset_index(drop=True) for i in range(0, len(odf), 10_000)]
+    cpaths = O.categorify_fit(parts, ["C1", "C2", "C3"], str(tmp_path / "cpu"), tie_break="stable")
+    exp = O.categorify_transform(odf, ["C1", "C2", "C3"], cpaths)
+    for c in ("C1", "C2", "C3"):
+        assert got[c].dtype == np.int64
+        np.testing.assert_array_equal(got[c].to_numpy(), exp[c].to_numpy())
+    filled = [O.fill_missing(p[["I1", "I2"]].copy(), ["I1", "I2"], 0) for p in parts]
+    mom = O.custom_moments(filled, ["I1", "I2"])
+    op = [n for n in [wf.output_node] for _ in [0]][0]
+    ofull = O.fill_missing(odf[["I1", "I2"]].copy(), ["I1", "I2"], 0)
+    ref = O.normalize_transform(ofull, ["I1", "I2"], mom["mean"].to_dict(), mom["std"].to_dict())
+    np.testing.assert_allclose(got["I1"].to_numpy(), ref["I1"].to_numpy(), rtol=1e-6, atol=1e-9)
+    # float32 input: the reference subtracts in float32 (pandas), the kernel in fp64
+    np.testing.assert_allclose(got["I2"].to_numpy(), ref["I2"].to_numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(got["label"].to_numpy(), df["label"].to_numpy())
+    # schema: test_categorify.py:532-540 / categorify.py:564-577
+    props = wf.output_schema["C2"].properties
+    card = len(pd.read_parquet(cpaths["C2"])) + 3
+    assert props["embedding_sizes"]["cardinality"] == card and props["domain"]["max"] == card - 1
+
+
+def test_list_columns_int_categorify_and_hashbucket(tmp_path):
+    """cfg5 shape: multi-hot list<int> column; Categorify and HashBucket act on the leaves and
+    keep the offsets (categorify.py:1696,1803; hash_bucket.py:93-96)."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(5)
+    n = 5000
+    lens = rng.integers(0, 6, n)
+    rows = [rng.zipf(1.3, k).astype("int64") % 300 for k in lens]
+    df = pd.DataFrame({"tags": rows, "item": rng.integers(0, 50, n)})
+    wf = nvt.Workflow(["tags", "item"] >> ops.Categorify(out_path=str(tmp_path / "g"), freq_threshold=3))
+    got = wf.fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    paths = O.categorify_fit([df], ["tags", "item"], str(tmp_path / "c"), freq_threshold=3,
+                             tie_break="stable")
+    exp = O.categorify_transform(df, ["tags", "item"], paths)
+    assert [len(r) for r in got["tags"]] == lens.tolist()
+    np.testing.assert_array_equal(np.concatenate(got["tags"].to_list()),
+                                  np.concatenate(exp["tags"].to_list()))
+    np.testing.assert_array_equal(got["item"].to_numpy(), exp["item"].to_numpy())
+    hb = nvt.Workflow(["tags"] >> ops.HashBucket(64)).transform(df)
+    ehb = O.hash_bucket_op(df.copy(), 64, cols=["tags"])
+    np.testing.assert_array_equal(np.concatenate(hb["tags"].to_list()),
+                                  np.concatenate(ehb["tags"].to_list()))
+    assert hb["tags"].iloc[int(np.argmax(lens))].dtype == np.int32
+
+
+def test_joint_group_mixed_dtypes_and_lists(tmp_path):
+    """test_categorify.py:636-665 with integers: a scalar int32 column and a list<int64>
+    column sharing one vocabulary."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    df = pd.DataFrame({
+        "Author": np.array([10, 50, 20, 30], dtype="int32"),
+        "Engaging": [np.array([20, 30], dtype="int64"), np.array([], dtype="int64"),
+                     np.array([10, 40], dtype="int64"), np.array([10], dtype="int64")],
+    })
+    cats = [["Author", "Engaging"]] >> ops.Categorify(out_path=str(tmp_path))
+    out = nvt.Workflow(cats).fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    assert out["Author"].tolist() == [3, 7, 4, 5]
+    assert np.concatenate(out["Engaging"].to_list()).tolist() == [4, 5, 3, 6, 3]
+
+
+def test_user_vocabs_and_single_table(tmp_path):
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    # test_categorify.py:123-157 (vocabs branch): given order is kept, labels start at 3
+    df = pd.DataFrame({"Authors": [["User_A"], ["User_A", "User_E"], ["User_B", "User_C"], ["User_C"]]})
+    vocabs = {"Authors": pd.Series([f"User_{x}" for x in "ACBE"])}
+    out = nvt.Workflow(["Authors"] >> ops.Categorify(out_path=str(tmp_path / "v"), vocabs=vocabs)) \
+        .fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    assert [list(r) for r in out["Authors"]] == [[3], [3, 6], [5, 4], [4]]
+    # test_categorify.py:509-529: single_table gives monotone, non-overlapping ranges
+    df2 = pd.DataFrame({
+        "Authors": [None, "User_A", "User_A", "User_E", "User_B", "User_C"],
+        "Engaging_User": [None, "User_B", "User_B", "User_A", "User_D", "User_D"],
+    })
+    wf = nvt.Workflow(["Authors", "Engaging_User"] >> ops.Categorify(out_path=str(tmp_path / "s"),
+                                                                     single_table=True))
+    new = wf.fit_transform(nvt.Dataset(df2)).to_ddf().compute()
+    old_max = 1
+    for name in ["Authors", "Engaging_User"]:
+        assert old_max <= new[name].min()
+        old_max += new[name].max()
+
+
+def test_save_load_roundtrip_and_eager_artifacts(tmp_path):
+    """tests/unit/workflow/test_workflow.py:691-759: a saved workflow transforms identically
+    after load (encoders rebuilt from unique.*.parquet), stats files live under artifacts/."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    df = _criteo_like(20_000, seed=3)
+    cats = ["C1", "C3"] >> ops.Categorify(out_path=str(tmp_path / "stats"))
+    conts = ["I1"] >> ops.FillMissing(fill_val=7) >> ops.Normalize()
+    jg = ["C2"] >> ops.JoinGroupby(cont_cols=["I2"], stats=["mean", "sum"], out_path=str(tmp_path / "stats"))
+    wf = nvt.Workflow(cats + conts + jg)
+    a = wf.fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    assert os.path.exists(tmp_path / "stats" / "categories" / "unique.C1.parquet")
+    wf.save(str(tmp_path / "saved"))
+    assert os.path.isdir(tmp_path / "saved" / "artifacts")
+    wf2 = nvt.Workflow.load(str(tmp_path / "saved"))
+    b = wf2.transform(nvt.Dataset(df)).to_ddf().compute()
+    pd.testing.assert_frame_equal(a, b)
+
+
+def test_target_encoding_parquet_partitions_fold_alignment(tmp_path):
+    """Folds are re-seeded per partition (target_encoding.py:427-439): identical partition
+    boundaries in fit and transform give the oracle's values."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(8)
+    n = 30_000
+    df = pd.DataFrame({"k": rng.integers(0, 200, n).astype("int32"),
+                       "y": rng.random(n).astype("float32")})
+    p = str(tmp_path / "d.parquet")
+    pq.write_table(pa.Table.from_pandas(df, preserve_index=False), p, row_group_size=8_000)
+    ds = nvt.Dataset(p)
+    te = ["k"] >> ops.TargetEncoding("y", kfold=5, fold_seed=42, p_smooth=20,
+                                     out_path=str(tmp_path / "g"))
+    got = nvt.Workflow(te).fit_transform(ds).to_ddf().compute()
+    parts = [df.iloc[i : i + 8_000].reset_index(drop=True) for i in range(0, n, 8_000)]
+    stats, means = O.target_encoding_fit([q.copy() for q in parts], ["k"], ["y"], str(tmp_path / "c"),
+                                         kfold=5, fold_seed=42)
+    exp = pd.concat([O.target_encoding_transform(q.copy(), ["k"], ["y"], stats, means, kfold=5,
+                                                 fold_seed=42, p_smooth=20) for q in parts],
+                    ignore_index=True)
+    np.testing.assert_allclose(got["TE_k_y"].to_numpy(), exp["TE_k_y"].to_numpy(), rtol=1e-5, atol=1e-6)
