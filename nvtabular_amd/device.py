@@ -50,6 +50,19 @@ def default_device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def to_device_async(arr: np.ndarray, device) -> torch.Tensor:
+    """Host array -> HBM through a pinned staging buffer with an asynchronous copy on the
+    CURRENT stream (the parquet prefetcher makes that a side stream, so the copy overlaps
+    the kernels of the previous partition; hipMemcpyAsync needs pinned memory to be async)."""
+    arr = np.ascontiguousarray(arr)
+    if not arr.flags.writeable:  # Arrow buffers are read-only; torch wants writable memory
+        arr = arr.copy()
+    t = torch.from_numpy(arr)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def pack_bitmap(valid_bool: np.ndarray) -> np.ndarray:
     """bool[n] -> Arrow LSB-first bitmap, padded to a multiple of 8 bytes."""
     bits = np.packbits(valid_bool.astype(np.uint8), bitorder="little")
@@ -172,15 +185,26 @@ class DeviceColumn:
             return DeviceColumn.from_pandas(arr.to_pandas(), device)
         np_dt = arr.type.to_pandas_dtype()
         n = len(arr)
+        valid = None
         if arr.null_count:
-            mask = np.asarray(arr.is_valid())
+            # Arrow already stores validity as an LSB-first bitmap: reuse its buffer when the
+            # array is not sliced, otherwise re-pack
+            bufs = arr.buffers()
+            if arr.offset == 0 and bufs[0] is not None:
+                bits = np.frombuffer(bufs[0], dtype=np.uint8)[: (n + 7) // 8]
+                pad = (-len(bits)) % 8
+                if pad:
+                    bits = np.concatenate([bits, np.zeros(pad, dtype=np.uint8)])
+                valid = to_device_async(bits, device)
+            else:
+                valid = to_device_async(pack_bitmap(np.asarray(arr.is_valid())), device)
             vals = arr.fill_null(0).to_numpy(zero_copy_only=False).astype(np_dt, copy=False)
-            valid = torch.from_numpy(pack_bitmap(mask)).to(device)
         else:
             vals = arr.to_numpy(zero_copy_only=False)
-            valid = None
         assert len(vals) == n
-        data = torch.from_numpy(np.ascontiguousarray(vals)).to(device)
+        if vals.dtype not in _NP_TO_TORCH:
+            vals = vals.astype(np.int64 if vals.dtype.kind in "iu" else np.float64)
+        data = to_device_async(vals, device)
         return DeviceColumn(data, valid)
 
     def valid_mask_host(self) -> Optional[np.ndarray]:

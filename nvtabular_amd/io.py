@@ -115,17 +115,31 @@ class Dataset:
             self._n = sum(1 for _ in self._parts_fn())
         return self._n
 
-    def to_iter(self, columns: Optional[Iterable[str]] = None, shard=None):
-        """Yield DeviceFrame partitions.  shard=(rank, world) keeps every world-th one."""
-        cols = list(columns) if columns is not None else None
-        for i, part in enumerate(self._parts_fn(cols) if _accepts_columns(self._parts_fn)
-                                 else self._parts_fn()):
+    def _host_parts(self, cols, shard):
+        it = self._parts_fn(cols) if _accepts_columns(self._parts_fn) else self._parts_fn()
+        for i, part in enumerate(it):
             if shard is not None and i % shard[1] != shard[0]:
                 continue
-            frame, _ = as_device_frame(part)
-            if cols is not None:
-                frame = frame[[c for c in cols if c in frame]]
-            yield frame
+            yield part
+
+    def to_iter(self, columns: Optional[Iterable[str]] = None, shard=None, prefetch=None):
+        """Yield DeviceFrame partitions.  shard=(rank, world) keeps every world-th one.
+
+        Parquet sources are double-buffered: a background thread decodes the NEXT row-group
+        range with pyarrow (GIL released), stages it in pinned memory and issues the
+        host-to-device copies on a side stream while the consumer's kernels run on the
+        current stream; the hand-over is a stream event, not a device synchronise."""
+        cols = list(columns) if columns is not None else None
+        if prefetch is None:
+            prefetch = hasattr(self, "_pieces")
+        if not prefetch:
+            for part in self._host_parts(cols, shard):
+                frame, _ = as_device_frame(part)
+                if cols is not None:
+                    frame = frame[[c for c in cols if c in frame]]
+                yield frame
+            return
+        yield from _prefetch_frames(self._host_parts(cols, shard), cols)
 
     def to_ddf(self, columns=None, **_):
         return _Collection(self if columns is None else self._select(columns))
@@ -168,6 +182,50 @@ class Dataset:
                 df = df.astype({k: v for k, v in dtypes.items() if k in df.columns})
             pq.write_table(pa.Table.from_pandas(df, preserve_index=False),
                            os.path.join(output_path, f"part_{i}.parquet"))
+
+
+def _prefetch_frames(host_parts, cols, depth: int = 2):
+    import queue
+    import threading
+
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    side = torch.cuda.Stream(device=dev)
+    q: "queue.Queue" = queue.Queue(maxsize=depth)
+    _END = object()
+
+    def producer():
+        try:
+            torch.cuda.set_device(dev)
+            for part in host_parts:
+                with torch.cuda.stream(side):
+                    frame, _ = as_device_frame(part, dev)
+                    if cols is not None:
+                        frame = frame[[c for c in cols if c in frame]]
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                q.put((frame, ev))
+            q.put(_END)
+        except BaseException as e:  # surface decode / copy errors in the consumer
+            q.put(e)
+
+    t = threading.Thread(target=producer, daemon=True)
+    t.start()
+    while True:
+        item = q.get()
+        if item is _END:
+            break
+        if isinstance(item, BaseException):
+            raise item
+        frame, ev = item
+        torch.cuda.current_stream().wait_event(ev)
+        for _, col in frame.items():  # the buffers were allocated on the side stream
+            for tns in (col.data, col.valid, col.offsets):
+                if tns is not None:
+                    tns.record_stream(torch.cuda.current_stream())
+        yield frame
+    t.join()
 
 
 def _is_arrow_table(x) -> bool:

@@ -198,3 +198,22 @@ def test_target_encoding_parquet_partitions_fold_alignment(tmp_path):
                                                  fold_seed=42, p_smooth=20) for q in parts],
                     ignore_index=True)
     np.testing.assert_allclose(got["TE_k_y"].to_numpy(), exp["TE_k_y"].to_numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_parquet_prefetch_side_stream_equals_synchronous(tmp_path):
+    """pinned staging + async copies on a side stream must not change
+    results."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    import nvtabular_amd as nvt
+
+    df = _criteo_like(40_000, seed=9)
+    p = str(tmp_path / "d.parquet")
+    pq.write_table(pa.Table.from_pandas(df, preserve_index=False), p, row_group_size=5_000)
+    ds = nvt.Dataset(p)
+    a = pd.concat([f.to_pandas() for f in ds.to_iter(prefetch=True)], ignore_index=True)
+    b = pd.concat([f.to_pandas() for f in ds.to_iter(prefetch=False)], ignore_index=True)
+    pd.testing.assert_frame_equal(a, b)
+    pd.testing.assert_frame_equal(a[["C3", "label"]], df[["C3", "label"]].reset_index(drop=True))
+    np.testing.assert_array_equal(a["C1"].isna().to_numpy(), df["C1"].isna().to_numpy())
