@@ -762,6 +762,8 @@ def get_embedding_sizes(source, output_dtypes=None):
     """categorify.py:616-660: {col: (cardinality, dimension)} from a Workflow or node."""
     from ..workflow import Workflow
 
+    if isinstance(source, Workflow):
+        _ = source.output_schema  # folds the fitted properties in (lazy after fit)
     output_node = source.output_node if isinstance(source, Workflow) else source
     output = {}
     multihot = set()

@@ -35,8 +35,22 @@ class Workflow:
         self.output_node = Node.construct_from(output_node)
         self.client = client  # accepted for API compatibility (no dask here)
         self.input_schema: Optional[Schema] = None
-        self.output_schema: Optional[Schema] = None
+        self._output_schema: Optional[Schema] = None
+        self._stale_schema_root: Optional[Schema] = None  # set by fit(): properties need a refresh
         self.output_dtypes = None
+
+    @property
+    def output_schema(self) -> Optional[Schema]:
+        """Output schema; after fit() the fitted properties (embedding sizes, domains) are
+        folded in lazily on first access so that transform can start right away."""
+        if self._stale_schema_root is not None:
+            root, self._stale_schema_root = self._stale_schema_root, None
+            self.fit_schema(root)
+        return self._output_schema
+
+    @output_schema.setter
+    def output_schema(self, value):
+        self._output_schema = value
 
     # ---- schema ----------------------------------------------------------------
     def fit_schema(self, input_schema: Schema) -> "Workflow":
@@ -108,8 +122,8 @@ class Workflow:
             for n in phase:
                 n.op.fit_finalize(n.op.fit_end(states[id(n)], n.input_columns))
                 fitted.add(id(n))
-        # properties such as embedding sizes depend on the fitted state
-        self.fit_schema(dataset.schema)
+        # properties such as embedding sizes depend on the fitted state: refreshed lazily
+        self._stale_schema_root = dataset.schema
         if any(getattr(n.op, "dynamic_dtypes", False) for n in nodes if n.op is not None):
             self._capture_dtypes(dataset)
         return self
@@ -130,7 +144,7 @@ class Workflow:
     # ---- transform ---------------------------------------------------------------------
     def transform(self, data):
         if isinstance(data, Dataset):
-            if self.output_schema is None:
+            if self._output_schema is None:
                 self.fit_schema(data.schema)
             roots = self._root_columns()
 
@@ -138,14 +152,14 @@ class Workflow:
                 for part in data.to_iter(columns=roots):
                     yield self._run(self.output_node, part, {})
 
-            return Dataset(gen, schema=self.output_schema, npartitions=data.npartitions)
+            return Dataset(gen, schema=self._output_schema, npartitions=data.npartitions)
         if isinstance(data, pd.DataFrame):
-            if self.output_schema is None:
+            if self._output_schema is None:
                 self.fit_schema(Schema.from_frame(data))
             frame, _ = as_device_frame(data[self._root_columns()])
             return self._run(self.output_node, frame, {}).to_pandas()
         if isinstance(data, DeviceFrame):
-            if self.output_schema is None:
+            if self._output_schema is None:
                 self.fit_schema(Schema.from_frame(data))
             return self._run(self.output_node, data, {})
         raise TypeError(f"Workflow.transform: unsupported input {type(data)}")
