@@ -166,11 +166,14 @@ __device__ __forceinline__ void lds_flush(const K *lkeys, const C *lcnt, K *out_
   }
 }
 
-// Same, but into a caller-assigned region [out_keys, out_keys + kLdsMaxFill) -- used for
-// the per-chunk partial lists of split (skewed) buckets.  *out_len receives the count.
+// Same, but into a caller-assigned region (no cursor): used for the per-chunk partial lists
+// of split (skewed) buckets and for P3's atomic-free staging of its results.  *out_len
+// receives the entry count; with `state` the largest count is folded into
+// state[NVT_ST_MAXCOUNT].
 template <typename K, typename C, int BS, int SLOTS = kLdsSlots>
 __device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, K *out_keys,
-                                                 int64_t *out_cnt, unsigned *out_len) {
+                                                 int64_t *out_cnt, unsigned *out_len,
+                                                 uint64_t *state = nullptr) {
   constexpr K EMPTY = DKey<K>::empty;
   __shared__ unsigned wsum2[BS / kWave];
   constexpr int PER = SLOTS / BS;
@@ -194,13 +197,27 @@ __device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, 
   }
   if (threadIdx.x == 0) *out_len = total;
   unsigned pos = wbase + inc - mine;
+  unsigned long long mx = 0;
 #pragma unroll 8
   for (int j = 0; j < PER; ++j) {
     K k = lkeys[first + j];
     if (k != EMPTY) {
+      unsigned long long c = (unsigned long long)lcnt[first + j];
       out_keys[pos] = k;
-      out_cnt[pos] = (int64_t)lcnt[first + j];
+      out_cnt[pos] = (int64_t)c;
+      mx = c > mx ? c : mx;
       ++pos;
+    }
+  }
+  if (state != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      unsigned long long o = __shfl_down(mx, off, 64);
+      mx = o > mx ? o : mx;
+    }
+    if (lane == 0 && mx > 0) {
+      unsigned long long *gm = reinterpret_cast<unsigned long long *>(&state[NVT_ST_MAXCOUNT]);
+      if (mx > __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gm, mx);
     }
   }
 }
@@ -738,8 +755,8 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
     const K *__restrict__ keys, const int64_t *__restrict__ weights,
     const unsigned long long *__restrict__ fine_start, const unsigned *__restrict__ chunk_start,
     const unsigned *__restrict__ pchunk_start, int nb, uint64_t chunk_rows, K *part_keys,
-    int64_t *part_cnt, unsigned *part_len, K *out_keys, int64_t *out_cnt, uint64_t out_cap,
-    unsigned long long *cursor, uint64_t *state) {
+    int64_t *part_cnt, unsigned *part_len, K *tmp_keys, int64_t *tmp_cnt, unsigned *blk_cnt,
+    unsigned long long *blk_lo, uint64_t *state) {
   constexpr K EMPTY = DKey<K>::empty;
   using C = typename std::conditional<WEIGHTED, unsigned long long, unsigned>::type;
   __shared__ K lkeys[SLOTS];
@@ -768,7 +785,10 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
   }
   __syncthreads();
   const int f = s_f;
-  if (f < 0) return;
+  if (f < 0) {
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = 0;
+    return;
+  }
   const unsigned j = blockIdx.x - chunk_start[f];
   const unsigned nchunks = chunk_start[f + 1] - chunk_start[f];
   const uint64_t lo = fine_start[f] + (uint64_t)j * chunk_rows;
@@ -807,16 +827,73 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
   if (lovf || lfill > (unsigned)max_fill(SLOTS)) {
     if (threadIdx.x == 0) {
       atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
+      blk_cnt[blockIdx.x] = 0;
     }
     return;
   }
   if (threadIdx.x == 0 && s_sent) atomicAdd((unsigned long long *)&state[DS_SENT], s_sent);
   if (nchunks == 1) {
-    lds_flush<K, C, BS, SLOTS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
+    // No output cursor here: thousands of workgroups bumping one word serialise at the
+    // memory side and made this kernel 2x slower.  The distinct keys of rows [lo, hi) fit in
+    // tmp[lo, hi); part_offsets_kernel / part_copy_kernel pack the pieces afterwards.
+    if (threadIdx.x == 0) blk_lo[blockIdx.x] = lo;
+    lds_flush_region<K, C, BS, SLOTS>(lkeys, lcnt, tmp_keys + lo, tmp_cnt + lo,
+                                      &blk_cnt[blockIdx.x], state);
   } else {
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = 0;
     const uint64_t region = (uint64_t)(pchunk_start[f] + j);
     lds_flush_region<K, C, BS, SLOTS>(lkeys, lcnt, part_keys + region * max_fill(SLOTS),
                                       part_cnt + region * max_fill(SLOTS), &part_len[region]);
+  }
+}
+
+// P3b: exclusive scan of the per-workgroup result counts -> packed offsets; the total seeds
+// the output cursor that P4 continues from.  One workgroup.
+__global__ __launch_bounds__(1024) void part_offsets_kernel(const unsigned *__restrict__ blk_cnt,
+                                                            unsigned nblk,
+                                                            unsigned long long *blk_off,
+                                                            uint64_t out_cap, uint64_t *state) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < nblk; base += 1024) {
+    unsigned i = base + threadIdx.x;
+    unsigned long long v = i < nblk ? blk_cnt[i] : 0, inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned long long o = __shfl_up(inc, off, 64);
+      if (lane_id() >= (unsigned)off) inc += o;
+    }
+    const unsigned w = threadIdx.x / kWave;
+    if (lane_id() == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned long long wb = carry;
+    for (unsigned k = 0; k < w; ++k) wb += wsum[k];
+    if (i < nblk) blk_off[i] = wb + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = wb + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (carry > out_cap) atomicOr((unsigned long long *)&state[DS_OVF], 2ull);
+    state[DS_OUT] = carry > out_cap ? 0 : carry;
+  }
+}
+
+// P3c: pack every workgroup's staged result into the output list (coalesced copies)
+template <typename K>
+__global__ __launch_bounds__(kBlock) void part_copy_kernel(
+    const K *__restrict__ tmp_keys, const int64_t *__restrict__ tmp_cnt,
+    const unsigned *__restrict__ blk_cnt, const unsigned long long *__restrict__ blk_off,
+    const unsigned long long *__restrict__ blk_lo, K *out_keys, int64_t *out_cnt,
+    const uint64_t *__restrict__ state) {
+  const unsigned cnt = blk_cnt[blockIdx.x];
+  if (cnt == 0 || (state[DS_OVF] & 2)) return;
+  const unsigned long long src = blk_lo[blockIdx.x], dst = blk_off[blockIdx.x];
+  for (unsigned i = threadIdx.x; i < cnt; i += kBlock) {
+    out_keys[dst + i] = tmp_keys[src + i];
+    out_cnt[dst + i] = tmp_cnt[src + i];
   }
 }
 
@@ -900,6 +977,10 @@ struct DenseWs {
   char *part_keys;
   int64_t *part_cnt;
   uint64_t max_regions;
+  char *tmp_keys;      // [n] staged P3 results (row-range addressed)
+  int64_t *tmp_cnt;    // [n]
+  unsigned *blk_cnt;   // [t3 max]
+  unsigned long long *blk_off, *blk_lo;
 };
 
 // Path S reduction tree: 256 -> 32 -> 4 -> 1 workgroups (fan-in 8 per level)
@@ -949,6 +1030,12 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
     w.part_len = (unsigned *)take(w.max_regions * 4);
     w.part_keys = take(w.max_regions * max_fill(cfg.slots) * key_bytes);
     w.part_cnt = (int64_t *)take(w.max_regions * max_fill(cfg.slots) * 8);
+    const uint64_t t3max = n / cfg.chunk_rows + kMaxFine + 1;
+    w.tmp_keys = take(n * key_bytes);
+    w.tmp_cnt = (int64_t *)take(n * 8);
+    w.blk_cnt = (unsigned *)take(t3max * 4);
+    w.blk_off = (unsigned long long *)take(t3max * 8);
+    w.blk_lo = (unsigned long long *)take(t3max * 8);
   }
   if (ws) *ws = w;
   return off;
@@ -1061,8 +1148,13 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
   do {                                                                                            \
     part_count_kernel<K, WEIGHTED, SLOTS, BS><<<t3, BS, 0, s>>>(                                  \
         fine_keys, fine_w, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits, chunk_rows,    \
-        (K *)w.part_keys, w.part_cnt, w.part_len, out_keys, out_cnt, out_cap, &cur[DS_OUT],       \
-        state);                                                                                   \
+        (K *)w.part_keys, w.part_cnt, w.part_len, (K *)w.tmp_keys, w.tmp_cnt, w.blk_cnt,         \
+        w.blk_lo, state);                                                                         \
+    NVT_CHECK_LAUNCH();                                                                           \
+    part_offsets_kernel<<<1, 1024, 0, s>>>(w.blk_cnt, t3, w.blk_off, out_cap, state);             \
+    NVT_CHECK_LAUNCH();                                                                           \
+    part_copy_kernel<K><<<t3, kBlock, 0, s>>>((const K *)w.tmp_keys, w.tmp_cnt, w.blk_cnt,        \
+                                              w.blk_off, w.blk_lo, out_keys, out_cnt, state);     \
     NVT_CHECK_LAUNCH();                                                                           \
     part_merge_kernel<K, C, SLOTS><<<1u << bits, kStageBS, 0, s>>>(                               \
         w.chunk_start, w.pchunk_start, (const K *)w.part_keys, w.part_cnt, w.part_len, out_keys,  \
