@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "nvt_common.hpp"
+#include "nvt_scan.hpp"
 
 #ifndef NVT_STAGE_U
 #define NVT_STAGE_U 4
@@ -378,80 +379,102 @@ __device__ __forceinline__ uint32_t part_hash(K key) {
   return fmix32((uint32_t)slot_hash(key) * 0x9E3779B1u + 0x7F4A7C15u);
 }
 
-// P0: per-block histogram over the fine bucket id = top (b1+b2) bits of part_hash
+// P0, tile by tile (same kTile-row tiles as the P1 scatter).  Per tile: the histogram over
+// the COARSE bucket (top b1 hash bits) goes to tile_hist[bucket * ntiles + tile]; after a
+// device-wide exclusive scan of that bucket-major array every (tile, bucket) pair knows
+// exactly where it writes, so P1 needs no cursor atomics (they cost half its time: 5.5 k
+// tiles bumping the same 64-256 words) and the partition is deterministic.  Per workgroup:
+// the histogram over the FINE bucket (top b1+b2 bits) for the bucket boundaries.
 template <typename K>
 __global__ __launch_bounds__(1024) void part_hist_kernel(const K *__restrict__ keys,
                                                            const uint8_t *__restrict__ valid,
                                                            const int64_t *__restrict__ weights,
-                                                           uint64_t n, int bits, unsigned *block_hist,
-                                                           uint64_t *state) {
+                                                           uint64_t n, int b1, int bits,
+                                                           unsigned *block_hist, unsigned *tile_hist,
+                                                           uint64_t ntiles, uint64_t *state) {
   __shared__ unsigned h[kMaxFine];
-  const int nb = 1 << bits;
+  __shared__ unsigned ht[256];
+  __shared__ unsigned long long s_nulls;
+  const int nb = 1 << bits, nc = 1 << b1;
   for (int i = threadIdx.x; i < nb; i += 1024) h[i] = 0;
-  __syncthreads();
+  if (threadIdx.x == 0) s_nulls = 0;
   unsigned long long nulls = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * 1024;
   constexpr int VEC = DKey<K>::vec;
-  constexpr int U = 4;  // independent 16-byte loads in flight per lane
+  constexpr int NV = kTile / VEC / 1024;  // 16-byte vectors per thread per tile (2 or 4)
   using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
-  const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
-  const uint64_t nvec = n / VEC;
-  for (uint64_t v0 = (uint64_t)blockIdx.x * 1024 + threadIdx.x; v0 < nvec; v0 += stride * U) {
-    VecT pack[U];
-    unsigned vb[U];
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x < 256) ht[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t row0 = tile * kTile;
+    VecT pack[NV];
+    unsigned vb[NV];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t v = v0 + (uint64_t)u * stride;
-      vb[u] = 0x10000;  // out of range marker
-      if (v < nvec) {
-        pack[u] = vkeys[v];
-        // raw bitmap byte only: shifting it here would make the compiler wait for this load
-        // before issuing the next one and serialise the whole batch
-        vb[u] = valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu;
+    for (int u = 0; u < NV; ++u) {
+      const uint64_t i0 = row0 + ((uint64_t)u * 1024 + threadIdx.x) * VEC;
+      vb[u] = 0x10000;  // not a full in-range vector
+      if (i0 + VEC <= n) {
+        pack[u] = *reinterpret_cast<const VecT *>(keys + i0);
+        vb[u] = valid ? (unsigned)valid[i0 >> 3] : 0xFFu;  // raw bitmap byte, shifted later
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (vb[u] & 0x10000) continue;
-      vb[u] = (vb[u] >> (((v0 + (uint64_t)u * stride) * VEC) & 7)) & ((1u << VEC) - 1u);
+    for (int u = 0; u < NV; ++u) {
+      const uint64_t i0 = row0 + ((uint64_t)u * 1024 + threadIdx.x) * VEC;
       K kv[VEC];
-      if constexpr (sizeof(K) == 4) {
-        kv[0] = pack[u].x;
-        kv[1] = pack[u].y;
-        kv[2] = pack[u].z;
-        kv[3] = pack[u].w;
+      unsigned bits_ok = 0, in_range = 0;
+      if (!(vb[u] & 0x10000)) {
+        if constexpr (sizeof(K) == 4) {
+          kv[0] = pack[u].x;
+          kv[1] = pack[u].y;
+          kv[2] = pack[u].z;
+          kv[3] = pack[u].w;
+        } else {
+          kv[0] = pack[u].x;
+          kv[1] = pack[u].y;
+        }
+        bits_ok = (vb[u] >> (i0 & 7)) & ((1u << VEC) - 1u);
+        in_range = (1u << VEC) - 1u;
       } else {
-        kv[0] = pack[u].x;
-        kv[1] = pack[u].y;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          kv[j] = 0;
+          if (i0 + j < n) {
+            in_range |= 1u << j;
+            if (bit_valid(valid, i0 + j)) {
+              kv[j] = keys[i0 + j];
+              bits_ok |= 1u << j;
+            }
+          }
+        }
       }
 #pragma unroll
-      for (int j = 0; j < VEC; ++j)
-        if ((vb[u] >> j) & 1) atomicAdd(&h[part_hash<K>(kv[j]) >> (32 - bits)], 1u);
-      // nulls: one popcount per vector (a per-row else-branch here tripled the kernel time
-      // on columns with nulls); the weighted form only occurs in list merges
-      const unsigned nmask = (~vb[u]) & ((1u << VEC) - 1u);
+      for (int j = 0; j < VEC; ++j) {
+        if ((bits_ok >> j) & 1) {
+          const unsigned fine = part_hash<K>(kv[j]) >> (32 - bits);
+          atomicAdd(&ht[fine >> (bits - b1)], 1u);
+          if (bits > b1) atomicAdd(&h[fine], 1u);
+        }
+      }
+      const unsigned nmask = in_range & ~bits_ok;
       if (weights == nullptr) {
         nulls += __popc(nmask);
       } else if (nmask) {
         for (int j = 0; j < VEC; ++j)
-          if ((nmask >> j) & 1)
-            nulls += (unsigned long long)weights[(v0 + (uint64_t)u * stride) * VEC + j];
+          if ((nmask >> j) & 1) nulls += (unsigned long long)weights[i0 + j];
       }
     }
-  }
-  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) {
-    if (bit_valid(valid, i))
-      atomicAdd(&h[part_hash<K>(keys[i]) >> (32 - bits)], 1u);
-    else
-      nulls += weights ? (unsigned long long)weights[i] : 1ull;
+    __syncthreads();
+    if ((int)threadIdx.x < nc) {
+      const unsigned c = ht[threadIdx.x];
+      tile_hist[(uint64_t)threadIdx.x * ntiles + tile] = c;
+      if (bits == b1) h[threadIdx.x] += c;  // one level: fine == coarse
+    }
+    __syncthreads();
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nb; i += 1024) block_hist[(uint64_t)blockIdx.x * nb + i] = h[i];
   // one device atomic per WORKGROUP (an atomic per wave on this single word serialised at the
   // memory side: +85 us on every column that has nulls)
-  __shared__ unsigned long long s_nulls;
-  if (threadIdx.x == 0) s_nulls = 0;
-  __syncthreads();
   if (nulls) atomicAdd(&s_nulls, nulls);
   __syncthreads();
   if (threadIdx.x == 0 && s_nulls) atomicAdd((unsigned long long *)&state[DS_NULLS], s_nulls);
@@ -584,8 +607,8 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid,
     const int64_t *__restrict__ weights, uint64_t n, int b1, int nbits,
     const unsigned long long *__restrict__ fine_start, unsigned long long *cursor,
-    const unsigned *__restrict__ tile_start, K *__restrict__ out_keys,
-    int64_t *__restrict__ out_w) {
+    const unsigned *__restrict__ tile_start, const unsigned *__restrict__ tile_off,
+    K *__restrict__ out_keys, int64_t *__restrict__ out_w) {
   constexpr int ROWS = kTile / kBlock;
   __shared__ K stage[kTile];
   __shared__ unsigned lcnt[256], loff[256];
@@ -724,8 +747,13 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
     for (unsigned q = 0; q < w; ++q) add += ws4[q];
     loff[threadIdx.x] = add + inc - v;
     if ((int)threadIdx.x < nbk && v) {
-      unsigned long long *cur = cursor + (LEVEL == 1 ? 0 : (uint64_t)coarse_s * nbk);
-      gbase[threadIdx.x] = atomicAdd(&cur[threadIdx.x], (unsigned long long)v);
+      if (LEVEL == 1) {
+        // exact offset of this (tile, bucket) from the scanned per-tile histograms
+        gbase[threadIdx.x] = tile_off[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x];
+      } else {
+        unsigned long long *cur = cursor + (uint64_t)coarse_s * nbk;
+        gbase[threadIdx.x] = atomicAdd(&cur[threadIdx.x], (unsigned long long)v);
+      }
     }
   }
   __syncthreads();
@@ -971,7 +999,8 @@ struct DenseWs {
   // path P
   char *bufA, *bufB;
   int64_t *wA, *wB;
-  unsigned *block_hist, *tile_start;
+  unsigned *block_hist, *tile_start, *tile_hist;
+  unsigned long long *scan_tot;
   unsigned long long *fine_start, *fine_cursor, *coarse_cursor, *totals;
   unsigned *chunk_start, *pchunk_start, *part_len;
   char *part_keys;
@@ -1018,6 +1047,11 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
     }
     w.block_hist = (unsigned *)take((uint64_t)kHistBlocks * kMaxFine * 4);
     w.tile_start = (unsigned *)take(260 * 4);
+    {
+      const uint64_t ntiles = (n + kTile - 1) / kTile, len = 256 * ntiles;
+      w.tile_hist = (unsigned *)take(len * 4);
+      w.scan_tot = (unsigned long long *)take(scan_chunks(len) * 8 + 8);
+    }
     w.fine_start = (unsigned long long *)take((kMaxFine + 1) * 8);
     w.fine_cursor = (unsigned long long *)take((kMaxFine + 1) * 8);
     w.coarse_cursor = (unsigned long long *)take(256 * 8);
@@ -1099,9 +1133,14 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
     const PathCfg cfg = path_cfg(path, (int)sizeof(K), weights != nullptr, n);
     const int b1 = cfg.b1, b2 = cfg.b2, bits = b1 + b2;
     const uint64_t chunk_rows = cfg.chunk_rows;
-    part_hist_kernel<K><<<kHistBlocks, 1024, 0, s>>>(keys, valid, weights, n, bits, w.block_hist,
-                                                       state);
+    const unsigned t1 = (unsigned)((n + kTile - 1) / kTile);
+    part_hist_kernel<K><<<kHistBlocks, 1024, 0, s>>>(keys, valid, weights, n, b1, bits,
+                                                       w.block_hist, w.tile_hist, t1, state);
     NVT_CHECK_LAUNCH();
+    {
+      int rc = exclusive_scan_u32(w.tile_hist, ((uint64_t)1 << b1) * t1, w.scan_tot, s);
+      if (rc) return rc;
+    }
     part_reduce_kernel<<<((1 << bits) + 63) / 64, kBlock, 0, s>>>(w.block_hist, kHistBlocks,
                                                                   1 << bits, w.totals);
     NVT_CHECK_LAUNCH();
@@ -1109,7 +1148,6 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                                         w.coarse_cursor, w.tile_start, w.chunk_start,
                                         w.pchunk_start, chunk_rows);
     NVT_CHECK_LAUNCH();
-    const unsigned t1 = (unsigned)((n + kTile - 1) / kTile);
     const unsigned t2 = t1 + (1u << b1);  // upper bound: every coarse bucket rounds up once
     const unsigned t3 = (unsigned)(n / chunk_rows) + (1u << bits);  // upper bound on P3 chunks
     const K *fine_keys;
@@ -1117,14 +1155,16 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
     if (weights) {
       part_scatter_kernel<K, 1, true><<<t1, kBlock, 0, s>>>(keys, valid, weights, n, b1, b1,
                                                             w.fine_start, w.coarse_cursor,
-                                                            w.tile_start, (K *)w.bufA, w.wA);
+                                                            w.tile_start, w.tile_hist, (K *)w.bufA,
+                                                            w.wA);
       NVT_CHECK_LAUNCH();
       fine_keys = (const K *)w.bufA;
       fine_w = w.wA;
       if (b2) {
         part_scatter_kernel<K, 2, true><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, w.wA, n,
                                                               b1, b2, w.fine_start, w.fine_cursor,
-                                                              w.tile_start, (K *)w.bufB, w.wB);
+                                                              w.tile_start, nullptr, (K *)w.bufB,
+                                                              w.wB);
         NVT_CHECK_LAUNCH();
         fine_keys = (const K *)w.bufB;
         fine_w = w.wB;
@@ -1132,13 +1172,14 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
     } else {
       part_scatter_kernel<K, 1, false><<<t1, kBlock, 0, s>>>(keys, valid, nullptr, n, b1, b1,
                                                              w.fine_start, w.coarse_cursor,
-                                                             w.tile_start, (K *)w.bufA, nullptr);
+                                                             w.tile_start, w.tile_hist, (K *)w.bufA,
+                                                             nullptr);
       NVT_CHECK_LAUNCH();
       fine_keys = (const K *)w.bufA;
       if (b2) {
         part_scatter_kernel<K, 2, false><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, nullptr,
                                                                n, b1, b2, w.fine_start,
-                                                               w.fine_cursor, w.tile_start,
+                                                               w.fine_cursor, w.tile_start, nullptr,
                                                                (K *)w.bufB, nullptr);
         NVT_CHECK_LAUNCH();
         fine_keys = (const K *)w.bufB;

@@ -1,0 +1,92 @@
+// Device-wide exclusive scan of a uint32 array (chunk scan -> chunk-total scan -> add), shared
+// by the vocabulary radix sort and the partitioned count (per-tile bucket offsets).
+#pragma once
+#include "nvt_common.hpp"
+
+namespace nvt {
+
+// Exclusive scan of `len` uint32 in three steps (chunk scan, chunk-total scan, add).
+constexpr int kScanChunk = 2048;  // 256 threads x 8
+static __global__ __launch_bounds__(kBlock) void scan_chunk_kernel(unsigned *data, uint64_t len,
+                                                            unsigned long long *chunk_tot) {
+  __shared__ unsigned wsum[kBlock / kWave];
+  const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * 8;
+  unsigned v[8];
+  unsigned tot = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = (base + j < len) ? data[base + j] : 0;
+    tot += v[j];
+  }
+  unsigned inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned o = __shfl_up(inc, off, 64);
+    if (lane_id() >= (unsigned)off) inc += o;
+  }
+  const unsigned w = threadIdx.x / kWave;
+  if (lane_id() == 63) wsum[w] = inc;
+  __syncthreads();
+  unsigned wbase = 0;
+  for (unsigned i = 0; i < w; ++i) wbase += wsum[i];
+  unsigned run = wbase + inc - tot;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (base + j < len) data[base + j] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == kBlock - 1) chunk_tot[blockIdx.x] = (unsigned long long)(wbase + inc);
+}
+static __global__ __launch_bounds__(kBlock) void scan_totals_kernel(unsigned long long *chunk_tot,
+                                                             uint64_t nchunks) {
+  __shared__ unsigned long long carry;
+  __shared__ unsigned long long wsum[kBlock / kWave];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint64_t b = 0; b < nchunks; b += kBlock) {
+    uint64_t i = b + threadIdx.x;
+    unsigned long long v = i < nchunks ? chunk_tot[i] : 0;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned long long o = __shfl_up(inc, off, 64);
+      if (lane_id() >= (unsigned)off) inc += o;
+    }
+    const unsigned w = threadIdx.x / kWave;
+    if (lane_id() == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned long long wbase = carry;
+    for (unsigned k = 0; k < w; ++k) wbase += wsum[k];
+    if (i < nchunks) chunk_tot[i] = wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry = wbase + inc;
+    __syncthreads();
+  }
+}
+static __global__ __launch_bounds__(kBlock) void scan_add_kernel(unsigned *data, uint64_t len,
+                                                          const unsigned long long *chunk_tot) {
+  const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * 8;
+  const unsigned add = (unsigned)chunk_tot[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (base + j < len) data[base + j] += add;
+}
+
+
+inline uint64_t scan_chunks(uint64_t len) { return (len + kScanChunk - 1) / kScanChunk; }
+
+// data[0..len) -> exclusive prefix sums in place; chunk_tot: scan_chunks(len) uint64 scratch
+inline int exclusive_scan_u32(unsigned *data, uint64_t len, unsigned long long *chunk_tot,
+                              hipStream_t stream) {
+  if (len == 0) return NVT_OK;
+  const uint64_t nchunks = scan_chunks(len);
+  scan_chunk_kernel<<<(unsigned)nchunks, kBlock, 0, stream>>>(data, len, chunk_tot);
+  NVT_CHECK_LAUNCH();
+  scan_totals_kernel<<<1, kBlock, 0, stream>>>(chunk_tot, nchunks);
+  NVT_CHECK_LAUNCH();
+  scan_add_kernel<<<(unsigned)nchunks, kBlock, 0, stream>>>(data, len, chunk_tot);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+}  // namespace nvt

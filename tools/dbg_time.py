@@ -10,7 +10,7 @@ for card,s in ((39884406.,1.05),(39043.,1.1)):
     keys=((x.floor().clamp_(1,card).to(torch.int64)*2654435761)%(2**31)).to(torch.int32)
     del u,x
     for it in range(3):
-        j=K.DenseCountJob(keys,None,None,hint=6_000_000); j.path=2
+        j=K.DenseCountJob(keys,None,None,hint=6_000_000); j.path=1
         st=torch.zeros(1,_lib.STATE_WORDS,dtype=torch.int64,device=dev); j.state=st[0]
         torch.cuda.synchronize(); a=torch.cuda.Event(enable_timing=True); b=torch.cuda.Event(enable_timing=True)
         a.record(); j.launch(); b.record(); torch.cuda.synchronize()
