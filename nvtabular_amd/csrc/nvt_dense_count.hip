@@ -271,19 +271,32 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     // 8 independent 16-byte loads in flight per lane before any LDS work: with only
     // 2 workgroups (8 waves) per CU the HBM latency has to be covered by ILP
     constexpr int U = NVT_STAGE_U;
+    // software pipeline: the vectors of iteration i+1 are requested before iteration i is
+    // pushed through the LDS table (one workgroup per CU: the latency is not hidden by TLP)
+    VecT npack[U];
+    unsigned nvb[U];
+    auto issue = [&](uint64_t v0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint64_t v = v0 + (uint64_t)u * stride;
+        nvb[u] = 0x10000;  // out of range
+        if (v < nvec) {
+          npack[u] = vkeys[v];
+          nvb[u] = valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu;  // raw byte, shifted later
+        }
+      }
+    };
+    issue((uint64_t)blockIdx.x * kStageBS + threadIdx.x);
     for (uint64_t v0 = (uint64_t)blockIdx.x * kStageBS + threadIdx.x; v0 < nvec; v0 += stride * U) {
       if (lfill > (unsigned)max_fill(SLOTS)) break;  // table is filling up: this column belongs on path P
       VecT pack[U];
       unsigned vb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        uint64_t v = v0 + (uint64_t)u * stride;
-        vb[u] = 0x10000;  // out of range
-        if (v < nvec) {
-          pack[u] = vkeys[v];
-          vb[u] = valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu;  // raw byte, shifted later
-        }
+        pack[u] = npack[u];
+        vb[u] = nvb[u];
       }
+      issue(v0 + stride * U);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (vb[u] & 0x10000)
@@ -825,19 +838,31 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
   bool failed = false;
   unsigned long long my_sent = 0;
   constexpr int U = 8;
+  // software pipeline: batch i+1 is requested before batch i goes through the LDS table
+  K nk[U];
+  unsigned long long nw[U];
+  auto issue = [&](uint64_t i0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint64_t i = i0 + (uint64_t)u * BS;
+      nw[u] = 0;
+      if (i < hi) {
+        nk[u] = keys[i];
+        nw[u] = WEIGHTED ? (unsigned long long)weights[i] : 1ull;
+      }
+    }
+  };
+  issue(lo + threadIdx.x);
   for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (uint64_t)BS * U) {
     if (lfill > (unsigned)max_fill(SLOTS)) break;
     K kk[U];
     unsigned long long ww[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      uint64_t i = i0 + (uint64_t)u * BS;
-      ww[u] = 0;
-      if (i < hi) {
-        kk[u] = keys[i];
-        ww[u] = WEIGHTED ? (unsigned long long)weights[i] : 1ull;
-      }
+      kk[u] = nk[u];
+      ww[u] = nw[u];
     }
+    issue(i0 + (uint64_t)BS * U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (i0 + (uint64_t)u * BS >= hi) continue;

@@ -266,18 +266,32 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
   const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
   constexpr int U = 2;
   constexpr int NK = U * VEC;
+  // software pipeline: the key vectors (and bitmap bytes) of iteration i+1 are requested
+  // before iteration i is processed -- with one 1024-thread workgroup per CU the stream
+  // latency is otherwise exposed once per iteration (~20 iterations per column)
+  VecT nxt_pack[U];
+  unsigned nxt_vb[U];
+  auto issue_loads = [&](uint64_t v0, VecT (&pk)[U], unsigned (&bits)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint64_t v = v0 + (uint64_t)u * stride;
+      bits[u] = 0;
+      if (v < nvec) {
+        pk[u] = vkeys[v];
+        bits[u] = 0x10000u | (valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu);  // raw byte
+      }
+    }
+  };
+  issue_loads((uint64_t)blockIdx.x * kEncBS + threadIdx.x, nxt_pack, nxt_vb);
   for (uint64_t v0 = (uint64_t)blockIdx.x * kEncBS + threadIdx.x; v0 < nvec; v0 += stride * U) {
     VecT pack[U];
     unsigned vb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      uint64_t v = v0 + (uint64_t)u * stride;
-      vb[u] = 0;
-      if (v < nvec) {
-        pack[u] = vkeys[v];
-        vb[u] = 0x10000u | (valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu);  // raw byte
-      }
+      pack[u] = nxt_pack[u];
+      vb[u] = nxt_vb[u];
     }
+    issue_loads(v0 + stride * U, nxt_pack, nxt_vb);
 #pragma unroll
     for (int u = 0; u < U; ++u)  // shift after ALL loads are in flight (no early s_waitcnt)
       if (vb[u])
