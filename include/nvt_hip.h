@@ -182,6 +182,16 @@ int nvt_fill_normalize(const void *x, int dtype, const uint8_t *valid, uint64_t 
                        double fill_val, int do_norm, double shift, double scale, void *out,
                        int out_dtype, uint8_t *filled, void *stream);
 
+/* ---- Clip + LogOp (the reference benchmark's default continuous branch,
+ * bench/examples/dask-nvtabular-criteo-benchmark.py:201-204; clip.py:49-55, logop.py:43-53),
+ * fused with a pending FillMissing constant:
+ *   v = isnull(x) ? (has_fill ? fill_val : null) : x;  v = clamp(v, vmin, vmax);
+ *   out = do_log ? logf((float)v + 1) : v          (nulls stay null; NaN for float outputs)
+ * out_dtype: NVT_F32 / NVT_F64, or the input dtype for integer clipping without log. */
+int nvt_clip_log(const void *x, int dtype, const uint8_t *valid, uint64_t n, int has_fill,
+                 double fill_val, int has_min, double vmin, int has_max, double vmax, int do_log,
+                 void *out, int out_dtype, void *stream);
+
 /* ---- JoinGroupby / TargetEncoding / combo-Categorify: multi-key groupby tables ----
  * A table over nkeys (1..3) key columns (each int64 after widening; null components
  * allowed and form their own groups, pandas dropna=False) and nvals (0..8) value

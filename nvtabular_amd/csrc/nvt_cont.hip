@@ -248,6 +248,66 @@ __global__ __launch_bounds__(kBlock) void fill_norm_kernel(
   }
 }
 
+// Clip (clip.py:49-55) and LogOp (logop.py:43-53), fused with a pending FillMissing constant:
+//   v = isnull ? (has_fill ? fill : null) : x;  v = clamp(v, lo, hi);  out = do_log ? log(f32(v) + 1) : v
+// Nulls stay null: NaN for float outputs, untouched validity bit for integer outputs.
+template <typename T, typename OUT>
+__global__ __launch_bounds__(kBlock) void clip_log_kernel(
+    const T *__restrict__ x, const uint8_t *__restrict__ valid, uint64_t n, int has_fill,
+    double fill_val, int has_min, double vmin, int has_max, double vmax, int do_log,
+    OUT *__restrict__ out) {
+  constexpr int VEC = VecOf<T>::n;
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  auto f = [&](T raw, bool ok) -> OUT {
+    bool isnull = !ok || is_nan(raw);
+    double v = (double)raw;
+    if (isnull) {
+      if (!has_fill) {
+        if constexpr (std::is_floating_point<OUT>::value) return (OUT)qnan;
+        return (OUT)0;
+      }
+      v = fill_val;
+    }
+    if (has_min && v < vmin) v = vmin;
+    if (has_max && v > vmax) v = vmax;
+    if (do_log) return (OUT)logf((float)v + 1.0f);  // the reference computes in float32
+    return (OUT)v;
+  };
+  const uint64_t nvec = n / VEC;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    T v[VEC];
+    load_vec<T>(x + i * VEC, v);
+    unsigned vbits = 0xF;
+    if (valid != nullptr) {
+      uint64_t row = i * VEC;
+      vbits = valid[row >> 3] >> (row & 7);
+    }
+    OUT r[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) r[j] = f(v[j], (vbits >> j) & 1);
+    OUT *dst = out + i * VEC;
+    constexpr int OB = VEC * (int)sizeof(OUT);
+    if constexpr (OB == 32) {
+      int4 a, b;
+      memcpy(&a, &r[0], 16);
+      memcpy(&b, &r[VEC / 2], 16);
+      reinterpret_cast<int4 *>(dst)[0] = a;
+      reinterpret_cast<int4 *>(dst)[1] = b;
+    } else if constexpr (OB == 16) {
+      int4 a;
+      memcpy(&a, &r[0], 16);
+      reinterpret_cast<int4 *>(dst)[0] = a;
+    } else {
+      int2 a;
+      memcpy(&a, &r[0], 8);
+      reinterpret_cast<int2 *>(dst)[0] = a;
+    }
+  }
+  for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    out[i] = f(x[i], bit_valid(valid, i));
+}
+
 template <typename OUT>
 __global__ __launch_bounds__(kBlock) void gather_kernel(const double *__restrict__ src,
                                                         const int64_t *__restrict__ group,
@@ -425,6 +485,50 @@ int nvt_fill_normalize(const void *x, int dtype, const uint8_t *valid, uint64_t 
 #undef NVT_FN
   set_error("nvt_fill_normalize: unsupported dtype combination in=%d out=%d norm=%d", dtype,
             out_dtype, do_norm);
+  return NVT_EINVAL;
+}
+
+int nvt_clip_log(const void *x, int dtype, const uint8_t *valid, uint64_t n, int has_fill,
+                 double fill_val, int has_min, double vmin, int has_max, double vmax, int do_log,
+                 void *out, int out_dtype, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(x && out, "null x/out");
+  NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                "x/out must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+#define NVT_CL(T, O)                                                                           \
+  do {                                                                                         \
+    unsigned grid = stream_grid(n / VecOf<T>::n + 1, kBlock * 2, 8);                           \
+    clip_log_kernel<T, O><<<grid, kBlock, 0, s>>>((const T *)x, valid, n, has_fill, fill_val,  \
+                                                  has_min, vmin, has_max, vmax, do_log,        \
+                                                  (O *)out);                                   \
+    NVT_CHECK_LAUNCH();                                                                        \
+    return NVT_OK;                                                                             \
+  } while (0)
+  if (out_dtype == NVT_F32) {
+    switch (dtype) {
+      case NVT_F32: NVT_CL(float, float);
+      case NVT_F64: NVT_CL(double, float);
+      case NVT_I32: NVT_CL(int32_t, float);
+      case NVT_I64: NVT_CL(int64_t, float);
+    }
+  } else if (out_dtype == NVT_F64) {
+    switch (dtype) {
+      case NVT_F32: NVT_CL(float, double);
+      case NVT_F64: NVT_CL(double, double);
+      case NVT_I32: NVT_CL(int32_t, double);
+      case NVT_I64: NVT_CL(int64_t, double);
+    }
+  } else if (!do_log && out_dtype == dtype) {
+    switch (dtype) {
+      case NVT_I32: NVT_CL(int32_t, int32_t);
+      case NVT_I64: NVT_CL(int64_t, int64_t);
+    }
+  }
+#undef NVT_CL
+  set_error("nvt_clip_log: unsupported dtype combination in=%d out=%d log=%d", dtype, out_dtype,
+            do_log);
   return NVT_EINVAL;
 }
 

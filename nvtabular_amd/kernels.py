@@ -559,6 +559,26 @@ def fill_normalize(
     return out, (filled.view(torch.bool) if filled is not None else None)
 
 
+def clip_log(x, valid, fill, vmin, vmax, do_log: bool, out_dtype: torch.dtype) -> torch.Tensor:
+    """Clip / LogOp pass (optionally consuming a pending FillMissing constant)."""
+    _lib.require_gpu()
+    x = aligned(x)
+    n = x.numel()
+    out = torch.empty(n, dtype=out_dtype, device=x.device)
+    with _timed("clip_log", n * (x.element_size() + out.element_size())):
+        check(
+            _lib.load().nvt_clip_log(
+                x.data_ptr(), dtype_code(x.dtype), ptr(valid), n, 0 if fill is None else 1,
+                0.0 if fill is None else float(fill), 0 if vmin is None else 1,
+                0.0 if vmin is None else float(vmin), 0 if vmax is None else 1,
+                0.0 if vmax is None else float(vmax), 1 if do_log else 0, out.data_ptr(),
+                dtype_code(out_dtype), stream_ptr(),
+            ),
+            "nvt_clip_log",
+        )
+    return out
+
+
 def widen_i64(x: torch.Tensor) -> torch.Tensor:
     if x.dtype == torch.int64:
         return x

@@ -3,6 +3,7 @@
 graph-plumbing ops the DSL creates."""
 from .base import Operator, StatOperator  # noqa: F401
 from .categorify import Categorify, get_embedding_sizes  # noqa: F401
+from .clip_log import Clip, LogOp  # noqa: F401
 from .fill import FillMissing  # noqa: F401
 from .hash_bucket import HashBucket  # noqa: F401
 from .join_groupby import JoinGroupby  # noqa: F401

@@ -75,6 +75,8 @@ __all__ = [
     "minmax_fit",
     "minmax_transform",
     "fill_missing",
+    "clip_transform",
+    "logop_transform",
     "join_groupby_fit",
     "join_groupby_transform",
     "add_fold",
@@ -781,6 +783,24 @@ def minmax_transform(df, cols, mins, maxs, out_dtype=None):
             new[name] = df[name] / (2 * df[name])
         new[name] = new[name].astype(out_dtype or np.float64)
     return new
+
+
+def clip_transform(df, cols, min_value=None, max_value=None):
+    """clip.py:49-55."""
+    z = df[list(cols)].copy()
+    if min_value is not None:
+        z[z < min_value] = min_value
+    if max_value is not None:
+        z[z > max_value] = max_value
+    return z
+
+
+def logop_transform(df, cols):
+    """logop.py:43-53 (float32, log(1 + x))."""
+    out = df.copy()
+    for name in cols:
+        out[name] = np.log(out[name].astype(np.float32) + 1)
+    return out
 
 
 def fill_missing(df, cols, fill_val=0, add_binary_cols=False):

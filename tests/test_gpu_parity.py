@@ -563,3 +563,35 @@ def test_virtual_shard_vocab_merge_matches_single_shot():
     k0 = per_rank[0][0]
     np.testing.assert_array_equal(dist._hip_owner([k0], G).cpu().numpy(),
                                   (O.nvt_hash32(k0.cpu().numpy()) % G).astype("int32"))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64", "int32"])
+def test_fill_clip_log_vs_oracle(dtype):
+    """The reference benchmark's default continuous branch: FillMissing >> Clip(min_value=0) >>
+    LogOp (dask-nvtabular-criteo-benchmark.py:201-204; clip.py:49-55, logop.py:43-53)."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(4)
+    n = 50_003
+    x = (rng.normal(size=n) * 50).astype(dtype)
+    df = pd.DataFrame({"x": x.astype("float64") if dtype == "int32" else x})
+    df.loc[rng.random(n) < 0.2, "x"] = np.nan
+    gdf = df.copy()
+    if dtype == "int32":
+        gdf["x"] = pd.array(np.where(df["x"].isna(), 0, df["x"]).astype("int32"), dtype="Int32")
+        gdf.loc[df["x"].isna(), "x"] = pd.NA
+    wf = nvt.Workflow(["x"] >> ops.FillMissing() >> ops.Clip(min_value=0) >> ops.LogOp())
+    got = wf.transform(gdf)["x"].to_numpy()
+    assert got.dtype == np.float32
+    ref = O.fill_missing(df.copy(), ["x"], 0)
+    ref = O.clip_transform(ref, ["x"], min_value=0)
+    ref = O.logop_transform(ref, ["x"])["x"].to_numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-7)  # float32 log: last-ulp differences
+    # Clip alone keeps dtype and nulls (clip.py:49-55)
+    c = nvt.Workflow(["x"] >> ops.Clip(min_value=-10, max_value=25)).transform(gdf)["x"]
+    ec = O.clip_transform(df, ["x"], -10, 25)["x"]
+    np.testing.assert_array_equal(np.isnan(c.to_numpy(dtype="float64")), ec.isna().to_numpy())
+    np.testing.assert_allclose(c.to_numpy(dtype="float64"), ec.to_numpy(), rtol=0, atol=0, equal_nan=True)
+    with pytest.raises(ValueError):
+        ops.Clip()
