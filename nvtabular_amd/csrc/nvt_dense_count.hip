@@ -224,27 +224,58 @@ __device__ __forceinline__ void lds_flush_region(const K *lkeys, const C *lcnt, 
 }
 
 // ---------------------------------------------------------------------------
-// Path S, stage kernel.  FIRST: input is the key column (+validity, optional
-// weights); otherwise input is a (key, weight) partials list whose length is read
-// from *in_len on the device.
+// Path S.  Two launches, no tree:
+//
+//   stage 1  (256 << split_bits) workgroups.  Workgroup b owns row slab `slab` (grid-stride
+//            over the column, 256 slabs) and key class q = low split_bits bits of slot_hash;
+//            it counts the rows of its slab whose key is in its class into a private LDS
+//            table.  With split_bits = 0 that is every row (<= ~11 k distinct keys); with
+//            2 / 3 bits the column is read 4 / 8 times but tables hold a quarter / an
+//            eighth of the vocabulary each (<= ~43 k / ~86 k distinct), which is still far
+//            cheaper than one partition pass.  The 8 * SPLIT workgroups that share slabs
+//            8g .. 8g+7 are consecutive block ids: block b runs on XCD b % 8, so all SPLIT
+//            readers of a slab sit on ONE XCD and the re-reads are L2 hits.
+//            The table is flushed GROUPED BY HOME RANGE (top 8 bits of the home slot) into
+//            a fixed region per workgroup, with a 257-entry offset row -- no cursor atomics.
+//   stage 2  one workgroup per (class q, range r): gathers segment r of the 256 partial
+//            lists of class q (a wave per list) into a 512-slot LDS table and appends the
+//            result to the output (one reservation atomic per workgroup).  Every key has
+//            exactly one (q, r), so the merge is embarrassingly parallel: 1.9 M partial
+//            entries (7 k-key column) merge in ~10 us instead of ~190 us for the former
+//            32 -> 4 -> 1 workgroup tree.
 // ---------------------------------------------------------------------------
-constexpr int kStageBS = 1024;  // 16 waves per workgroup, one 64-96 KiB LDS table per CU
-template <typename K, bool FIRST, typename C, int SLOTS>
+constexpr int kStageBS = 1024;  // 16 waves per workgroup, one 96-128 KiB LDS table per CU
+constexpr int kSlabs = 256;     // row slabs of stage 1 (= workgroups per key class)
+constexpr int kRanges = 256;    // home ranges per table
+constexpr int kMergeBS = 256, kMergeSlots = 512;
+constexpr unsigned kRepFill = 256;  // replicate hot keys per lane group while fill <= this
+
+template <typename K, int SLOTS>
+__device__ __forceinline__ uint32_t home_slot(K key) {
+  return (uint32_t)(slot_hash(key) >> 17) & (SLOTS - 1);
+}
+template <typename K>
+__device__ __forceinline__ uint32_t key_class(K key, unsigned split_mask) {
+  return (uint32_t)slot_hash(key) & split_mask;
+}
+
+template <typename K, typename C, int SLOTS>
 __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid,
-    const int64_t *__restrict__ weights, uint64_t n, const unsigned long long *in_len,
-    K *out_keys, int64_t *out_cnt, uint64_t out_cap, unsigned long long *cursor, uint64_t *state,
-    int final_stage) {
+    const int64_t *__restrict__ weights, uint64_t n, int split_bits, int tiny, K *part_keys,
+    int64_t *part_cnt, unsigned *seg_off, uint64_t *state) {
   constexpr K EMPTY = DKey<K>::empty;
   constexpr int VEC = DKey<K>::vec;
   __shared__ K lkeys[SLOTS];
   __shared__ C lcnt[SLOTS];
+  __shared__ unsigned rcnt[kRanges], wtot[kRanges / kWave];
   __shared__ unsigned lfill, lovf;
   __shared__ unsigned long long s_nulls, s_sent;
   for (int i = threadIdx.x; i < SLOTS; i += kStageBS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
   }
+  if (threadIdx.x < kRanges) rcnt[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     lfill = 0;
     lovf = 0;
@@ -252,27 +283,38 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     s_sent = 0;
   }
   __syncthreads();
-  if (!FIRST) n = (uint64_t)*in_len;
+  const unsigned split = 1u << split_bits, split_mask = split - 1;
+  const unsigned q = (blockIdx.x >> 3) & split_mask;
+  const unsigned slab = ((blockIdx.x >> (3 + split_bits)) << 3) | (blockIdx.x & 7);
+  const unsigned nlists = gridDim.x;
   unsigned long long my_nulls = 0, my_sent = 0;
   bool failed = false;
+  // A column with a handful of keys (Criteo has five with <= 14) makes every lane of a wave
+  // hit the same 1-3 LDS words, and same-address LDS atomics serialise (106 us for 3 keys vs
+  // 55 us for 36, tools/micro/lds_cfg_probe.hip).  On the `tiny` path (the caller expects
+  // <= 64 distinct keys) each group of 8 lanes probes from its own offset: up to 8 copies
+  // of a key, merged for free by stage 2 (duplicates within a partial list are legal).
+  // A wrong expectation only costs duplicates: past kRepFill entries replication stops.
+  uint32_t rep = tiny ? (lane_id() & 7u) * 2053u : 0u;
   auto add = [&](K key, unsigned long long w) {
     if (key == EMPTY) {
-      my_sent += w;
+      if (q == 0) my_sent += w;
       return;
     }
-    if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, key, (C)w, (uint32_t)(slot_hash(key) >> 17)))
+    const auto h = slot_hash(key);
+    if (((uint32_t)h & split_mask) != q) return;
+    if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, key, (C)w, (uint32_t)(h >> 17) + rep))
       failed = true;
   };
-  const uint64_t stride = (uint64_t)gridDim.x * kStageBS;
-  if (FIRST && weights == nullptr) {
+  const uint64_t stride = (uint64_t)kSlabs * kStageBS;
+  const uint64_t first = (uint64_t)slab * kStageBS + threadIdx.x;
+  if (weights == nullptr) {
     const uint64_t nvec = n / VEC;
     using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
     const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
-    // 8 independent 16-byte loads in flight per lane before any LDS work: with only
-    // 2 workgroups (8 waves) per CU the HBM latency has to be covered by ILP
+    // software pipeline: the U vectors of iteration i+1 are requested before iteration i is
+    // pushed through the LDS table (one workgroup per CU: latency is covered by ILP, not TLP)
     constexpr int U = NVT_STAGE_U;
-    // software pipeline: the vectors of iteration i+1 are requested before iteration i is
-    // pushed through the LDS table (one workgroup per CU: the latency is not hidden by TLP)
     VecT npack[U];
     unsigned nvb[U];
     auto issue = [&](uint64_t v0) {
@@ -286,9 +328,11 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
         }
       }
     };
-    issue((uint64_t)blockIdx.x * kStageBS + threadIdx.x);
-    for (uint64_t v0 = (uint64_t)blockIdx.x * kStageBS + threadIdx.x; v0 < nvec; v0 += stride * U) {
-      if (lfill > (unsigned)max_fill(SLOTS)) break;  // table is filling up: this column belongs on path P
+    issue(first);
+    for (uint64_t v0 = first; v0 < nvec; v0 += stride * U) {
+      const unsigned fill_now = lfill;
+      if (fill_now > (unsigned)max_fill(SLOTS)) break;  // filling up: the column needs a larger path
+      if (fill_now > kRepFill) rep = 0;
       VecT pack[U];
       unsigned vb[U];
 #pragma unroll
@@ -322,7 +366,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
         }
       }
     }
-    for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kStageBS + threadIdx.x; i < n; i += stride) {
+    for (uint64_t i = nvec * VEC + first; i < n; i += stride) {
       if (bit_valid(valid, i))
         add(keys[i], 1ull);
       else
@@ -330,8 +374,10 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     }
   } else {
     constexpr int UW = 4;
-    for (uint64_t i0 = (uint64_t)blockIdx.x * kStageBS + threadIdx.x; i0 < n; i0 += stride * UW) {
-      if (lfill > (unsigned)max_fill(SLOTS)) break;
+    for (uint64_t i0 = first; i0 < n; i0 += stride * UW) {
+      const unsigned fill_now = lfill;
+      if (fill_now > (unsigned)max_fill(SLOTS)) break;
+      if (fill_now > kRepFill) rep = 0;
       K kk[UW];
       unsigned long long ww[UW];
       int st[UW];  // 0 = out of range, 1 = key, 2 = null row
@@ -341,7 +387,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
         st[u] = 0;
         if (i < n) {
           ww[u] = (unsigned long long)weights[i];
-          st[u] = (FIRST && !bit_valid(valid, i)) ? 2 : 1;
+          st[u] = !bit_valid(valid, i) ? 2 : 1;
           if (st[u] == 1) kk[u] = keys[i];
         }
       }
@@ -355,20 +401,199 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     }
   }
   if (failed) atomicOr(&lovf, 1u);
-  if (my_nulls) atomicAdd(&s_nulls, my_nulls);
+  if (q == 0 && my_nulls) atomicAdd(&s_nulls, my_nulls);
   if (my_sent) atomicAdd(&s_sent, my_sent);
   __syncthreads();
   if (lovf || lfill > (unsigned)max_fill(SLOTS)) {
     if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
+    // stage 2 must not read stale offsets from this list
+    for (int r = threadIdx.x; r <= kRanges; r += kStageBS) seg_off[(uint64_t)r * nlists + blockIdx.x] = 0;
     return;
   }
   if (threadIdx.x == 0) {
     if (s_nulls) atomicAdd((unsigned long long *)&state[DS_NULLS], s_nulls);
     if (s_sent) atomicAdd((unsigned long long *)&state[DS_SENT], s_sent);
-    if (FIRST && blockIdx.x == 0) atomicAdd((unsigned long long *)&state[DS_ROWS], (unsigned long long)n);
+    if (blockIdx.x == 0) atomicAdd((unsigned long long *)&state[DS_ROWS], (unsigned long long)n);
   }
-  lds_flush<K, C, kStageBS, SLOTS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
-  (void)final_stage;
+#ifdef NVT_EXP_NOFLUSH
+  for (int r = threadIdx.x; r <= kRanges; r += kStageBS) seg_off[(uint64_t)r * nlists + blockIdx.x] = 0;
+  return;
+#endif
+  // ---- flush grouped by home range: LDS histogram -> scan -> ranked scatter ----
+  constexpr int RSHIFT = (SLOTS == 16384 ? 14 : SLOTS == 8192 ? 13 : 12) - 8;
+  for (int i = threadIdx.x; i < SLOTS; i += kStageBS) {
+    K k = lkeys[i];
+    if (k != EMPTY) atomicAdd(&rcnt[home_slot<K, SLOTS>(k) >> RSHIFT], 1u);
+  }
+  __syncthreads();
+  unsigned mine = 0, inc = 0;
+  if (threadIdx.x < kRanges) {
+    mine = rcnt[threadIdx.x];
+    inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned o = __shfl_up(inc, off, 64);
+      if (lane_id() >= (unsigned)off) inc += o;
+    }
+    if (lane_id() == 63) wtot[threadIdx.x / kWave] = inc;
+  }
+  __syncthreads();
+  if (threadIdx.x < kRanges) {
+    unsigned wbase = 0;
+    for (unsigned i = 0; i < threadIdx.x / kWave; ++i) wbase += wtot[i];
+    const unsigned startv = wbase + inc - mine;
+    rcnt[threadIdx.x] = startv;  // becomes the range's write cursor
+    seg_off[(uint64_t)threadIdx.x * nlists + blockIdx.x] = startv;
+    if (threadIdx.x == kRanges - 1)
+      seg_off[(uint64_t)kRanges * nlists + blockIdx.x] = startv + mine;
+  }
+  __syncthreads();
+  K *ok = part_keys + (uint64_t)blockIdx.x * max_fill(SLOTS);
+  int64_t *oc = part_cnt + (uint64_t)blockIdx.x * max_fill(SLOTS);
+  for (int i = threadIdx.x; i < SLOTS; i += kStageBS) {
+    K k = lkeys[i];
+    if (k != EMPTY) {
+      unsigned pos = atomicAdd(&rcnt[home_slot<K, SLOTS>(k) >> RSHIFT], 1u);
+      ok[pos] = k;
+      oc[pos] = (int64_t)lcnt[i];
+    }
+  }
+}
+
+// Path S, stage 2: workgroup (q, r) merges segment r of the kSlabs partial lists of class q.
+template <typename K>
+__global__ __launch_bounds__(kMergeBS) void range_merge_kernel(
+    const K *__restrict__ part_keys, const int64_t *__restrict__ part_cnt,
+    const unsigned *__restrict__ seg_off, int split_bits, uint64_t region, K *out_keys,
+    int64_t *out_cnt, uint64_t out_cap, uint64_t *state) {
+  constexpr K EMPTY = DKey<K>::empty;
+  using C = unsigned long long;
+  __shared__ K lkeys[kMergeSlots];
+  __shared__ C lcnt[kMergeSlots];
+  __shared__ unsigned lfill, lovf, wsum[kMergeBS / kWave];
+  __shared__ unsigned long long base_s;
+  for (int i = threadIdx.x; i < kMergeSlots; i += kMergeBS) {
+    lkeys[i] = EMPTY;
+    lcnt[i] = 0;
+  }
+  if (threadIdx.x == 0) {
+    lfill = 0;
+    lovf = 0;
+  }
+  __syncthreads();
+  const unsigned r = blockIdx.x & (kRanges - 1), q = blockIdx.x >> 8;
+  const unsigned nlists = (unsigned)kSlabs << split_bits;
+  const unsigned lane = lane_id(), w = threadIdx.x / kWave;
+  // thread t owns list t of this class: segment bounds -> LDS, exclusive scan of the lengths
+  // gives a flat index space over all 256 segments, so the loads below are independent and
+  // balanced (a wave-per-list loop here was a 64-deep chain of dependent global loads).
+  static_assert(kMergeBS == kSlabs, "one thread per partial list");
+  __shared__ unsigned seg_lo[kSlabs], seg_start[kSlabs + 1];
+  {
+    const unsigned li = threadIdx.x;
+    const unsigned b1 = ((((li >> 3) << split_bits) | q) << 3) | (li & 7);
+    const unsigned lo = seg_off[(uint64_t)r * nlists + b1];
+    const unsigned hi = seg_off[(uint64_t)(r + 1) * nlists + b1];
+    const unsigned len = hi - lo;
+    unsigned inc = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned o = __shfl_up(inc, off, 64);
+      if (lane >= (unsigned)off) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (unsigned i = 0; i < w; ++i) wbase += wsum[i];
+    seg_lo[li] = lo;
+    seg_start[li] = wbase + inc - len;
+    if (li == kSlabs - 1) seg_start[kSlabs] = wbase + inc;
+  }
+  __syncthreads();
+  const unsigned total_in = seg_start[kSlabs];
+  bool failed = false;
+  constexpr int UM = 4;
+  for (unsigned j0 = threadIdx.x; j0 < total_in; j0 += kMergeBS * UM) {
+    K kk[UM];
+    int64_t cc[UM];
+    bool ok[UM];
+#pragma unroll
+    for (int u = 0; u < UM; ++u) {
+      const unsigned j = j0 + u * kMergeBS;
+      ok[u] = j < total_in;
+      if (ok[u]) {
+        unsigned a = 0, bnd = kSlabs;  // largest li with seg_start[li] <= j
+        while (bnd - a > 1) {
+          const unsigned m = (a + bnd) >> 1;
+          if (seg_start[m] <= j) a = m; else bnd = m;
+        }
+        const unsigned b1 = ((((a >> 3) << split_bits) | q) << 3) | (a & 7);
+        const uint64_t idx = (uint64_t)b1 * region + seg_lo[a] + (j - seg_start[a]);
+        kk[u] = part_keys[idx];
+        cc[u] = part_cnt[idx];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UM; ++u)
+      if (ok[u] && !lds_add<K, C, kMergeSlots>(lkeys, lcnt, &lfill, kk[u], (C)cc[u],
+                                               (uint32_t)(slot_hash(kk[u]) >> 4)))
+        failed = true;
+  }
+  if (failed) atomicOr(&lovf, 1u);
+  __syncthreads();
+  if (lovf || lfill > (unsigned)max_fill(kMergeSlots)) {
+    if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
+    return;
+  }
+  // compact (2 slots per thread) and append with one reservation
+  constexpr int PER = kMergeSlots / kMergeBS;
+  unsigned mine = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) mine += (lkeys[threadIdx.x * PER + j] != EMPTY);
+  unsigned inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned o = __shfl_up(inc, off, 64);
+    if (lane >= (unsigned)off) inc += o;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  unsigned wbase = 0, total = 0;
+  for (unsigned i = 0; i < kMergeBS / kWave; ++i) {
+    if (i < w) wbase += wsum[i];
+    total += wsum[i];
+  }
+  if (total == 0) return;
+  if (threadIdx.x == 0)
+    base_s = atomicAdd(reinterpret_cast<unsigned long long *>(&state[DS_OUT]),
+                       (unsigned long long)total);
+  __syncthreads();
+  if (base_s + total > out_cap) {
+    if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 2ull);
+    return;
+  }
+  uint64_t pos = base_s + wbase + inc - mine;
+  unsigned long long mx = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    K k = lkeys[threadIdx.x * PER + j];
+    if (k != EMPTY) {
+      unsigned long long c = lcnt[threadIdx.x * PER + j];
+      out_keys[pos] = k;
+      out_cnt[pos] = (int64_t)c;
+      mx = c > mx ? c : mx;
+      ++pos;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0 && mx > 0) {
+    unsigned long long *gm = reinterpret_cast<unsigned long long *>(&state[NVT_ST_MAXCOUNT]);
+    if (mx > __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gm, mx);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1044,8 +1269,9 @@ inline PathCfg path_cfg(int path, int key_bytes, int weighted, uint64_t n) {
 
 struct DenseWs {
   // path S
-  char *p1_keys, *p2_keys, *p3_keys;
-  int64_t *p1_cnt, *p2_cnt, *p3_cnt;
+  char *p1_keys;
+  int64_t *p1_cnt;
+  unsigned *seg_off;
   // path P
   char *bufA, *bufB;
   int64_t *wA, *wB;
@@ -1062,14 +1288,13 @@ struct DenseWs {
   unsigned long long *blk_off, *blk_lo;
 };
 
-// Path S reduction tree: 256 -> 32 -> 4 -> 1 workgroups (fan-in 8 per level)
-constexpr uint64_t kStage1Blocks = 256, kStage2Blocks = 32, kStage3Blocks = 4;
-constexpr uint64_t kP1Cap = kStage1Blocks * max_fill(kLdsSlotsBig),
-                   kP2Cap = kStage2Blocks * max_fill(kLdsSlotsBig),
-                   kP3Cap = kStage3Blocks * max_fill(kLdsSlotsBig);
-// intermediate list cursors live in the spare words of the caller's state block, the final
-// list length IS state[NVT_ST_OCCUPIED]: one memset, no finish kernel
-constexpr int DS_CUR1 = 5, DS_CUR2 = 6, DS_CUR3 = 7;
+// path argument -> stage-1 key-class bits (-1: a partitioned path)
+inline int split_bits_of(int path) {
+  return (path == 0 || path == 6) ? 0 : path == 4 ? 2 : path == 5 ? 3 : -1;
+}
+inline int stage_slots(int key_bytes, int weighted) {
+  return (weighted || key_bytes == 8) ? kLdsSlots : kLdsSlotsBig;
+}
 
 inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighted, char *base,
                                 DenseWs *ws) {
@@ -1081,13 +1306,12 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
   };
   DenseWs w;
   memset(&w, 0, sizeof(w));
-  if (path == 0) {
-    w.p1_keys = take(kP1Cap * key_bytes);
-    w.p1_cnt = (int64_t *)take(kP1Cap * 8);
-    w.p2_keys = take(kP2Cap * key_bytes);
-    w.p2_cnt = (int64_t *)take(kP2Cap * 8);
-    w.p3_keys = take(kP3Cap * key_bytes);
-    w.p3_cnt = (int64_t *)take(kP3Cap * 8);
+  if (split_bits_of(path) >= 0) {
+    const uint64_t nlists = (uint64_t)kSlabs << split_bits_of(path);
+    const uint64_t cap = nlists * max_fill(stage_slots(key_bytes, weighted));
+    w.p1_keys = take(cap * key_bytes);
+    w.p1_cnt = (int64_t *)take(cap * 8);
+    w.seg_off = (unsigned *)take((kRanges + 1) * nlists * 4);
   } else {
     w.bufA = take(n * key_bytes);
     w.bufB = take(n * key_bytes);
@@ -1130,7 +1354,9 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                 void *wsp, K *out_keys, int64_t *out_cnt, uint64_t out_cap, uint64_t *state,
                 hipStream_t s) {
   NVT_CHECK_ARG(state && wsp, "null state/workspace");
-  NVT_CHECK_ARG(path >= 0 && path <= 3, "path must be 0 (LDS), 1 (256 buckets), 2 (64 x 64) or 3 (64 x 256)");
+  NVT_CHECK_ARG(path >= 0 && path <= 6,
+                "path must be 0 / 4 / 5 / 6 (LDS tables: 1 / 4 / 8 key classes / tiny) or 1 / 2 / 3 "
+                "(partitioned)");
   NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
   NVT_CHECK_ARG(n == 0 || (keys && out_keys && out_cnt), "null keys/out");
   NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 rows per call (32-bit LDS counters)");
@@ -1139,46 +1365,30 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
   dense_ws_layout((int)sizeof(K), n, path, weights != nullptr, (char *)wsp, &w);
   unsigned long long *cur = reinterpret_cast<unsigned long long *>(state);
   if (n == 0) return NVT_OK;
-  if (path == 0) {
-    // unweighted: every partial sum is < 2^32 (n is), so u32 counts and 16384-slot tables
-    // all the way down the tree; weighted merges need u64 counts and use 8192 slots
+  const int sbits = split_bits_of(path);
+  if (sbits >= 0) {
+    // unweighted: every partial sum is < 2^32 (n is), so u32 counts and (int32 keys)
+    // 16384-slot tables; weighted merges need u64 counts and use 8192 slots
+    const unsigned nlists = (unsigned)kSlabs << sbits;
+#define NVT_STAGE(C, S)                                                                          \
+  do {                                                                                           \
+    lds_stage_kernel<K, C, S><<<nlists, kStageBS, 0, s>>>(keys, valid, weights, n, sbits,        \
+                                                          path == 6, (K *)w.p1_keys, w.p1_cnt,   \
+                                                          w.seg_off, state);                     \
+    NVT_CHECK_LAUNCH();                                                                          \
+    range_merge_kernel<K><<<(unsigned)kRanges << sbits, kMergeBS, 0, s>>>(                       \
+        (const K *)w.p1_keys, w.p1_cnt, w.seg_off, sbits, (uint64_t)max_fill(S), out_keys,       \
+        out_cnt, out_cap, state);                                                                \
+    NVT_CHECK_LAUNCH();                                                                          \
+  } while (0)
     if (weights) {
-      using C = unsigned long long;
-      constexpr int S = kLdsSlots;
-      lds_stage_kernel<K, true, C, S><<<(unsigned)kStage1Blocks, kStageBS, 0, s>>>(
-          keys, valid, weights, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &cur[DS_CUR1], state, 0);
-      NVT_CHECK_LAUNCH();
-      lds_stage_kernel<K, false, C, S><<<(unsigned)kStage2Blocks, kStageBS, 0, s>>>(
-          (const K *)w.p1_keys, nullptr, w.p1_cnt, 0, &cur[DS_CUR1], (K *)w.p2_keys, w.p2_cnt,
-          kP2Cap, &cur[DS_CUR2], state, 0);
-      NVT_CHECK_LAUNCH();
-      lds_stage_kernel<K, false, C, S><<<(unsigned)kStage3Blocks, kStageBS, 0, s>>>(
-          (const K *)w.p2_keys, nullptr, w.p2_cnt, 0, &cur[DS_CUR2], (K *)w.p3_keys, w.p3_cnt,
-          kP3Cap, &cur[DS_CUR3], state, 0);
-      NVT_CHECK_LAUNCH();
-      lds_stage_kernel<K, false, C, S><<<1, kStageBS, 0, s>>>(
-          (const K *)w.p3_keys, nullptr, w.p3_cnt, 0, &cur[DS_CUR3], out_keys, out_cnt, out_cap,
-          &cur[DS_OUT], state, 1);
-      NVT_CHECK_LAUNCH();
+      NVT_STAGE(unsigned long long, kLdsSlots);
+    } else if constexpr (sizeof(K) == 4) {
+      NVT_STAGE(unsigned, kLdsSlotsBig);
     } else {
-      using C = unsigned;
-      constexpr int S = sizeof(K) == 4 ? kLdsSlotsBig : kLdsSlots;  // 128 KiB / 96 KiB of LDS
-      lds_stage_kernel<K, true, C, S><<<(unsigned)kStage1Blocks, kStageBS, 0, s>>>(
-          keys, valid, nullptr, n, nullptr, (K *)w.p1_keys, w.p1_cnt, kP1Cap, &cur[DS_CUR1], state, 0);
-      NVT_CHECK_LAUNCH();
-      lds_stage_kernel<K, false, C, S><<<(unsigned)kStage2Blocks, kStageBS, 0, s>>>(
-          (const K *)w.p1_keys, nullptr, w.p1_cnt, 0, &cur[DS_CUR1], (K *)w.p2_keys, w.p2_cnt,
-          kP2Cap, &cur[DS_CUR2], state, 0);
-      NVT_CHECK_LAUNCH();
-      lds_stage_kernel<K, false, C, S><<<(unsigned)kStage3Blocks, kStageBS, 0, s>>>(
-          (const K *)w.p2_keys, nullptr, w.p2_cnt, 0, &cur[DS_CUR2], (K *)w.p3_keys, w.p3_cnt,
-          kP3Cap, &cur[DS_CUR3], state, 0);
-      NVT_CHECK_LAUNCH();
-      lds_stage_kernel<K, false, C, S><<<1, kStageBS, 0, s>>>(
-          (const K *)w.p3_keys, nullptr, w.p3_cnt, 0, &cur[DS_CUR3], out_keys, out_cnt, out_cap,
-          &cur[DS_OUT], state, 1);
-      NVT_CHECK_LAUNCH();
+      NVT_STAGE(unsigned, kLdsSlots);
     }
+#undef NVT_STAGE
   } else {
     const PathCfg cfg = path_cfg(path, (int)sizeof(K), weights != nullptr, n);
     const int b1 = cfg.b1, b2 = cfg.b2, bits = b1 + b2;
@@ -1274,7 +1484,7 @@ extern "C" {
 
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
-  NVT_CHECK_ARG(path >= 0 && path <= 3, "path must be 0..3");
+  NVT_CHECK_ARG(path >= 0 && path <= 6, "path must be 0..6");
   *bytes = dense_ws_layout(key_bytes, n, path, weighted, nullptr, nullptr) + 64;
   return NVT_OK;
 }

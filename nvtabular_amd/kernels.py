@@ -217,6 +217,14 @@ def count_into_new_table(
 # --------------------------------------------------------------------------
 PATH_S_MAX_DISTINCT = 11000         # path 0 (int32 keys, unweighted): 16384-slot LDS tables
 PATH_S_MAX_WEIGHTED = 5000          # path 0 for weighted merges / int64 keys: 8192 slots
+# Paths 4 / 5 (path 0 with 4 / 8 key classes per row slab: the column is read 4x / 8x, each
+# LDS table holds a quarter / an eighth of the vocabulary) are exposed by the C ABI and covered
+# by the parity tests, but measured no faster than path 1 on MI355X (490 vs 530 us per 45 M-row
+# column at 13-39 k distinct keys, with 4x the HBM reads), so the driver never picks them.
+# escalation order when a path's LDS tables overflow (C-ABI path ids, include/nvt_hip.h)
+PATH_ORDER = [6, 0, 1, 2, 3]
+_S_CLASSES = {6: 1, 0: 1, 4: 4, 5: 8}
+PATH_TINY_MAX = 64                  # path 6: path 0 with hot keys replicated per lane group
 PATH_P1_MAX_DISTINCT = 2_400_000    # path 1: ONE level, 256 buckets x 16384-slot tables (int32)
 PATH_P1_MAX_SMALL = 1_100_000       #         ... 8192-slot tables (int64 keys / weighted merges)
 PATH_P2_MAX_DISTINCT = 9_000_000    # path 2: 64 x 64 buckets, 4096-slot tables
@@ -238,7 +246,10 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def _path_for(hint: int, small_tables: bool = False) -> int:
-    if hint <= (PATH_S_MAX_WEIGHTED if small_tables else PATH_S_MAX_DISTINCT):
+    s_max = PATH_S_MAX_WEIGHTED if small_tables else PATH_S_MAX_DISTINCT
+    if 0 < hint <= PATH_TINY_MAX:
+        return 6
+    if hint <= s_max:
         return 0
     if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
         return 1
@@ -246,7 +257,7 @@ def _path_for(hint: int, small_tables: bool = False) -> int:
         return 2
     if hint <= PATH_P3_MAX_DISTINCT:
         return 3
-    return 4  # global-table fallback
+    return -1  # global-table fallback
 
 
 class DenseCountJob:
@@ -264,7 +275,7 @@ class DenseCountJob:
         self.suffix = _key_suffix(self.keys)
         self.kb = 4 if self.suffix == "i32" else 8
         self.hint = hint
-        self.path = _path_for(hint if hint > 0 else 1,
+        self.path = _path_for(hint,
                               small_tables=(weights is not None or self.kb == 8))
         self.cap_guess = max(1 << 16, 2 * max(hint, 1))
         self.state = None  # device uint64[STATE_WORDS] view, assigned by dense_count_many
@@ -273,8 +284,9 @@ class DenseCountJob:
     def launch(self):
         n, path = self.n, self.path
         out_cap = min(self.cap_guess, n) + 1
-        if path == 0:
-            out_cap = min(out_cap, 16384)
+        if path in _S_CLASSES:
+            # stage 2 has 256 workgroups per key class, each emitting <= 384 keys
+            out_cap = min(out_cap, _S_CLASSES[path] * 256 * 384 + 1)
         self.out_k = torch.empty(out_cap + 1, dtype=self.keys.dtype, device=self.dev)
         self.out_c = torch.empty(out_cap + 1, dtype=torch.int64, device=self.dev)
         nbytes = C.c_uint64()
@@ -295,12 +307,16 @@ class DenseCountJob:
         """Inspect the state words read back for this job; False = relaunch needed."""
         ovf = st[_lib.ST_OVERFLOW]
         if ovf & 1:
-            self.path += 1
-            if self.path > 3:
+            # forced paths 4 / 5 (tests, probes) escalate to the partitioned path 1
+            nxt = PATH_ORDER.index(self.path) + 1 if self.path in PATH_ORDER else PATH_ORDER.index(1)
+            if nxt >= len(PATH_ORDER):
                 self._fallback()
                 return True
+            self.path = PATH_ORDER[nxt]
             return False
         if ovf & 2:
+            if self.cap_guess > self.n:
+                raise _lib.NvtHipError("dense count: output list overflowed at full capacity")
             self.cap_guess = max(4 * self.cap_guess, 1 << 20)
             return False
         m = st[_lib.ST_OCCUPIED]
@@ -325,7 +341,7 @@ class DenseCountJob:
         k, c = tab.compact()
         mx = int(c.max().item()) if c.numel() else 0
         self.result = (k, c, st[_lib.ST_NULLS],
-                       dict(path=4, distinct=int(k.numel()), max_count=mx, rows=self.n))
+                       dict(path=-1, distinct=int(k.numel()), max_count=mx, rows=self.n))
 
 
 def dense_count_many(jobs):
@@ -338,6 +354,9 @@ def dense_count_many(jobs):
             j.result = (torch.empty(0, dtype=j.keys.dtype, device=j.dev),
                         torch.empty(0, dtype=torch.int64, device=j.dev), 0,
                         dict(path=0, distinct=0, max_count=0, rows=0))
+    for j in jobs:
+        if j.result is None and j.path < 0:
+            j._fallback()
     pending = [j for j in jobs if j.result is None]
     while pending:
         states = torch.zeros(len(pending), _lib.STATE_WORDS, dtype=torch.int64,

@@ -6,8 +6,14 @@ from nvtabular_amd import kernels as K
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 45_000_000
 dev = torch.device("cuda", 0)
-for card, s in [(3, 1.1), (36, 1.1), (976, 1.1), (3000, 1.15), (39043, 1.1), (403346, 1.2),
-                (2953546, 1.15), (39884406, 1.05)]:
+CASES = [(3, 1.1), (36, 1.1), (976, 1.1), (3000, 1.15), (7420, 1.1), (12972, 1.1), (20263, 1.1), (39043, 1.1), (403346, 1.2),
+                (2953546, 1.15), (39884406, 1.05)]
+if os.environ.get("PROBE_CARDS"):
+    want = {int(x) for x in os.environ["PROBE_CARDS"].split(",")}
+    CASES = [c for c in CASES if c[0] in want]
+if os.environ.get("PROBE_S"):
+    CASES = [(c, float(os.environ["PROBE_S"])) for c, _ in CASES]
+for card, s in CASES:
     g = torch.Generator(device=dev).manual_seed(card)
     u = torch.rand(n, device=dev, dtype=torch.float64, generator=g)
     c = float(card)

@@ -1,8 +1,11 @@
 #!/bin/bash
-# try each libnvt_hip_U*.so variant on the small-cardinality probe
+# usage: probe_variants.sh v1 v2 ...  -- traces tools/probe_dense.py with libnvt_v_<v>.so swapped in
 cp nvtabular_amd/libnvt_hip.so /tmp/orig.so
-for U in 1 2 4; do
-  cp nvtabular_amd/libnvt_hip_U$U.so nvtabular_amd/libnvt_hip.so
-  echo "== U=$U"; timeout 200 python tools/probe_dense.py 2>&1 | grep -E "card=  *(3|36|976|3000) "
+for v in orig "$@"; do
+  if [ $v != orig ]; then cp nvtabular_amd/libnvt_v_$v.so nvtabular_amd/libnvt_hip.so; fi
+  out=/root/repo/gpurun_out/pv_$v; mkdir -p $out
+  (cd /tmp && export TMPDIR=/tmp && timeout 60 rocprofv3 --kernel-trace --output-format csv -d $out -o p -- python /root/repo/tools/probe_dense.py > $out/log.txt 2>&1)
+  echo "== $v"; grep card= $out/log.txt
+  python /root/repo/tools/trace_probe_summary.py $out/p_kernel_trace.csv | grep -E "lds_stage|range_merge" | awk '{print $NF}' | paste - - | awk 'NR%3==0{printf "stage %s merge %s; ", $1, $2}'; echo
 done
 cp /tmp/orig.so nvtabular_amd/libnvt_hip.so
