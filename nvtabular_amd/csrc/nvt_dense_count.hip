@@ -37,6 +37,9 @@
 #ifndef NVT_STAGE_U
 #define NVT_STAGE_U 4
 #endif
+#ifndef NVT_SMALL_DIV
+#define NVT_SMALL_DIV 4
+#endif
 
 namespace nvt {
 
@@ -295,6 +298,9 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
   // <= 64 distinct keys) each group of 8 lanes probes from its own offset: up to 8 copies
   // of a key, merged for free by stage 2 (duplicates within a partial list are legal).
   // A wrong expectation only costs duplicates: past kRepFill entries replication stops.
+  // (Counting a sampled hot key in registers instead -- what P3 does for split buckets --
+  // was tried here too: the extra compare per key costs more than the conflicts it removes,
+  // +20 us per column; this loop is issue-bound, not LDS-bound.)
   uint32_t rep = tiny ? (lane_id() & 7u) * 2053u : 0u;
   auto add = [&](K key, unsigned long long w) {
     if (key == EMPTY) {
@@ -748,7 +754,8 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const unsigned long lon
                                                          unsigned *tile_start,
                                                          unsigned *chunk_start,
                                                          unsigned *pchunk_start,
-                                                         unsigned long long chunk_rows) {
+                                                         unsigned long long chunk_rows,
+                                                         unsigned long long small_rows) {
   __shared__ unsigned long long wsum[16];
   __shared__ unsigned long long carry;
   const int nb = 1 << bits;
@@ -788,9 +795,9 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const unsigned long lon
     }
     tile_start[nc] = t;
   }
-  // P3 work list: a fine bucket is processed in chunks of kChunk rows; buckets that need
-  // more than one chunk (skew: a hot key drags its whole bucket) are "split" and get one
-  // partial-list region per chunk, merged per bucket by P4.  Two more block scans.
+  // P3 work list: a fine bucket is processed as one primary chunk of chunk_rows plus, when a
+  // hot key drags its whole bucket (skew), excess chunks of small_rows; such "split" buckets
+  // get one partial-list region per chunk, merged per bucket by P4.  Two more block scans.
   __syncthreads();
   __shared__ unsigned long long wsum2[16][2];
   __shared__ unsigned long long carry2[2];
@@ -799,7 +806,9 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const unsigned long lon
   for (int base = 0; base < nb; base += 1024) {
     int f = base + threadIdx.x;
     unsigned long long sz = f < nb ? fine_start[f + 1] - fine_start[f] : 0;
-    unsigned long long k = (sz + chunk_rows - 1) / chunk_rows;
+    // primary chunk of chunk_rows, the excess (skew) in chunks of small_rows
+    unsigned long long k = sz <= chunk_rows ? (sz > 0)
+                                            : 1 + (sz - chunk_rows + small_rows - 1) / small_rows;
     unsigned long long v0 = k, v1 = (k > 1) ? k : 0, i0 = v0, i1 = v1;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1020,8 +1029,8 @@ template <typename K, bool WEIGHTED, int SLOTS, int BS>
 __global__ __launch_bounds__(BS) void part_count_kernel(
     const K *__restrict__ keys, const int64_t *__restrict__ weights,
     const unsigned long long *__restrict__ fine_start, const unsigned *__restrict__ chunk_start,
-    const unsigned *__restrict__ pchunk_start, int nb, uint64_t chunk_rows, K *part_keys,
-    int64_t *part_cnt, unsigned *part_len, K *tmp_keys, int64_t *tmp_cnt, unsigned *blk_cnt,
+    const unsigned *__restrict__ pchunk_start, int nb, uint64_t chunk_rows, uint64_t small_rows,
+    K *part_keys, int64_t *part_cnt, unsigned *part_len, K *tmp_keys, int64_t *tmp_cnt, unsigned *blk_cnt,
     unsigned long long *blk_lo, uint64_t *state) {
   constexpr K EMPTY = DKey<K>::empty;
   using C = typename std::conditional<WEIGHTED, unsigned long long, unsigned>::type;
@@ -1030,24 +1039,32 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
   __shared__ unsigned lfill, lovf;
   __shared__ unsigned long long s_sent;
   __shared__ int s_f;
+  __shared__ unsigned s_j;
+  // Unit order = dispatch order: the nb primary chunks first (one per bucket), then the small
+  // excess chunks of split buckets, which fill the tail.  (With equal-size chunks a hot
+  // bucket's ~30 extra units started a whole second round on the 256 CUs: +130 us per column.)
   if (threadIdx.x == 0) {
     int f = -1;
-    if (blockIdx.x < chunk_start[nb]) {
-      int lo = 0, hi = nb - 1;  // last f with chunk_start[f] <= blockIdx.x (skips empty buckets)
-      while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (chunk_start[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    unsigned j = 0;
+    if ((int)blockIdx.x < nb) {
+      if (chunk_start[blockIdx.x + 1] > chunk_start[blockIdx.x]) f = (int)blockIdx.x;
+    } else {
+      const unsigned p = blockIdx.x - (unsigned)nb;  // index into the split buckets' regions
+      if (p < pchunk_start[nb]) {
+        int lo = 0, hi = nb - 1;  // last f with pchunk_start[f] <= p (skips unsplit buckets)
+        while (lo < hi) {
+          int mid = (lo + hi + 1) >> 1;
+          if (pchunk_start[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        j = p - pchunk_start[lo];
+        if (j > 0) f = lo;  // j == 0 is the primary chunk, already a unit of its own
       }
-      f = lo;
     }
     s_f = f;
+    s_j = j;
     lfill = 0;
     lovf = 0;
     s_sent = 0;
-  }
-  for (int i = threadIdx.x; i < SLOTS; i += BS) {
-    lkeys[i] = EMPTY;
-    lcnt[i] = 0;
   }
   __syncthreads();
   const int f = s_f;
@@ -1055,16 +1072,58 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = 0;
     return;
   }
-  const unsigned j = blockIdx.x - chunk_start[f];
+  for (int i = threadIdx.x; i < SLOTS; i += BS) {
+    lkeys[i] = EMPTY;
+    lcnt[i] = 0;
+  }
+  __syncthreads();
+  const unsigned j = s_j;
   const unsigned nchunks = chunk_start[f + 1] - chunk_start[f];
-  const uint64_t lo = fine_start[f] + (uint64_t)j * chunk_rows;
   const uint64_t end = fine_start[f + 1];
-  const uint64_t hi = lo + chunk_rows < end ? lo + chunk_rows : end;
+  const uint64_t lo = fine_start[f] + (j == 0 ? 0 : chunk_rows + (uint64_t)(j - 1) * small_rows);
+  const uint64_t span = j == 0 ? chunk_rows : small_rows;
+  const uint64_t hi = lo + span < end ? lo + span : end;
   bool failed = false;
   unsigned long long my_sent = 0;
+  // Split buckets exist because of a hot key, and in their chunks most lanes of every wave
+  // would add to the SAME LDS word (a 64-way same-address conflict serialises the atomic:
+  // such chunks ran ~4x slower per row).  Sample 64 rows of the chunk; a key holding >= 25 %
+  // of the sample is counted in a per-lane register instead and added once per wave.
+  __shared__ K s_hk;
+  __shared__ int s_has_hk;
+  K hk = EMPTY;
+  bool has_hk = false;
+  if (nchunks > 1) {  // workgroup-uniform
+    if (threadIdx.x < kWave) {
+      const K smp = keys[lo + ((hi - lo) * threadIdx.x) / kWave];
+      K best = EMPTY;
+      int bestc = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const K cand = __shfl(smp, c * 16 + 5, 64);
+        const int m = __popcll(__ballot(smp == cand));
+        if (m > bestc) {
+          bestc = m;
+          best = cand;
+        }
+      }
+      if (threadIdx.x == 0) {
+        s_has_hk = (bestc >= 16 && best != EMPTY) ? 1 : 0;
+        s_hk = best;
+      }
+    }
+    __syncthreads();
+    has_hk = s_has_hk != 0;
+    hk = s_hk;
+  }
+  unsigned long long my_hot = 0;
   auto add_one = [&](K key, unsigned long long w) {
     if (key == EMPTY) {
       my_sent += w;
+      return;
+    }
+    if (has_hk && key == hk) {
+      my_hot += w;
       return;
     }
     if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, key, (C)w, part_hash<K>(key))) failed = true;
@@ -1123,6 +1182,13 @@ __global__ __launch_bounds__(BS) void part_count_kernel(
       for (int u = 0; u < U; ++u)
         if (i0 + (uint64_t)u * BS < hi) add_one(kk[u], ww[u]);
     }
+  }
+  if (has_hk) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_hot += __shfl_down(my_hot, off, 64);
+    if (lane_id() == 0 && my_hot > 0 &&
+        !lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, hk, (C)my_hot, part_hash<K>(hk)))
+      failed = true;
   }
   if (failed) atomicOr(&lovf, 1u);
   if (my_sent) atomicAdd(&s_sent, my_sent);
@@ -1225,14 +1291,33 @@ __global__ __launch_bounds__(kStageBS) void part_merge_kernel(
   }
   __syncthreads();
   bool failed = false;
-  for (unsigned j = 0; j < nchunks; ++j) {
+  // a wave per region, 4 independent loads in flight per lane: a hot bucket has ~200 short
+  // regions, and walking them one after the other with the whole workgroup was a chain of
+  // ~400 dependent global-load latencies (140 us)
+  const unsigned lane = lane_id(), wv = threadIdx.x / kWave;
+  constexpr int UM = 4;
+  for (unsigned j = wv; j < nchunks; j += kStageBS / kWave) {
     const uint64_t region = (uint64_t)(pchunk_start[f] + j);
     const unsigned len = part_len[region];
     const K *pk = part_keys + region * max_fill(SLOTS);
     const int64_t *pc = part_cnt + region * max_fill(SLOTS);
-    for (unsigned i = threadIdx.x; i < len; i += kStageBS)
-      if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, pk[i], (C)pc[i], part_hash<K>(pk[i])))
-        failed = true;
+    for (unsigned i0 = lane; i0 < len; i0 += kWave * UM) {
+      K kk[UM];
+      int64_t cc[UM];
+#pragma unroll
+      for (int u = 0; u < UM; ++u) {
+        const unsigned i = i0 + u * kWave;
+        if (i < len) {
+          kk[u] = pk[i];
+          cc[u] = pc[i];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UM; ++u)
+        if (i0 + u * kWave < len &&
+            !lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, kk[u], (C)cc[u], part_hash<K>(kk[u])))
+          failed = true;
+    }
   }
   if (failed) atomicOr(&lovf, 1u);
   __syncthreads();
@@ -1252,8 +1337,16 @@ inline uint64_t align16(uint64_t x) { return (x + 15) & ~15ull; }
 //   3: 64 x 256 buckets, 8192-slot tables                          up to ~32 M distinct.
 struct PathCfg {
   int b1, b2, slots;
-  uint64_t chunk_rows;
+  uint64_t chunk_rows;  // primary chunk of a bucket
+  uint64_t small_rows;  // chunk size for a bucket's excess rows (skew)
 };
+// upper bounds on the partial-list regions of split buckets and on P3 work units
+inline uint64_t max_regions_of(const PathCfg &c, uint64_t n) {
+  return n / c.small_rows + n / c.chunk_rows + 2;  // excess chunks + one primary per split bucket
+}
+inline uint64_t max_units_of(const PathCfg &c, uint64_t n, int nb) {
+  return (uint64_t)nb + max_regions_of(c, n);
+}
 inline PathCfg path_cfg(int path, int key_bytes, int weighted, uint64_t n) {
   const bool small = weighted || key_bytes == 8;
   if (path == 1) {
@@ -1261,10 +1354,13 @@ inline PathCfg path_cfg(int path, int key_bytes, int weighted, uint64_t n) {
     // buckets inflated by a hot key are split (and merged by P4)
     uint64_t chunk = (n / 256) + (n / 256) / 7 + 1;
     chunk = chunk < 65536 ? 65536 : (chunk > (1ull << 20) ? (1ull << 20) : chunk);
-    return {8, 0, small ? kLdsSlots : kLdsSlotsBig, chunk};
+    // the excess of a bucket inflated by a hot key is cut into eighths, dispatched after all
+    // primary chunks, so it fills the tail instead of starting a second round
+    uint64_t small_rows = chunk / NVT_SMALL_DIV < 16384 ? 16384 : chunk / NVT_SMALL_DIV;
+    return {8, 0, small ? kLdsSlots : kLdsSlotsBig, chunk, small_rows};
   }
-  if (path == 2) return {6, 6, weighted ? kLdsSlots : 4096, (uint64_t)kChunk};
-  return {6, 8, kLdsSlots, (uint64_t)kChunk};
+  if (path == 2) return {6, 6, weighted ? kLdsSlots : 4096, (uint64_t)kChunk, (uint64_t)kChunk};
+  return {6, 8, kLdsSlots, (uint64_t)kChunk, (uint64_t)kChunk};
 }
 
 struct DenseWs {
@@ -1332,13 +1428,12 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
     w.totals = (unsigned long long *)take((uint64_t)kMaxFine * 8);
     w.chunk_start = (unsigned *)take((kMaxFine + 1) * 4);
     w.pchunk_start = (unsigned *)take((kMaxFine + 1) * 4);
-    // split buckets have >= 2 chunks, all but the last full: at most 2n / chunk_rows regions
     const PathCfg cfg = path_cfg(path, key_bytes, weighted, n);
-    w.max_regions = 2 * (n / cfg.chunk_rows) + 2;
+    w.max_regions = max_regions_of(cfg, n);
     w.part_len = (unsigned *)take(w.max_regions * 4);
     w.part_keys = take(w.max_regions * max_fill(cfg.slots) * key_bytes);
     w.part_cnt = (int64_t *)take(w.max_regions * max_fill(cfg.slots) * 8);
-    const uint64_t t3max = n / cfg.chunk_rows + kMaxFine + 1;
+    const uint64_t t3max = max_units_of(cfg, n, kMaxFine) + 1;
     w.tmp_keys = take(n * key_bytes);
     w.tmp_cnt = (int64_t *)take(n * 8);
     w.blk_cnt = (unsigned *)take(t3max * 4);
@@ -1406,10 +1501,10 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
     NVT_CHECK_LAUNCH();
     part_scan_kernel<<<1, 1024, 0, s>>>(w.totals, bits, b1, w.fine_start, w.fine_cursor,
                                         w.coarse_cursor, w.tile_start, w.chunk_start,
-                                        w.pchunk_start, chunk_rows);
+                                        w.pchunk_start, chunk_rows, cfg.small_rows);
     NVT_CHECK_LAUNCH();
     const unsigned t2 = t1 + (1u << b1);  // upper bound: every coarse bucket rounds up once
-    const unsigned t3 = (unsigned)(n / chunk_rows) + (1u << bits);  // upper bound on P3 chunks
+    const unsigned t3 = (unsigned)max_units_of(cfg, n, 1 << bits);  // upper bound on P3 units
     const K *fine_keys;
     const int64_t *fine_w = nullptr;
     if (weights) {
@@ -1449,6 +1544,7 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
   do {                                                                                            \
     part_count_kernel<K, WEIGHTED, SLOTS, BS><<<t3, BS, 0, s>>>(                                  \
         fine_keys, fine_w, w.fine_start, w.chunk_start, w.pchunk_start, 1 << bits, chunk_rows,    \
+        cfg.small_rows,                                                                           \
         (K *)w.part_keys, w.part_cnt, w.part_len, (K *)w.tmp_keys, w.tmp_cnt, w.blk_cnt,         \
         w.blk_lo, state);                                                                         \
     NVT_CHECK_LAUNCH();                                                                           \
