@@ -259,7 +259,18 @@ class Categorify(StatOperator):
         base = os.path.join(self.out_path, "categories")
         os.makedirs(base, exist_ok=True)
         paths = {}
-        for g in state.values():
+        groups = list(state.values())
+        if dist.world_size() == 1:
+            # largest vocabularies first: their sorts / table builds keep the stream busy while
+            # the host runs ahead enqueueing the small ones (whose kernels are shorter than the
+            # ~60 us of Python per column).  Multi-rank keeps column order: the merge
+            # collectives must be issued in the same order on every rank.
+            def _size(g):
+                t = g.table
+                return int(t[0].numel()) if isinstance(t, tuple) else 0
+
+            groups.sort(key=_size, reverse=True)
+        for g in groups:
             nb = _pick(self.num_buckets, g.name) if self.num_buckets else None
             oov_count = nb or 1
             max_emb = _pick(self.max_size, g.name) if self.max_size else 0
@@ -276,7 +287,7 @@ class Categorify(StatOperator):
             paths[g.name] = self._save_encodings(
                 g, vocab, base, first_n=max_emb, freq_threshold=freq, oov_count=oov_count
             )
-        return paths
+        return {name: paths[name] for name in state if name in paths}
 
     # -- vocabulary finalisation ------------------------------------------------
     def _finalize_single(self, g: _GroupFit, dist):

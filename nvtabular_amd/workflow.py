@@ -37,6 +37,7 @@ class Workflow:
         self.input_schema: Optional[Schema] = None
         self._output_schema: Optional[Schema] = None
         self._stale_schema_root: Optional[Schema] = None  # set by fit(): properties need a refresh
+        self._fit_root_schema: Optional[Schema] = None  # input schema the node schemas were built for
         self.output_dtypes = None
 
     @property
@@ -99,7 +100,11 @@ class Workflow:
     # ---- fit ------------------------------------------------------------------------
     def fit(self, dataset: Dataset) -> "Workflow":
         self.clear_stats()
-        self.fit_schema(dataset.schema)
+        # (re)fitting on an unchanged input schema: the graph's column schemas are already in
+        # place (only fitted properties change, and those are refreshed lazily after the fit)
+        if getattr(self, "_fit_root_schema", None) is None or not (dataset.schema == self._fit_root_schema):
+            self.fit_schema(dataset.schema)
+            self._fit_root_schema = dataset.schema
         nodes = iter_nodes(self.output_node)
         stat_nodes = [n for n in nodes if isinstance(n.op, StatOperator)]
         fitted: set = set()
