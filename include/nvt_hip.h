@@ -96,14 +96,26 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
                           int64_t *out_counts, uint64_t *out_n, void *stream);
 
 /* ---- Categorify.fit, atomic-free: key column -> dense (key,count) list ----
- * path 0: <= ~11000 distinct keys, LDS-table stages (256 -> 32 -> 4 -> 1 workgroups);
- * path 1 / 2 / 3: hash-partition the rows into 256 / 64 x 64 / 64 x 256 buckets, then one
- * LDS table per bucket (chunked + merged when a hot key makes a bucket huge).  weights (optional, int64 per row) turns the count into a weighted
- * sum -- the tree-merge of (key,count) lists (_mid_level_groupby).  ws: device scratch
- * of nvt_dense_count_ws_bytes().  state (device uint64[NVT_STATE_WORDS], written):
+ * Replaces categorify.py:1018 (the groupby-size of _top_level_groupby) and, with weights,
+ * the concat + re-groupby of categorify.py:1059-1063.  `path` selects the kernel family:
+ *   0  LDS tables, two launches: 256 workgroups count their row slab into a private LDS
+ *      table and flush it grouped by home range; 256 workgroups merge one range each
+ *      (<= ~11000 distinct int32 keys, ~5000 for int64 keys / weighted input);
+ *   6  path 0 for <= 64 distinct keys: hot keys replicated per 8-lane group (same-address
+ *      LDS atomics serialise);
+ *   4 / 5  path 0 with 4 / 8 key classes per row slab (4x / 8x the vocabulary, column read
+ *      4x / 8x) -- exact, tested, but not faster than path 1 on MI355X;
+ *   1 / 2 / 3  hash-partition the rows into 256 / 64 x 64 / 64 x 256 buckets (exact
+ *      per-tile histograms + scan, no cursor atomics), then one LDS table per bucket; a
+ *      bucket inflated by a hot key is cut into a primary chunk plus small excess chunks
+ *      (dispatched last) whose partial lists are merged per bucket.
+ * weights (optional, int64 per row) turns the count into a weighted sum -- the tree-merge
+ * of (key,count) lists (_mid_level_groupby).  ws: device scratch of
+ * nvt_dense_count_ws_bytes().  state (device uint64[NVT_STATE_WORDS], written):
  * [NVT_ST_NULLS] null rows (weighted), [NVT_ST_SENTINEL] rows whose key is the empty
- * sentinel (NOT in the list), [NVT_ST_OCCUPIED] entries written, [NVT_ST_OVERFLOW]
- * bit0: an LDS table filled up (rerun on a larger path), bit1: out_capacity too small. */
+ * sentinel (NOT in the list), [NVT_ST_OCCUPIED] entries written, [NVT_ST_MAXCOUNT] the
+ * largest count, [NVT_ST_OVERFLOW] bit0: an LDS table filled up (rerun on a larger path),
+ * bit1: out_capacity too small.  The output list is in no particular order. */
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes);
 int nvt_dense_count_i32(const int32_t *keys, const uint8_t *valid, const int64_t *weights,
                         uint64_t n, int path, void *ws, int32_t *out_keys, int64_t *out_counts,
