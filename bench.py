@@ -128,7 +128,9 @@ def cpu_baseline(frame, cat_names, cont_names, sample_rows, tmp):
 _PMC_KERNEL = {"encode_i32": "nvt::encode_hot_kernel<int, long>",
                "dense_count_p1": "nvt::part_scatter_kernel<int, 1, false>",
                "dense_count_p2": "nvt::part_scatter_kernel<int, 1, false>",
-               "dense_count_p0": "nvt::lds_stage_kernel<int, true, unsigned int, 16384>",
+               "dense_count_p0": "nvt::lds_stage_kernel<int, unsigned int, 16384>",
+               "dense_count_p6": "nvt::lds_stage_kernel<int, unsigned int, 16384>",
+               "vocab_sort": "nvt::sort2_scatter_kernel<false, false>",
                "fill_normalize": "nvt::fill_norm_kernel<int, double>",
                "moments": "nvt::moments_kernel<int>"}
 

@@ -478,6 +478,7 @@ __global__ __launch_bounds__(kMergeBS) void range_merge_kernel(
   __shared__ C lcnt[kMergeSlots];
   __shared__ unsigned lfill, lovf, wsum[kMergeBS / kWave];
   __shared__ unsigned long long base_s;
+  __shared__ int s_skip;
   for (int i = threadIdx.x; i < kMergeSlots; i += kMergeBS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
@@ -485,8 +486,11 @@ __global__ __launch_bounds__(kMergeBS) void range_merge_kernel(
   if (threadIdx.x == 0) {
     lfill = 0;
     lovf = 0;
+    // stage 1 already overflowed: the result is discarded anyway
+    s_skip = (int)(__hip_atomic_load(&state[DS_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1);
   }
   __syncthreads();
+  if (s_skip) return;  // workgroup-uniform (read once by thread 0)
   const unsigned r = blockIdx.x & (kRanges - 1), q = blockIdx.x >> 8;
   const unsigned nlists = (unsigned)kSlabs << split_bits;
   const unsigned lane = lane_id(), w = threadIdx.x / kWave;
@@ -520,6 +524,7 @@ __global__ __launch_bounds__(kMergeBS) void range_merge_kernel(
   bool failed = false;
   constexpr int UM = 4;
   for (unsigned j0 = threadIdx.x; j0 < total_in; j0 += kMergeBS * UM) {
+    if (lfill > (unsigned)max_fill(kMergeSlots)) break;  // too many keys for path 0
     K kk[UM];
     int64_t cc[UM];
     bool ok[UM];
@@ -1283,16 +1288,22 @@ __global__ __launch_bounds__(kStageBS) void part_merge_kernel(
   const int f = blockIdx.x;
   const unsigned nchunks = chunk_start[f + 1] - chunk_start[f];
   if (nchunks <= 1) return;
+  // an earlier kernel of this call already overflowed: the result is discarded anyway
+  // (and a full table would make every insert below walk kLdsProbe slots: 8 ms per launch)
   __shared__ K lkeys[SLOTS];
   __shared__ C lcnt[SLOTS];
   __shared__ unsigned lfill, lovf;
-  for (int i = threadIdx.x; i < SLOTS; i += kStageBS) {
-    lkeys[i] = EMPTY;
-    lcnt[i] = 0;
-  }
+  __shared__ int s_skip;
   if (threadIdx.x == 0) {
     lfill = 0;
     lovf = 0;
+    s_skip = (int)(__hip_atomic_load(&state[DS_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1);
+  }
+  __syncthreads();
+  if (s_skip) return;  // workgroup-uniform
+  for (int i = threadIdx.x; i < SLOTS; i += kStageBS) {
+    lkeys[i] = EMPTY;
+    lcnt[i] = 0;
   }
   __syncthreads();
   bool failed = false;
@@ -1307,6 +1318,7 @@ __global__ __launch_bounds__(kStageBS) void part_merge_kernel(
     const K *pk = part_keys + region * max_fill(SLOTS);
     const int64_t *pc = part_cnt + region * max_fill(SLOTS);
     for (unsigned i0 = lane; i0 < len; i0 += kWave * UM) {
+      if (lfill > (unsigned)max_fill(SLOTS)) break;  // filling up: the call fails below
       K kk[UM];
       int64_t cc[UM];
 #pragma unroll

@@ -595,3 +595,29 @@ def test_fill_clip_log_vs_oracle(dtype):
     np.testing.assert_allclose(c.to_numpy(dtype="float64"), ec.to_numpy(), rtol=0, atol=0, equal_nan=True)
     with pytest.raises(ValueError):
         ops.Clip()
+
+
+@pytest.mark.parametrize("card", [40, 30_000, 10**9])
+def test_dense_count_cold_start_presample(card):
+    """No cardinality hint + a long column: the first path comes from the distinct count of a
+    256 K-row prefix (kernels._presample); the result must be exact whatever it picks."""
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.device import pack_bitmap
+
+    n = K.SAMPLE_MIN_ROWS + 4099
+    rng = np.random.default_rng(card % 97)
+    ids, mask = _nullable_int_frame(rng, n, card, 0.05, "int32", zipf=1.3)
+    keys = torch.from_numpy(ids).cuda()
+    valid = torch.from_numpy(pack_bitmap(~mask)).cuda()
+    job = K.DenseCountJob(keys, valid, None, hint=0)
+    k, c, nulls, info = K.dense_count_many([job])[0]
+    exp = pd.Series(np.ones(int((~mask).sum()), dtype="int64")).groupby(ids[~mask]).sum()
+    got = pd.Series(c.cpu().numpy(), index=k.cpu().numpy()).sort_index()
+    np.testing.assert_array_equal(got.index.to_numpy(), exp.index.to_numpy())
+    np.testing.assert_array_equal(got.to_numpy(), exp.to_numpy())
+    assert nulls == int(mask.sum()) and info["rows"] == n
+    if card <= 40:
+        assert info["path"] in (6, 0)
+    if card >= 30_000 and len(exp) > K.PATH_S_MAX_DISTINCT:
+        assert info["path"] not in (6, 0)
+    assert job.hint > 0  # the estimate replaced the missing hint
