@@ -270,6 +270,24 @@ class Categorify(StatOperator):
                 return int(t[0].numel()) if isinstance(t, tuple) else 0
 
             groups.sort(key=_size, reverse=True)
+        if dist.world_size() > 1:
+            # ONE exchange for every single-vocabulary group of this fit (dist.merge_counts_many)
+            singles = [g for g in groups if not g.combo]
+            tabs = []
+            for g in singles:
+                if g.table is None:
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                    k = torch.empty(0, dtype=torch.int64, device=dev)
+                    c = torch.empty(0, dtype=torch.int64, device=dev)
+                    mx = 0
+                else:
+                    k, c, mx = g.table
+                tabs.append((k, c, [int(g.nulls), int(g.valid_rows), int(mx)]))
+            if tabs:
+                for g, (k, c, sc) in zip(singles, dist.merge_counts_many(tabs)):
+                    g.table = (k, c, sc[2])  # the sum of the per-rank maxima bounds the max count
+                    g.nulls, g.valid_rows = sc[0], sc[1]
+                    g.merged = True
         for g in groups:
             nb = _pick(self.num_buckets, g.name) if self.num_buckets else None
             oov_count = nb or 1
@@ -299,7 +317,7 @@ class Categorify(StatOperator):
         else:
             keys, counts, max_count = g.table
         nulls = g.nulls
-        if dist.world_size() > 1:
+        if dist.world_size() > 1 and not getattr(g, "merged", False):
             keys, counts, nulls = dist.merge_counts(keys, counts, nulls)
             tot = dist.all_reduce_sum(torch.tensor([max_count, g.valid_rows], dtype=torch.int64,
                                                    device=keys.device)).tolist()

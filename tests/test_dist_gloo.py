@@ -51,6 +51,20 @@ def _worker(rank, world, port, q):
     k = torch.from_numpy(local.index.to_numpy())
     c = torch.from_numpy(local.to_numpy())
     gk, gc, nulls = dist.merge_counts(k, c, nulls=rank + 3)
+    # several columns in ONE exchange: int64 + int32 keys, and a column that is empty on rank 1
+    k32 = torch.from_numpy(rng.integers(0, 40, 300).astype("int32"))
+    l32 = pd.Series(1, index=k32.numpy()).groupby(level=0).sum()
+    tabs = [(k, c, [rank + 3, 10]),
+            (torch.from_numpy(l32.index.to_numpy()), torch.from_numpy(l32.to_numpy()), [1, 2, 3]),
+            (torch.arange(7 if rank == 0 else 0, dtype=torch.int64),
+             torch.ones(7 if rank == 0 else 0, dtype=torch.int64), [rank])]
+    many = dist.merge_counts_many(tabs)
+    assert many[1][0].dtype == torch.int32 and many[0][0].dtype == torch.int64
+    assert many[0][2] == [3 + 4, 20] and many[1][2] == [2, 4, 6] and many[2][2] == [1]
+    m0 = pd.Series(many[0][1].numpy(), index=many[0][0].numpy()).sort_index()
+    assert sorted(many[2][0].tolist()) == list(range(7)) and many[2][1].tolist() == [1] * 7
+    q.put(("many", rank, m0.index.to_numpy(), m0.to_numpy(), many[1][0].numpy(), many[1][1].numpy(),
+           k32.numpy()))
     mom = dist.all_reduce_sum(torch.tensor([[1.0 + rank, 2.0, 3.0]], dtype=torch.float64))
     mn = dist.all_reduce_min(torch.tensor([float("nan") if rank == 0 else 4.0, 2.0 + rank]))
     lut = dist.merge_string_luts({rank: f"s{rank}"})
@@ -70,7 +84,9 @@ def test_merge_counts_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=150) for _ in procs], key=lambda t: t[0])
+    items = [q.get(timeout=150) for _ in range(2 * len(procs))]
+    many = sorted([t[1:] for t in items if t[0] == "many"], key=lambda t: t[0])
+    res = sorted([t for t in items if t[0] != "many"], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -84,3 +100,11 @@ def test_merge_counts_world2_gloo():
         assert r[4] == [[3.0, 4.0, 6.0]]
         assert r[5] == [4.0, 2.0]
         assert r[6] == {0: "s0", 1: "s1"}
+    # the batched exchange: same int64 table, and the int32 column summed over both ranks
+    exp32 = pd.Series(1, index=np.concatenate([m[5] for m in many])).groupby(level=0).sum().sort_index()
+    for m in many:
+        np.testing.assert_array_equal(m[1], exp.index.to_numpy())
+        np.testing.assert_array_equal(m[2], exp.to_numpy())
+        got32 = pd.Series(m[4], index=m[3]).sort_index()
+        np.testing.assert_array_equal(got32.index.to_numpy(), exp32.index.to_numpy())
+        np.testing.assert_array_equal(got32.to_numpy(), exp32.to_numpy())
