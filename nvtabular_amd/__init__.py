@@ -14,7 +14,8 @@ schema logic is host code), running an operator needs the built
 ``libnvt_hip.so`` and a visible GPU.
 """
 from . import ops  # noqa: F401
-from .io import Dataset  # noqa: F401
+from . import io  # noqa: F401
+from .io import Dataset, Shuffle  # noqa: F401
 from .node import Node  # noqa: F401
 from .node import Node as WorkflowNode  # noqa: F401
 from .schema import ColumnSchema, Schema, Tags  # noqa: F401

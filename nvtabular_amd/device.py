@@ -279,6 +279,30 @@ class DeviceFrame:
     def copy(self, deep=False) -> "DeviceFrame":
         return DeviceFrame({k: v.shallow_copy() for k, v in self._cols.items()})
 
+    def take_rows(self, index: torch.Tensor) -> "DeviceFrame":
+        """Rows in the order of ``index`` (int64 on the device) -- the per-partition shuffle
+        of Dataset.to_parquet.  Torch gathers: output plumbing, not on the fit/transform path."""
+        out = DeviceFrame()
+        for name, col in self._cols.items():
+            col = col.materialize()
+            if col.is_list:
+                starts = col.offsets[:-1][index]
+                lens = (col.offsets[1:] - col.offsets[:-1])[index]
+                new_off = torch.zeros(index.numel() + 1, dtype=torch.int64, device=index.device)
+                torch.cumsum(lens, 0, out=new_off[1:])
+                total = int(new_off[-1].item())
+                within = torch.arange(total, device=index.device) - torch.repeat_interleave(new_off[:-1], lens)
+                leaf = torch.repeat_interleave(starts, lens) + within
+                take, offsets = leaf, new_off
+            else:
+                take, offsets = index, None
+            valid = None
+            if col.valid is not None:
+                bits = (col.valid[take >> 3] >> (take & 7).to(torch.uint8)) & 1
+                valid = pack_bitmap_device(bits.to(torch.bool))
+            out[name] = DeviceColumn(col.data[take], valid, offsets, None, col.strings)
+        return out
+
     def drop(self, columns: Iterable[str]) -> "DeviceFrame":
         drop = set(columns)
         return DeviceFrame({k: v for k, v in self._cols.items() if k not in drop})

@@ -169,19 +169,147 @@ class Dataset:
         return self
 
     def to_parquet(self, output_path, shuffle=None, out_files_per_proc=None, dtypes=None,
-                   cats=None, conts=None, labels=None, **_):
-        """One parquet file per partition under output_path (plus nothing else):
-        the I/O path is SURVEY section 8(f) item 2, kept minimal here."""
+                   cats=None, conts=None, labels=None, preserve_files=False, suffix=".parquet",
+                   num_threads=0, **_):
+        """Write the (transformed) dataset as parquet (merlin.io.Dataset.to_parquet; contract in
+        tests/unit/workflow/test_workflow.py:171-187,363-396,444-500 and
+        bench/datasets/tools/nvt_etl.py:154-171 of the reference).
+
+        * ``out_files_per_proc=k``: every partition is cut into k pieces, piece j appended to
+          ``part_j.parquet`` -- k files per process (``part_{rank*k + j}`` under torchrun).
+          ``None``: one file per input partition.
+        * ``shuffle``: ``Shuffle.PER_PARTITION`` permutes the rows of each partition (on the
+          device, before the copy out); ``Shuffle.PER_WORKER`` additionally permutes each
+          output file as a whole (its pieces are held on the host until the end); ``None`` /
+          ``False`` keeps the row order.
+        * ``dtypes``: {column: dtype} casts applied on the way out.
+        * writes ``_metadata`` (parquet summary of all row groups), ``_file_list.txt`` and
+          ``_metadata.json`` (file stats + cats / conts / labels) next to the data files.
+        """
+        import json
+
+        import numpy as np
         import pyarrow as pa
         import pyarrow.parquet as pq
 
-        os.makedirs(output_path, exist_ok=True)
-        for i, part in enumerate(self.to_iter()):
+        from . import dist
+
+        shuffle = Shuffle.coerce(shuffle)
+        os.makedirs(str(output_path), exist_ok=True)
+        output_path = str(output_path)
+        rank, world = dist.rank(), dist.world_size()
+        k = int(out_files_per_proc) if out_files_per_proc else None
+        rng = np.random.default_rng()
+        writers, held, names, rows_in = {}, {}, {}, {}
+        collector = []
+
+        def fname(j):
+            return f"part_{(rank * k + j) if k else j}{suffix}"
+
+        def emit(j, table):
+            if shuffle == Shuffle.PER_WORKER and k:
+                held.setdefault(j, []).append(table)
+                return
+            w = writers.get(j)
+            if w is None:
+                names[j] = fname(j)
+                w = writers[j] = pq.ParquetWriter(os.path.join(output_path, names[j]), table.schema,
+                                                  metadata_collector=collector)
+            w.write_table(table)
+            rows_in[j] = rows_in.get(j, 0) + table.num_rows
+
+        shard = (rank, world) if world > 1 else None
+        for i, part in enumerate(self.to_iter(shard=shard)):
+            n = len(part)
+            if shuffle is not None and n > 1:
+                part = part.take_rows(_device_permutation(n, part))
             df = part.to_pandas()
             if dtypes:
-                df = df.astype({k: v for k, v in dtypes.items() if k in df.columns})
-            pq.write_table(pa.Table.from_pandas(df, preserve_index=False),
-                           os.path.join(output_path, f"part_{i}.parquet"))
+                df = df.astype({c: t for c, t in dtypes.items() if c in df.columns})
+            table = pa.Table.from_pandas(df, preserve_index=False)
+            if k is None:
+                emit(i, table)
+                continue
+            bounds = [(n * j) // k for j in range(k + 1)]
+            for j in range(k):
+                if bounds[j + 1] > bounds[j] or j not in writers and j not in held:
+                    emit(j, table.slice(bounds[j], bounds[j + 1] - bounds[j]))
+        for j, pieces in sorted(held.items()):
+            table = pa.concat_tables(pieces)
+            if table.num_rows > 1:
+                table = table.take(pa.array(rng.permutation(table.num_rows)))
+            names[j] = fname(j)
+            w = writers[j] = pq.ParquetWriter(os.path.join(output_path, names[j]), table.schema,
+                                              metadata_collector=collector)
+            w.write_table(table)
+            rows_in[j] = table.num_rows
+        schema = None
+        order = sorted(writers)
+        for j in order:
+            schema = schema or writers[j].schema
+            writers[j].close()
+        # every ParquetWriter appended its FileMetaData on close, in closing order
+        for md, j in zip(collector, order):
+            md.set_file_path(names[j])
+        if world > 1:
+            gathered = [None] * world
+            import torch.distributed as td
+
+            td.all_gather_object(gathered, [(names[j], rows_in.get(j, 0)) for j in order])
+            td.barrier()
+            files = [x for g in gathered for x in g]
+        else:
+            files = [(names[j], rows_in.get(j, 0)) for j in order]
+        if rank == 0 and schema is not None:
+            if world > 1:  # summary over every rank's files
+                collector = []
+                for name, _ in files:
+                    md = pq.read_metadata(os.path.join(output_path, name))
+                    md.set_file_path(name)
+                    collector.append(md)
+            pq.write_metadata(schema, os.path.join(output_path, "_metadata"),
+                              metadata_collector=collector)
+            with open(os.path.join(output_path, "_file_list.txt"), "w") as f:
+                f.write(str(len(files)) + "\n")
+                for name, _ in files:
+                    f.write(name + "\n")
+            cols = schema.names
+            pick = lambda lst: [{"col_name": c, "index": cols.index(c)} for c in (lst or []) if c in cols]
+            meta = {"file_stats": [{"file_name": name, "num_rows": int(nr)} for name, nr in files],
+                    "cats": pick(cats), "conts": pick(conts), "labels": pick(labels)}
+            with open(os.path.join(output_path, "_metadata.json"), "w") as f:
+                json.dump(meta, f)
+        return None
+
+
+class Shuffle:
+    """merlin.io.Shuffle: how ``Dataset.to_parquet`` randomises rows."""
+
+    PER_PARTITION = "per-partition"
+    PER_WORKER = "per-worker"
+    FULL = "full"  # treated as PER_WORKER: there is one writer process per GPU
+
+    @staticmethod
+    def coerce(value):
+        if value is None or value is False:
+            return None
+        if value is True:
+            return Shuffle.PER_WORKER
+        if value in (Shuffle.PER_PARTITION, Shuffle.PER_WORKER):
+            return value
+        if value == Shuffle.FULL:
+            return Shuffle.PER_WORKER
+        raise ValueError(f"unknown shuffle option {value!r}")
+
+
+def _device_permutation(n: int, frame):
+    import torch
+
+    dev = None
+    for _, col in frame.items():
+        dev = col.data.device
+        break
+    return torch.randperm(n, device=dev)
 
 
 def _prefetch_frames(host_parts, cols, depth: int = 2):

@@ -217,3 +217,65 @@ def test_parquet_prefetch_side_stream_equals_synchronous(tmp_path):
     pd.testing.assert_frame_equal(a, b)
     pd.testing.assert_frame_equal(a[["C3", "label"]], df[["C3", "label"]].reset_index(drop=True))
     np.testing.assert_array_equal(a["C1"].isna().to_numpy(), df["C1"].isna().to_numpy())
+
+
+@pytest.mark.parametrize("shuffle", ["per-worker", "per-partition", None])
+def test_parquet_output_contract(tmp_path, shuffle):
+    """tests/unit/workflow/test_workflow.py:363-396 (test_parquet_output) and :444-500
+    (test_workflow_apply) of the reference: file count, _metadata, dtypes."""
+    import glob
+    import os
+
+    import pyarrow.parquet as pq
+
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    assert nvt.io.Shuffle.PER_WORKER == "per-worker"
+    size, k = 25, 2
+    path = str(tmp_path / "simple.parquet")
+    pd.DataFrame({"a": np.arange(size)}).to_parquet(path, row_group_size=5, engine="pyarrow")
+    ds = nvt.Dataset(path, engine="parquet", row_groups_per_part=1)
+    out = str(tmp_path / "processed")
+    wf = nvt.Workflow(["a"] >> ops.Normalize())
+    wf.fit_transform(ds).to_parquet(output_path=out, shuffle=shuffle, out_files_per_proc=k)
+    files = glob.glob(os.path.join(out, "*.parquet"))
+    assert len(files) == k
+    md = pq.read_metadata(os.path.join(out, "_metadata"))
+    assert md.num_rows == size and md.schema.names == ["a"]
+    got = pd.concat([pd.read_parquet(f) for f in sorted(files)])["a"].to_numpy()
+    exp = (np.arange(size) - np.arange(size).mean()) / np.arange(size).std(ddof=1)
+    np.testing.assert_allclose(np.sort(got), np.sort(exp), rtol=1e-6, atol=1e-9)
+    if shuffle is None:
+        np.testing.assert_allclose(pd.read_parquet(sorted(files)[0])["a"].to_numpy()[:2], exp[:2],
+                                   rtol=1e-6, atol=1e-9)
+    assert open(os.path.join(out, "_file_list.txt")).read().split()[0] == str(k)
+    # round trip through Dataset
+    back = nvt.Dataset(files).to_ddf().compute()
+    assert len(back) == size
+
+    # forced dtypes (test_workflow_apply)
+    df = pd.DataFrame({
+        "cont1": np.arange(size, dtype=np.float64), "cont2": np.arange(size, dtype=np.float64),
+        "cat1": np.arange(size, dtype=np.int32), "cat2": np.arange(size, dtype=np.int32),
+        "label": np.arange(size, dtype=np.float64)})
+    p2 = str(tmp_path / "five.parquet")
+    df.to_parquet(p2, row_group_size=5, engine="pyarrow")
+    ds2 = nvt.Dataset(p2, engine="parquet", row_groups_per_part=1)
+    cats = ["cat1", "cat2"] >> ops.Categorify(out_path=str(tmp_path / "cats"))
+    conts = ["cont1", "cont2"] >> ops.FillMissing() >> ops.Clip(min_value=0) >> ops.LogOp
+    wf2 = nvt.Workflow(cats + conts + ["label"]).fit(ds2)
+    want = {"cont1": np.float32, "cont2": np.float32, "cat1": np.float32, "cat2": np.float32,
+            "label": np.int64}
+    out2 = str(tmp_path / "processed2")
+    wf2.transform(ds2).to_parquet(output_path=out2, shuffle=shuffle, out_files_per_proc=k,
+                                  dtypes=want, cats=["cat1", "cat2"], conts=["cont1", "cont2"],
+                                  labels=["label"])
+    for f in glob.glob(os.path.join(out2, "*.parquet")):
+        g = pd.read_parquet(f)
+        assert {c: g[c].dtype for c in g.columns} == {c: np.dtype(t) for c, t in want.items()}
+    import json
+
+    meta = json.load(open(os.path.join(out2, "_metadata.json")))
+    assert sum(x["num_rows"] for x in meta["file_stats"]) == size
+    assert [c["col_name"] for c in meta["cats"]] == ["cat1", "cat2"]
