@@ -1,0 +1,443 @@
+"""Workflow persistence as ``graph.json`` + ``artifacts/node_<id>/`` -- the layout of the
+reference's nvtabular/workflow/graph_serializer.py (format_version 1, :15-29; node record
+:985-1021; operator records :319-431,507-566,579-646,649-720,775-820), written and read by
+this engine so that a workflow fitted here opens in stock NVTabular and vice versa:
+
+    saved_workflow/
+      metadata.json      versions + timestamp            (workflow.py:283-294)
+      graph.json         {"format_version": 1, "output_node_id": k, "nodes": [...]}
+      artifacts/node_<id>/categories/unique.<col>.parquet ...
+
+Operator class paths in ``op_class`` are the reference's (``nvtabular.ops.fill.FillMissing``,
+``merlin.dag.ops.selection.SelectionOp`` ...): they are the interchange vocabulary, mapped
+to this package's classes by ``_REGISTRY``.  No pickle; lambdas are refused exactly like
+the reference does (:71-88).
+"""
+from __future__ import annotations
+
+import importlib
+import json
+import os
+from typing import Dict, List
+
+import numpy as np
+
+from .node import Node
+from .schema import ColumnSchema, Schema, Tags
+from .selector import ColumnSelector
+
+
+class WorkflowSerializationError(Exception):
+    """A workflow cannot be expressed in the JSON format (e.g. a LambdaOp holding a lambda)."""
+
+
+# ---- leaves of the format -------------------------------------------------------------
+def _callable_to_dict(f):
+    if f is None:
+        return None
+    if getattr(f, "__name__", "") == "<lambda>":
+        raise WorkflowSerializationError(
+            f"Cannot serialize {f!r}: lambda functions cannot be serialized by the JSON workflow "
+            "serializer; use a named function defined in an importable module."
+        )
+    if f.__module__ == "__main__":
+        raise WorkflowSerializationError(
+            f"Cannot serialize '{f.__qualname__}': it is defined in __main__. "
+            "Move it to an importable module."
+        )
+    return {"module": f.__module__, "qualname": f.__qualname__}
+
+
+def _callable_from_dict(d):
+    if d is None:
+        return None
+    obj = importlib.import_module(d["module"])
+    for part in d["qualname"].split("."):
+        obj = getattr(obj, part)
+    return obj
+
+
+def _tags_to_list(tags) -> List[str]:
+    return [f"Tags.{t.name}" if isinstance(t, Tags) else str(t) for t in (tags or [])]
+
+
+def _tags_from_list(strs):
+    out = []
+    for s in strs or []:
+        name = str(s).split(".")[-1]
+        try:
+            out.append(Tags[name])
+        except KeyError:
+            try:
+                out.append(Tags(name.lower()))
+            except ValueError:
+                pass  # a tag this engine does not model
+    return out
+
+
+_KIND = {"i": "int", "u": "uint", "f": "float", "b": "bool", "O": "object", "U": "string",
+         "S": "string", "M": "datetime"}
+
+
+def _dtype_to_dict(dtype, is_list=False, is_ragged=False, with_shape=False):
+    """merlin DType record (:130-153): name / element_type / element_size / signed / shape."""
+    if dtype is None:
+        return None
+    try:
+        dt = np.dtype(dtype)
+    except TypeError:
+        return {"name": str(dtype)}
+    d = {"name": "str" if dt.kind in "OUS" else dt.name, "element_type": _KIND.get(dt.kind, "unknown")}
+    if dt.kind in "iuf":
+        d["element_size"] = dt.itemsize * 8
+    if dt.kind in "iu":
+        d["signed"] = dt.kind == "i"
+    if with_shape:
+        dims = [{"min": None, "max": None}]
+        if is_list:
+            dims.append({"min": 0 if is_ragged else None, "max": None})
+        d["shape"] = dims
+    return d
+
+
+def _dtype_from_dict(d):
+    if d is None:
+        return None
+    name = d if isinstance(d, str) else d.get("name", "")
+    if name in ("str", "string", "object"):
+        return np.dtype("O")
+    try:
+        return np.dtype(name)
+    except TypeError:
+        et, size = (d.get("element_type"), d.get("element_size")) if isinstance(d, dict) else (None, None)
+        if et in ("int", "uint", "float") and size:
+            return np.dtype(f"{et}{size}")
+        return None
+
+
+def _json_safe(v):
+    if isinstance(v, dict):
+        return {str(k): _json_safe(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_json_safe(x) for x in v]
+    if isinstance(v, np.generic):
+        return v.item()
+    return v
+
+
+def _column_schema_to_dict(cs: ColumnSchema):
+    return {"name": cs.name, "tags": _tags_to_list(cs.tags), "properties": _json_safe(cs.properties),
+            "dtype": _dtype_to_dict(cs.dtype, cs.is_list, cs.is_ragged, with_shape=True),
+            "is_list": bool(cs.is_list), "is_ragged": bool(cs.is_ragged)}
+
+
+def _column_schema_from_dict(d) -> ColumnSchema:
+    return ColumnSchema(name=d["name"], dtype=_dtype_from_dict(d.get("dtype")),
+                        tags=tuple(_tags_from_list(d.get("tags", []))),
+                        properties=d.get("properties") or {}, is_list=bool(d.get("is_list")),
+                        is_ragged=bool(d.get("is_ragged")))
+
+
+def _schema_to_dict(schema):
+    return None if schema is None else [_column_schema_to_dict(c) for c in schema]
+
+
+def _schema_from_dict(d):
+    return None if d is None else Schema([_column_schema_from_dict(c) for c in d])
+
+
+def _selector_to_dict(sel):
+    if sel is None:
+        return None
+    return {"names": list(sel.names), "tags": []}
+
+
+def _selector_from_dict(d):
+    return None if d is None else ColumnSelector(d["names"])
+
+
+def _paths_to_json(mapping, artifact_dir):
+    """{key: absolute path under artifact_dir} -> [{"key": [...], "path": relative}] (:257-273)."""
+    out = []
+    for k, v in (mapping or {}).items():
+        key = list(k) if isinstance(k, tuple) else [k]
+        out.append({"key": key, "path": os.path.relpath(str(v), artifact_dir)})
+    return out
+
+
+def _paths_from_json(records, artifact_dir):
+    out = {}
+    for item in records or []:
+        key = item["key"]
+        out[tuple(key) if len(key) > 1 else key[0]] = os.path.join(artifact_dir, item["path"])
+    return out
+
+
+def _np_dtype_param(dt):
+    return None if dt is None else {"name": np.dtype(dt).str}
+
+
+def _np_dtype_from_param(d):
+    return None if not d else np.dtype(d["name"])
+
+
+def _plain(v):
+    return v if isinstance(v, (int, type(None))) else dict(v)
+
+
+# ---- operators --------------------------------------------------------------------------
+def _build_registry():
+    from . import ops
+    from .ops.selection import ConcatColumns
+
+    reg: Dict[str, tuple] = {}
+
+    def add(path, cls, to_dict, from_dict):
+        reg[path] = (cls, to_dict, from_dict)
+
+    add("merlin.dag.ops.concat_columns.ConcatColumns", ConcatColumns,
+        lambda op, d: ({}, {}), lambda p, s, d: ConcatColumns())
+    add("nvtabular.ops.fill.FillMissing", ops.FillMissing,
+        lambda op, d: ({"fill_val": op.fill_val, "add_binary_cols": op.add_binary_cols}, {}),
+        lambda p, s, d: ops.FillMissing(fill_val=p.get("fill_val", 0),
+                                        add_binary_cols=p.get("add_binary_cols", False)))
+
+    def norm_from(p, s, d):
+        op = ops.Normalize(out_dtype=_np_dtype_from_param(p.get("out_dtype")))
+        op.means = {k: float(v) for k, v in s.get("means", {}).items()}
+        op.stds = {k: float(v) for k, v in s.get("stds", {}).items()}
+        return op
+
+    add("nvtabular.ops.normalize.Normalize", ops.Normalize,
+        lambda op, d: ({"out_dtype": _dtype_to_dict(op.out_dtype)},
+                       {"means": {str(k): float(v) for k, v in op.means.items()},
+                        "stds": {str(k): float(v) for k, v in op.stds.items()}}),
+        norm_from)
+
+    def minmax_from(p, s, d):
+        op = ops.NormalizeMinMax(out_dtype=_np_dtype_from_param(p.get("out_dtype")))
+        op.mins = {k: float(v) for k, v in s.get("mins", {}).items()}
+        op.maxs = {k: float(v) for k, v in s.get("maxs", {}).items()}
+        return op
+
+    add("nvtabular.ops.normalize.NormalizeMinMax", ops.NormalizeMinMax,
+        lambda op, d: ({"out_dtype": _dtype_to_dict(op.out_dtype)},
+                       {"mins": {str(k): float(v) for k, v in op.mins.items()},
+                        "maxs": {str(k): float(v) for k, v in op.maxs.items()}}),
+        minmax_from)
+    add("nvtabular.ops.clip.Clip", ops.Clip,
+        lambda op, d: ({"min_value": op.min_value, "max_value": op.max_value}, {}),
+        lambda p, s, d: ops.Clip(min_value=p.get("min_value"), max_value=p.get("max_value")))
+    add("nvtabular.ops.logop.LogOp", ops.LogOp, lambda op, d: ({}, {}), lambda p, s, d: ops.LogOp())
+    add("nvtabular.ops.hash_bucket.HashBucket", ops.HashBucket,
+        lambda op, d: ({"num_buckets": _json_safe(op.num_buckets)}, {}),
+        lambda p, s, d: ops.HashBucket(num_buckets=p["num_buckets"]))
+    add("nvtabular.ops.rename.Rename", ops.Rename,
+        lambda op, d: ({"f": _callable_to_dict(op.f), "postfix": op.postfix, "name": op.name}, {}),
+        lambda p, s, d: ops.Rename(f=_callable_from_dict(p.get("f")), postfix=p.get("postfix"),
+                                   name=p.get("name")))
+
+    def lambda_to(op, d):
+        dep = op.dependency
+        names = [dep] if isinstance(dep, str) else [str(x) for x in dep] if isinstance(dep, list) else []
+        return ({"f": _callable_to_dict(op.f), "dependency": names,
+                 "dtype": _dtype_to_dict(op._dtype), "tags": _tags_to_list(op._tags),
+                 "properties": _json_safe(op._properties)}, {})
+
+    def lambda_from(p, s, d):
+        return ops.LambdaOp(_callable_from_dict(p.get("f")), dependency=p.get("dependency") or None,
+                            dtype=_dtype_from_dict(p.get("dtype")),
+                            tags=_tags_from_list(p.get("tags")) or None,
+                            properties=p.get("properties") or None)
+
+    add("nvtabular.ops.lambdaop.LambdaOp", ops.LambdaOp, lambda_to, lambda_from)
+    reg["merlin.dag.ops.udf.UDF"] = reg["nvtabular.ops.lambdaop.LambdaOp"]
+
+    def cat_to(op, d):
+        os.makedirs(d, exist_ok=True)
+        op.set_storage_path(d, copy=True)
+        params = {
+            "freq_threshold": _json_safe(op.freq_threshold),
+            "cat_cache": op.cat_cache if isinstance(op.cat_cache, str) else "host",
+            "dtype": _np_dtype_param(op.dtype), "on_host": op.on_host,
+            "encode_type": op.encode_type, "name_sep": op.name_sep,
+            "search_sorted": op.search_sorted, "num_buckets": _plain(op.num_buckets),
+            "max_size": _plain(op.max_size), "single_table": op.single_table,
+            "cardinality_memory_limit": None if op.cardinality_memory_limit is None
+            else str(op.cardinality_memory_limit),
+            "split_out": _plain(op.split_out), "split_every": _plain(op.split_every),
+        }
+        state = {"categories": _paths_to_json(op.categories, d),
+                 "storage_name": {str(k): str(v) for k, v in op.storage_name.items()}}
+        return params, state
+
+    def cat_from(p, s, d):
+        op = ops.Categorify(
+            freq_threshold=p.get("freq_threshold", 0), cat_cache=p.get("cat_cache", "host"),
+            dtype=_np_dtype_from_param(p.get("dtype")), on_host=p.get("on_host", True),
+            encode_type=p.get("encode_type", "joint"), name_sep=p.get("name_sep", "_"),
+            search_sorted=p.get("search_sorted", False), num_buckets=p.get("num_buckets"),
+            max_size=p.get("max_size", 0), single_table=p.get("single_table", False),
+            cardinality_memory_limit=p.get("cardinality_memory_limit"),
+            split_out=p.get("split_out", 1), split_every=p.get("split_every", 8))
+        op.categories = _paths_from_json(s.get("categories"), d)
+        op.out_path = d
+        op.storage_name = dict(s.get("storage_name", {}))
+        return op
+
+    add("nvtabular.ops.categorify.Categorify", ops.Categorify, cat_to, cat_from)
+
+    def jg_to(op, d):
+        os.makedirs(d, exist_ok=True)
+        op.set_storage_path(d, copy=True)
+        cont = list(op._cont_names.names) if op._cont_names is not None else None
+        params = {"cont_cols": cont, "stats": list(op.stats), "split_out": op.split_out,
+                  "split_every": op.split_every, "on_host": op.on_host,
+                  "cat_cache": op.cat_cache if isinstance(op.cat_cache, str) else "host",
+                  "name_sep": op.name_sep}
+        state = {"categories": _paths_to_json(op.categories, d),
+                 "storage_name": {str(k): str(v) for k, v in op.storage_name.items()}}
+        return params, state
+
+    def jg_from(p, s, d):
+        op = ops.JoinGroupby(cont_cols=p.get("cont_cols"), stats=tuple(p.get("stats", ("count",))),
+                             split_out=p.get("split_out"), split_every=p.get("split_every"),
+                             on_host=p.get("on_host", True), cat_cache=p.get("cat_cache", "host"),
+                             name_sep=p.get("name_sep", "_"))
+        op.categories = _paths_from_json(s.get("categories"), d)
+        op.out_path = d
+        op.storage_name = dict(s.get("storage_name", {}))
+        return op
+
+    add("nvtabular.ops.join_groupby.JoinGroupby", ops.JoinGroupby, jg_to, jg_from)
+
+    def te_to(op, d):
+        os.makedirs(d, exist_ok=True)
+        op.set_storage_path(d, copy=True)
+        t = op.target
+        if isinstance(t, Node):
+            cols = t.output_schema.column_names if t.output_schema else list(t.selector.names)
+        else:
+            cols = [t] if isinstance(t, str) else list(t)
+        params = {"target_cols": cols, "target_mean": op.target_mean, "kfold": op.kfold,
+                  "fold_seed": op.fold_seed, "p_smooth": op.p_smooth, "out_col": op.out_col,
+                  "out_dtype": _np_dtype_param(op.out_dtype), "split_out": op.split_out,
+                  "split_every": op.split_every, "on_host": op.on_host,
+                  "cat_cache": op.cat_cache if isinstance(op.cat_cache, str) else "host",
+                  "name_sep": op.name_sep, "drop_folds": op.drop_folds}
+        state = {"stats": _paths_to_json(op.stats, d),
+                 "means": {str(k): float(v) for k, v in op.means.items()}}
+        return params, state
+
+    def te_from(p, s, d):
+        op = ops.TargetEncoding(
+            target=p.get("target_cols", []), target_mean=p.get("target_mean"),
+            kfold=p.get("kfold", 3), fold_seed=p.get("fold_seed", 42), p_smooth=p.get("p_smooth", 20),
+            out_col=p.get("out_col"), out_dtype=_np_dtype_from_param(p.get("out_dtype")),
+            split_out=p.get("split_out"), split_every=p.get("split_every"),
+            on_host=p.get("on_host", True), cat_cache=p.get("cat_cache", "host"),
+            name_sep=p.get("name_sep", "_"), drop_folds=p.get("drop_folds", True))
+        op.stats = _paths_from_json(s.get("stats"), d)
+        op.means = {k: float(v) for k, v in s.get("means", {}).items()}
+        op.out_path = d
+        return op
+
+    add("nvtabular.ops.target_encoding.TargetEncoding", ops.TargetEncoding, te_to, te_from)
+    return reg
+
+
+_REGISTRY: Dict[str, tuple] = {}
+_SELECTION = "merlin.dag.ops.selection.SelectionOp"
+# exist in the reference too, but its JSON serializer defers them (:920-930)
+_DEFERRED = {"SubsetColumns", "SubtractionOp"}
+
+
+def _registry():
+    if not _REGISTRY:
+        _REGISTRY.update(_build_registry())
+    return _REGISTRY
+
+
+def _lookup(op):
+    for path, (cls, to_dict, _) in _registry().items():
+        if type(op) is cls:
+            return path, to_dict
+    for path, (cls, to_dict, _) in _registry().items():
+        if isinstance(op, cls):
+            return path, to_dict
+    if type(op).__name__ in _DEFERRED:
+        raise NotImplementedError(
+            f"The operator '{type(op).__name__}' is not yet supported by the JSON workflow serializer.")
+    raise WorkflowSerializationError(
+        f"No serializer registered for operator '{type(op).__module__}.{type(op).__qualname__}'.")
+
+
+# ---- graph ------------------------------------------------------------------------------
+def _collect(output_node: Node) -> List[Node]:
+    """Breadth-first from the output through parents + dependencies, reversed: leaves first,
+    output node last -- ids are positions in this list (:942-964)."""
+    seen, order, queue = set(), [], [output_node]
+    while queue:
+        n = queue.pop(0)
+        if id(n) in seen:
+            continue
+        seen.add(id(n))
+        order.append(n)
+        queue.extend(c for c in n.parents_with_dependencies if id(c) not in seen)
+    order.reverse()
+    return order
+
+
+def serialize_graph(workflow, path: str):
+    nodes = _collect(workflow.output_node)
+    ids = {id(n): i for i, n in enumerate(nodes)}
+    records = []
+    for n in nodes:
+        i = ids[id(n)]
+        adir = os.path.join(path, "artifacts", f"node_{i}")
+        if n.op is None:  # a column selection: merlin's SelectionOp
+            cls, params, state = _SELECTION, {"selector": _selector_to_dict(n.selector)}, {}
+        else:
+            cls, to_dict = _lookup(n.op)
+            params, state = to_dict(n.op, adir)
+        records.append({
+            "id": i, "op_class": cls, "op_params": params, "op_state": state,
+            "parent_ids": [ids[id(p)] for p in n.parents],
+            "dependency_ids": [ids[id(d)] for d in n.dependencies],
+            "selector": _selector_to_dict(n.selector),
+            "input_schema": _schema_to_dict(n.input_schema),
+            "output_schema": _schema_to_dict(n.output_schema),
+        })
+    with open(os.path.join(path, "graph.json"), "w") as f:
+        json.dump({"format_version": 1, "output_node_id": ids[id(workflow.output_node)],
+                   "nodes": records}, f, indent=2)
+
+
+def deserialize_graph(path: str) -> Node:
+    with open(os.path.join(path, "graph.json")) as f:
+        data = json.load(f)
+    if data.get("format_version", 1) != 1:
+        raise WorkflowSerializationError(
+            f"Unsupported graph.json format_version={data.get('format_version')}.")
+    built: Dict[int, Node] = {}
+    for rec in sorted(data["nodes"], key=lambda r: r["id"]):
+        adir = os.path.join(path, "artifacts", f"node_{rec['id']}")
+        node = Node()
+        cls = rec.get("op_class")
+        if cls is not None and cls != _SELECTION:
+            entry = _registry().get(cls)
+            if entry is None:
+                raise WorkflowSerializationError(
+                    f"Unknown operator class '{cls}' in graph.json. Cannot deserialize this workflow.")
+            node.op = entry[2](rec.get("op_params", {}), rec.get("op_state", {}), adir)
+        sel = rec.get("selector") or (rec.get("op_params", {}).get("selector") if cls == _SELECTION else None)
+        if sel:
+            node.selector = _selector_from_dict(sel)
+        node.input_schema = _schema_from_dict(rec.get("input_schema"))
+        node.output_schema = _schema_from_dict(rec.get("output_schema"))
+        for pid in rec.get("parent_ids", []):
+            node.add_parent(built[pid])
+        for did in rec.get("dependency_ids", []):
+            node.add_dependency(built[did])
+        built[rec["id"]] = node
+    return built[data["output_node_id"]]

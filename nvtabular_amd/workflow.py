@@ -173,24 +173,48 @@ class Workflow:
         self.fit(dataset)
         return self.transform(dataset)
 
-    # ---- persistence (minimal, artefact-compatible layout) --
+    # ---- persistence: graph.json + artifacts/ (reference workflow.py:256-297, 299-358) ------
     def save(self, path):
+        """Save as ``metadata.json`` + ``graph.json`` + ``artifacts/node_<id>/`` -- the
+        reference's pickle-free layout (graph_serializer.py:15-29), see graph_json.py."""
+        import sys
+
+        from . import __version__ as version
+        from .graph_json import serialize_graph
+
+        path = str(path)
         os.makedirs(path, exist_ok=True)
-        for i, node in enumerate(iter_nodes(self.output_node)):
-            if isinstance(node.op, StatOperator):
-                node.op.set_storage_path(os.path.join(path, "artifacts", f"node_{i}"), copy=True)
-        meta = {"generated_timestamp": int(time.time()), "engine": "nvtabular_amd"}
+        _ = self.output_schema  # fold the fitted properties into the node schemas first
+        meta = {
+            "versions": {"nvtabular": version, pd.__name__: pd.__version__, "python": sys.version},
+            "generated_timestamp": int(time.time()),
+            "engine": "nvtabular_amd",
+        }
         with open(os.path.join(path, "metadata.json"), "w") as f:
             json.dump(meta, f)
-        dev = _strip_device_state(self)
-        try:
-            with open(os.path.join(path, "workflow.pkl"), "wb") as f:
-                pickle.dump(self, f)
-        finally:
-            _restore_device_state(dev)
+        serialize_graph(self, path)
 
     @classmethod
     def load(cls, path, client=None) -> "Workflow":
+        path = str(path)
+        if not os.path.exists(os.path.join(path, "graph.json")):
+            return cls._load_pickle(path, client)
+        from .graph_json import deserialize_graph
+
+        wf = cls(deserialize_graph(path), client=client)
+        wf._output_schema = wf.output_node.output_schema
+        if wf._output_schema is not None:
+            wf.output_dtypes = {c.name: c.dtype for c in wf._output_schema}
+        roots = []
+        for node in iter_nodes(wf.output_node):
+            if node.op is None and node.input_schema is not None:
+                roots += [c for c in node.input_schema if c.name not in {r.name for r in roots}]
+        wf.input_schema = Schema(roots) if roots else None
+        return wf
+
+    @classmethod
+    def _load_pickle(cls, path, client=None) -> "Workflow":
+        """Workflows saved by the first revision of this package (workflow.pkl)."""
         with open(os.path.join(path, "workflow.pkl"), "rb") as f:
             wf = pickle.load(f)
         wf.client = client

@@ -1,5 +1,7 @@
 """Host logic of the drop-in boundary: the graph DSL and schema propagation
 (ported from /root/reference/tests/unit/workflow/test_workflow_node.py, lines cited)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -135,3 +137,96 @@ def test_lambda_auto_wrap():
     # tests/unit/ops/test_lambda.py:118-120: a bare callable after >> becomes a LambdaOp
     node = ColumnSelector(["a"]) >> (lambda col: col + 1)
     assert isinstance(node.op, ops.LambdaOp)
+
+
+# ---- graph.json persistence (reference: nvtabular/workflow/graph_serializer.py) ----------
+def _named_double(col):
+    return col * 2
+
+
+def test_graph_json_roundtrip_layout(tmp_path):
+    """Layout + vocabulary of the reference's pickle-free format (graph_serializer.py:15-29,
+    985-1021): metadata.json, graph.json (format_version 1, leaves first, reference op class
+    paths), artifacts/node_<id>/ holding the Categorify files; load rebuilds an equal graph."""
+    import json
+
+    import numpy as np
+    import pandas as pd
+
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+    from nvtabular_amd.schema import Schema
+
+    stats = tmp_path / "stats" / "categories"
+    stats.mkdir(parents=True)
+    pd.DataFrame({"c": [5, 7], "c_size": [3, 1]}, index=[3, 4]).to_parquet(stats / "unique.c.parquet")
+    pd.DataFrame({"kind": ["pad", "null", "oov", "unique"], "offset": [0, 1, 2, 3],
+                  "num_indices": [1, 1, 1, 2]}).to_parquet(stats / "meta.c.parquet")
+    cat = ops.Categorify(out_path=str(tmp_path / "stats"), freq_threshold=2, num_buckets={"c": 4},
+                         dtype=np.int32)
+    cat.categories = {"c": str(stats / "unique.c.parquet")}
+    cat.storage_name = {"c": "c"}
+    norm = ops.Normalize(out_dtype=np.float32)
+    norm.means, norm.stds = {"x": 1.5}, {"x": 0.25}
+    graph = (["c"] >> cat) + (["x"] >> ops.FillMissing(fill_val=3) >> ops.Clip(min_value=0) >> norm
+                              >> ops.Rename(postfix="_n")) + (["x"] >> ops.LambdaOp(_named_double)
+                                                              >> ops.Rename(name="x2")) + ["y"]
+    wf = nvt.Workflow(graph)
+    wf.fit_schema(Schema.from_frame(pd.DataFrame({"c": np.array([5], dtype="int32"),
+                                                  "x": [1.0], "y": [0.0]})))
+    out = str(tmp_path / "saved")
+    wf.save(out)
+    meta = json.load(open(f"{out}/metadata.json"))
+    assert "nvtabular" in meta["versions"] and "generated_timestamp" in meta
+    g = json.load(open(f"{out}/graph.json"))
+    assert g["format_version"] == 1 and g["output_node_id"] == len(g["nodes"]) - 1
+    by_cls = {}
+    for rec in g["nodes"]:
+        assert set(rec) == {"id", "op_class", "op_params", "op_state", "parent_ids", "dependency_ids",
+                            "selector", "input_schema", "output_schema"}
+        assert all(p < rec["id"] for p in rec["parent_ids"] + rec["dependency_ids"])  # leaves first
+        by_cls.setdefault(rec["op_class"], []).append(rec)
+    assert set(by_cls) == {
+        "merlin.dag.ops.selection.SelectionOp", "merlin.dag.ops.concat_columns.ConcatColumns",
+        "nvtabular.ops.categorify.Categorify", "nvtabular.ops.fill.FillMissing",
+        "nvtabular.ops.clip.Clip", "nvtabular.ops.normalize.Normalize", "nvtabular.ops.rename.Rename",
+        "nvtabular.ops.lambdaop.LambdaOp"}
+    crec = by_cls["nvtabular.ops.categorify.Categorify"][0]
+    assert crec["op_params"]["num_buckets"] == {"c": 4} and crec["op_params"]["dtype"] == {"name": "<i4"}
+    assert crec["op_state"]["categories"] == [{"key": ["c"], "path": "categories/unique.c.parquet"}]
+    assert os.path.exists(f"{out}/artifacts/node_{crec['id']}/categories/unique.c.parquet")
+    assert os.path.exists(f"{out}/artifacts/node_{crec['id']}/categories/meta.c.parquet")
+    nrec = by_cls["nvtabular.ops.normalize.Normalize"][0]
+    assert nrec["op_state"] == {"means": {"x": 1.5}, "stds": {"x": 0.25}}
+    assert nrec["op_params"]["out_dtype"]["name"] == "float32"
+    col = crec["output_schema"][0]
+    assert col["dtype"]["name"] == "int32" and col["dtype"]["element_type"] == "int"
+    assert "Tags.CATEGORICAL" in col["tags"]
+    lrec = by_cls["nvtabular.ops.lambdaop.LambdaOp"][0]
+    assert lrec["op_params"]["f"] == {"module": _named_double.__module__, "qualname": "_named_double"}
+
+    wf2 = nvt.Workflow.load(out)
+    assert wf2.output_schema.column_names == wf.output_schema.column_names
+    assert [c.dtype for c in wf2.output_schema] == [c.dtype for c in wf.output_schema]
+    assert sorted(wf2.input_schema.column_names) == ["c", "x", "y"]
+    ops2 = {type(n.op).__name__: n.op for n in nvt.workflow.iter_nodes(wf2.output_node) if n.op}
+    assert ops2["Normalize"].means == {"x": 1.5} and ops2["Normalize"].out_dtype == np.float32
+    assert ops2["Categorify"].num_buckets == {"c": 4} and ops2["Categorify"].freq_threshold == 2
+    assert ops2["Categorify"].categories["c"].startswith(out) and ops2["Categorify"].dtype == np.int32
+    assert ops2["FillMissing"].fill_val == 3 and ops2["Clip"].min_value == 0
+    assert ops2["LambdaOp"].f is _named_double
+
+
+def test_graph_json_refuses_lambdas(tmp_path):
+    """graph_serializer.py:71-88."""
+    import pandas as pd
+
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+    from nvtabular_amd.graph_json import WorkflowSerializationError
+    from nvtabular_amd.schema import Schema
+
+    wf = nvt.Workflow(["x"] >> ops.LambdaOp(lambda col: col + 1))
+    wf.fit_schema(Schema.from_frame(pd.DataFrame({"x": [1.0]})))
+    with pytest.raises(WorkflowSerializationError):
+        wf.save(str(tmp_path / "w"))
