@@ -204,6 +204,12 @@ int nvt_clip_log(const void *x, int dtype, const uint8_t *valid, uint64_t n, int
                  double fill_val, int has_min, double vmin, int has_max, double vmax, int do_log,
                  void *out, int out_dtype, void *stream);
 
+/* ---- Bucketize (bucketize.py:76-94): out[i] = np.digitize(x[i], boundaries, right=False),
+ * i.e. the number of (ascending, float64, device) boundaries <= x[i]; null / NaN rows get
+ * n_boundaries (numpy's answer for NaN).  n_boundaries <= 8192. */
+int nvt_bucketize(const void *x, int dtype, const uint8_t *valid, uint64_t n,
+                  const double *boundaries, int n_boundaries, int32_t *out, void *stream);
+
 /* ---- JoinGroupby / TargetEncoding / combo-Categorify: multi-key groupby tables ----
  * A table over nkeys (1..3) key columns (each int64 after widening; null components
  * allowed and form their own groups, pandas dropna=False) and nvals (0..8) value

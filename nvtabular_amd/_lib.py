@@ -65,6 +65,7 @@ SIGNATURES = {
     "nvt_minmax": [_vp, _i32, _vp, _u64, _i32, _vp, _vp, _vp],
     "nvt_fill_normalize": [_vp, _i32, _vp, _u64, _i32, _dbl, _i32, _dbl, _dbl, _vp, _i32, _vp, _vp],
     "nvt_clip_log": [_vp, _i32, _vp, _u64, _i32, _dbl, _i32, _dbl, _i32, _dbl, _i32, _vp, _i32, _vp],
+    "nvt_bucketize": [_vp, _i32, _vp, _u64, _vp, _i32, _vp, _vp],
     "nvt_gb_create": [_i32, _i32, _i32, _u64, _pp],
     "nvt_gb_destroy": [_vp],
     "nvt_gb_clear": [_vp, _vp],

@@ -308,6 +308,36 @@ __global__ __launch_bounds__(kBlock) void clip_log_kernel(
     out[i] = f(x[i], bit_valid(valid, i));
 }
 
+// Bucketize (bucketize.py:76-94): out = np.digitize(x, boundaries, right=False) = number of
+// boundaries <= x, boundaries ascending; NaN / null rows get len(boundaries) like numpy's NaN.
+// Boundaries live in LDS; one branch-free binary search per element.
+constexpr int kMaxBoundaries = 8192;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bucketize_kernel(const T *__restrict__ x,
+                                                           const uint8_t *__restrict__ valid,
+                                                           uint64_t n,
+                                                           const double *__restrict__ bounds,
+                                                           int nb, int32_t *__restrict__ out) {
+  __shared__ double b[kMaxBoundaries];
+  for (int i = threadIdx.x; i < nb; i += kBlock) b[i] = bounds[i];
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const T raw = x[i];
+    int r = nb;
+    if (bit_valid(valid, i) && !is_nan(raw)) {
+      const double v = (double)raw;
+      int lo = 0, hi = nb;  // first index with b[idx] > v
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (b[mid] <= v) lo = mid + 1; else hi = mid;
+      }
+      r = lo;
+    }
+    out[i] = r;
+  }
+}
+
 template <typename OUT>
 __global__ __launch_bounds__(kBlock) void gather_kernel(const double *__restrict__ src,
                                                         const int64_t *__restrict__ group,
@@ -530,6 +560,35 @@ int nvt_clip_log(const void *x, int dtype, const uint8_t *valid, uint64_t n, int
   set_error("nvt_clip_log: unsupported dtype combination in=%d out=%d log=%d", dtype, out_dtype,
             do_log);
   return NVT_EINVAL;
+}
+
+int nvt_bucketize(const void *x, int dtype, const uint8_t *valid, uint64_t n,
+                  const double *boundaries, int n_boundaries, int32_t *out, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(x && out, "null x/out");
+  NVT_CHECK_ARG(n_boundaries >= 0 && n_boundaries <= kMaxBoundaries, "at most 8192 boundaries");
+  NVT_CHECK_ARG(n_boundaries == 0 || boundaries, "null boundaries");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = stream_grid(n, kBlock * 4, 8);
+  switch (dtype) {
+    case NVT_F32:
+      bucketize_kernel<float><<<grid, kBlock, 0, s>>>((const float *)x, valid, n, boundaries, n_boundaries, out);
+      break;
+    case NVT_F64:
+      bucketize_kernel<double><<<grid, kBlock, 0, s>>>((const double *)x, valid, n, boundaries, n_boundaries, out);
+      break;
+    case NVT_I32:
+      bucketize_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)x, valid, n, boundaries, n_boundaries, out);
+      break;
+    case NVT_I64:
+      bucketize_kernel<int64_t><<<grid, kBlock, 0, s>>>((const int64_t *)x, valid, n, boundaries, n_boundaries, out);
+      break;
+    default:
+      set_error("nvt_bucketize: unsupported dtype %d", dtype);
+      return NVT_EINVAL;
+  }
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
 }
 
 int nvt_gather_f64(const double *src, const int64_t *group, uint64_t n, double miss, void *out,

@@ -232,6 +232,15 @@ def _build_registry():
     add("nvtabular.ops.hash_bucket.HashBucket", ops.HashBucket,
         lambda op, d: ({"num_buckets": _json_safe(op.num_buckets)}, {}),
         lambda p, s, d: ops.HashBucket(num_buckets=p["num_buckets"]))
+    def bucketize_to(op, d):
+        if op._original_boundaries is None:
+            raise WorkflowSerializationError(
+                "Bucketize with callable boundaries cannot be serialized; use a list or dict.")
+        b = op._original_boundaries
+        return ({"boundaries": _json_safe(b if isinstance(b, dict) else list(b))}, {})
+
+    add("nvtabular.ops.bucketize.Bucketize", ops.Bucketize, bucketize_to,
+        lambda p, s, d: ops.Bucketize(p["boundaries"]))
     add("nvtabular.ops.rename.Rename", ops.Rename,
         lambda op, d: ({"f": _callable_to_dict(op.f), "postfix": op.postfix, "name": op.name}, {}),
         lambda p, s, d: ops.Rename(f=_callable_from_dict(p.get("f")), postfix=p.get("postfix"),
@@ -349,7 +358,7 @@ def _build_registry():
 _REGISTRY: Dict[str, tuple] = {}
 _SELECTION = "merlin.dag.ops.selection.SelectionOp"
 # exist in the reference too, but its JSON serializer defers them (:920-930)
-_DEFERRED = {"SubsetColumns", "SubtractionOp"}
+_DEFERRED = {"SubsetColumns", "SubtractionOp", "HashedCross"}
 
 
 def _registry():

@@ -656,6 +656,20 @@ def clip_log(x, valid, fill, vmin, vmax, do_log: bool, out_dtype: torch.dtype) -
     return out
 
 
+def bucketize(x: torch.Tensor, valid, boundaries: torch.Tensor) -> torch.Tensor:
+    """np.digitize(x, boundaries, right=False) as int32; boundaries float64 ascending on device."""
+    _lib.require_gpu()
+    x = x.contiguous()
+    out = torch.empty(x.numel(), dtype=torch.int32, device=x.device)
+    check(
+        _lib.load().nvt_bucketize(x.data_ptr(), dtype_code(x.dtype), ptr(valid), x.numel(),
+                                  ptr(boundaries), int(boundaries.numel()), out.data_ptr(),
+                                  stream_ptr()),
+        "nvt_bucketize",
+    )
+    return out
+
+
 def widen_i64(x: torch.Tensor) -> torch.Tensor:
     if x.dtype == torch.int64:
         return x

@@ -76,6 +76,8 @@ __all__ = [
     "minmax_transform",
     "fill_missing",
     "clip_transform",
+    "hashed_cross",
+    "bucketize",
     "logop_transform",
     "join_groupby_fit",
     "join_groupby_transform",
@@ -193,6 +195,25 @@ def hash_bucket(df, num_buckets: Dict[str, int], cols: List[str], encode_type="j
     for c in cols:
         acc ^= hash_values(df[c])
     return ((acc >> np.uint64(32)) % np.uint64(nb)).astype(np.int64)
+
+
+def hashed_cross(df: pd.DataFrame, cols: List[str], num_buckets: int) -> pd.DataFrame:
+    """hashed_cross.py:56-67: XOR of the per-column hashes, modulo num_buckets, int32,
+    named a_X_b (hash = this engine's documented hash)."""
+    acc = np.zeros(len(df), dtype=np.uint64)
+    for c in cols:
+        acc ^= hash_values(df[c])
+    out = pd.DataFrame()
+    out["_X_".join(cols)] = ((acc >> np.uint64(32)) % np.uint64(num_buckets)).astype(np.int32)
+    return out
+
+
+def bucketize(df: pd.DataFrame, boundaries: Dict[str, list]) -> pd.DataFrame:
+    """bucketize.py:76-94 (use_digitize branch)."""
+    out = pd.DataFrame()
+    for col, b in boundaries.items():
+        out[col] = np.digitize(df[col].values, np.asarray(b), right=False).astype(np.int32)
+    return out
 
 
 def hash_bucket_op(df: pd.DataFrame, num_buckets: Union[int, Dict[str, int]], cols=None):

@@ -621,3 +621,35 @@ def test_dense_count_cold_start_presample(card):
     if card >= 30_000 and len(exp) > K.PATH_S_MAX_DISTINCT:
         assert info["path"] not in (6, 0)
     assert job.hint > 0  # the estimate replaced the missing hint
+
+
+def test_hashed_cross_and_bucketize_vs_oracle():
+    """hashed_cross.py:56-67, bucketize.py:76-94; reference tests: tests/unit/ops/test_ops.py:189-236
+    (range + determinism for the cross, range for the buckets) -- here bit-exact vs the oracle."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(21)
+    n = 40_001
+    df = pd.DataFrame({"a": rng.integers(-5, 1000, n).astype("int32"), "b": rng.integers(0, 10**12, n),
+                       "s": rng.choice(["u", "v", "w", "xyz"], n),
+                       "x": rng.normal(size=n) * 3, "y": rng.integers(-10, 200, n).astype("int32")})
+    df.loc[rng.random(n) < 0.1, "x"] = np.nan
+    cross = [["a", "b", "s"]] >> ops.HashedCross(10)
+    got = nvt.Workflow(cross).fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    exp = O.hashed_cross(df, ["a", "b", "s"], 10)
+    assert got.columns.tolist() == ["a_X_b_X_s"] and got["a_X_b_X_s"].dtype == np.int32
+    np.testing.assert_array_equal(got["a_X_b_X_s"].to_numpy(), exp["a_X_b_X_s"].to_numpy())
+    assert got["a_X_b_X_s"].between(0, 9).all()
+
+    bounds = {"x": [-1, 0, 1], "y": [-4, 100]}
+    bk = ["x", "y"] >> ops.Bucketize(bounds)
+    wf = nvt.Workflow(bk)
+    g2 = wf.fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    e2 = O.bucketize(df, bounds)
+    for c in ("x", "y"):
+        assert g2[c].dtype == np.int32
+        np.testing.assert_array_equal(g2[c].to_numpy(), e2[c].to_numpy())
+    assert wf.output_schema["x"].tags == (nvt.Tags.CATEGORICAL,) or nvt.Tags.CATEGORICAL in wf.output_schema["x"].tags
+    with pytest.raises(TypeError):
+        ops.Bucketize(3)
