@@ -11,6 +11,7 @@ Index layout (categorify.py:53-71): 0 pad, 1 null, [2, 2+nb) OOV / hash buckets,
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import warnings
 from copy import deepcopy
@@ -288,7 +289,18 @@ class Categorify(StatOperator):
                     g.table = (k, c, sc[2])  # the sum of the per-rank maxima bounds the max count
                     g.nulls, g.valid_rows = sc[0], sc[1]
                     g.merged = True
-        for g in groups:
+        # Independent vocabularies are finalised on a few HIP streams: the 13 small Criteo
+        # vocabularies are one-workgroup kernels (LDS bitonic sort, table clear / build) that
+        # leave 255 CUs idle when they run back to back behind each other.
+        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        side = self._finalize_streams() if (main is not None and dist.world_size() == 1
+                                            and len(groups) > 1) else []
+        if side:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for st in side:
+                st.wait_event(ready)
+        for gi, g in enumerate(groups):
             nb = _pick(self.num_buckets, g.name) if self.num_buckets else None
             oov_count = nb or 1
             max_emb = _pick(self.max_size, g.name) if self.max_size else 0
@@ -298,14 +310,31 @@ class Categorify(StatOperator):
                     "`max_size` can never be less than the maximum of `num_buckets + 2` and `3`, "
                     "because we must always reserve pad, null and at least 1 oov-bucket index."
                 )
-            if g.combo:
-                vocab = self._finalize_combo(g, dist)
-            else:
-                vocab = self._finalize_single(g, dist)
-            paths[g.name] = self._save_encodings(
-                g, vocab, base, first_n=max_emb, freq_threshold=freq, oov_count=oov_count
-            )
+            st = side[gi % len(side)] if side and not g.combo else None
+            if st is not None and isinstance(g.table, tuple):
+                for t in g.table[:2]:  # allocated on the main stream, consumed on `st`
+                    t.record_stream(st)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                if g.combo:
+                    vocab = self._finalize_combo(g, dist)
+                else:
+                    vocab = self._finalize_single(g, dist)
+                paths[g.name] = self._save_encodings(
+                    g, vocab, base, first_n=max_emb, freq_threshold=freq, oov_count=oov_count
+                )
+            if st is not None:
+                _record_vocab_streams(self._encoders.get(g.name), self._pending.get(g.name), main)
+        for st in side:
+            main.wait_stream(st)
         return {name: paths[name] for name in state if name in paths}
+
+    def _finalize_streams(self):
+        dev = torch.cuda.current_device()
+        cache = getattr(self, "_fin_streams", None)
+        if cache is None or cache[0] != dev:
+            cache = (dev, [torch.cuda.Stream(device=dev) for _ in range(3)])
+            self._fin_streams = cache
+        return cache[1]
 
     # -- vocabulary finalisation ------------------------------------------------
     def _finalize_single(self, g: _GroupFit, dist):
@@ -752,6 +781,19 @@ class _ComboEncoder:
             all_null = isnull if all_null is None else (all_null & isnull)
         labels = torch.where(all_null, torch.full_like(labels, null_label), labels)
         return DeviceColumn(labels.to(out_dtype))
+
+
+def _record_vocab_streams(encoder, final, stream):
+    """Tensors created on a finalisation stream are later read on the main stream."""
+    tensors = []
+    if isinstance(encoder, _SingleEncoder):
+        tab = encoder.table
+        tensors += [tab.table, tab.sentinel_label, tab.vocab_keys]
+    if final:
+        tensors += list(final.get("keys") or []) + [final.get("counts"), final.get("null_mask")]
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(stream)
 
 
 def _build_encoder(keys, null_mask, first_label, combo, unique=True):
