@@ -310,3 +310,33 @@ def test_save_load_graph_json_all_ops(tmp_path):
     b = wf2.transform(nvt.Dataset(df)).to_ddf().compute()
     pd.testing.assert_frame_equal(a, b[a.columns.tolist()])
     assert wf2.output_schema["a"].properties == wf.output_schema["a"].properties
+
+
+def test_cfg1_movielens_shape_vs_oracle(tmp_path):
+    """BASELINE.json configs[0] (MovieLens-25M: userId / movieId int categoricals, rating
+    float), synthesised at 2 M rows with the real id counts (162 541 users, 59 047 movies) so
+    the pandas oracle finishes in seconds: Categorify indices bit-exact, Normalize mean / std
+    within 1e-6 relative."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(25)
+    n = 2_000_000
+    df = pd.DataFrame({
+        "userId": np.minimum(rng.zipf(1.4, n), 162_541).astype("int64"),
+        "movieId": (np.minimum(rng.zipf(1.2, n), 59_047) * 7 % 209_171).astype("int64"),
+        "rating": (rng.integers(1, 11, n) * 0.5).astype("float32"),
+    })
+    wf = nvt.Workflow((["userId", "movieId"] >> ops.Categorify(out_path=str(tmp_path / "g")))
+                      + (["rating"] >> ops.Normalize()))
+    got = wf.fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    paths = O.categorify_fit([df], ["userId", "movieId"], str(tmp_path / "c"), tie_break="stable")
+    exp = O.categorify_transform(df, ["userId", "movieId"], paths)
+    for c in ("userId", "movieId"):
+        np.testing.assert_array_equal(got[c].to_numpy(), exp[c].to_numpy())
+    mom = O.custom_moments([df[["rating"]]], ["rating"])
+    norm = next(n_.op for n_ in nvt.workflow.iter_nodes(wf.output_node) if isinstance(n_.op, ops.Normalize))
+    assert abs(norm.means["rating"] - mom["mean"]["rating"]) <= 1e-6 * abs(mom["mean"]["rating"])
+    assert abs(norm.stds["rating"] - mom["std"]["rating"]) <= 1e-6 * abs(mom["std"]["rating"])
+    ref = O.normalize_transform(df[["rating"]].copy(), ["rating"], mom["mean"].to_dict(), mom["std"].to_dict())
+    np.testing.assert_allclose(got["rating"].to_numpy(), ref["rating"].to_numpy(), rtol=1e-5, atol=1e-6)
