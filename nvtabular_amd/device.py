@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, List, Optional
 
+import os
+
 import numpy as np
 import pandas as pd
 import torch
@@ -51,16 +53,30 @@ def default_device() -> torch.device:
 
 
 def to_device_async(arr: np.ndarray, device) -> torch.Tensor:
-    """Host array -> HBM through a pinned staging buffer with an asynchronous copy on the
-    CURRENT stream (the parquet prefetcher makes that a side stream, so the copy overlaps
-    the kernels of the previous partition; hipMemcpyAsync needs pinned memory to be async)."""
+    """Host array -> HBM: ONE host copy into a pinned staging tensor (torch's caching host
+    allocator recycles the blocks), then an asynchronous copy on the CURRENT stream (the
+    parquet prefetcher makes that a side stream, so it overlaps the kernels of the previous
+    partition; hipMemcpyAsync is only asynchronous from pinned memory).  Read-only Arrow
+    buffers are fine: they are only read."""
     arr = np.ascontiguousarray(arr)
-    if not arr.flags.writeable:  # Arrow buffers are read-only; torch wants writable memory
-        arr = arr.copy()
-    t = torch.from_numpy(arr)
-    if device.type != "cuda":
-        return t.to(device)
-    return t.pin_memory().to(device, non_blocking=True)
+    if device.type != "cuda" or arr.dtype not in _NP_TO_TORCH:
+        return torch.from_numpy(arr.copy() if not arr.flags.writeable else arr).to(device)
+    pin = torch.empty(arr.shape, dtype=_NP_TO_TORCH[arr.dtype], pin_memory=True)
+    np.copyto(pin.numpy(), arr)  # releases the GIL: columns are staged from several threads
+    return pin.to(device, non_blocking=True)
+
+
+_STAGE_POOL = None
+
+
+def _stage_pool():
+    global _STAGE_POOL
+    if _STAGE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _STAGE_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1),
+                                         thread_name_prefix="nvt-stage")
+    return _STAGE_POOL
 
 
 def pack_bitmap(valid_bool: np.ndarray) -> np.ndarray:
@@ -198,7 +214,13 @@ class DeviceColumn:
                 valid = to_device_async(bits, device)
             else:
                 valid = to_device_async(pack_bitmap(np.asarray(arr.is_valid())), device)
-            vals = arr.fill_null(0).to_numpy(zero_copy_only=False).astype(np_dt, copy=False)
+            if pa.types.is_boolean(arr.type) or bufs[1] is None:
+                vals = arr.fill_null(False).to_numpy(zero_copy_only=False).astype(np_dt, copy=False)
+            else:
+                # the values buffer as it is: slots under a null hold arbitrary bytes, every
+                # kernel goes by the bitmap (a fill_null(0) here was a full extra host copy)
+                vals = np.frombuffer(bufs[1], dtype=np.dtype(np_dt), count=n,
+                                     offset=arr.offset * np.dtype(np_dt).itemsize)
         else:
             vals = arr.to_numpy(zero_copy_only=False)
         assert len(vals) == n
@@ -328,10 +350,22 @@ class DeviceFrame:
 
     @staticmethod
     def from_arrow(table, device=None) -> "DeviceFrame":
+        """Columns are staged (host memcpy into pinned memory) by a small thread pool -- one
+        thread copies at ~5 GB/s, a fifth of what the PCIe link takes -- and every copy is
+        enqueued on the caller's current stream."""
         device = device or default_device()
-        return DeviceFrame(
-            {n: DeviceColumn.from_arrow(table.column(n), device) for n in table.column_names}
-        )
+        names = table.column_names
+        if device.type != "cuda" or len(names) < 2 or table.num_rows < (1 << 16):
+            return DeviceFrame({n: DeviceColumn.from_arrow(table.column(n), device) for n in names})
+        stream = torch.cuda.current_stream(device)
+
+        def stage(name):
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(stream):
+                return DeviceColumn.from_arrow(table.column(name), device)
+
+        cols = list(_stage_pool().map(stage, names))
+        return DeviceFrame(dict(zip(names, cols)))
 
     def to_pandas(self) -> pd.DataFrame:
         return pd.DataFrame({k: v.to_pandas(k) for k, v in self._cols.items()})
