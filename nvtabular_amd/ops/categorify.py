@@ -47,6 +47,9 @@ def _pick(opt, name, default=None):
     return opt
 
 
+MERGE_FAN_IN = 8
+
+
 class _GroupFit:
     """Accumulated groupby-size state of one column group on this GPU."""
 
@@ -55,6 +58,7 @@ class _GroupFit:
         self.cols = cols
         self.combo = combo  # multi-column key tuple (nvt_gb_*) vs single key column
         self.table = None  # (keys, counts, max_count) dense list | K.GroupbyTable (combo)
+        self.parts = []    # per-partition dense lists not merged into `table` yet
         self.nulls = 0
         self.valid_rows = 0  # non-null key rows seen (== sum of counts)
         self.hint = 1 << 12  # expected distinct keys per partition, learned as we go
@@ -227,15 +231,26 @@ class Categorify(StatOperator):
             g.valid_rows += info["rows"] - nulls
             per_group.setdefault(g.name, (g, []))[1].append((dk, dc, info["max_count"]))
         for g, lists in per_group.values():
-            if g.table is not None:
-                lists = [g.table] + lists
-            if len(lists) == 1:
-                g.table = lists[0]
-            else:
-                # tree merge (_mid_level_groupby): weighted re-count of the concatenated lists
-                g.table = K.merge_dense(lists, hint=self._cap_hints.get(g.name, 0))
-            if g.table is not None:
-                self._cap_hints[g.name] = max(64, int(g.table[0].numel()))
+            # tree merge with the reference's fan-in (_mid_level_groupby, split_every = 8,
+            # categorify.py:1054-1070): partial lists pile up and are re-counted (weighted
+            # dense count of their concatenation) eight at a time, not after every partition
+            g.parts.extend(lists)
+            if len(g.parts) >= MERGE_FAN_IN:
+                self._merge_parts(g)
+            elif g.table is None and len(g.parts) == 1:
+                g.table, g.parts = g.parts[0], []
+
+    def _merge_parts(self, g: "_GroupFit"):
+        lists = ([g.table] if g.table is not None else []) + g.parts
+        g.parts = []
+        if not lists:
+            return
+        if len(lists) == 1:
+            g.table = lists[0]
+        else:
+            g.table = K.merge_dense(lists, hint=self._cap_hints.get(g.name, 0))
+        if g.table is not None:
+            self._cap_hints[g.name] = max(64, int(g.table[0].numel()))
 
     def _fit_partition_combo(self, g: _GroupFit, keys, valids):
         hint = self._cap_hints.get(g.name, g.hint)
@@ -261,6 +276,9 @@ class Categorify(StatOperator):
         os.makedirs(base, exist_ok=True)
         paths = {}
         groups = list(state.values())
+        for g in groups:
+            if not g.combo and g.parts:
+                self._merge_parts(g)
         if dist.world_size() == 1:
             # largest vocabularies first: their sorts / table builds keep the stream busy while
             # the host runs ahead enqueueing the small ones (whose kernels are shorter than the
