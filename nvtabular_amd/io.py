@@ -18,6 +18,9 @@ from .device import DeviceFrame, as_device_frame
 from .schema import Schema
 
 
+DECODE_AHEAD = int(os.environ.get("NVT_DECODE_AHEAD", "3"))  # parquet partitions decoded concurrently ahead of the consumer
+
+
 class _Collection:
     """What ``Dataset.to_ddf()`` returns: ``.compute()`` gives one pandas frame."""
 
@@ -95,9 +98,35 @@ class Dataset:
         if self._schema is None:
             self._schema = Schema.from_frame(pq.ParquetFile(files[0]).schema_arrow)
 
-        def gen(columns=None):
-            for f, groups in pieces:
-                yield pq.ParquetFile(f).read_row_groups(groups, columns=columns)
+        def gen(columns=None, only=None):
+            # decode a few partitions ahead on host threads (pyarrow parallelises over the
+            # columns of ONE read; several reads in flight keep more of the host cores busy)
+            from collections import deque
+            from concurrent.futures import ThreadPoolExecutor
+
+            todo = [p for i, p in enumerate(pieces) if only is None or only(i)]
+            if len(todo) <= 1:
+                for f, groups in todo:
+                    yield pq.ParquetFile(f).read_row_groups(groups, columns=columns)
+                return
+
+            def read(piece):
+                f, groups = piece
+                return pq.ParquetFile(f).read_row_groups(groups, columns=columns)
+
+            with ThreadPoolExecutor(max_workers=DECODE_AHEAD) as pool:
+                window = deque()
+                it = iter(todo)
+                for piece in it:
+                    window.append(pool.submit(read, piece))
+                    if len(window) >= DECODE_AHEAD:
+                        break
+                while window:
+                    table = window.popleft().result()
+                    nxt = next(it, None)
+                    if nxt is not None:
+                        window.append(pool.submit(read, nxt))
+                    yield table
 
         self._parts_fn = gen
 
@@ -116,6 +145,10 @@ class Dataset:
         return self._n
 
     def _host_parts(self, cols, shard):
+        if shard is not None and getattr(self, "_pieces", None) is not None:
+            # parquet: a rank decodes only its own partitions
+            yield from self._parts_fn(cols, only=lambda i: i % shard[1] == shard[0])
+            return
         it = self._parts_fn(cols) if _accepts_columns(self._parts_fn) else self._parts_fn()
         for i, part in enumerate(it):
             if shard is not None and i % shard[1] != shard[0]:
