@@ -103,8 +103,10 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
  *      (<= ~11000 distinct int32 keys, ~5000 for int64 keys / weighted input);
  *   6  path 0 for <= 64 distinct keys: hot keys replicated per 8-lane group (same-address
  *      LDS atomics serialise);
- *   4 / 5  path 0 with 4 / 8 key classes per row slab (4x / 8x the vocabulary, column read
- *      4x / 8x) -- exact, tested, but not faster than path 1 on MI355X;
+ *   7  path 0 with 2 key classes per row slab: each LDS table keeps the keys of one class,
+ *      the column is read twice (<= ~21000 distinct keys; 350 us against 420 us on path 1);
+ *   4 / 5  the same with 4 / 8 classes (column read 4x / 8x) -- exact, tested, but not faster
+ *      than path 1 on MI355X;
  *   1 / 2 / 3  hash-partition the rows into 256 / 64 x 64 / 64 x 256 buckets (exact
  *      per-tile histograms + scan, no cursor atomics), then one LDS table per bucket; a
  *      bucket inflated by a hot key is cut into a primary chunk plus small excess chunks
@@ -154,7 +156,12 @@ int nvt_encode_build_i64(const int64_t *vocab_keys, uint64_t n_vocab, int64_t fi
  *        = oov_label + h32(key) % num_buckets   otherwise      (out_bytes: 4 or 8)
  * vocab_keys / n_vocab / first_label (optional: pass NULL, 0, 0): the ordered, duplicate-free
  * vocabulary the table was built from.  Its head -- the most frequent keys -- is then
- * staged in LDS by every workgroup and only rows that miss it probe the table in HBM. */
+ * staged in LDS by every workgroup and only rows that miss it probe the table in HBM.
+ * A vocabulary of at most NVT_ENCODE_RESIDENT_I32 (12288) int32 / NVT_ENCODE_RESIDENT_I64
+ * (6144) int64 keys is staged in full: table and sentinel_label may then be NULL and
+ * nvt_encode_build_* need not be called at all. */
+#define NVT_ENCODE_RESIDENT_I32 12288
+#define NVT_ENCODE_RESIDENT_I64 6144
 int nvt_encode_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, const void *table,
                    uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                    int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,

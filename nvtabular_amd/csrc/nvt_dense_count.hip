@@ -1403,7 +1403,7 @@ struct DenseWs {
 
 // path argument -> stage-1 key-class bits (-1: a partitioned path)
 inline int split_bits_of(int path) {
-  return (path == 0 || path == 6) ? 0 : path == 4 ? 2 : path == 5 ? 3 : -1;
+  return (path == 0 || path == 6) ? 0 : path == 7 ? 1 : path == 4 ? 2 : path == 5 ? 3 : -1;
 }
 inline int stage_slots(int key_bytes, int weighted) {
   return (weighted || key_bytes == 8) ? kLdsSlots : kLdsSlotsBig;
@@ -1466,9 +1466,9 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                 void *wsp, K *out_keys, int64_t *out_cnt, uint64_t out_cap, uint64_t *state,
                 hipStream_t s) {
   NVT_CHECK_ARG(state && wsp, "null state/workspace");
-  NVT_CHECK_ARG(path >= 0 && path <= 6,
-                "path must be 0 / 4 / 5 / 6 (LDS tables: 1 / 4 / 8 key classes / tiny) or 1 / 2 / 3 "
-                "(partitioned)");
+  NVT_CHECK_ARG(path >= 0 && path <= 7,
+                "path must be 0 / 7 / 4 / 5 / 6 (LDS tables: 1 / 2 / 4 / 8 key classes / tiny) or "
+                "1 / 2 / 3 (partitioned)");
   NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
   NVT_CHECK_ARG(n == 0 || (keys && out_keys && out_cnt), "null keys/out");
   NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 rows per call (32-bit LDS counters)");
@@ -1597,7 +1597,7 @@ extern "C" {
 
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
-  NVT_CHECK_ARG(path >= 0 && path <= 6, "path must be 0..6");
+  NVT_CHECK_ARG(path >= 0 && path <= 7, "path must be 0..7");
   *bytes = dense_ws_layout(key_bytes, n, path, weighted, nullptr, nullptr) + 64;
   return NVT_OK;
 }

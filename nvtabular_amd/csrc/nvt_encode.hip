@@ -221,14 +221,19 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
   using L = decltype(EncSlot<K>::label);
   using C = typename EncTraits<K>::cas_t;
   __shared__ EncSlot<K> lt[SLOTS];
+  __shared__ long long s_sent;  // label of the sentinel key when it is among the staged keys
   for (int i = threadIdx.x; i < SLOTS; i += kEncBS) {
     lt[i].key = EMPTY;
     lt[i].label = 0;
   }
+  if (threadIdx.x == 0) s_sent = -1;
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < n_hot; i += kEncBS) {
     K key = hot_keys[i];
-    if (key == EMPTY) continue;
+    if (key == EMPTY) {
+      s_sent = first_label + (long long)i;
+      continue;
+    }
     uint32_t s = (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
     while (true) {
       K prev = (K)atomicCAS(reinterpret_cast<C *>(&lt[s].key), (C)EMPTY, (C)key);
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     }
   }
   __syncthreads();
-  const int64_t sent = *sentinel_label;
+  // a vocabulary staged in full needs neither the global table nor its sentinel word
+  const int64_t sent = global_needed ? *sentinel_label : (int64_t)s_sent;
 
   // LDS lookup: label, or -1 when the key is not in the staged head of the vocabulary
   auto hot_lookup = [&](K key) -> int64_t {
@@ -469,8 +475,12 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
                   uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
                   const K *hot_keys, uint64_t n_vocab, int64_t first_label, hipStream_t s) {
-  NVT_CHECK_ARG(table && sentinel_label, "null table");
-  NVT_CHECK_ARG(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be 2^k >= 64");
+  // a duplicate-free vocabulary that fits the LDS table is encoded without the global table
+  const bool resident = hot_keys != nullptr && n_vocab > 0 &&
+                        n_vocab <= (uint64_t)HotCfg<K>::slots / 4 * 3;
+  NVT_CHECK_ARG(resident || (table && sentinel_label), "null table");
+  NVT_CHECK_ARG(resident || (capacity >= 64 && (capacity & (capacity - 1)) == 0),
+                "capacity must be 2^k >= 64");
   NVT_CHECK_ARG(out_bytes == 4 || out_bytes == 8, "out_bytes must be 4 or 8");
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(keys && out, "null keys/out");

@@ -218,13 +218,16 @@ def count_into_new_table(
 # --------------------------------------------------------------------------
 PATH_S_MAX_DISTINCT = 11000         # path 0 (int32 keys, unweighted): 16384-slot LDS tables
 PATH_S_MAX_WEIGHTED = 5000          # path 0 for weighted merges / int64 keys: 8192 slots
+# Path 7 = path 0 with 2 key classes per row slab (column read twice): 350 us against 420 us on
+# path 1 for 12-21 k distinct keys.
 # Paths 4 / 5 (path 0 with 4 / 8 key classes per row slab: the column is read 4x / 8x, each
 # LDS table holds a quarter / an eighth of the vocabulary) are exposed by the C ABI and covered
 # by the parity tests, but measured no faster than path 1 on MI355X (490 vs 530 us per 45 M-row
 # column at 13-39 k distinct keys, with 4x the HBM reads), so the driver never picks them.
 # escalation order when a path's LDS tables overflow (C-ABI path ids, include/nvt_hip.h)
-PATH_ORDER = [6, 0, 1, 2, 3]
-_S_CLASSES = {6: 1, 0: 1, 4: 4, 5: 8}
+PATH_ORDER = [6, 0, 7, 1, 2, 3]
+_S_CLASSES = {6: 1, 0: 1, 7: 2, 4: 4, 5: 8}
+PATH_S2_FACTOR = 1.95               # path 7: path 0 with 2 key classes per row slab (column read twice)
 PATH_TINY_MAX = 64                  # path 6: path 0 with hot keys replicated per lane group
 PATH_P1_MAX_DISTINCT = 2_400_000    # path 1: ONE level, 256 buckets x 16384-slot tables (int32)
 PATH_P1_MAX_SMALL = 1_100_000       #         ... 8192-slot tables (int64 keys / weighted merges)
@@ -252,6 +255,8 @@ def _path_for(hint: int, small_tables: bool = False) -> int:
         return 6
     if hint <= s_max:
         return 0
+    if hint <= PATH_S2_FACTOR * s_max:
+        return 7
     if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
         return 1
     if hint <= PATH_P2_MAX_DISTINCT:
@@ -349,7 +354,7 @@ class DenseCountJob:
 SAMPLE_ROWS = 1 << 18               # cold start: distinct keys of this many leading rows ...
 SAMPLE_MIN_ROWS = 8 * SAMPLE_ROWS   # ... when the column is at least this long
 # distinct keys each path is sized for (output-capacity guess when a path is entered by escalation)
-_PATH_MAX = {6: 1024, 0: 98304, 4: 393216, 5: 786432, 1: PATH_P1_MAX_DISTINCT,
+_PATH_MAX = {6: 1024, 0: 98304, 7: 196608, 4: 393216, 5: 786432, 1: PATH_P1_MAX_DISTINCT,
              2: PATH_P2_MAX_DISTINCT, 3: PATH_P3_MAX_DISTINCT}
 
 
@@ -483,6 +488,9 @@ def vocab_sort(keys: torch.Tensor, counts: torch.Tensor, max_count: int = 0):
 # --------------------------------------------------------------------------
 # Categorify.transform: encode tables
 # --------------------------------------------------------------------------
+ENCODE_RESIDENT_I32, ENCODE_RESIDENT_I64 = 12288, 6144  # include/nvt_hip.h
+
+
 class EncodeTable:
     """key -> label probe table built from an ordered vocabulary."""
 
@@ -496,13 +504,19 @@ class EncodeTable:
         self.first_label = int(first_label)
         self.capacity = next_pow2(max(64, (4 if self.n_vocab <= (1 << 20) else 2) * self.n_vocab + 1))
         dev = vocab_keys.device
+        vk = vocab_keys.contiguous()
+        # kept: the head of the (frequency-ordered, duplicate-free) vocabulary is staged in LDS
+        self.vocab_keys = vk if unique else None
+        # a duplicate-free vocabulary that fits the LDS table in full (include/nvt_hip.h:
+        # NVT_ENCODE_RESIDENT_*) is encoded from LDS alone: no global table, no build kernel
+        resident = ENCODE_RESIDENT_I32 if self.key_bytes == 4 else ENCODE_RESIDENT_I64
+        self.table = self.sentinel_label = None
+        if unique and 0 < self.n_vocab <= resident:
+            return
         nbytes = C.c_uint64()
         check(self.lib.nvt_encode_table_bytes(self.key_bytes, self.capacity, C.byref(nbytes)))
         self.table = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         self.sentinel_label = torch.empty(1, dtype=torch.int64, device=dev)
-        vk = vocab_keys.contiguous()
-        # kept: the head of the (frequency-ordered, duplicate-free) vocabulary is staged in LDS
-        self.vocab_keys = vk if unique else None
         with _timed("encode_build", 0):
             check(
                 getattr(self.lib, f"nvt_encode_build_{self.suffix}")(
@@ -531,8 +545,8 @@ class EncodeTable:
         with _timed(f"encode_{self.suffix}", keys.numel() * (self.key_bytes + out.element_size())):
             check(
                 getattr(self.lib, f"nvt_encode_{self.suffix}")(
-                    keys.data_ptr(), ptr(valid), keys.numel(), self.table.data_ptr(),
-                    self.capacity, self.sentinel_label.data_ptr(), int(null_label),
+                    keys.data_ptr(), ptr(valid), keys.numel(), ptr(self.table),
+                    self.capacity, ptr(self.sentinel_label), int(null_label),
                     int(oov_label), int(num_buckets or 0), out.data_ptr(), out.element_size(),
                     ptr(self.vocab_keys) if self.n_vocab else None,
                     self.n_vocab if self.vocab_keys is not None else 0, self.first_label,
