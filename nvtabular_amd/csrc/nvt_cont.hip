@@ -47,16 +47,29 @@ __global__ __launch_bounds__(kBlock) void moments_kernel(const T *__restrict__ x
   };
   const uint64_t nvec = n / VEC;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-    T v[VEC];
-    load_vec<T>(x + i * VEC, v);
-    unsigned vbits = 0xF;
-    if (valid != nullptr) {
-      uint64_t row = i * VEC;
-      vbits = valid[row >> 3] >> (row & 7);
+  // 4 independent 16-byte loads (+ bitmap bytes) in flight per lane: with one load per
+  // iteration the kernel ran at 2.9 TB/s, latency-bound
+  constexpr int U = 4;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i0 < nvec; i0 += stride * U) {
+    T v[U][VEC];
+    unsigned vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * stride;
+      vb[u] = 0;
+      if (i < nvec) {
+        load_vec<T>(x + i * VEC, v[u]);
+        vb[u] = 0x100u | (valid != nullptr ? (unsigned)valid[(i * VEC) >> 3] : 0xFFu);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc(v[j], (vbits >> j) & 1);
+    for (int u = 0; u < U; ++u) {
+      if (!vb[u]) continue;
+      const uint64_t row = (i0 + (uint64_t)u * stride) * VEC;
+      const unsigned vbits = (vb[u] & 0xFFu) >> (row & 7);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc(v[u][j], (vbits >> j) & 1);
+    }
   }
   for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
     acc(x[i], bit_valid(valid, i));
