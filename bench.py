@@ -152,7 +152,7 @@ def pmc_traffic(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=45_000_000, help="rows per GPU")
     ap.add_argument("--cpu-sample", type=int, default=5_000_000)
