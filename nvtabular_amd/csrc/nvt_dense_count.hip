@@ -796,14 +796,38 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(const unsigned long lon
   __syncthreads();
   const int nc = 1 << b1, sub = nb >> b1;
   if ((int)threadIdx.x < nc) coarse_cursor[threadIdx.x] = fine_start[threadIdx.x * sub];
-  if (threadIdx.x == 0) {
-    unsigned t = 0;
-    for (int c = 0; c < nc; ++c) {
-      tile_start[c] = t;
-      unsigned long long sz = fine_start[(c + 1) * sub] - fine_start[c * sub];
-      t += (unsigned)((sz + kTile - 1) / kTile);
+  {  // per-coarse-bucket tile counts -> exclusive scan (nc <= 256: one value per thread; a
+     // serial loop over dependent global loads here cost 25 us per column)
+    __shared__ unsigned tcnt[256];
+    if ((int)threadIdx.x < nc) {
+      const unsigned long long sz =
+          fine_start[(threadIdx.x + 1) * sub] - fine_start[threadIdx.x * sub];
+      tcnt[threadIdx.x] = (unsigned)((sz + kTile - 1) / kTile);
     }
-    tile_start[nc] = t;
+    __syncthreads();
+    if (threadIdx.x < kWave) {  // one wave scans the <= 256 counts, 4 per lane
+      unsigned v[4], tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (int)threadIdx.x * 4 + j;
+        v[j] = c < nc ? tcnt[c] : 0;
+        tot += v[j];
+      }
+      unsigned inc = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        unsigned o = __shfl_up(inc, off, 64);
+        if (lane_id() >= (unsigned)off) inc += o;
+      }
+      unsigned run = inc - tot;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (int)threadIdx.x * 4 + j;
+        if (c < nc) tile_start[c] = run;
+        run += v[j];
+      }
+      if (threadIdx.x == kWave - 1) tile_start[nc] = inc;
+    }
   }
   // P3 work list: a fine bucket is processed as one primary chunk of chunk_rows plus, when a
   // hot key drags its whole bucket (skew), excess chunks of small_rows; such "split" buckets
