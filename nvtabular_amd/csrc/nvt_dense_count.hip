@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
   constexpr K EMPTY = DKey<K>::empty;
   constexpr int VEC = DKey<K>::vec;
   __shared__ K lkeys[SLOTS];
-  __shared__ C lcnt[SLOTS];
+  __shared__ C lcnt[SLOTS + kWave];  // + one scratch word per lane (see the unconditional add)
   __shared__ unsigned rcnt[kRanges], wtot[kRanges / kWave];
   __shared__ unsigned lfill, lovf;
   __shared__ unsigned long long s_nulls, s_sent;
@@ -323,20 +323,28 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     constexpr int U = NVT_STAGE_U;
     VecT npack[U];
     unsigned nvb[U];
+    // Each slab is a CONTIGUOUS range of the column, walked front to back in 16 KiB steps
+    // (a grid-stride walk had every workgroup jump 4 MiB between consecutive loads: 1024
+    // widely separated 16 KiB windows live at any time).
+    const uint64_t per_slab = (nvec + kSlabs - 1) / kSlabs;
+    const uint64_t slab_lo = (uint64_t)slab * per_slab;
+    const uint64_t slab_hi = slab_lo + per_slab < nvec ? slab_lo + per_slab : nvec;
+    constexpr uint64_t vstride = kStageBS;  // distance between the U vectors of one batch
     auto issue = [&](uint64_t v0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        uint64_t v = v0 + (uint64_t)u * stride;
+        uint64_t v = v0 + (uint64_t)u * vstride;
         nvb[u] = 0x10000;  // out of range
-        if (v < nvec) {
+        if (v < slab_hi) {
           npack[u] = vkeys[v];
           nvb[u] = valid ? (unsigned)valid[(v * VEC) >> 3] : 0xFFu;  // raw byte, shifted later
         }
       }
     };
-    issue(first);
-    for (uint64_t v0 = first; v0 < nvec; v0 += stride * U) {
-      const unsigned fill_now = lfill;
+    issue(slab_lo + threadIdx.x);
+    unsigned fill_now = 0;  // refreshed with the batched home-slot reads below: a separate read
+                            // here would drain every queued LDS atomic of the previous batch
+    for (uint64_t v0 = slab_lo + threadIdx.x; v0 < slab_hi; v0 += vstride * U) {
       if (fill_now > (unsigned)max_fill(SLOTS)) break;  // filling up: the column needs a larger path
       if (fill_now > kRepFill) rep = 0;
       VecT pack[U];
@@ -346,30 +354,68 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
         pack[u] = npack[u];
         vb[u] = nvb[u];
       }
-      issue(v0 + stride * U);
+      issue(v0 + vstride * U);
+      // Probe in two sweeps.  Sweep 1 reads the HOME slot of every key of the batch -- U * VEC
+      // independent LDS reads behind one wait; a key already sitting there (the common case
+      // once the table is warm) only needs a fire-and-forget ds_add.  Sweep 2 walks the
+      // probe chain for the rest.  One key at a time, each read -> compare -> add chain was
+      // a full LDS round trip exposed to a workgroup with only 4 waves per SIMD: the loop
+      // was latency-bound (which is also why masking 3/4 of the lanes never made it faster).
+      constexpr int NKB = U * VEC;
+      K kq[NKB];
+      uint32_t hq[NKB];
+      unsigned live = 0;  // bit q: key q is valid, of this class, not the sentinel
+      // Branch-free classification (PMC: the per-key if / else ladders cost as many SALU
+      // exec-mask instructions as there were VALU instructions, 37 + 36 per key).
+      unsigned nnull = 0, nsent = 0;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (vb[u] & 0x10000)
-          vb[u] = 0xF0000;  // out of range: no valid rows, no nulls either
-        else
-          vb[u] = (vb[u] >> (((v0 + (uint64_t)u * stride) * VEC) & 7)) & ((1u << VEC) - 1u);
-        K k[VEC];
+        const bool inrange = !(vb[u] & 0x10000);
+        const unsigned bits =
+            inrange ? (vb[u] >> (((v0 + (uint64_t)u * vstride) * VEC) & 7)) & ((1u << VEC) - 1u) : 0u;
         if constexpr (sizeof(K) == 4) {
-          k[0] = pack[u].x;
-          k[1] = pack[u].y;
-          k[2] = pack[u].z;
-          k[3] = pack[u].w;
+          kq[u * VEC + 0] = pack[u].x;
+          kq[u * VEC + 1] = pack[u].y;
+          kq[u * VEC + 2] = pack[u].z;
+          kq[u * VEC + 3] = pack[u].w;
         } else {
-          k[0] = pack[u].x;
-          k[1] = pack[u].y;
+          kq[u * VEC + 0] = pack[u].x;
+          kq[u * VEC + 1] = pack[u].y;
         }
+        nnull += inrange ? (unsigned)VEC - (unsigned)__popc(bits) : 0u;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          if ((vb[u] >> j) & 1)
-            add(k[j], 1ull);
-          else if (!(vb[u] & 0xF0000))
-            ++my_nulls;
+          const int qi = u * VEC + j;
+          const bool v = (bits >> j) & 1;
+          const bool is_sent = v & (kq[qi] == EMPTY);
+          const auto h = slot_hash(kq[qi]);
+          const bool lv = v & !is_sent & (((uint32_t)h & split_mask) == q);
+          nsent += is_sent ? 1u : 0u;
+          hq[qi] = lv ? (((uint32_t)(h >> 17) + rep) & (SLOTS - 1)) : 0u;
+          live |= (lv ? 1u : 0u) << qi;
         }
+      }
+      my_nulls += nnull;
+      if (q == 0) my_sent += nsent;
+      K cur[NKB];
+#pragma unroll
+      for (int qi = 0; qi < NKB; ++qi) cur[qi] = lkeys[hq[qi]];
+      fill_now = lfill;
+      unsigned missbits = 0;
+#pragma unroll
+      for (int qi = 0; qi < NKB; ++qi) {
+        const bool lv = (live >> qi) & 1;
+        const bool hit = lv & (cur[qi] == kq[qi]);
+        // unconditional add: lanes without a hit bump a per-lane scratch word past the table
+        atomicAdd(&lcnt[hit ? hq[qi] : (uint32_t)SLOTS + lane_id()], (C)1);
+        missbits |= ((lv & !hit) ? 1u : 0u) << qi;
+      }
+      if (missbits) {
+#pragma unroll
+        for (int qi = 0; qi < NKB; ++qi)
+          if (((missbits >> qi) & 1) &&
+              !lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, kq[qi], (C)1, hq[qi]))
+            failed = true;
       }
     }
     for (uint64_t i = nvec * VEC + first; i < n; i += stride) {
