@@ -145,15 +145,24 @@ class Dataset:
         return self._n
 
     def _host_parts(self, cols, shard):
-        if shard is not None and getattr(self, "_pieces", None) is not None:
-            # parquet: a rank decodes only its own partitions
-            yield from self._parts_fn(cols, only=lambda i: i % shard[1] == shard[0])
+        """Partitions of this rank.  Under torch.distributed (shard = (rank, world)):
+
+        * a parquet dataset is a GLOBAL list of files / row groups that every rank opens the
+          same way: rank r takes every world-th partition and decodes only those;
+        * frames handed over in memory (DataFrame, DeviceFrame, Arrow table, list of them) were
+          built by THIS process: they are the rank's own shard already and are all kept;
+        * a derived dataset (Workflow.transform) defers to its source."""
+        if getattr(self, "_pieces", None) is not None:
+            if shard is not None:
+                yield from self._parts_fn(cols, only=lambda i: i % shard[1] == shard[0])
+            else:
+                yield from self._parts_fn(cols)
+            return
+        if getattr(self, "_forwards_shard", False):
+            yield from self._parts_fn(cols, shard=shard)
             return
         it = self._parts_fn(cols) if _accepts_columns(self._parts_fn) else self._parts_fn()
-        for i, part in enumerate(it):
-            if shard is not None and i % shard[1] != shard[0]:
-                continue
-            yield part
+        yield from it
 
     def to_iter(self, columns: Optional[Iterable[str]] = None, shard=None, prefetch=None):
         """Yield DeviceFrame partitions.  shard=(rank, world) keeps every world-th one.
@@ -237,7 +246,7 @@ class Dataset:
         collector = []
 
         def fname(j):
-            return f"part_{(rank * k + j) if k else j}{suffix}"
+            return f"part_{(rank * k + j) if k else (j * world + rank)}{suffix}"
 
         def emit(j, table):
             if shuffle == Shuffle.PER_WORKER and k:

@@ -217,11 +217,13 @@ class Workflow:
                 self.fit_schema(data.schema)
             roots = self._root_columns()
 
-            def gen(columns=None):
-                for part in data.to_iter(columns=roots):
+            def gen(columns=None, shard=None):
+                for part in data.to_iter(columns=roots, shard=shard):
                     yield self._run(self.output_node, part, {})
 
-            return Dataset(gen, schema=self._output_schema, npartitions=data.npartitions)
+            out = Dataset(gen, schema=self._output_schema, npartitions=data.npartitions)
+            out._forwards_shard = True  # rank sharding is decided by the source dataset
+            return out
         if isinstance(data, pd.DataFrame):
             if self._output_schema is None:
                 self.fit_schema(Schema.from_frame(data))
