@@ -173,7 +173,14 @@ def main():
         import torch.distributed as td
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # NVT_BENCH_BACKEND=gloo (+ NVT_BENCH_SHARE_GPU=1): end-to-end rehearsal of the multi-rank
+        # code on a single GPU, collectives staged through the host -- a correctness tool, its
+        # timings mean nothing.  The measured configuration is nccl (= RCCL), one rank per GPU.
+        backend = os.environ.get("NVT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
 
     import nvtabular_amd as nvt
     from nvtabular_amd import kernels as K

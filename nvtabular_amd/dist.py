@@ -43,9 +43,38 @@ def _backend() -> str:
 # --------------------------------------------------------------------------
 # collectives with a gloo-safe fallback
 # --------------------------------------------------------------------------
+def _staged() -> bool:
+    """gloo moves host memory only: with gloo (CPU tests, or the single-GPU end-to-end rehearsal
+    `NVT_BENCH_BACKEND=gloo`) device tensors go through the host around every collective."""
+    return _backend() == "gloo"
+
+
+def _all_reduce(t: torch.Tensor, op=td.ReduceOp.SUM) -> torch.Tensor:
+    if _staged() and t.is_cuda:
+        h = t.cpu()
+        td.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        td.all_reduce(t, op=op)
+    return t
+
+
+def _all_gather_same(t: torch.Tensor) -> List[torch.Tensor]:
+    """Every rank's tensor of identical shape, rank order."""
+    G = world_size()
+    if _staged() and t.is_cuda:
+        h = t.cpu()
+        bufs = [torch.empty_like(h) for _ in range(G)]
+        td.all_gather(bufs, h)
+        return [b.to(t.device) for b in bufs]
+    bufs = [torch.empty_like(t) for _ in range(G)]
+    td.all_gather(bufs, t.contiguous())
+    return bufs
+
+
 def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
     if world_size() > 1:
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+        _all_reduce(t, td.ReduceOp.SUM)
     return t
 
 
@@ -54,7 +83,7 @@ def _nan_reduce(t: torch.Tensor, op) -> torch.Tensor:
         return t
     big = float("inf") if op == td.ReduceOp.MIN else float("-inf")
     x = torch.where(torch.isnan(t), torch.full_like(t, big), t)
-    td.all_reduce(x, op=op)
+    _all_reduce(x, op)
     return torch.where(torch.isinf(x), torch.full_like(x, float("nan")), x)
 
 
@@ -73,10 +102,8 @@ def _all_to_all_counts(send_counts: torch.Tensor) -> torch.Tensor:
     if _backend() == "nccl":
         td.all_to_all_single(recv, send_counts)
     else:
-        gathered = [torch.empty_like(send_counts) for _ in range(G)]
-        td.all_gather(gathered, send_counts)
         r = rank()
-        recv = torch.stack([g[r] for g in gathered])
+        recv = torch.stack([g[r] for g in _all_gather_same(send_counts)])
     return recv
 
 
@@ -89,7 +116,11 @@ def _all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[
         td.all_to_all_single(out, send.contiguous(), output_split_sizes=recv_counts,
                              input_split_sizes=send_counts)
         return out
-    # gloo: pairwise exchange (CPU tests only)
+    # gloo: pairwise exchange through host memory (tests / single-GPU rehearsal only)
+    dev = send.device
+    if send.is_cuda:
+        send = send.cpu()
+        out = torch.empty(out.shape, dtype=out.dtype)
     r = rank()
     s_off = [0]
     for c in send_counts:
@@ -107,13 +138,12 @@ def _all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[
     for peer in range(G):
         if peer == r or not recv_counts[peer]:
             continue
-        buf = torch.empty((recv_counts[peer],) + tuple(send.shape[1:]), dtype=send.dtype,
-                          device=send.device)
+        buf = torch.empty((recv_counts[peer],) + tuple(send.shape[1:]), dtype=send.dtype)
         td.recv(buf, peer)
         out[r_off[peer] : r_off[peer + 1]] = buf
     for q in reqs:
         q.wait()
-    return out
+    return out.to(dev)
 
 
 def _all_gather_v(t: torch.Tensor, sizes: Optional[List[int]] = None) -> torch.Tensor:
@@ -122,14 +152,11 @@ def _all_gather_v(t: torch.Tensor, sizes: Optional[List[int]] = None) -> torch.T
     G = world_size()
     if sizes is None:
         n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-        got = [torch.empty_like(n) for _ in range(G)]
-        td.all_gather(got, n)
-        sizes = [int(s.item()) for s in got]
+        sizes = [int(s.item()) for s in _all_gather_same(n)]
     m = max(sizes) if sizes else 0
     pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
-    bufs = [torch.empty_like(pad) for _ in range(G)]
-    td.all_gather(bufs, pad)
+    bufs = _all_gather_same(pad)
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
 
 
@@ -228,9 +255,7 @@ def merge_counts_many(tables):
         recv_mat = torch.empty_like(send_mat)
         td.all_to_all_single(recv_mat, send_mat.contiguous())
     else:
-        mats = [torch.empty_like(send_mat) for _ in range(G)]
-        td.all_gather(mats, send_mat.contiguous())
-        recv_mat = torch.stack([m[rank()] for m in mats])
+        recv_mat = torch.stack([m[rank()] for m in _all_gather_same(send_mat.contiguous())])
     send_h, recv_h = send_mat.cpu(), recv_mat.cpu()
     recv = _all_to_all_v(rows[order].contiguous(), send_h.sum(1).tolist(), recv_h.sum(1).tolist())
     # ---- owner-side merge, column by column ------------------------------------------------
@@ -248,9 +273,7 @@ def merge_counts_many(tables):
             merged.append(torch.empty((0, 2), dtype=torch.int64, device=dev))
     # ---- replicate: every rank gets every owner's share ---------------------------------------
     mlen = torch.tensor([m.shape[0] for m in merged], dtype=torch.int64, device=dev)
-    all_len = [torch.empty_like(mlen) for _ in range(G)]
-    td.all_gather(all_len, mlen)
-    all_len = torch.stack(all_len).cpu()  # [G, ncol]
+    all_len = torch.stack(_all_gather_same(mlen)).cpu()  # [G, ncol]
     everything = _all_gather_v(torch.cat(merged), sizes=all_len.sum(1).tolist())
     goff = torch.zeros(G * ncol + 1, dtype=torch.int64)
     goff[1:] = torch.cumsum(all_len.reshape(-1), 0)
@@ -258,7 +281,7 @@ def merge_counts_many(tables):
     nsc = max(len(sc) for _, _, sc in tables)
     scal = torch.tensor([list(sc) + [0] * (nsc - len(sc)) for _, _, sc in tables],
                         dtype=torch.int64, device=dev)
-    td.all_reduce(scal)
+    _all_reduce(scal)
     scal = scal.cpu().tolist()
     out = []
     for j in range(ncol):

@@ -1,0 +1,46 @@
+"""2 ranks (one GPU, gloo): each rank fits its OWN frame; the merged vocabularies and moments
+must equal a single-process fit of the concatenated frames, and every rank must encode its
+own rows with them."""
+import os, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pandas as pd
+import torch
+import torch.distributed as td
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+td.init_process_group("gloo", rank=rank, world_size=world)
+import nvtabular_amd as nvt
+from nvtabular_amd import ops
+
+
+def make(r, n=200_000):
+    rng = np.random.default_rng(100 + r)
+    df = pd.DataFrame({
+        "a": (np.minimum(rng.zipf(1.2, n), 50_000) * 7919 % 1_000_003).astype("int32"),
+        "b": rng.integers(0, 30, n).astype("int64"),
+        "x": rng.normal(3.0, 2.0, n)})
+    df.loc[rng.random(n) < 0.1, "x"] = np.nan
+    return df
+
+
+mine = make(rank)
+tmp = tempfile.mkdtemp()
+wf = nvt.Workflow((["a", "b"] >> ops.Categorify(out_path=os.path.join(tmp, f"r{rank}")))
+                  + (["x"] >> ops.FillMissing() >> ops.Normalize()))
+got = wf.fit_transform(nvt.Dataset(mine)).to_ddf().compute()
+td.barrier()
+# single-process reference on the union (world_size() is 1 inside this block)
+td.destroy_process_group()
+full = pd.concat([make(r) for r in range(world)], ignore_index=True)
+ref = nvt.Workflow((["a", "b"] >> ops.Categorify(out_path=os.path.join(tmp, f"ref{rank}")))
+                   + (["x"] >> ops.FillMissing() >> ops.Normalize()))
+exp_all = ref.fit_transform(nvt.Dataset(full)).to_ddf().compute()
+lo = sum(len(make(r)) for r in range(rank))
+exp = exp_all.iloc[lo: lo + len(mine)].reset_index(drop=True)
+for c in ("a", "b"):
+    np.testing.assert_array_equal(got[c].to_numpy(), exp[c].to_numpy(), err_msg=c)
+np.testing.assert_allclose(got["x"].to_numpy(), exp["x"].to_numpy(), rtol=1e-9, atol=1e-12)
+print(f"rank {rank}: multi-rank fit == single-process fit of the union "
+      f"({len(mine)} of {len(full)} rows, vocab a = {int(exp_all['a'].max()) - 2})", flush=True)
