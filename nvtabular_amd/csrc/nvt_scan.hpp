@@ -159,4 +159,32 @@ inline int exclusive_scan_u32(unsigned *data, uint64_t len, unsigned long long *
   return NVT_OK;
 }
 
+// Same scan, but the last step is left to the consumer: on return
+//   prefix(i) = data[i] + (unsigned)chunk_base[i / kScanChunk]      (scan_lookup below)
+// with chunk_base == nullptr meaning data[] already holds the full prefix (short arrays).
+// Saves one launch + one pass over the array per radix pass of a large vocabulary.
+inline int exclusive_scan_u32_deferred(unsigned *data, uint64_t len, unsigned long long *chunk_tot,
+                                       const unsigned long long **chunk_base, hipStream_t stream) {
+  *chunk_base = nullptr;
+  if (len == 0) return NVT_OK;
+  if (len <= kScanSmallMax && (reinterpret_cast<uintptr_t>(data) & 15) == 0) {
+    scan_small_kernel<<<1, kScanSmallBS, 0, stream>>>(data, len);
+    NVT_CHECK_LAUNCH();
+    return NVT_OK;
+  }
+  const uint64_t nchunks = scan_chunks(len);
+  scan_chunk_kernel<<<(unsigned)nchunks, kBlock, 0, stream>>>(data, len, chunk_tot);
+  NVT_CHECK_LAUNCH();
+  scan_totals_kernel<<<1, kBlock, 0, stream>>>(chunk_tot, nchunks);
+  NVT_CHECK_LAUNCH();
+  *chunk_base = chunk_tot;
+  return NVT_OK;
+}
+__device__ __forceinline__ unsigned scan_lookup(const unsigned *data,
+                                                const unsigned long long *chunk_base, uint64_t i) {
+  unsigned v = data[i];
+  if (chunk_base != nullptr) v += (unsigned)chunk_base[i / kScanChunk];
+  return v;
+}
+
 }  // namespace nvt

@@ -235,9 +235,14 @@ __global__ __launch_bounds__(kS2BS) void sort2_hist_kernel(const uint64_t *__res
     uint64_t c = 0;
     if (act) c = FIRST ? comp_make(keys[i], cnts[i]) : comp[i];
     const unsigned d = (unsigned)(c >> shift) & 0xFF;
-    // count passes see one or two digit values: aggregate equal digits per wave first
-    const unsigned long long peers = match_digit(d, act);
-    if (act && (peers & ((1ull << lane_id()) - 1ull)) == 0) atomicAdd(&h[d], (unsigned)__popcll(peers));
+    if (shift < 32) {
+      if (act) atomicAdd(&h[d], 1u);  // key bytes: digits spread over 256 bins
+    } else {
+      // count passes see one or two digit values: aggregate equal digits per wave first
+      const unsigned long long peers = match_digit(d, act);
+      if (act && (peers & ((1ull << lane_id()) - 1ull)) == 0)
+        atomicAdd(&h[d], (unsigned)__popcll(peers));
+    }
   }
   __syncthreads();
   tile_hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -247,7 +252,8 @@ template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(kS2BS) void sort2_scatter_kernel(
     const uint64_t *__restrict__ comp, const int32_t *__restrict__ keys,
     const int64_t *__restrict__ cnts, uint64_t n, int shift, const unsigned *__restrict__ tile_off,
-    uint64_t ntiles, uint64_t *out_comp, int32_t *out_keys, int64_t *out_cnts) {
+    const unsigned long long *__restrict__ chunk_base, uint64_t ntiles, uint64_t *out_comp,
+    int32_t *out_keys, int64_t *out_cnts) {
   constexpr int NW = kS2BS / kWave;
   __shared__ unsigned wcnt[NW][256];
   __shared__ unsigned goff[256];
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(kS2BS) void sort2_scatter_kernel(
       wcnt[q][d] = run;
       run += t[q];
     }
-    goff[d] = tile_off[(uint64_t)d * ntiles + blockIdx.x] - dstart;
+    goff[d] = scan_lookup(tile_off, chunk_base, (uint64_t)d * ntiles + blockIdx.x) - dstart;
   }
   __syncthreads();
 #pragma unroll
@@ -368,20 +374,21 @@ inline int vocab_sort_packed(int32_t *keys, int64_t *counts, uint64_t n, int64_t
       sort2_hist_kernel<false><<<(unsigned)ntiles, kS2BS, 0, stream>>>(src, nullptr, nullptr, n,
                                                                         shift, tile_hist, ntiles);
     NVT_CHECK_LAUNCH();
+    const unsigned long long *cbase = nullptr;
     {
-      int rc = exclusive_scan_u32(tile_hist, hist_len, chunk_tot, stream);
+      int rc = exclusive_scan_u32_deferred(tile_hist, hist_len, chunk_tot, &cbase, stream);
       if (rc) return rc;
     }
     uint64_t *dst = bufs[flip];
     if (first)
       sort2_scatter_kernel<true, false><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
-          nullptr, keys, counts, n, shift, tile_hist, ntiles, dst, nullptr, nullptr);
+          nullptr, keys, counts, n, shift, tile_hist, cbase, ntiles, dst, nullptr, nullptr);
     else if (last)
       sort2_scatter_kernel<false, true><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
-          src, nullptr, nullptr, n, shift, tile_hist, ntiles, nullptr, keys, counts);
+          src, nullptr, nullptr, n, shift, tile_hist, cbase, ntiles, nullptr, keys, counts);
     else
       sort2_scatter_kernel<false, false><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
-          src, nullptr, nullptr, n, shift, tile_hist, ntiles, dst, nullptr, nullptr);
+          src, nullptr, nullptr, n, shift, tile_hist, cbase, ntiles, dst, nullptr, nullptr);
     NVT_CHECK_LAUNCH();
     src = dst;
     flip ^= 1;
