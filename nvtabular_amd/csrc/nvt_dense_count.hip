@@ -935,7 +935,8 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
     const int64_t *__restrict__ weights, uint64_t n, int b1, int nbits,
     const unsigned long long *__restrict__ fine_start, unsigned long long *cursor,
     const unsigned *__restrict__ tile_start, const unsigned *__restrict__ tile_off,
-    K *__restrict__ out_keys, int64_t *__restrict__ out_w) {
+    const unsigned long long *__restrict__ tile_off_base, K *__restrict__ out_keys,
+    int64_t *__restrict__ out_w) {
   constexpr int ROWS = kTile / kBlock;
   __shared__ K stage[kTile];
   __shared__ unsigned lcnt[256], loff[256];
@@ -1076,7 +1077,8 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(
     if ((int)threadIdx.x < nbk && v) {
       if (LEVEL == 1) {
         // exact offset of this (tile, bucket) from the scanned per-tile histograms
-        gbase[threadIdx.x] = tile_off[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x];
+        gbase[threadIdx.x] =
+            scan_lookup(tile_off, tile_off_base, (uint64_t)threadIdx.x * gridDim.x + blockIdx.x);
       } else {
         unsigned long long *cur = cursor + (uint64_t)coarse_s * nbk;
         gbase[threadIdx.x] = atomicAdd(&cur[threadIdx.x], (unsigned long long)v);
@@ -1579,8 +1581,10 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
     part_hist_kernel<K><<<kHistBlocks, 1024, 0, s>>>(keys, valid, weights, n, b1, bits,
                                                        w.block_hist, w.tile_hist, t1, state);
     NVT_CHECK_LAUNCH();
+    const unsigned long long *tile_base = nullptr;  // last scan step is done by the P1 scatter
     {
-      int rc = exclusive_scan_u32(w.tile_hist, ((uint64_t)1 << b1) * t1, w.scan_tot, s);
+      int rc = exclusive_scan_u32_deferred(w.tile_hist, ((uint64_t)1 << b1) * t1, w.scan_tot,
+                                           &tile_base, s);
       if (rc) return rc;
     }
     part_reduce_kernel<<<((1 << bits) + 63) / 64, 64 * kReduceGroups, 0, s>>>(w.block_hist, kHistBlocks,
@@ -1597,16 +1601,16 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
     if (weights) {
       part_scatter_kernel<K, 1, true><<<t1, kBlock, 0, s>>>(keys, valid, weights, n, b1, b1,
                                                             w.fine_start, w.coarse_cursor,
-                                                            w.tile_start, w.tile_hist, (K *)w.bufA,
-                                                            w.wA);
+                                                            w.tile_start, w.tile_hist, tile_base,
+                                                            (K *)w.bufA, w.wA);
       NVT_CHECK_LAUNCH();
       fine_keys = (const K *)w.bufA;
       fine_w = w.wA;
       if (b2) {
         part_scatter_kernel<K, 2, true><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, w.wA, n,
                                                               b1, b2, w.fine_start, w.fine_cursor,
-                                                              w.tile_start, nullptr, (K *)w.bufB,
-                                                              w.wB);
+                                                              w.tile_start, nullptr, nullptr,
+                                                              (K *)w.bufB, w.wB);
         NVT_CHECK_LAUNCH();
         fine_keys = (const K *)w.bufB;
         fine_w = w.wB;
@@ -1614,15 +1618,15 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
     } else {
       part_scatter_kernel<K, 1, false><<<t1, kBlock, 0, s>>>(keys, valid, nullptr, n, b1, b1,
                                                              w.fine_start, w.coarse_cursor,
-                                                             w.tile_start, w.tile_hist, (K *)w.bufA,
-                                                             nullptr);
+                                                             w.tile_start, w.tile_hist, tile_base,
+                                                             (K *)w.bufA, nullptr);
       NVT_CHECK_LAUNCH();
       fine_keys = (const K *)w.bufA;
       if (b2) {
         part_scatter_kernel<K, 2, false><<<t2, kBlock, 0, s>>>((const K *)w.bufA, nullptr, nullptr,
                                                                n, b1, b2, w.fine_start,
                                                                w.fine_cursor, w.tile_start, nullptr,
-                                                               (K *)w.bufB, nullptr);
+                                                               nullptr, (K *)w.bufB, nullptr);
         NVT_CHECK_LAUNCH();
         fine_keys = (const K *)w.bufB;
       }
