@@ -587,7 +587,9 @@ _scratch = {}
 
 
 def _partials(device) -> torch.Tensor:
-    key = (device.type, device.index)
+    # one scratch block per (device, stream): reductions of different operators may be in
+    # flight on different streams at the same time
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _scratch:
         nbytes = _lib.load().nvt_moments_scratch_bytes()
         _scratch[key] = torch.empty(nbytes // 8, dtype=torch.float64, device=device)

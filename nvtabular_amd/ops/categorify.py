@@ -350,7 +350,7 @@ class Categorify(StatOperator):
         dev = torch.cuda.current_device()
         cache = getattr(self, "_fin_streams", None)
         if cache is None or cache[0] != dev:
-            cache = (dev, [torch.cuda.Stream(device=dev) for _ in range(3)])
+            cache = (dev, [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("NVT_FINALIZE_STREAMS", "3")))])
             self._fin_streams = cache
         return cache[1]
 
