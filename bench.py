@@ -13,7 +13,6 @@ every rank owns its own N-row shard; fit statistics are merged over RCCL).
 """
 import argparse
 import json
-import math
 import os
 import sys
 import tempfile

@@ -15,7 +15,7 @@ import contextlib
 import os
 import warnings
 from copy import deepcopy
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 import pandas as pd

@@ -11,7 +11,7 @@ from inspect import signature
 
 import pandas as pd
 
-from ..device import DeviceColumn, DeviceFrame, as_device_frame
+from ..device import DeviceFrame, as_device_frame
 from ..selector import ColumnSelector
 from .base import Operator
 

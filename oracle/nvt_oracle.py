@@ -31,7 +31,6 @@ Reference files restated (all under /root/reference/nvtabular/ops/):
 """
 from __future__ import annotations
 
-import math
 import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Union
