@@ -3,10 +3,12 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nvtabular_amd import kernels as K
+if os.environ.get("NVT_PATH_TINY_MAX"):
+    K.PATH_TINY_MAX = int(os.environ["NVT_PATH_TINY_MAX"])
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 45_000_000
 dev = torch.device("cuda", 0)
-CASES = [(3, 1.1), (36, 1.1), (976, 1.1), (3000, 1.15), (7420, 1.1), (12972, 1.1), (20263, 1.1), (39043, 1.1), (403346, 1.2),
+CASES = [(3, 1.1), (36, 1.1), (155, 1.1), (976, 1.1), (3000, 1.15), (7420, 1.1), (12972, 1.1), (20263, 1.1), (39043, 1.1), (403346, 1.2),
                 (2953546, 1.15), (39884406, 1.05)]
 if os.environ.get("PROBE_CARDS"):
     want = {int(x) for x in os.environ["PROBE_CARDS"].split(",")}
