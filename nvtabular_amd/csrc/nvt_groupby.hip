@@ -91,6 +91,7 @@ __device__ __forceinline__ int64_t find_slot(const GbView &t, const long long (&
                                              unsigned *ovf) {
   uint64_t slot = tuple_hash(k, nm, t.nkeys) & t.mask;
   int probe = 0;
+  unsigned spins = 0;  // bounded wait on a LOCKED slot: report overflow rather than hang the GPU
   while (probe < kGbMaxProbe) {
     unsigned st = __hip_atomic_load(&t.slot_state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st == ST_EMPTY) {
@@ -109,7 +110,11 @@ __device__ __forceinline__ int64_t find_slot(const GbView &t, const long long (&
       }
       st = prev;  // somebody else got it: fall through with its state
     }
-    if (st == ST_LOCKED) continue;  // writer is a few instructions from READY: re-read
+    if (st == ST_LOCKED) {  // writer is a few instructions from READY: re-read
+      if (++spins < (1u << 22)) continue;
+      *ovf = 1;
+      return -1;
+    }
     // READY: compare
     bool same = __hip_atomic_load(&t.nullmask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nm;
     for (int j = 0; same && j < t.nkeys; ++j)
