@@ -241,14 +241,19 @@ def merge_counts_many(tables):
     dtypes = [k.dtype for k, _, _ in tables]
     lens = [int(k.numel()) for k, _, _ in tables]
     # ---- rows grouped by (owner, column) --------------------------------------------
-    dest_parts = []
+    own_parts, dest_parts = [], []
     for j, (k, _, _) in enumerate(tables):
         own = _owner_fn([k], G).to(torch.int64) if lens[j] else torch.empty(0, dtype=torch.int64, device=dev)
+        own_parts.append(own)
         dest_parts.append(own * ncol + j)
+    owner_all = torch.cat(own_parts)
     dest = torch.cat(dest_parts)
     rows = torch.stack([torch.cat([k.to(torch.int64) for k, _, _ in tables]),
                         torch.cat([c.to(torch.int64) for _, c, _ in tables])], dim=1)
-    order = torch.argsort(dest, stable=True)
+    # rows are concatenated column by column, so the ascending row indices of one owner are
+    # already grouped by column: G compactions give the (owner, column) order -- a full
+    # argsort of ~3e7 destinations was the most expensive step of the whole exchange
+    order = torch.cat([torch.nonzero(owner_all == g).squeeze(1) for g in range(G)])
     send_mat = torch.bincount(dest, minlength=G * ncol).to(torch.int64).view(G, ncol)
     # ---- count matrix: row g of mine goes to rank g ------------------------------------
     if _backend() == "nccl":
