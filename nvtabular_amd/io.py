@@ -265,10 +265,12 @@ class Dataset:
             n = len(part)
             if shuffle is not None and n > 1:
                 part = part.take_rows(_device_permutation(n, part))
-            df = part.to_pandas()
+            table = part.to_arrow()  # pinned async copies, no pandas round trip
             if dtypes:
-                df = df.astype({c: t for c, t in dtypes.items() if c in df.columns})
-            table = pa.Table.from_pandas(df, preserve_index=False)
+                for c, t in dtypes.items():
+                    if c in table.column_names:
+                        i = table.column_names.index(c)
+                        table = table.set_column(i, c, table.column(c).cast(pa.from_numpy_dtype(np.dtype(t))))
             if k is None:
                 emit(i, table)
                 continue

@@ -361,3 +361,24 @@ def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     for r in (0, 1):
         assert f"rank {r}: multi-rank fit == single-process fit of the union" in res.stdout
+
+
+def test_frame_to_arrow_keeps_types_nulls_and_lists():
+    """DeviceFrame.to_arrow (the output half of the parquet path): integer columns keep their
+    type and their nulls, floats their NaNs, list columns their offsets."""
+    import pyarrow as pa
+
+    from nvtabular_amd.device import DeviceFrame
+
+    t = pa.table({
+        "i": pa.array([1, None, 3, 4, None, 6, 7, 8, 9], type=pa.int32()),
+        "l": pa.array([5, 6, 7, 8, 9, 10, 11, 12, 13], type=pa.int64()),
+        "f": pa.array([0.5, float("nan"), 2.5, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0], type=pa.float64()),
+        "lst": pa.array([[1, 2], [], [3], [4, 5, 6], [], [7], [8], [9], [10]], type=pa.list_(pa.int64())),
+    })
+    back = DeviceFrame.from_arrow(t).to_arrow()
+    assert back.column("i").type == pa.int32() and back.column("i").to_pylist() == t.column("i").to_pylist()
+    assert back.column("l").to_pylist() == t.column("l").to_pylist()
+    f = back.column("f").to_pylist()
+    assert f[0] == 0.5 and f[1] != f[1] and f[2:] == t.column("f").to_pylist()[2:]
+    assert back.column("lst").to_pylist() == t.column("lst").to_pylist()
