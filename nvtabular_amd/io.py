@@ -243,22 +243,46 @@ class Dataset:
         k = int(out_files_per_proc) if out_files_per_proc else None
         rng = np.random.default_rng()
         writers, held, names, rows_in = {}, {}, {}, {}
+        touched = set()
         collector = []
 
         def fname(j):
             return f"part_{(rank * k + j) if k else (j * world + rank)}{suffix}"
 
+        # Parquet encoding (dictionary + compression) is host work that pyarrow does with the
+        # GIL released: file j is always written by lane j % NLANES, in order, so up to NLANES
+        # files are encoded at once while the next partition is transformed and copied out.
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        NLANES = 4
+        lanes = [ThreadPoolExecutor(max_workers=1) for _ in range(NLANES)]
+        inflight = threading.BoundedSemaphore(2 * NLANES)  # bounds the host memory queued up
+        pending = []
+
+        def write(j, table):
+            try:
+                w = writers.get(j)
+                if w is None:
+                    names[j] = fname(j)
+                    w = writers[j] = pq.ParquetWriter(os.path.join(output_path, names[j]),
+                                                      table.schema, metadata_collector=collector)
+                w.write_table(table)
+                rows_in[j] = rows_in.get(j, 0) + table.num_rows
+            finally:
+                inflight.release()
+
         def emit(j, table):
             if shuffle == Shuffle.PER_WORKER and k:
                 held.setdefault(j, []).append(table)
                 return
-            w = writers.get(j)
-            if w is None:
-                names[j] = fname(j)
-                w = writers[j] = pq.ParquetWriter(os.path.join(output_path, names[j]), table.schema,
-                                                  metadata_collector=collector)
-            w.write_table(table)
-            rows_in[j] = rows_in.get(j, 0) + table.num_rows
+            inflight.acquire()
+            pending.append(lanes[j % NLANES].submit(write, j, table))
+
+        def drain():
+            for f in pending:
+                f.result()  # re-raises a writer's exception here
+            pending.clear()
 
         shard = (rank, world) if world > 1 else None
         for i, part in enumerate(self.to_iter(shard=shard)):
@@ -276,8 +300,12 @@ class Dataset:
                 continue
             bounds = [(n * j) // k for j in range(k + 1)]
             for j in range(k):
-                if bounds[j + 1] > bounds[j] or j not in writers and j not in held:
+                if bounds[j + 1] > bounds[j] or j not in touched:
+                    touched.add(j)
                     emit(j, table.slice(bounds[j], bounds[j + 1] - bounds[j]))
+        drain()
+        for ex in lanes:
+            ex.shutdown(wait=True)
         for j, pieces in sorted(held.items()):
             table = pa.concat_tables(pieces)
             if table.num_rows > 1:

@@ -43,3 +43,11 @@ for it in range(3):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"iter {it}: fit {1e3*(t1-t0):.0f} ms, transform {1e3*(t2-t1):.0f} ms, "
           f"{n/(t2-t0)/1e6:.1f} M rows/s parquet -> HBM -> fit+transform", flush=True)
+
+# output leg: transform + write the result as parquet (one file per partition)
+out_dir = os.path.join(tmp, "out")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+wf.transform(ds).to_parquet(out_dir)
+dt = time.perf_counter() - t0
+size = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
+print(f"transform + to_parquet: {1e3*dt:.0f} ms, {n/dt/1e6:.1f} M rows/s, {size/1e9:.2f} GB written", flush=True)
