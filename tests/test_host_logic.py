@@ -36,3 +36,58 @@ def test_rank_sharding_semantics(tmp_path):
     firsts = lambda shard: [t.column("a")[0].as_py() for t in pq._host_parts(None, shard)]
     assert firsts(None) == [0, 10, 20, 30, 40]
     assert firsts((0, 2)) == [0, 20, 40] and firsts((1, 2)) == [10, 30]
+
+
+def test_path_selection_thresholds():
+    """kernels._path_for: the C-ABI path id for an expected distinct count (include/nvt_hip.h)."""
+    from nvtabular_amd import kernels as K
+
+    assert K._path_for(0) == 0                      # unknown: start on the plain LDS-table path
+    assert K._path_for(3) == 6 and K._path_for(64) == 6
+    assert K._path_for(65) == 0 and K._path_for(K.PATH_S_MAX_DISTINCT) == 0
+    assert K._path_for(K.PATH_S_MAX_DISTINCT + 1) == 7
+    assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_DISTINCT) + 1) == 1
+    assert K._path_for(K.PATH_P1_MAX_DISTINCT + 1) == 2
+    assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1) == 3
+    assert K._path_for(K.PATH_P3_MAX_DISTINCT + 1) == -1   # global-table fallback
+    # int64 keys / weighted merges use the smaller tables
+    assert K._path_for(K.PATH_S_MAX_WEIGHTED + 1, small_tables=True) == 7
+    assert K._path_for(K.PATH_P1_MAX_SMALL + 1, small_tables=True) == 2
+    # escalation order covers every automatic path exactly once
+    assert sorted(K.PATH_ORDER) == [0, 1, 2, 3, 6, 7] and set(K._PATH_MAX) >= set(K.PATH_ORDER)
+
+
+def test_shuffle_option_coercion():
+    from nvtabular_amd.io import Shuffle
+
+    assert Shuffle.coerce(None) is None and Shuffle.coerce(False) is None
+    assert Shuffle.coerce(True) == Shuffle.PER_WORKER
+    assert Shuffle.coerce(Shuffle.PER_PARTITION) == Shuffle.PER_PARTITION
+    assert Shuffle.coerce(Shuffle.FULL) == Shuffle.PER_WORKER
+    import pytest
+
+    with pytest.raises(ValueError):
+        Shuffle.coerce("sideways")
+
+
+def test_graph_json_dtype_and_tag_records():
+    """The merlin DType / Tags records of graph_serializer.py:106-153 as this engine writes
+    and reads them."""
+    from nvtabular_amd import Tags
+    from nvtabular_amd import graph_json as G
+
+    d = G._dtype_to_dict(np.dtype("int32"), with_shape=True)
+    assert d == {"name": "int32", "element_type": "int", "element_size": 32, "signed": True,
+                 "shape": [{"min": None, "max": None}]}
+    assert G._dtype_to_dict(np.float64)["element_type"] == "float"
+    lst = G._dtype_to_dict(np.int64, is_list=True, is_ragged=True, with_shape=True)
+    assert len(lst["shape"]) == 2 and lst["shape"][1] == {"min": 0, "max": None}
+    assert G._dtype_from_dict({"name": "int64"}) == np.dtype("int64")
+    assert G._dtype_from_dict("float32") == np.dtype("float32")
+    assert G._dtype_from_dict({"name": "str"}) == np.dtype("O")
+    assert G._dtype_from_dict({"name": "weird", "element_type": "uint", "element_size": 8}) == np.dtype("uint8")
+    assert G._tags_to_list([Tags.CATEGORICAL, Tags.LIST]) == ["Tags.CATEGORICAL", "Tags.LIST"]
+    assert G._tags_from_list(["Tags.CONTINUOUS", "categorical", "Tags.NOT_A_TAG"]) == [
+        Tags.CONTINUOUS, Tags.CATEGORICAL]
+    assert G._paths_from_json(G._paths_to_json({("a", "b"): "/x/art/categories/u.parquet"}, "/x/art"),
+                              "/y") == {("a", "b"): "/y/categories/u.parquet"}
