@@ -7,6 +7,7 @@ every O(rows) computation below is a hand-written gfx950 kernel reached through
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import List, Optional, Sequence, Tuple
 
@@ -229,7 +230,7 @@ PATH_ORDER = [6, 0, 7, 1, 2, 3]
 _S_CLASSES = {6: 1, 0: 1, 7: 2, 4: 4, 5: 8}
 PATH_S2_FACTOR = 1.95               # path 7: path 0 with 2 key classes per row slab (column read twice)
 PATH_TINY_MAX = 64                  # path 6: path 0 with hot keys replicated per lane group
-PATH_P1_MAX_DISTINCT = 2_400_000    # path 1: ONE level, 256 buckets x 16384-slot tables (int32)
+PATH_P1_MAX_DISTINCT = int(os.environ.get("NVT_P1_MAX", 2_400_000))    # path 1: ONE level, 256 buckets x 16384-slot tables (int32)
 PATH_P1_MAX_SMALL = 1_100_000       #         ... 8192-slot tables (int64 keys / weighted merges)
 PATH_P2_MAX_DISTINCT = 9_000_000    # path 2: 64 x 64 buckets, 4096-slot tables
 PATH_P2_MAX_WEIGHTED = 18_000_000   #         weighted: 8192-slot tables
