@@ -70,7 +70,10 @@ int main(){ uint64_t n=45000000; int32_t* k; unsigned* out; uint8_t* valid; CK(h
     float b2=run<16384,1024,3>(256,k,valid,n,out);
     float b3=run<16384,1024,11>(256,k,valid,n,out);
     float b4=run<16384,512,11>(256,k,valid,n,out);
+    float d0=run<8192,1024,0>(512,k,valid,n,out);   // 2 WGs x 16 waves per CU
+    float d1=run<8192,1024,11>(512,k,valid,n,out);
+    float d2=run<4096,1024,0>(1024,k,valid,n,out);  // up to 4 WGs per CU (wave slots permitting)
     float c0=run<16384,1024,4>(256,k,valid,n,out);
     float c1=run<16384,1024,15>(256,k,valid,n,out);
-    printf("%6.0f | %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f us\n",c,a0,a1,a2,a3,b0,b1,b2,b3,b4,c0,c1); }
+    printf("%6.0f | %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f us || 8k/1024x2: %.1f  +v+f+U4: %.1f  4k/1024x4: %.1f\n",c,a0,a1,a2,a3,b0,b1,b2,b3,b4,c0,c1,d0,d1,d2); }
   return 0; }
