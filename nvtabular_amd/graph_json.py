@@ -358,7 +358,7 @@ def _build_registry():
 _REGISTRY: Dict[str, tuple] = {}
 _SELECTION = "merlin.dag.ops.selection.SelectionOp"
 # exist in the reference too, but its JSON serializer defers them (:920-930)
-_DEFERRED = {"SubsetColumns", "SubtractionOp", "HashedCross"}
+_DEFERRED = {"SubsetColumns", "SubtractionOp", "HashedCross", "Groupby"}
 
 
 def _registry():

@@ -6,6 +6,7 @@ from .bucketize import Bucketize  # noqa: F401
 from .categorify import Categorify, get_embedding_sizes  # noqa: F401
 from .clip_log import Clip, LogOp  # noqa: F401
 from .fill import FillMissing  # noqa: F401
+from .groupby import Groupby  # noqa: F401
 from .hash_bucket import HashBucket  # noqa: F401
 from .hashed_cross import HashedCross  # noqa: F401
 from .join_groupby import JoinGroupby  # noqa: F401

@@ -76,6 +76,7 @@ __all__ = [
     "fill_missing",
     "clip_transform",
     "hashed_cross",
+    "groupby_op",
     "bucketize",
     "logop_transform",
     "join_groupby_fit",
@@ -213,6 +214,65 @@ def bucketize(df: pd.DataFrame, boundaries: Dict[str, list]) -> pd.DataFrame:
     for col, b in boundaries.items():
         out[col] = np.digitize(df[col].values, np.asarray(b), right=False).astype(np.int32)
     return out
+
+
+def groupby_op(df, selector_names, groupby_cols, sort_cols=None, aggs="list", name_sep="_",
+               ascending=True):
+    """groupby.py:88-107 (aggregation split), :113-141 (transform), :232-261 (_apply_aggs),
+    :287-319 (_first_or_last) -- the pandas branch, literally."""
+    import re
+
+    sort_cols = [sort_cols] if isinstance(sort_cols, str) else (sort_cols or [])
+    groupby_cols = [groupby_cols] if isinstance(groupby_cols, str) else list(groupby_cols)
+    list_aggs, conv_aggs = {}, {}
+    if isinstance(aggs, str):
+        aggs = {"__all__": [aggs]}
+    elif isinstance(aggs, list):
+        aggs = {"__all__": aggs}
+    for col, v in aggs.items():
+        _aggs = v if isinstance(v, list) else [v]
+        _conv, _list = [], []
+        for a in _aggs:
+            if a in ("list", list, "first", "last"):
+                a2 = "list" if a == list else a
+                if a2 not in _list:
+                    _list.append(a2)
+                if list not in _conv:
+                    _conv.append(list)
+            elif a not in _conv:
+                _conv.append(a)
+        if _conv:
+            conv_aggs[col] = _conv
+        if _list:
+            list_aggs[col] = _list
+    allowed = [c for c in selector_names if c not in groupby_cols]
+
+    def ensure(d):
+        if "__all__" in d:
+            return {c: d["__all__"] for c in allowed}
+        return {k: v for k, v in d.items() if k in allowed}
+
+    _list_aggs, _conv_aggs = ensure(list_aggs), ensure(conv_aggs)
+    if sort_cols:
+        df = df.sort_values(sort_cols, ascending=ascending, ignore_index=True, kind="stable")
+    columns = list(dict.fromkeys(list(groupby_cols) + list(_conv_aggs) + list(_list_aggs)))
+    out = df[columns].groupby(groupby_cols).agg(_conv_aggs).reset_index()
+    out.columns = [name_sep.join([n for n in name if n != ""]) for name in out.columns.to_flat_index()]
+    for col, lst in _list_aggs.items():
+        for a in lst:
+            if a in ("first", "last"):
+                src = out[f"{col}{name_sep}list"]
+                first = (a == "first" and ascending) or (a == "last" and not ascending)
+                out[f"{col}{name_sep}{a}"] = src.apply((lambda y: y[0]) if first else (lambda y: y[-1]))
+        if "list" not in lst:
+            out.drop(columns=[col + f"{name_sep}list"], inplace=True)
+    for col in out.columns:
+        if re.search(f"{name_sep}(count|nunique)$", col):
+            out[col] = out[col].astype(np.int32)
+        elif re.search(f"{name_sep}(mean|median|std|var|sum)$", col):
+            out[col] = out[col].astype(np.float32)
+    keep = [c for c in out.columns if c not in groupby_cols or c in selector_names]
+    return out[keep]
 
 
 def hash_bucket_op(df: pd.DataFrame, num_buckets: Union[int, Dict[str, int]], cols=None):

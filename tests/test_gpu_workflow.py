@@ -382,3 +382,45 @@ def test_frame_to_arrow_keeps_types_nulls_and_lists():
     f = back.column("f").to_pylist()
     assert f[0] == 0.5 and f[1] != f[1] and f[2:] == t.column("f").to_pylist()[2:]
     assert back.column("lst").to_pylist() == t.column("lst").to_pylist()
+
+
+@pytest.mark.parametrize("ascending", [True, False])
+def test_groupby_vs_oracle(ascending):
+    """ops.Groupby (groupby.py:113-261; reference test tests/unit/ops/test_groupyby.py:27-110):
+    list / first / last in sort order, conventional aggregations, null keys dropped."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ColumnSelector, ops
+
+    rng = np.random.default_rng(3)
+    n = 5000
+    df = pd.DataFrame({
+        "name": rng.choice(["Dave", "Zelda", "Ann", "Bo"], n),
+        "id": rng.integers(0, 40, n).astype("int64"),
+        "ts": rng.permutation(n).astype("int64"),          # unique: the sort is unambiguous
+        "x": rng.integers(0, 1000, n).astype("int64"),
+        "y": rng.normal(size=n),
+    })
+    df.loc[rng.random(n) < 0.1, "y"] = np.nan
+    kdf = df.copy()
+    kdf["id"] = pd.array(df["id"], dtype="Int64")
+    kdf.loc[rng.random(n) < 0.05, "id"] = pd.NA            # null keys are dropped
+    odf = kdf.copy()
+    odf["id"] = odf["id"].astype("float64")
+    aggs = {"x": ["list", "sum", "first", "last"], "y": ["first", "last", "mean", "count", "std"],
+            "ts": ["min", "max"]}
+    sel = ["name", "id", "ts", "x", "y"]
+    feats = ColumnSelector(sel) >> ops.Groupby(groupby_cols=["name", "id"], sort_cols=["ts"],
+                                               aggs=aggs, name_sep="-", ascending=ascending)
+    got = nvt.Workflow(feats).fit_transform(nvt.Dataset(kdf)).to_ddf().compute()
+    exp = O.groupby_op(odf, sel, ["name", "id"], ["ts"], aggs, "-", ascending)
+    assert sorted(got.columns) == sorted(exp.columns) and len(got) == len(exp)
+    assert got["name"].tolist() == exp["name"].tolist()
+    np.testing.assert_array_equal(got["id"].to_numpy().astype("int64"), exp["id"].to_numpy().astype("int64"))
+    for g, e in zip(got["x-list"], exp["x-list"]):
+        assert list(g) == list(e)
+    for c in ("x-first", "x-last", "ts-min", "ts-max", "y-count"):
+        np.testing.assert_array_equal(got[c].to_numpy().astype("int64"), exp[c].to_numpy().astype("int64"), err_msg=c)
+    assert got["y-count"].dtype == np.int32 and got["x-sum"].dtype == np.float32
+    for c in ("x-sum", "y-mean", "y-std", "y-first", "y-last"):
+        np.testing.assert_allclose(got[c].to_numpy().astype("float64"), exp[c].to_numpy().astype("float64"),
+                                   rtol=1e-5, atol=1e-6, equal_nan=True, err_msg=c)

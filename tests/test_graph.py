@@ -230,3 +230,27 @@ def test_graph_json_refuses_lambdas(tmp_path):
     wf.fit_schema(Schema.from_frame(pd.DataFrame({"x": [1.0]})))
     with pytest.raises(WorkflowSerializationError):
         wf.save(str(tmp_path / "w"))
+
+
+def test_groupby_schema_and_selector_cols():
+    """tests/unit/ops/test_groupyby.py:131-164 of the reference: key columns appear in the output
+    only when the selector names them; list aggregations are ragged lists, count is int32, sum
+    float32."""
+    from nvtabular_amd import Tags
+
+    aggs = {"x": ["list", "sum"], "y": ["first", "last"], "ts": ["min", "count"]}
+    full = ColumnSelector(["name", "id", "ts", "x", "y"]) >> ops.Groupby(
+        groupby_cols=["name"], sort_cols=["ts"], aggs=aggs, name_sep="-")
+    wf = Workflow(full).fit_schema(Schema(["name", "id", "ts", "x", "y"]))
+    assert wf.output_node.output_schema.column_names == [
+        "name", "x-list", "y-first", "y-last", "x-sum", "ts-min", "ts-count"]
+    part = ColumnSelector(["id", "ts", "x", "y"]) >> ops.Groupby(
+        groupby_cols=["name"], sort_cols=["ts"], aggs=aggs, name_sep="-")
+    wf2 = Workflow(part).fit_schema(Schema(["name", "id", "ts", "x", "y"]))
+    assert "name" not in wf2.output_node.output_schema.column_names
+    out = wf.output_node.output_schema
+    assert out["x-list"].is_list and out["x-list"].is_ragged and Tags.LIST in out["x-list"].tags
+    assert out["ts-count"].dtype == np.int32 and out["x-sum"].dtype == np.float32
+    assert not out["y-first"].is_list
+    with pytest.raises(NotImplementedError):
+        ops.Groupby(groupby_cols=["a"], aggs="median")
