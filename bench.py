@@ -155,22 +155,24 @@ def cpu_baseline(frame, cat_names, cont_names, sample_rows, tmp):
         par = json.loads(res.stdout.strip().splitlines()[-1])
     except Exception:  # the parallel leg is best effort; the serial one below always runs
         par = None
+    # serial leg: the deterministic tie rule (count desc, value asc), so that its outputs double
+    # as the oracle for the GPU parity check below (the parallel leg times the literal mode)
     t0 = time.perf_counter()
-    paths = O.categorify_fit([df], cat_names, os.path.join(tmp, "cpu"), tie_break="pandas")
+    paths = O.categorify_fit([df], cat_names, os.path.join(tmp, "cpu"), tie_break="stable")
     filled = O.fill_missing(df[cont_names].copy(), cont_names, 0)
     mom = O.custom_moments([filled], cont_names)
     enc = O.categorify_transform(df, cat_names, paths)
     filled = O.fill_missing(df[cont_names].copy(), cont_names, 0)
-    O.normalize_transform(filled, cont_names, mom["mean"].to_dict(), mom["std"].to_dict())
+    norm = O.normalize_transform(filled, cont_names, mom["mean"].to_dict(), mom["std"].to_dict())
     dt = time.perf_counter() - t0
-    del enc
+    oracle_out = {"enc": enc, "norm": norm, "mom": mom}
     pandas_v = __import__("pandas").__version__
     serial = sample_rows / dt
     if par is None:
         return {"value": serial, "unit": "rows/s", "cores": 1, "kind": "port",
                 "sample": f"first {sample_rows} rows of the same synthetic frame, fit+transform, "
                           f"single process pandas {pandas_v} ({os.cpu_count()} host cores visible), "
-                          f"{dt:.1f} s"}
+                          f"{dt:.1f} s"}, oracle_out
     return {
         "value": sample_rows / par["seconds"], "unit": "rows/s", "cores": par["procs"], "kind": "port",
         "sample": f"first {sample_rows} rows of the same synthetic frame, fit+transform, pandas "
@@ -178,7 +180,40 @@ def cpu_baseline(frame, cat_names, cont_names, sample_rows, tmp):
                   f"({os.cpu_count()} host cores visible): {par['seconds']:.1f} s; "
                   f"single process: {dt:.1f} s = {serial:.0f} rows/s",
         "single_process_rows_per_s": serial,
-    }
+    }, oracle_out
+
+
+def parity_check(frame, cat_names, cont_names, rows, oracle_out, tmp):
+    """GPU fit + transform of the first `rows` rows (the cpu_baseline sample) against the
+    oracle outputs of the same rows: Categorify labels bit-exact, means / stds and normalised
+    values within 1e-6 relative (BASELINE.json north_star).  Outside every timed region."""
+    import nvtabular_amd as nvt
+
+    sub = frame.slice_rows(0, rows)
+    wf = build_workflow(cat_names, cont_names, os.path.join(tmp, "parity"))
+    wf.fit(nvt.Dataset(sub))
+    out = wf.transform(sub)
+    bad = []
+    for c in cat_names:
+        got = out[c].data.cpu().numpy()
+        exp = oracle_out["enc"][c].to_numpy()
+        if got.shape != exp.shape or not (got == exp).all():
+            bad.append(c)
+    mom = oracle_out["mom"]
+    from nvtabular_amd.node import iter_nodes
+
+    norm_op = [n.op for n in iter_nodes(wf.output_node) if type(n.op).__name__ == "Normalize"][0]
+    worst = 0.0
+    for c in cont_names:
+        for got, exp in ((norm_op.means[c], float(mom["mean"][c])), (norm_op.stds[c], float(mom["std"][c]))):
+            worst = max(worst, abs(got - exp) / max(abs(exp), 1e-300))
+        g = out[c].data.cpu().numpy()
+        e = oracle_out["norm"][c].to_numpy()
+        err = float(np.max(np.abs(g - e) / np.maximum(np.abs(e), 1.0)))
+        worst = max(worst, err)
+    ok = not bad and worst <= 1e-6
+    return {"parity_checked_rows": rows, "parity_ok": bool(ok), "categorify_mismatch_columns": bad,
+            "normalize_max_rel_err": worst}
 
 
 _PMC_KERNEL = {"encode_i32": "nvt::encode_hot_kernel<int, long>",
@@ -196,7 +231,9 @@ def pmc_traffic(name):
     (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected separately with
     rocprofv3 --pmc and corrected per MI355X_MICROARCH.md).  PMC cannot be sampled from
     inside the timed run, so this is the figure of the same command at the same size."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"][_PMC_KERNEL[name]]
@@ -222,9 +259,25 @@ def main():
                             args.cpu_baseline_procs)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare: start one rank per GPU ourselves (the reference's benchmark also
+        # brings up its own workers, bench/examples/dask-nvtabular-criteo-benchmark.py:176-194)
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+               str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # one rank per GPU; NVT_BENCH_SHARE_GPU=1 folds ranks onto the visible devices (debug only)
@@ -232,6 +285,7 @@ def main():
         else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         import torch.distributed as td
 
@@ -244,6 +298,7 @@ def main():
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             td.init_process_group(backend, rank=rank, world_size=world)
+        assert td.get_world_size() == args.gpus, (td.get_world_size(), args.gpus)
 
     import nvtabular_amd as nvt
     from nvtabular_amd import kernels as K
@@ -272,26 +327,42 @@ def main():
 
     import gc
 
-    for _ in range(args.warmup):
+    # cold step: a fresh workflow with no cardinality hints (reported, never `value`)
+    barrier()
+    t0 = time.perf_counter()
+    step()
+    barrier()
+    cold_ms = 1e3 * (time.perf_counter() - t0)
+    for _ in range(max(args.warmup - 1, 0)):
         step()
     gc.collect()
     gc.disable()  # no collector pauses inside the timed region
+    # ---- timed region: exactly `steps` steps, no per-kernel instrumentation ----
     barrier()
-    K.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    # ---- second pass, same steps, HIP events on every kernel family (inside the library,
+    # on the launch streams): per-kernel durations, GPU-busy time.  Not the number of record.
+    barrier()
+    K.profile_begin()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt_prof = time.perf_counter() - t1
+    rep = K.profile_report()
+    prof = rep["kernels"]
     gc.enable()
-    prof = K.profile_end()
     del out
     if world > 1:
         import torch.distributed as td
 
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, dt_prof], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_prof = (float(v) for v in t.tolist())
 
     ms_per_step = 1e3 * dt / args.steps
     rows_per_s = world * n * args.steps / dt
@@ -300,12 +371,11 @@ def main():
     bytes_per_row = (C * 4 + Kc * 4) + (C * 12 + Kc * 12)
     gbs = rows_per_s * bytes_per_row / 1e9
 
-    # dominant kernel by summed launch time (HIP events around each launch, timed region only)
+    # dominant kernel by summed launch time (HIP events around each kernel family, recorded by
+    # the library on the launch stream during the profiled pass), among the kernels that
+    # stream the column data (algorithmic bytes > 0)
     roofline = None
     if prof:
-        # among the kernels that stream the column data (algorithmic bytes > 0): the vocabulary
-        # sort / table build run concurrently on three streams during fit_end, so the sum of
-        # their per-launch event times double-counts wall time and carries no byte count
         name, (tot_ms, launches, alg_bytes) = max(
             ((k, v) for k, v in prof.items() if v[2] > 0), key=lambda kv: kv[1][0])
         avg_s = tot_ms / launches / 1e3
@@ -315,7 +385,9 @@ def main():
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": pmc_traffic(name),
             "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
+            "algorithmic_bytes_per_launch": alg_bytes // launches,
             "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
+            "launch_scopes_per_step": round(sum(v[1] for v in prof.values()) / args.steps, 1),
         }
 
     result = {
@@ -326,6 +398,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "gpu_busy_ms_per_step": round(rep["busy_ms"] / args.steps, 3),
+        "profiled_pass_ms_per_step": round(1e3 * dt_prof / args.steps, 3),
+        "cold_step_ms": round(cold_ms, 2),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -339,14 +414,18 @@ def main():
             "algorithmic_bytes_per_row": bytes_per_row,
             "tie_break": "value (count desc, value asc)",
             "artifacts": "deferred (no parquet I/O inside the timed region)",
+            "state": "steady-state refit (cardinality hints from the warm-up steps; "
+                     "cold_step_ms = first step of a fresh workflow)",
+            "collective_backend": backend,
         },
         "algorithmic_GBps": gbs,
         "frac_of_hbm_peak": gbs / (HBM_PEAK_GBS * world),
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(frame, cat_names, cont_names,
-                                              min(args.cpu_sample, n), tmp)
+        sample = min(args.cpu_sample, n) // 8 * 8
+        result["cpu_baseline"], oracle_out = cpu_baseline(frame, cat_names, cont_names, sample, tmp)
+        result["parity"] = parity_check(frame, cat_names, cont_names, sample, oracle_out, tmp)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -268,6 +268,104 @@ int nvt_te_apply(const int64_t *group_all, const int64_t *group_fold, const doub
                  uint64_t n, double p_smooth, double y_mean, void *out, int out_dtype,
                  void *stream);
 
+/* ---- batched entry points: ONE call per operator per partition -----------------------
+ * The reference hands a whole dataframe to the backend per operator call
+ * (`df[cols].fillna(...)`, `for col in columns: _encode(...)` -- categorify.py:477-537,
+ * normalize.py:71-90, moments.py:64-77); the per-column functions above cost one host
+ * round trip (ctypes + launch) per column per step, which made the 45 M-row Criteo step
+ * host-bound on slow hosts.  These take an array of per-column descriptors (HOST memory,
+ * plain pointers and sizes) and enqueue every launch from C++; where the columns are
+ * independent streaming passes they run as ONE kernel launch (blockIdx.y = column).
+ * Results are bit-identical to calling the per-column function on each descriptor. */
+typedef struct nvt_moments_col {
+  const void *x;            /* device column                                    */
+  const uint8_t *valid;     /* bitmap or NULL                                   */
+  uint64_t n;
+  int32_t dtype, has_fill;
+  double fill_val;
+  double *out3;             /* device double[3], accumulated into               */
+} nvt_moments_col;
+/* partials: device scratch of ncols * nvt_moments_scratch_bytes() */
+int nvt_moments_many(const nvt_moments_col *cols, int ncols, void *partials, void *stream);
+
+typedef struct nvt_fillnorm_col {
+  const void *x;
+  const uint8_t *valid;
+  uint64_t n;
+  int32_t dtype, has_fill;
+  double fill_val;
+  int32_t do_norm, out_dtype;
+  double shift, scale;
+  void *out;
+  uint8_t *filled;          /* optional                                         */
+} nvt_fillnorm_col;
+int nvt_fill_normalize_many(const nvt_fillnorm_col *cols, int ncols, void *stream);
+
+/* one column of Categorify.fit's groupby-size; fields as the arguments of nvt_dense_count_* */
+typedef struct nvt_count_col {
+  const void *keys;
+  const uint8_t *valid;
+  const int64_t *weights;
+  uint64_t n;
+  int32_t key_bytes, path;
+  void *ws;                 /* nvt_dense_count_ws_bytes(); may be shared by columns of a call */
+  void *out_keys;
+  int64_t *out_counts;
+  uint64_t out_capacity;
+  uint64_t *state;          /* device uint64[NVT_STATE_WORDS]                   */
+} nvt_count_col;
+int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream);
+
+/* one vocabulary of Categorify.fit_end: sort (count desc, key asc) in place, then build its
+ * encode table (skipped when table == NULL: LDS-resident vocabularies).  Independent
+ * vocabularies are spread over a few internal HIP streams forked from / joined into
+ * `stream` (the one-workgroup kernels of small vocabularies run beside the radix passes of
+ * large ones); all small vocabularies of a call are sorted by ONE launch. */
+typedef struct nvt_vocab_col {
+  void *keys;               /* device int32/int64[n], sorted in place            */
+  int64_t *counts;          /* device int64[n], permuted with the keys           */
+  uint64_t n;
+  int64_t max_count;        /* upper bound on counts (<= 0: unknown)             */
+  int32_t key_bytes, unique_keys;
+  void *sort_tmp;           /* nvt_vocab_sort_tmp_bytes(); per column            */
+  int64_t first_label;
+  void *table;              /* encode table to build, or NULL                    */
+  uint64_t capacity;
+  int64_t *sentinel_label;
+} nvt_vocab_col;
+int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, void *stream);
+
+/* one column of Categorify.transform; fields as the arguments of nvt_encode_* */
+typedef struct nvt_encode_col {
+  const void *keys;
+  const uint8_t *valid;
+  uint64_t n;
+  const void *table;
+  uint64_t capacity;
+  const int64_t *sentinel_label;
+  int64_t null_label, oov_label;
+  uint32_t num_buckets;
+  int32_t key_bytes, out_bytes;
+  void *out;
+  const void *vocab_keys;
+  uint64_t n_vocab;
+  int64_t first_label;
+} nvt_encode_col;
+int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream);
+
+/* ---- instrumentation ------------------------------------------------------------------
+ * HIP-event timing of every kernel family, recorded on the stream the kernels are launched
+ * on.  nvt_prof_begin() arms it; nvt_prof_report() synchronises the device, disarms it and
+ * writes a JSON object {"kernels": {name: [total_ms, launches, algorithmic_bytes]},
+ * "busy_ms": union of the recorded intervals, "span_ms": first start .. last stop} into buf
+ * (*needed = bytes required).  Off = zero cost.  Every scope is also a roctx range, and
+ * nvt_range_push/pop let the host layer open ranges named after the reference's @annotate
+ * strings (categorify.py:345,477,955,1054,1073,1149). */
+int nvt_prof_begin(void);
+int nvt_prof_report(char *buf, uint64_t cap, uint64_t *needed);
+void nvt_range_push(const char *name);
+void nvt_range_pop(void);
+
 /* ---- small utilities used by the host layer ---- */
 /* widen an int32/uint8 key column to int64 (multi-key tables take int64 components) */
 int nvt_widen_i64(const void *src, int dtype, uint64_t n, int64_t *out, void *stream);

@@ -80,10 +80,58 @@ SIGNATURES = {
     "nvt_widen_i64": [_vp, _i32, _u64, _vp, _vp],
     "nvt_popcount": [_vp, _u64, _vp, _vp],
 }
+
+
+class MomentsCol(C.Structure):
+    _fields_ = [("x", _vp), ("valid", _vp), ("n", _u64), ("dtype", C.c_int32),
+                ("has_fill", C.c_int32), ("fill_val", _dbl), ("out3", _vp)]
+
+
+class FillNormCol(C.Structure):
+    _fields_ = [("x", _vp), ("valid", _vp), ("n", _u64), ("dtype", C.c_int32),
+                ("has_fill", C.c_int32), ("fill_val", _dbl), ("do_norm", C.c_int32),
+                ("out_dtype", C.c_int32), ("shift", _dbl), ("scale", _dbl), ("out", _vp),
+                ("filled", _vp)]
+
+
+class CountCol(C.Structure):
+    _fields_ = [("keys", _vp), ("valid", _vp), ("weights", _vp), ("n", _u64),
+                ("key_bytes", C.c_int32), ("path", C.c_int32), ("ws", _vp), ("out_keys", _vp),
+                ("out_counts", _vp), ("out_capacity", _u64), ("state", _vp)]
+
+
+class VocabCol(C.Structure):
+    _fields_ = [("keys", _vp), ("counts", _vp), ("n", _u64), ("max_count", _i64),
+                ("key_bytes", C.c_int32), ("unique_keys", C.c_int32), ("sort_tmp", _vp),
+                ("first_label", _i64), ("table", _vp), ("capacity", _u64),
+                ("sentinel_label", _vp)]
+
+
+class EncodeCol(C.Structure):
+    _fields_ = [("keys", _vp), ("valid", _vp), ("n", _u64), ("table", _vp), ("capacity", _u64),
+                ("sentinel_label", _vp), ("null_label", _i64), ("oov_label", _i64),
+                ("num_buckets", _u32), ("key_bytes", C.c_int32), ("out_bytes", C.c_int32),
+                ("out", _vp), ("vocab_keys", _vp), ("n_vocab", _u64), ("first_label", _i64)]
+
+
+SIGNATURES.update({
+    "nvt_moments_many": [C.POINTER(MomentsCol), _i32, _vp, _vp],
+    "nvt_fill_normalize_many": [C.POINTER(FillNormCol), _i32, _vp],
+    "nvt_dense_count_many": [C.POINTER(CountCol), _i32, _vp],
+    "nvt_vocab_finalize_many": [C.POINTER(VocabCol), _i32, _vp],
+    "nvt_encode_many": [C.POINTER(EncodeCol), _i32, _vp],
+    "nvt_prof_begin": [],
+    "nvt_prof_report": [C.c_char_p, _u64, C.POINTER(_u64)],
+    "nvt_range_push": [C.c_char_p],
+    "nvt_range_pop": [],
+})
+
 _RESTYPES = {
     "nvt_last_error": C.c_char_p,
     "nvt_moments_scratch_bytes": C.c_uint64,
     "nvt_gb_destroy": None,
+    "nvt_range_push": None,
+    "nvt_range_pop": None,
 }
 
 _lock = threading.Lock()

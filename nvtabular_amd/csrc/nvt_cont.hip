@@ -7,8 +7,10 @@
 // join_groupby.py:175-217, target_encoding.py:340-374.
 #include <limits>
 #include <type_traits>
+#include <vector>
 
 #include "nvt_common.hpp"
+#include "nvt_prof.hpp"
 
 namespace nvt {
 
@@ -29,10 +31,10 @@ __device__ __forceinline__ void load_vec(const T *p, T (&v)[VecOf<T>::n]) {
 // moments: per-block partial {count, sum, sumsq} -> deterministic final reduce
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kBlock) void moments_kernel(const T *__restrict__ x,
-                                                         const uint8_t *__restrict__ valid,
-                                                         uint64_t n, int has_fill, double fill_val,
-                                                         double *__restrict__ partials) {
+__device__ __forceinline__ void moments_body(const T *__restrict__ x,
+                                             const uint8_t *__restrict__ valid, uint64_t n,
+                                             int has_fill, double fill_val,
+                                             double *__restrict__ partials) {
   constexpr int VEC = VecOf<T>::n;
   double cnt = 0, sum = 0, sq = 0;
   auto acc = [&](T raw, bool ok) {
@@ -92,8 +94,43 @@ __global__ __launch_bounds__(kBlock) void moments_kernel(const T *__restrict__ x
   }
 }
 
-__global__ __launch_bounds__(kBlock) void moments_final_kernel(const double *__restrict__ partials,
-                                                               unsigned nblocks, double *out3) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void moments_kernel(const T *__restrict__ x,
+                                                         const uint8_t *__restrict__ valid,
+                                                         uint64_t n, int has_fill, double fill_val,
+                                                         double *__restrict__ partials) {
+  moments_body<T>(x, valid, n, has_fill, fill_val, partials);
+}
+
+// Batched form (nvt_moments_many): blockIdx.y = column; every column of a Normalize.fit
+// partition in ONE launch (the per-column version was 26 launches per partition for Criteo's
+// 13 continuous columns).  Same grid.x and block-to-row mapping as the single-column kernel,
+// so the partial sums -- and therefore the results -- are bit-identical to it.
+constexpr int kBatchCols = 32;
+struct MomCol {
+  const void *x;
+  const uint8_t *valid;
+  uint64_t n;
+  double fill_val;
+  double *out3;
+  int dtype, has_fill;
+};
+struct MomBatch {
+  MomCol c[kBatchCols];
+};
+__global__ __launch_bounds__(kBlock) void moments_many_kernel(MomBatch b, double *partials) {
+  const MomCol &c = b.c[blockIdx.y];
+  double *p = partials + (uint64_t)blockIdx.y * 3 * gridDim.x;
+  switch (c.dtype) {
+    case NVT_F32: moments_body<float>((const float *)c.x, c.valid, c.n, c.has_fill, c.fill_val, p); break;
+    case NVT_F64: moments_body<double>((const double *)c.x, c.valid, c.n, c.has_fill, c.fill_val, p); break;
+    case NVT_I32: moments_body<int32_t>((const int32_t *)c.x, c.valid, c.n, c.has_fill, c.fill_val, p); break;
+    default: moments_body<int64_t>((const int64_t *)c.x, c.valid, c.n, c.has_fill, c.fill_val, p); break;
+  }
+}
+
+__device__ __forceinline__ void moments_final_body(const double *__restrict__ partials,
+                                                   unsigned nblocks, double *out3) {
   __shared__ double red[kBlock / kWave];
   for (int q = 0; q < 3; ++q) {
     double t = 0;
@@ -108,6 +145,15 @@ __global__ __launch_bounds__(kBlock) void moments_final_kernel(const double *__r
     }
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(kBlock) void moments_final_kernel(const double *__restrict__ partials,
+                                                               unsigned nblocks, double *out3) {
+  moments_final_body(partials, nblocks, out3);
+}
+__global__ __launch_bounds__(kBlock) void moments_final_many_kernel(MomBatch b,
+                                                                    const double *__restrict__ partials,
+                                                                    unsigned nblocks) {
+  moments_final_body(partials + (uint64_t)blockIdx.x * 3 * nblocks, nblocks, b.c[blockIdx.x].out3);
 }
 
 // ---------------------------------------------------------------------------
@@ -187,7 +233,7 @@ __global__ void minmax_final_kernel(const double *__restrict__ partials, unsigne
 // fused FillMissing + Normalize
 // ---------------------------------------------------------------------------
 template <typename T, typename OUT>
-__global__ __launch_bounds__(kBlock) void fill_norm_kernel(
+__device__ __forceinline__ void fill_norm_body(
     const T *__restrict__ x, const uint8_t *__restrict__ valid, uint64_t n, int has_fill,
     double fill_val, int do_norm, double shift, double scale, OUT *__restrict__ out,
     uint8_t *__restrict__ filled) {
@@ -259,6 +305,35 @@ __global__ __launch_bounds__(kBlock) void fill_norm_kernel(
     out[i] = f(x[i], bit_valid(valid, i), m);
     if (filled != nullptr) filled[i] = m;
   }
+}
+
+template <typename T, typename OUT>
+__global__ __launch_bounds__(kBlock) void fill_norm_kernel(
+    const T *__restrict__ x, const uint8_t *__restrict__ valid, uint64_t n, int has_fill,
+    double fill_val, int do_norm, double shift, double scale, OUT *__restrict__ out,
+    uint8_t *__restrict__ filled) {
+  fill_norm_body<T, OUT>(x, valid, n, has_fill, fill_val, do_norm, shift, scale, out, filled);
+}
+
+// Batched form (nvt_fill_normalize_many): blockIdx.y = column, one launch per (input dtype,
+// output dtype) combination of a FillMissing >> Normalize.transform partition.
+struct FnCol {
+  const void *x;
+  const uint8_t *valid;
+  uint64_t n;
+  double fill_val, shift, scale;
+  void *out;
+  uint8_t *filled;
+  int has_fill, do_norm;
+};
+struct FnBatch {
+  FnCol c[kBatchCols];
+};
+template <typename T, typename OUT>
+__global__ __launch_bounds__(kBlock) void fill_norm_many_kernel(FnBatch b) {
+  const FnCol &c = b.c[blockIdx.y];
+  fill_norm_body<T, OUT>((const T *)c.x, c.valid, c.n, c.has_fill, c.fill_val, c.do_norm, c.shift,
+                         c.scale, (OUT *)c.out, c.filled);
 }
 
 // Clip (clip.py:49-55) and LogOp (logop.py:43-53), fused with a pending FillMissing constant:
@@ -414,6 +489,7 @@ template <typename T>
 int moments_launch(const T *x, const uint8_t *valid, uint64_t n, int has_fill, double fill_val,
                    double *out3, double *partials, hipStream_t s) {
   unsigned grid = stream_grid(n / VecOf<T>::n + 1, kBlock * 4, 4);
+  NVT_PROF("moments", n * sizeof(T), s);
   moments_kernel<T><<<grid, kBlock, 0, s>>>(x, valid, n, has_fill, fill_val, partials);
   NVT_CHECK_LAUNCH();
   moments_final_kernel<<<1, kBlock, 0, s>>>(partials, grid, out3);
@@ -435,6 +511,7 @@ int fill_norm_launch(const void *x, const uint8_t *valid, uint64_t n, int has_fi
                      int do_norm, double shift, double scale, void *out, uint8_t *filled,
                      hipStream_t s) {
   unsigned grid = stream_grid(n / VecOf<T>::n + 1, kBlock * 2, 8);
+  NVT_PROF("fill_normalize", n * (sizeof(T) + sizeof(OUT)), s);
   fill_norm_kernel<T, OUT><<<grid, kBlock, 0, s>>>(reinterpret_cast<const T *>(x), valid, n,
                                                    has_fill, fill_val, do_norm, shift, scale,
                                                    reinterpret_cast<OUT *>(out), filled);
@@ -469,6 +546,138 @@ int nvt_moments(const void *x, int dtype, const uint8_t *valid, uint64_t n, int 
   }
   set_error("nvt_moments: unsupported dtype %d", dtype);
   return NVT_EINVAL;
+}
+
+static inline int dtype_bytes(int dtype) {
+  return dtype == NVT_F32 || dtype == NVT_I32 ? 4 : dtype == NVT_U8 ? 1 : 8;
+}
+
+int nvt_moments_many(const nvt_moments_col *cols, int ncols, void *partials, void *stream) {
+  NVT_CHECK_ARG(ncols == 0 || (cols && partials), "null descriptors/partials");
+  hipStream_t s = (hipStream_t)stream;
+  double *pbase = reinterpret_cast<double *>(partials);
+  for (int c0 = 0; c0 < ncols; c0 += kBatchCols) {
+    const int nc = ncols - c0 < kBatchCols ? ncols - c0 : kBatchCols;
+    MomBatch b;
+    memset(&b, 0, sizeof(b));
+    unsigned grid = 1;
+    uint64_t bytes = 0;
+    int live = 0;
+    for (int i = 0; i < nc; ++i) {
+      const nvt_moments_col &c = cols[c0 + i];
+      if (c.n == 0) continue;
+      NVT_CHECK_ARG(c.x && c.out3 && (reinterpret_cast<uintptr_t>(c.x) & 15) == 0,
+                    "x must be non-null and 16-byte aligned");
+      NVT_CHECK_ARG(c.dtype == NVT_F32 || c.dtype == NVT_F64 || c.dtype == NVT_I32 ||
+                        c.dtype == NVT_I64, "unsupported dtype");
+      MomCol &m = b.c[live++];
+      m.x = c.x;
+      m.valid = c.valid;
+      m.n = c.n;
+      m.fill_val = c.fill_val;
+      m.out3 = c.out3;
+      m.dtype = c.dtype;
+      m.has_fill = c.has_fill;
+      const unsigned g = stream_grid(c.n / (16 / dtype_bytes(c.dtype)) + 1, kBlock * 4, 4);
+      grid = g > grid ? g : grid;
+      bytes += c.n * dtype_bytes(c.dtype);
+    }
+    if (!live) continue;
+    double *p = pbase + (uint64_t)c0 * 3 * kReduceGrid;
+    NVT_PROF("moments", bytes, s);
+    moments_many_kernel<<<dim3(grid, live), kBlock, 0, s>>>(b, p);
+    NVT_CHECK_LAUNCH();
+    moments_final_many_kernel<<<live, kBlock, 0, s>>>(b, p, grid);
+    NVT_CHECK_LAUNCH();
+  }
+  return NVT_OK;
+}
+
+int nvt_fill_normalize_many(const nvt_fillnorm_col *cols, int ncols, void *stream) {
+  NVT_CHECK_ARG(ncols == 0 || cols, "null descriptors");
+  hipStream_t s = (hipStream_t)stream;
+  // group the columns by (input dtype, output dtype): one launch per combination and
+  // kBatchCols columns
+  std::vector<char> done(ncols > 0 ? ncols : 0, 0);
+  for (int i0 = 0; i0 < ncols; ++i0) {
+    if (done[i0]) continue;
+    const int dt = cols[i0].dtype, odt = cols[i0].out_dtype;
+    FnBatch b;
+    memset(&b, 0, sizeof(b));
+    int live = 0;
+    unsigned grid = 1;
+    uint64_t bytes = 0;
+    auto flush = [&]() -> int {
+      if (!live) return NVT_OK;
+      NVT_PROF("fill_normalize", bytes, s);
+#define NVT_FNM(T, O)                                                    \
+  do {                                                                   \
+    fill_norm_many_kernel<T, O><<<dim3(grid, live), kBlock, 0, s>>>(b);  \
+    NVT_CHECK_LAUNCH();                                                  \
+    live = 0;                                                            \
+    grid = 1;                                                            \
+    bytes = 0;                                                           \
+    return NVT_OK;                                                       \
+  } while (0)
+      if (odt == NVT_F64) {
+        switch (dt) {
+          case NVT_F32: NVT_FNM(float, double);
+          case NVT_F64: NVT_FNM(double, double);
+          case NVT_I32: NVT_FNM(int32_t, double);
+          case NVT_I64: NVT_FNM(int64_t, double);
+        }
+      } else if (odt == NVT_F32) {
+        switch (dt) {
+          case NVT_F32: NVT_FNM(float, float);
+          case NVT_F64: NVT_FNM(double, float);
+          case NVT_I32: NVT_FNM(int32_t, float);
+          case NVT_I64: NVT_FNM(int64_t, float);
+        }
+      } else if (odt == dt) {
+        switch (dt) {
+          case NVT_I32: NVT_FNM(int32_t, int32_t);
+          case NVT_I64: NVT_FNM(int64_t, int64_t);
+        }
+      }
+#undef NVT_FNM
+      set_error("nvt_fill_normalize_many: unsupported dtype combination in=%d out=%d", dt, odt);
+      return NVT_EINVAL;
+    };
+    for (int i = i0; i < ncols; ++i) {
+      const nvt_fillnorm_col &c = cols[i];
+      if (done[i] || c.dtype != dt || c.out_dtype != odt) continue;
+      done[i] = 1;
+      if (c.n == 0) continue;
+      NVT_CHECK_ARG(c.x && c.out && (reinterpret_cast<uintptr_t>(c.x) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(c.out) & 15) == 0,
+                    "x/out must be non-null and 16-byte aligned");
+      NVT_CHECK_ARG(!c.filled || (reinterpret_cast<uintptr_t>(c.filled) & 3) == 0,
+                    "filled must be 4-byte aligned");
+      NVT_CHECK_ARG(odt == NVT_F32 || odt == NVT_F64 || !c.do_norm,
+                    "normalised output must be f32/f64");
+      FnCol &f = b.c[live++];
+      f.x = c.x;
+      f.valid = c.valid;
+      f.n = c.n;
+      f.fill_val = c.fill_val;
+      f.shift = c.shift;
+      f.scale = c.scale;
+      f.out = c.out;
+      f.filled = c.filled;
+      f.has_fill = c.has_fill;
+      f.do_norm = c.do_norm;
+      const unsigned g = stream_grid(c.n / (16 / dtype_bytes(dt)) + 1, kBlock * 2, 8);
+      grid = g > grid ? g : grid;
+      bytes += c.n * (uint64_t)(dtype_bytes(dt) + dtype_bytes(odt));
+      if (live == kBatchCols) {
+        int rc = flush();
+        if (rc) return rc;
+      }
+    }
+    int rc = flush();
+    if (rc) return rc;
+  }
+  return NVT_OK;
 }
 
 int nvt_minmax(const void *x, int dtype, const uint8_t *valid, uint64_t n, int accumulate,
@@ -543,6 +752,7 @@ int nvt_clip_log(const void *x, int dtype, const uint8_t *valid, uint64_t n, int
 #define NVT_CL(T, O)                                                                           \
   do {                                                                                         \
     unsigned grid = stream_grid(n / VecOf<T>::n + 1, kBlock * 2, 8);                           \
+    NVT_PROF("clip_log", n * (sizeof(T) + sizeof(O)), s);                                      \
     clip_log_kernel<T, O><<<grid, kBlock, 0, s>>>((const T *)x, valid, n, has_fill, fill_val,  \
                                                   has_min, vmin, has_max, vmax, do_log,        \
                                                   (O *)out);                                   \

@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "nvt_common.hpp"
+#include "nvt_prof.hpp"
 #include "nvt_scan.hpp"
 
 #ifndef NVT_STAGE_U
@@ -1581,7 +1582,7 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
 template <typename K>
 int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uint64_t n, int path,
                 void *wsp, K *out_keys, int64_t *out_cnt, uint64_t out_cap, uint64_t *state,
-                hipStream_t s) {
+                hipStream_t s, bool clear_state = true) {
   NVT_CHECK_ARG(state && wsp, "null state/workspace");
   NVT_CHECK_ARG(path >= 0 && path <= 7,
                 "path must be 0 / 7 / 4 / 5 / 6 (LDS tables: 1 / 2 / 4 / 8 key classes / tiny) or "
@@ -1589,7 +1590,11 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
   NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
   NVT_CHECK_ARG(n == 0 || (keys && out_keys && out_cnt), "null keys/out");
   NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 rows per call (32-bit LDS counters)");
-  NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
+  static const char *const kPathName[8] = {"dense_count_p0", "dense_count_p1", "dense_count_p2",
+                                           "dense_count_p3", "dense_count_p4", "dense_count_p5",
+                                           "dense_count_p6", "dense_count_p7"};
+  NVT_PROF(kPathName[path], n * sizeof(K), s);
+  if (clear_state) NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
   DenseWs w;
   dense_ws_layout((int)sizeof(K), n, path, weights != nullptr, (char *)wsp, &w);
   unsigned long long *cur = reinterpret_cast<unsigned long long *>(state);
@@ -1718,6 +1723,35 @@ int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, 
   NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
   NVT_CHECK_ARG(path >= 0 && path <= 7, "path must be 0..7");
   *bytes = dense_ws_layout(key_bytes, n, path, weighted, nullptr, nullptr) + 64;
+  return NVT_OK;
+}
+int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
+  NVT_CHECK_ARG(ncols == 0 || cols, "null descriptors");
+  // state blocks laid out back to back (the usual case: one tensor, one row per column) are
+  // cleared by ONE memset instead of one tiny fill kernel per column
+  bool contiguous = ncols > 1;
+  for (int i = 0; i < ncols && contiguous; ++i)
+    contiguous = cols[i].state != nullptr && cols[i].state == cols[0].state + (uint64_t)i * NVT_STATE_WORDS;
+  if (contiguous)
+    NVT_CHECK_HIP(hipMemsetAsync(cols[0].state, 0, (uint64_t)ncols * NVT_STATE_WORDS * 8,
+                                 (hipStream_t)stream));
+  for (int i = 0; i < ncols; ++i) {
+    const nvt_count_col &c = cols[i];
+    int rc;
+    if (c.key_bytes == 4)
+      rc = dense_count<int32_t>((const int32_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,
+                                (int32_t *)c.out_keys, c.out_counts, c.out_capacity, c.state,
+                                (hipStream_t)stream, !contiguous);
+    else if (c.key_bytes == 8)
+      rc = dense_count<int64_t>((const int64_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,
+                                (int64_t *)c.out_keys, c.out_counts, c.out_capacity, c.state,
+                                (hipStream_t)stream, !contiguous);
+    else {
+      set_error("nvt_dense_count_many: key_bytes must be 4 or 8 (column %d)", i);
+      return NVT_EINVAL;
+    }
+    if (rc) return rc;
+  }
   return NVT_OK;
 }
 int nvt_dense_count_i32(const int32_t *keys, const uint8_t *valid, const int64_t *weights,

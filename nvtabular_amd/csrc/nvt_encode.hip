@@ -13,6 +13,8 @@
 #include <type_traits>
 
 #include "nvt_common.hpp"
+#include "nvt_internal.hpp"
+#include "nvt_prof.hpp"
 
 namespace nvt {
 
@@ -478,6 +480,7 @@ int build_launch(const K *vocab, uint64_t n, int64_t first_label, void *table, u
   NVT_CHECK_ARG(capacity > n, "capacity must exceed the vocabulary size");
   NVT_CHECK_ARG(sizeof(K) == 8 || first_label + (int64_t)n < INT32_MAX, "labels overflow int32");
   auto *t = reinterpret_cast<EncSlot<K> *>(table);
+  NVT_PROF("encode_build", 0, s);
   enc_clear_kernel<K><<<stream_grid(capacity, kBlock * 4), kBlock, 0, s>>>(t, capacity,
                                                                            sentinel_label);
   NVT_CHECK_LAUNCH();
@@ -517,6 +520,7 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
                 "keys/out must be 16-byte aligned");
   constexpr int VEC = EncTraits<K>::vec;
   auto *t = reinterpret_cast<const EncSlot<K> *>(table);
+  NVT_PROF(sizeof(K) == 4 ? "encode_i32" : "encode_i64", n * (sizeof(K) + (uint64_t)out_bytes), s);
   if (hot_keys != nullptr && n_vocab > 0) {
     // head of the frequency-ordered vocabulary in LDS (load factor <= 0.75: LDS probes are
     // cheap, every extra resident key is a saved trip to L2 / HBM)
@@ -560,6 +564,7 @@ int hash_bucket_launch(const K *keys, uint64_t n, uint32_t nb, int32_t *out, con
   NVT_CHECK_ARG(keys && (out || xor_out), "null keys/out");
   bool aligned = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  NVT_PROF("hash_bucket", n * (sizeof(K) + 4), s);
   if (!xor_in && !xor_out && aligned)
     hash_bucket_vec_kernel<K><<<stream_grid(n / EncTraits<K>::vec + 1, kBlock * 2), kBlock, 0, s>>>(
         keys, n, nb, out);
@@ -568,6 +573,15 @@ int hash_bucket_launch(const K *keys, uint64_t n, uint32_t nb, int32_t *out, con
                                                                        xor_out);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
+}
+
+int encode_build_any(int key_bytes, const void *vocab, uint64_t n, int64_t first_label, void *table,
+                     uint64_t capacity, int64_t *sentinel_label, int unique_keys, hipStream_t s) {
+  if (key_bytes == 4)
+    return build_launch<int32_t>((const int32_t *)vocab, n, first_label, table, capacity,
+                                 sentinel_label, unique_keys, s);
+  return build_launch<int64_t>((const int64_t *)vocab, n, first_label, table, capacity,
+                               sentinel_label, unique_keys, s);
 }
 
 }  // namespace nvt
@@ -610,6 +624,29 @@ int nvt_encode_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, const 
   return encode_launch<int64_t>(keys, valid, n, table, capacity, sentinel_label, null_label,
                                 oov_label, num_buckets, out, out_bytes, vocab_keys, n_vocab,
                                 first_label, (hipStream_t)stream);
+}
+int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
+  NVT_CHECK_ARG(ncols == 0 || cols, "null descriptors");
+  for (int i = 0; i < ncols; ++i) {
+    const nvt_encode_col &c = cols[i];
+    int rc;
+    if (c.key_bytes == 4)
+      rc = encode_launch<int32_t>((const int32_t *)c.keys, c.valid, c.n, c.table, c.capacity,
+                                  c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,
+                                  c.out_bytes, (const int32_t *)c.vocab_keys, c.n_vocab,
+                                  c.first_label, (hipStream_t)stream);
+    else if (c.key_bytes == 8)
+      rc = encode_launch<int64_t>((const int64_t *)c.keys, c.valid, c.n, c.table, c.capacity,
+                                  c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,
+                                  c.out_bytes, (const int64_t *)c.vocab_keys, c.n_vocab,
+                                  c.first_label, (hipStream_t)stream);
+    else {
+      set_error("nvt_encode_many: key_bytes must be 4 or 8 (column %d)", i);
+      return NVT_EINVAL;
+    }
+    if (rc) return rc;
+  }
+  return NVT_OK;
 }
 int nvt_hash_bucket_i32(const int32_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
                         const uint64_t *xor_in, uint64_t *xor_out, void *stream) {

@@ -1,0 +1,120 @@
+// Categorify.fit_end on the device, for every vocabulary of a fit in ONE C-ABI call:
+// order each (key, count) list by (count desc, key asc) -- the two sort_values of
+// categorify.py:1300,1316 -- and build its encode table (categorify.py:1558-1807 consumes it).
+//
+// Why one call: the per-vocabulary Python loop (sort call + table allocation + build call,
+// ~60 us of host time each) was longer than the kernels of the 13 small Criteo vocabularies,
+// and on a slow host it left the GPU idle for half of every step.  Here the host enqueues
+// everything back to back:
+//   * all small vocabularies (int32 keys, <= 16384 entries) are sorted by ONE launch, one
+//     workgroup per vocabulary (LDS bitonic network over packed words);
+//   * the large ones go largest-first round-robin onto three internal streams forked from /
+//     joined into the caller's stream, so their short tail kernels overlap;
+//   * every table build follows its sort on the same stream.
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "nvt_common.hpp"
+#include "nvt_internal.hpp"
+#include "nvt_prof.hpp"
+
+namespace nvt {
+namespace {
+constexpr int kSide = 3;
+struct SidePool {
+  int dev = -1;
+  hipStream_t s[kSide];
+  hipEvent_t fork, join[kSide];
+};
+std::mutex g_pool_mu;
+std::vector<SidePool *> g_pools;
+
+int side_pool(SidePool **out) {
+  int dev = 0;
+  NVT_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (SidePool *p : g_pools)
+    if (p->dev == dev) {
+      *out = p;
+      return NVT_OK;
+    }
+  SidePool *p = new SidePool();
+  p->dev = dev;
+  for (int i = 0; i < kSide; ++i) {
+    NVT_CHECK_HIP(hipStreamCreateWithFlags(&p->s[i], hipStreamNonBlocking));
+    NVT_CHECK_HIP(hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming));
+  }
+  NVT_CHECK_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+  g_pools.push_back(p);
+  *out = p;
+  return NVT_OK;
+}
+}  // namespace
+}  // namespace nvt
+
+using namespace nvt;
+
+extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, void *stream) {
+  NVT_CHECK_ARG(ncols == 0 || cols, "null descriptors");
+  hipStream_t main_s = (hipStream_t)stream;
+  std::vector<int> small, big;
+  for (int i = 0; i < ncols; ++i) {
+    const nvt_vocab_col &c = cols[i];
+    NVT_CHECK_ARG(c.key_bytes == 4 || c.key_bytes == 8, "key_bytes must be 4 or 8");
+    NVT_CHECK_ARG(c.n <= 1 || (c.keys && c.counts), "null keys/counts");
+    NVT_CHECK_ARG(c.table == nullptr || c.sentinel_label, "table without sentinel_label");
+    if (vocab_sort_small_eligible(c.key_bytes, c.n, c.max_count))
+      small.push_back(i);
+    else
+      big.push_back(i);
+  }
+  std::sort(big.begin(), big.end(), [&](int a, int b) { return cols[a].n > cols[b].n; });
+  // large vocabularies: forked onto the internal streams (only when there is something to overlap)
+  const bool fork = big.size() + (small.empty() ? 0 : 1) > 1 && !getenv("NVT_FINALIZE_SERIAL");
+  SidePool *pool = nullptr;
+  if (fork) {
+    int rc = side_pool(&pool);
+    if (rc) return rc;
+    NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
+    for (int i = 0; i < kSide; ++i) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[i], pool->fork, 0));
+  }
+  auto finish = [&](const nvt_vocab_col &c, hipStream_t s) -> int {
+    if (c.table == nullptr) return NVT_OK;
+    return encode_build_any(c.key_bytes, c.keys, c.n, c.first_label, c.table, c.capacity,
+                            c.sentinel_label, c.unique_keys, s);
+  };
+  for (size_t j = 0; j < big.size(); ++j) {
+    const nvt_vocab_col &c = cols[big[j]];
+    hipStream_t s = fork ? pool->s[j % kSide] : main_s;
+    if (c.n > 1) {
+      NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
+      int rc = vocab_sort_any(c.key_bytes, c.keys, c.counts, c.n, c.max_count, c.sort_tmp, s);
+      if (rc) return rc;
+    }
+    int rc = finish(c, s);
+    if (rc) return rc;
+  }
+  if (!small.empty()) {
+    std::vector<SmallSortDesc> d(small.size());
+    for (size_t j = 0; j < small.size(); ++j) {
+      const nvt_vocab_col &c = cols[small[j]];
+      d[j].keys = (int32_t *)c.keys;
+      d[j].counts = c.counts;
+      d[j].n = (unsigned)c.n;
+    }
+    int rc = vocab_sort_small_batch(d.data(), (int)d.size(), main_s);
+    if (rc) return rc;
+    for (int i : small) {
+      rc = finish(cols[i], main_s);
+      if (rc) return rc;
+    }
+  }
+  if (fork) {
+    for (int i = 0; i < kSide; ++i) {
+      NVT_CHECK_HIP(hipEventRecord(pool->join[i], pool->s[i]));
+      NVT_CHECK_HIP(hipStreamWaitEvent(main_s, pool->join[i], 0));
+    }
+  }
+  return NVT_OK;
+}

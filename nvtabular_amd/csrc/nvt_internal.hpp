@@ -1,0 +1,24 @@
+// Cross-file entry points of the kernel library (host side), used by the batched C-ABI calls.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nvt {
+
+// nvt_sort.hip
+int vocab_sort_any(int key_bytes, void *keys, int64_t *counts, uint64_t n, int64_t max_count,
+                   void *tmp, hipStream_t s);
+struct SmallSortDesc {
+  int32_t *keys;
+  int64_t *counts;
+  unsigned n;
+};
+// int32 keys, 2 <= n <= 16384, 0 < max_count < 2^32: sorted by the one-launch batched kernel
+bool vocab_sort_small_eligible(int key_bytes, uint64_t n, int64_t max_count);
+int vocab_sort_small_batch(const SmallSortDesc *cols, int ncols, hipStream_t s);
+
+// nvt_encode.hip
+int encode_build_any(int key_bytes, const void *vocab, uint64_t n, int64_t first_label, void *table,
+                     uint64_t capacity, int64_t *sentinel_label, int unique_keys, hipStream_t s);
+
+}  // namespace nvt

@@ -12,7 +12,11 @@
 //    per-wave running digit counter in LDS (rows), and a 4-entry prefix over the waves.
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "nvt_common.hpp"
+#include "nvt_internal.hpp"
+#include "nvt_prof.hpp"
 #include "nvt_scan.hpp"
 
 namespace nvt {
@@ -341,6 +345,312 @@ __global__ __launch_bounds__(kS2BS) void sort2_scatter_kernel(
 
 inline uint64_t pad16(uint64_t x) { return (x + 15) & ~15ull; }
 
+// ---- int32 keys, packed words, ONESWEEP: one histogram read + one scatter launch per pass ---
+// The three-launch passes above (tile histogram -> device scan -> scatter) cost ~21-28 launches
+// and two extra reads of the array per sort; Criteo's 26 vocabularies spent more time in the
+// 7-17 us hist / scan kernels than in the scatters (profiles/r01_final_kernel_stats.csv).  Here:
+//   os_hist_kernel    ONE read of (keys, counts): the digit histograms of EVERY pass
+//   os_base_kernel    per pass: bucket totals -> exclusive scan = global digit bases
+//   os_scatter_kernel per pass: tile ranks as in sort2_scatter_kernel; the tile's offset inside
+//                     each digit bucket comes from a decoupled look-back over the preceding
+//                     tiles' published (aggregate | inclusive prefix) words instead of a scanned
+//                     per-tile histogram.  Tile ids are handed out by an atomic ticket, so a tile
+//                     only ever waits for tiles that are already running (no deadlock whatever
+//                     the dispatch order).  A status word is flag (2 bits) + count (30 bits):
+//                     the data IS the flag (one relaxed agent-scope 4-byte store / load, the
+//                     "R2 granule" form of cdna_hip_programming.md G16), so no fences are needed.
+constexpr int kOsMaxPass = 8;
+constexpr int kOsHistBlocks = 256;
+constexpr unsigned kOsAgg = 1u << 30, kOsPrefix = 2u << 30, kOsMask = (1u << 30) - 1u;
+
+__global__ __launch_bounds__(kS2BS) void os_hist_kernel(const int32_t *__restrict__ keys,
+                                                        const int64_t *__restrict__ cnts,
+                                                        uint64_t n, int npass,
+                                                        unsigned *__restrict__ block_hist) {
+  __shared__ unsigned h[kOsMaxPass * 256];
+  for (int i = threadIdx.x; i < npass * 256; i += kS2BS) h[i] = 0;
+  __syncthreads();
+  const unsigned l = lane_id();
+  unsigned c255[kOsMaxPass];  // digit 0xFF of the upper count bytes (nearly every entry) in registers
+#pragma unroll
+  for (int p = 0; p < kOsMaxPass; ++p) c255[p] = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kS2BS;
+  const uint64_t iters = (n + stride - 1) / stride;
+  for (uint64_t it = 0; it < iters; ++it) {
+    const uint64_t i = it * stride + (uint64_t)blockIdx.x * kS2BS + threadIdx.x;
+    const bool act = i < n;
+    const uint64_t c = act ? comp_make(keys[i], cnts[i]) : 0ull;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (act) atomicAdd(&h[p * 256 + ((unsigned)(c >> (8 * p)) & 0xFF)], 1u);
+    if (npass > 4) {  // lowest count byte: a few hot digits -> aggregate equal digits per wave
+      const unsigned d = (unsigned)(c >> 32) & 0xFF;
+      const unsigned long long peers = match_digit(d, act);
+      if (act && (peers & ((1ull << l) - 1ull)) == 0)
+        atomicAdd(&h[4 * 256 + d], (unsigned)__popcll(peers));
+    }
+#pragma unroll
+    for (int p = 5; p < kOsMaxPass; ++p) {
+      if (p < npass && act) {
+        const unsigned d = (unsigned)(c >> (8 * p)) & 0xFF;
+        if (d == 0xFF)
+          ++c255[p];
+        else
+          atomicAdd(&h[p * 256 + d], 1u);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 5; p < kOsMaxPass; ++p) {
+    if (p < npass) {
+      unsigned v = c255[p];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (l == 0 && v) atomicAdd(&h[p * 256 + 0xFF], v);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < npass * 256; i += kS2BS)
+    block_hist[(uint64_t)blockIdx.x * (kOsMaxPass * 256) + i] = h[i];
+}
+
+// one workgroup per pass: base[p][d] = number of entries whose digit (pass p) is < d
+__global__ __launch_bounds__(256) void os_base_kernel(const unsigned *__restrict__ block_hist,
+                                                      int nblocks, unsigned *__restrict__ base) {
+  __shared__ unsigned wtot[4];
+  const int p = blockIdx.x, d = threadIdx.x;
+  unsigned tot = 0;
+#pragma unroll 8
+  for (int b = 0; b < nblocks; ++b) tot += block_hist[(uint64_t)b * (kOsMaxPass * 256) + p * 256 + d];
+  unsigned inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned o = __shfl_up(inc, off, 64);
+    if (lane_id() >= (unsigned)off) inc += o;
+  }
+  const unsigned w = threadIdx.x / kWave;
+  if (lane_id() == 63) wtot[w] = inc;
+  __syncthreads();
+  unsigned wb = 0;
+  for (unsigned q = 0; q < w; ++q) wb += wtot[q];
+  base[p * 256 + d] = wb + inc - tot;
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kS2BS) void os_scatter_kernel(
+    const uint64_t *__restrict__ comp, const int32_t *__restrict__ keys,
+    const int64_t *__restrict__ cnts, uint64_t n, int shift, const unsigned *__restrict__ base,
+    unsigned *status, unsigned *ticket, uint64_t *out_comp, int32_t *out_keys, int64_t *out_cnts) {
+  constexpr int NW = kS2BS / kWave;
+  __shared__ unsigned wcnt[NW][256];
+  __shared__ unsigned goff[256];
+  __shared__ unsigned wtot[NW];
+  __shared__ unsigned s_tile;
+  __shared__ uint64_t stage[kS2Tile];
+  const unsigned w = threadIdx.x / kWave, l = lane_id();
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int q = 0; q < NW; ++q) wcnt[q][threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned tile = s_tile;
+  uint64_t c[kS2Rows];
+  unsigned short local[kS2Rows];
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    const uint64_t i = s2_elem(tile, w, r, l);
+    c[r] = ~0ull;
+    if (i < n) c[r] = FIRST ? comp_make(keys[i], cnts[i]) : comp[i];
+  }
+  const uint64_t tile_base = (uint64_t)tile * kS2Tile;
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    const bool act = s2_elem(tile, w, r, l) < n;
+    const unsigned d = (unsigned)(c[r] >> shift) & 0xFF;
+    const unsigned long long peers = match_digit(d, act);
+    const unsigned rank = __popcll(peers & ((1ull << l) - 1ull));
+    const unsigned before = act ? wcnt[w][d] : 0;  // equal digits in earlier rows of this wave
+    __builtin_amdgcn_wave_barrier();
+    if (act && rank == 0) wcnt[w][d] = before + (unsigned)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    local[r] = (unsigned short)(before + rank);
+  }
+  __syncthreads();
+  {  // thread d: tile count of digit d, tile-local start, look-back for the global offset
+    const unsigned d = threadIdx.x;
+    unsigned t[NW], tot = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      t[q] = wcnt[q][d];
+      tot += t[q];
+    }
+    // publish this tile's aggregate first: the tiles behind us only need this word
+    unsigned *my = status + (uint64_t)tile * 256 + d;
+    __hip_atomic_store(my, (tile == 0 ? kOsPrefix : kOsAgg) | tot, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    unsigned inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned o = __shfl_up(inc, off, 64);
+      if (l >= (unsigned)off) inc += o;
+    }
+    if (l == 63) wtot[w] = inc;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (unsigned q = 0; q < w; ++q) wbase += wtot[q];
+    const unsigned dstart = wbase + inc - tot;
+    unsigned run = dstart;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      wcnt[q][d] = run;
+      run += t[q];
+    }
+    unsigned excl = 0;
+    if (tile > 0) {
+      unsigned tb = tile - 1;
+      while (true) {
+        const unsigned v = __hip_atomic_load(status + (uint64_t)tb * 256 + d, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned f = v >> 30;
+        if (f == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += v & kOsMask;
+        if (f == 2) break;
+        --tb;  // tile 0 always publishes a prefix: never runs below 0
+      }
+      __hip_atomic_store(my, kOsPrefix | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    goff[d] = base[d] + excl - dstart;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    if (s2_elem(tile, w, r, l) < n) {
+      const unsigned d = (unsigned)(c[r] >> shift) & 0xFF;
+      stage[wcnt[w][d] + local[r]] = c[r];
+    }
+  }
+  __syncthreads();
+  const unsigned tile_n = (unsigned)(n - tile_base < (uint64_t)kS2Tile ? n - tile_base : kS2Tile);
+#pragma unroll 4
+  for (int j = 0; j < kS2Rows; ++j) {
+    const unsigned idx = j * kS2BS + threadIdx.x;
+    if (idx < tile_n) {
+      const uint64_t v = stage[idx];
+      const unsigned d = (unsigned)(v >> shift) & 0xFF;
+      const unsigned dst = goff[d] + idx;
+      if (LAST) {
+        out_keys[dst] = comp_key(v);
+        out_cnts[dst] = comp_cnt(v);
+      } else {
+        out_comp[dst] = v;
+      }
+    }
+  }
+}
+
+// tmp layout: compA[n] | compB[n] | block_hist | base | status[npass][ntiles][256] | tickets
+inline uint64_t os_tmp_bytes(uint64_t n) {
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  return 2 * n * 8 + (uint64_t)kOsHistBlocks * kOsMaxPass * 256 * 4 + kOsMaxPass * 256 * 4 +
+         (uint64_t)kOsMaxPass * ntiles * 256 * 4 + kOsMaxPass * 4 + 256;
+}
+
+inline int vocab_sort_onesweep(int32_t *keys, int64_t *counts, uint64_t n, int64_t max_count,
+                               void *tmp, hipStream_t stream) {
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  char *p = reinterpret_cast<char *>(tmp);
+  uint64_t *bufs[2];
+  bufs[0] = reinterpret_cast<uint64_t *>(p);
+  p += n * 8;
+  bufs[1] = reinterpret_cast<uint64_t *>(p);
+  p += n * 8;
+  unsigned *block_hist = reinterpret_cast<unsigned *>(p);
+  p += (uint64_t)kOsHistBlocks * kOsMaxPass * 256 * 4;
+  unsigned *base = reinterpret_cast<unsigned *>(p);
+  p += kOsMaxPass * 256 * 4;
+  unsigned *status = reinterpret_cast<unsigned *>(p);
+  int count_bytes = 0;
+  for (uint64_t m = (uint64_t)max_count; m; m >>= 8) ++count_bytes;
+  const int npass = 4 + count_bytes;  // 4 key bytes, then the live bytes of ~count
+  const uint64_t status_words = (uint64_t)npass * ntiles * 256;
+  unsigned *tickets = status + status_words;
+  NVT_CHECK_HIP(hipMemsetAsync(status, 0, (status_words + kOsMaxPass) * 4, stream));
+  const unsigned hb = (unsigned)(ntiles < (uint64_t)kOsHistBlocks ? ntiles : kOsHistBlocks);
+  os_hist_kernel<<<hb, kS2BS, 0, stream>>>(keys, counts, n, npass, block_hist);
+  NVT_CHECK_LAUNCH();
+  os_base_kernel<<<npass, 256, 0, stream>>>(block_hist, (int)hb, base);
+  NVT_CHECK_LAUNCH();
+  const uint64_t *src = nullptr;
+  int flip = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int shift = 8 * pass;
+    const bool first = pass == 0, last = pass == npass - 1;
+    unsigned *st = status + (uint64_t)pass * ntiles * 256;
+    uint64_t *dst = bufs[flip];
+    if (first)
+      os_scatter_kernel<true, false><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
+          nullptr, keys, counts, n, shift, base + pass * 256, st, tickets + pass, dst, nullptr,
+          nullptr);
+    else if (last)
+      os_scatter_kernel<false, true><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
+          src, nullptr, nullptr, n, shift, base + pass * 256, st, tickets + pass, nullptr, keys,
+          counts);
+    else
+      os_scatter_kernel<false, false><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
+          src, nullptr, nullptr, n, shift, base + pass * 256, st, tickets + pass, dst, nullptr,
+          nullptr);
+    NVT_CHECK_LAUNCH();
+    src = dst;
+    flip ^= 1;
+  }
+  return NVT_OK;
+}
+
+// ---- all small vocabularies of a fit in ONE launch: workgroup b sorts vocabulary b --------
+// packed words in LDS (128 KiB for up to 16384 entries), bitonic network, ascending.
+constexpr int kSmallPackedMax = 16384;
+struct SmallCol {
+  int32_t *keys;
+  int64_t *counts;
+  unsigned n;
+};
+constexpr int kSmallBatch = 64;
+struct SmallBatch {
+  SmallCol c[kSmallBatch];
+};
+__global__ __launch_bounds__(kSmallBS) void sort_small_packed_many_kernel(SmallBatch b) {
+  __shared__ uint64_t sv[kSmallPackedMax];
+  const SmallCol col = b.c[blockIdx.x];
+  const unsigned n = col.n;
+  unsigned m = 1;
+  while (m < n) m <<= 1;
+  for (unsigned i = threadIdx.x; i < m; i += kSmallBS)
+    sv[i] = i < n ? comp_make(col.keys[i], col.counts[i]) : ~0ull;  // padding sorts last
+  __syncthreads();
+  for (unsigned size = 2; size <= m; size <<= 1) {
+    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+      for (unsigned t = threadIdx.x; t < m / 2; t += kSmallBS) {
+        const unsigned lo = 2 * t - (t & (stride - 1));
+        const unsigned hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint64_t a = sv[lo], c = sv[hi];
+        if (up ? (c < a) : (a < c)) {
+          sv[lo] = c;
+          sv[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (unsigned i = threadIdx.x; i < n; i += kSmallBS) {
+    const uint64_t v = sv[i];
+    col.keys[i] = comp_key(v);
+    col.counts[i] = comp_cnt(v);
+  }
+}
+
 // tmp layout of the packed path: compA[n] | compB[n] | tile_hist | chunk_tot
 inline uint64_t sort2_tmp_bytes(uint64_t n) {
   const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile, hist_len = 256 * ntiles;
@@ -408,6 +718,8 @@ int vocab_sort(K *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tm
     return NVT_OK;
   }
   if constexpr (sizeof(K) == 4) {
+    if (max_count > 0 && max_count < (1ll << 32) && n < (1ull << 30) && !getenv("NVT_SORT_LEGACY"))
+      return vocab_sort_onesweep(keys, counts, n, max_count, tmp, stream);
     if (max_count > 0 && max_count < (1ll << 32) && n < (1ull << 31))
       return vocab_sort_packed(keys, counts, n, max_count, tmp, stream);
   }
@@ -478,6 +790,35 @@ int vocab_sort(K *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tm
   return NVT_OK;
 }
 
+int vocab_sort_any(int key_bytes, void *keys, int64_t *counts, uint64_t n, int64_t max_count,
+                   void *tmp, hipStream_t s) {
+  NVT_PROF("vocab_sort", 0, s);
+  if (key_bytes == 4) return vocab_sort<int32_t>((int32_t *)keys, counts, n, max_count, tmp, s);
+  return vocab_sort<int64_t>((int64_t *)keys, counts, n, max_count, tmp, s);
+}
+
+bool vocab_sort_small_eligible(int key_bytes, uint64_t n, int64_t max_count) {
+  return key_bytes == 4 && n >= 2 && n <= (uint64_t)kSmallPackedMax && max_count > 0 &&
+         max_count < (1ll << 32);
+}
+
+int vocab_sort_small_batch(const SmallSortDesc *cols, int ncols, hipStream_t s) {
+  for (int c0 = 0; c0 < ncols; c0 += kSmallBatch) {
+    const int nc = ncols - c0 < kSmallBatch ? ncols - c0 : kSmallBatch;
+    SmallBatch b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < nc; ++i) {
+      b.c[i].keys = cols[c0 + i].keys;
+      b.c[i].counts = cols[c0 + i].counts;
+      b.c[i].n = cols[c0 + i].n;
+    }
+    NVT_PROF("vocab_sort_small", 0, s);
+    sort_small_packed_many_kernel<<<nc, kSmallBS, 0, s>>>(b);
+    NVT_CHECK_LAUNCH();
+  }
+  return NVT_OK;
+}
+
 }  // namespace nvt
 
 using namespace nvt;
@@ -492,17 +833,18 @@ int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes) {
   *bytes = n * 8 + pad16(n * key_bytes) + pad16(hist_len * 4) + nchunks * 8 +
            (uint64_t)(key_bytes + 8) * 256 * 8 + 64;
   if (key_bytes == 4 && sort2_tmp_bytes(n) > *bytes) *bytes = sort2_tmp_bytes(n);
+  if (key_bytes == 4 && os_tmp_bytes(n) > *bytes) *bytes = os_tmp_bytes(n);
   return NVT_OK;
 }
 int nvt_vocab_sort_i32(int32_t *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tmp,
                        void *stream) {
   NVT_CHECK_ARG(n <= 1 || (keys && counts && tmp), "null pointer");
-  return vocab_sort<int32_t>(keys, counts, n, max_count, tmp, (hipStream_t)stream);
+  return vocab_sort_any(4, keys, counts, n, max_count, tmp, (hipStream_t)stream);
 }
 int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tmp,
                        void *stream) {
   NVT_CHECK_ARG(n <= 1 || (keys && counts && tmp), "null pointer");
-  return vocab_sort<int64_t>(keys, counts, n, max_count, tmp, (hipStream_t)stream);
+  return vocab_sort_any(8, keys, counts, n, max_count, tmp, (hipStream_t)stream);
 }
 
 }  // extern "C"

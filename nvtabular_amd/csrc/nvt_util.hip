@@ -1,7 +1,17 @@
-// Error reporting and version of the C ABI (include/nvt_hip.h).
+// Error reporting, version, and launch-side instrumentation (HIP-event profiler + roctx
+// ranges) of the C ABI (include/nvt_hip.h).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
 #include <cstdarg>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "nvt_common.hpp"
+#include "nvt_prof.hpp"
 
 namespace nvt {
 static thread_local char g_err[512] = "";
@@ -12,9 +22,164 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- HIP-event profiler ---------------------------------------------------------
+namespace {
+struct Rec {
+  const char *name;  // string literals only
+  uint64_t bytes;
+  hipEvent_t a, b;
+};
+std::atomic<int> g_on{0};
+std::mutex g_mu;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_base = nullptr;
+
+hipEvent_t take_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+void recycle_all() {
+  for (auto &r : g_recs) {
+    if (r.a) g_pool.push_back(r.a);
+    if (r.b) g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+}
+}  // namespace
+
+bool prof_enabled() { return g_on.load(std::memory_order_relaxed) != 0; }
+
+int prof_open(const char *name, uint64_t alg_bytes, hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r{name, alg_bytes, take_event(), take_event()};
+  if (!r.a || !r.b) return -1;
+  (void)hipEventRecord(r.a, stream);
+  g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
+}
+void prof_close(int id, hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (id >= 0 && id < (int)g_recs.size()) (void)hipEventRecord(g_recs[id].b, stream);
+}
+
+// ---- roctx (optional, dlopen'ed) ----------------------------------------------------
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)(void);
+std::once_flag g_roctx_once;
+roctx_push_t g_push = nullptr;
+roctx_pop_t g_pop = nullptr;
+void roctx_init() {
+  const char *off = getenv("NVT_ROCTX");
+  if (off && off[0] == '0') return;
+  const char *libs[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1",
+                        "libroctx64.so", "libroctx64.so.4"};
+  for (const char *l : libs) {
+    void *h = dlopen(l, RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) continue;
+    g_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+    g_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+    if (g_push && g_pop) return;
+    g_push = nullptr;
+    g_pop = nullptr;
+  }
+}
+}  // namespace
+void roctx_push(const char *name) {
+  std::call_once(g_roctx_once, roctx_init);
+  if (g_push) g_push(name);
+}
+void roctx_pop() {
+  if (g_pop) g_pop();
+}
 }  // namespace nvt
 
+using namespace nvt;
+
 extern "C" {
-int nvt_version(void) { return 100; }  // 0.1.0
+int nvt_version(void) { return 200; }  // 0.2.0
 const char *nvt_last_error(void) { return nvt::g_err; }
+
+int nvt_prof_begin(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  recycle_all();
+  if (!g_base) NVT_CHECK_HIP(hipEventCreate(&g_base));
+  NVT_CHECK_HIP(hipEventRecord(g_base, nullptr));
+  g_on.store(1);
+  return NVT_OK;
+}
+
+// Synchronises the device, then writes a JSON object
+//   {"kernels": {"<name>": [total_ms, launches, algorithmic_bytes], ...},
+//    "busy_ms": <union of all scope intervals>, "span_ms": <first start .. last stop>}
+// into buf (NUL-terminated, truncated to cap); *needed = bytes required incl. NUL.
+int nvt_prof_report(char *buf, uint64_t cap, uint64_t *needed) {
+  g_on.store(0);
+  NVT_CHECK_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(g_mu);
+  struct Agg {
+    double ms = 0;
+    uint64_t n = 0, bytes = 0;
+  };
+  std::map<std::string, Agg> agg;
+  std::vector<std::pair<float, float>> iv;
+  for (auto &r : g_recs) {
+    float ms = 0, t0 = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    Agg &a = agg[r.name];
+    a.ms += ms;
+    a.n += 1;
+    a.bytes += r.bytes;
+    if (g_base && hipEventElapsedTime(&t0, g_base, r.a) == hipSuccess) iv.push_back({t0, t0 + ms});
+  }
+  double busy = 0, span = 0;
+  if (!iv.empty()) {
+    std::sort(iv.begin(), iv.end());
+    float lo = iv[0].first, hi = iv[0].second, last = hi;
+    for (size_t i = 1; i < iv.size(); ++i) {
+      if (iv[i].first > hi) {
+        busy += hi - lo;
+        lo = iv[i].first;
+        hi = iv[i].second;
+      } else if (iv[i].second > hi) {
+        hi = iv[i].second;
+      }
+      last = std::max(last, iv[i].second);
+    }
+    busy += hi - lo;
+    span = last - iv[0].first;
+  }
+  std::string s = "{\"kernels\": {";
+  bool first = true;
+  char tmp[256];
+  for (auto &kv : agg) {
+    snprintf(tmp, sizeof(tmp), "%s\"%s\": [%.6f, %llu, %llu]", first ? "" : ", ", kv.first.c_str(),
+             kv.second.ms, (unsigned long long)kv.second.n, (unsigned long long)kv.second.bytes);
+    s += tmp;
+    first = false;
+  }
+  snprintf(tmp, sizeof(tmp), "}, \"busy_ms\": %.6f, \"span_ms\": %.6f}", busy, span);
+  s += tmp;
+  if (needed) *needed = s.size() + 1;
+  if (buf && cap) {
+    const size_t m = std::min<size_t>(s.size(), cap - 1);
+    memcpy(buf, s.data(), m);
+    buf[m] = 0;
+  }
+  recycle_all();
+  return NVT_OK;
+}
+
+// roctx range around host-side phases (operator fit / transform), named after the reference's
+// @annotate strings; no-ops when the roctx library is absent
+void nvt_range_push(const char *name) { roctx_push(name ? name : ""); }
+void nvt_range_pop(void) { roctx_pop(); }
 }

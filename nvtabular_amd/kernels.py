@@ -30,45 +30,64 @@ _DTYPE_CODE = {
 
 
 # --------------------------------------------------------------------------
-# optional per-launch timing (bench.py): HIP events on the launch stream
+# per-kernel timing (bench.py): HIP events recorded INSIDE the library, on the stream each
+# kernel family is launched on (nvt_prof_begin / nvt_prof_report); nothing is recorded -- and
+# nothing is paid -- while profiling is off
 # --------------------------------------------------------------------------
-_prof = None
-
-
 def profile_begin():
-    global _prof
-    _prof = {}
+    check(_lib.load().nvt_prof_begin(), "nvt_prof_begin")
+
+
+def profile_report():
+    """dict(kernels={name: (total_ms, launches, algorithmic_bytes)}, busy_ms, span_ms) for the
+    profiled region; busy_ms = union of the recorded kernel intervals (GPU-busy time)."""
+    import json
+
+    lib = _lib.load()
+    need = C.c_uint64()
+    buf = C.create_string_buffer(1 << 16)
+    check(lib.nvt_prof_report(buf, len(buf), C.byref(need)), "nvt_prof_report")
+    rep = json.loads(buf.value.decode())
+    rep["kernels"] = {k: tuple(v) for k, v in rep["kernels"].items()}
+    return rep
 
 
 def profile_end():
     """{kernel: (total_ms, launches, algorithmic_bytes)} for the profiled region."""
-    global _prof
-    rec, _prof = _prof, None
-    torch.cuda.synchronize()
-    out = {}
-    for name, evs in (rec or {}).items():
-        tot = sum(a.elapsed_time(b) for a, b, _ in evs)
-        out[name] = (tot, len(evs), sum(nb for _, _, nb in evs))
-    return out
+    return profile_report()["kernels"]
 
 
-class _timed:
-    """Record start/stop events around one kernel launch when profiling is on."""
+class annotate:
+    """roctx range named after the reference's @annotate of the step being replaced
+    (categorify.py:345,477,955,1054,1073,1149): attributes rocprofv3 traces to operators."""
 
-    def __init__(self, name, alg_bytes):
-        self.name, self.alg_bytes = name, alg_bytes
+    def __init__(self, name: str):
+        self.name = name.encode()
 
     def __enter__(self):
-        if _prof is not None:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.b = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+        try:
+            _lib.load().nvt_range_push(self.name)
+            self._on = True
+        except Exception:
+            self._on = False
         return self
 
     def __exit__(self, *exc):
-        if _prof is not None:
-            self.b.record()
-            _prof.setdefault(self.name, []).append((self.a, self.b, self.alg_bytes))
+        if self._on:
+            _lib.load().nvt_range_pop()
+        return False
+
+
+class _timed:
+    """Former Python-side event bracket; timing now lives in the library (NVT_PROF scopes)."""
+
+    def __init__(self, name, alg_bytes):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
         return False
 
 
@@ -237,6 +256,7 @@ PATH_P2_MAX_WEIGHTED = 18_000_000   #         weighted: 8192-slot tables
 PATH_P3_MAX_DISTINCT = 32_000_000   # path 3: 64 x 256 buckets, 8192-slot tables
 
 _ws_cache = {}
+_WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -288,7 +308,9 @@ class DenseCountJob:
         self.state = None  # device uint64[STATE_WORDS] view, assigned by dense_count_many
         self.result = None
 
-    def launch(self):
+    def prepare(self, desc: "_lib.CountCol") -> int:
+        """Allocate this attempt's output list and fill one nvt_count_col descriptor; returns
+        the workspace bytes the path needs (the caller shares ONE workspace per call)."""
         n, path = self.n, self.path
         out_cap = min(self.cap_guess, n) + 1
         if path in _S_CLASSES:
@@ -296,19 +318,24 @@ class DenseCountJob:
             out_cap = min(out_cap, _S_CLASSES[path] * 256 * 384 + 1)
         self.out_k = torch.empty(out_cap + 1, dtype=self.keys.dtype, device=self.dev)
         self.out_c = torch.empty(out_cap + 1, dtype=torch.int64, device=self.dev)
-        nbytes = C.c_uint64()
-        check(self.lib.nvt_dense_count_ws_bytes(self.kb, n, path,
-                                                0 if self.weights is None else 1, C.byref(nbytes)))
-        ws = _workspace(nbytes.value, self.dev)  # shared: calls are ordered on one stream
-        with _timed(f"dense_count_p{path}", n * self.kb):
-            check(
-                getattr(self.lib, f"nvt_dense_count_{self.suffix}")(
-                    self.keys.data_ptr(), ptr(self.valid), ptr(self.weights), n, path,
-                    ws.data_ptr(), self.out_k.data_ptr(), self.out_c.data_ptr(), out_cap,
-                    self.state.data_ptr(), stream_ptr(),
-                ),
-                "nvt_dense_count",
-            )
+        key = (self.kb, n, path, self.weights is not None)
+        nbytes = _WS_BYTES.get(key)
+        if nbytes is None:
+            out = C.c_uint64()
+            check(self.lib.nvt_dense_count_ws_bytes(self.kb, n, path,
+                                                    0 if self.weights is None else 1, C.byref(out)))
+            nbytes = _WS_BYTES[key] = out.value
+        desc.keys = self.keys.data_ptr()
+        desc.valid = ptr(self.valid)
+        desc.weights = ptr(self.weights)
+        desc.n = n
+        desc.key_bytes = self.kb
+        desc.path = path
+        desc.out_keys = self.out_k.data_ptr()
+        desc.out_counts = self.out_c.data_ptr()
+        desc.out_capacity = out_cap
+        desc.state = self.state.data_ptr()
+        return nbytes
 
     def resolve(self, st) -> bool:
         """Inspect the state words read back for this job; False = relaunch needed."""
@@ -403,34 +430,78 @@ def _presample(jobs):
         j.cap_guess = max(1 << 16, 2 * est)
 
 
+class CountBatch:
+    """Every column's groupby-size of one partition, enqueued by ONE C call
+    (nvt_dense_count_many); ``results()`` performs the single device->host read of all the
+    state words and relaunches the (rare, once hints are learned) columns whose LDS tables or
+    output lists overflowed.  Launch and read-back are separate so that the caller can queue
+    other work (Normalize's moments, the next partition's copies) before synchronising."""
+
+    def __init__(self, jobs):
+        self.jobs = list(jobs)
+        self._results = None
+        _presample(self.jobs)
+        for j in self.jobs:
+            if j.n == 0:
+                j.result = (torch.empty(0, dtype=j.keys.dtype, device=j.dev),
+                            torch.empty(0, dtype=torch.int64, device=j.dev), 0,
+                            dict(path=0, distinct=0, max_count=0, rows=0))
+        for j in self.jobs:
+            if j.result is None and j.path < 0:
+                j._fallback()
+        self.pending = [j for j in self.jobs if j.result is None]
+        self.states = None
+        self._launch()
+
+    def _launch(self):
+        pending = self.pending
+        if not pending:
+            return
+        dev = pending[0].dev
+        self.states = torch.empty(len(pending), _lib.STATE_WORDS, dtype=torch.int64, device=dev)
+        descs = (_lib.CountCol * len(pending))()
+        need = 0
+        for i, j in enumerate(pending):
+            j.state = self.states[i]
+            need = max(need, j.prepare(descs[i]))
+        ws = _workspace(need, dev)  # shared: the columns of a call are ordered on one stream
+        wp = ws.data_ptr()
+        for d in descs:
+            d.ws = wp
+        check(_lib.load().nvt_dense_count_many(descs, len(pending), stream_ptr()),
+              "nvt_dense_count_many")
+
+    def results(self):
+        if self._results is None:
+            while self.pending:
+                host = self.states.cpu().tolist()  # the single synchronisation point
+                self.pending = [j for i, j in enumerate(self.pending) if not j.resolve(host[i])]
+                self._launch()
+            self._results = [j.result for j in self.jobs]
+        return self._results
+
+
 def dense_count_many(jobs):
-    """Launch every job, then ONE readback for all their state words; jobs whose LDS
-    tables or output lists overflowed are relaunched on a larger path (rare once the
-    hints are learned)."""
-    jobs = [j for j in jobs]
-    _presample(jobs)
-    return _run_jobs(jobs)
+    """Launch every job (one C call), then ONE readback for all their state words."""
+    return CountBatch(jobs).results()
 
 
 def _run_jobs(jobs):
-    for j in jobs:
+    batch = CountBatch.__new__(CountBatch)
+    batch.jobs = list(jobs)
+    batch._results = None
+    for j in batch.jobs:
         if j.n == 0:
             j.result = (torch.empty(0, dtype=j.keys.dtype, device=j.dev),
                         torch.empty(0, dtype=torch.int64, device=j.dev), 0,
                         dict(path=0, distinct=0, max_count=0, rows=0))
-    for j in jobs:
+    for j in batch.jobs:
         if j.result is None and j.path < 0:
             j._fallback()
-    pending = [j for j in jobs if j.result is None]
-    while pending:
-        states = torch.zeros(len(pending), _lib.STATE_WORDS, dtype=torch.int64,
-                             device=pending[0].dev)
-        for i, j in enumerate(pending):
-            j.state = states[i]
-            j.launch()
-        host = states.cpu().tolist()  # the single synchronisation point
-        pending = [j for i, j in enumerate(pending) if not j.resolve(host[i])]
-    return [j.result for j in jobs]
+    batch.pending = [j for j in batch.jobs if j.result is None]
+    batch.states = None
+    batch._launch()
+    return batch.results()
 
 
 def dense_count(
@@ -490,12 +561,15 @@ def vocab_sort(keys: torch.Tensor, counts: torch.Tensor, max_count: int = 0):
 # Categorify.transform: encode tables
 # --------------------------------------------------------------------------
 ENCODE_RESIDENT_I32, ENCODE_RESIDENT_I64 = 12288, 6144  # include/nvt_hip.h
+_ENC_BYTES = {}   # (key_bytes, capacity) -> nvt_encode_table_bytes
+_SORT_BYTES = {}  # (key_bytes, n) -> nvt_vocab_sort_tmp_bytes
 
 
 class EncodeTable:
     """key -> label probe table built from an ordered vocabulary."""
 
-    def __init__(self, vocab_keys: torch.Tensor, first_label: int, unique: bool = False):
+    def __init__(self, vocab_keys: torch.Tensor, first_label: int, unique: bool = False,
+                 defer_build: bool = False):
         _lib.require_gpu()
         self.lib = _lib.load()
         self.suffix = _key_suffix(vocab_keys)
@@ -503,30 +577,82 @@ class EncodeTable:
         self.key_bytes = 4 if self.suffix == "i32" else 8
         self.n_vocab = int(vocab_keys.numel())
         self.first_label = int(first_label)
+        self.unique = bool(unique)
         self.capacity = next_pow2(max(64, (4 if self.n_vocab <= (1 << 20) else 2) * self.n_vocab + 1))
         dev = vocab_keys.device
         vk = vocab_keys.contiguous()
+        self._vk = vk
         # kept: the head of the (frequency-ordered, duplicate-free) vocabulary is staged in LDS
         self.vocab_keys = vk if unique else None
         # a duplicate-free vocabulary that fits the LDS table in full (include/nvt_hip.h:
         # NVT_ENCODE_RESIDENT_*) is encoded from LDS alone: no global table, no build kernel
         resident = ENCODE_RESIDENT_I32 if self.key_bytes == 4 else ENCODE_RESIDENT_I64
         self.table = self.sentinel_label = None
+        self.sort_tmp = None
         if unique and 0 < self.n_vocab <= resident:
             return
-        nbytes = C.c_uint64()
-        check(self.lib.nvt_encode_table_bytes(self.key_bytes, self.capacity, C.byref(nbytes)))
-        self.table = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        key = (self.key_bytes, self.capacity)
+        nbytes = _ENC_BYTES.get(key)
+        if nbytes is None:
+            out = C.c_uint64()
+            check(self.lib.nvt_encode_table_bytes(self.key_bytes, self.capacity, C.byref(out)))
+            nbytes = _ENC_BYTES[key] = out.value
+        self.table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.sentinel_label = torch.empty(1, dtype=torch.int64, device=dev)
-        with _timed("encode_build", 0):
-            check(
-                getattr(self.lib, f"nvt_encode_build_{self.suffix}")(
-                    vk.data_ptr() if self.n_vocab else None, self.n_vocab, self.first_label,
-                    self.table.data_ptr(), self.capacity, self.sentinel_label.data_ptr(),
-                    1 if unique else 0, stream_ptr(),
-                ),
-                "nvt_encode_build",
-            )
+        if defer_build:  # built by nvt_vocab_finalize_many, after the vocabulary is ordered
+            return
+        check(
+            getattr(self.lib, f"nvt_encode_build_{self.suffix}")(
+                vk.data_ptr() if self.n_vocab else None, self.n_vocab, self.first_label,
+                self.table.data_ptr(), self.capacity, self.sentinel_label.data_ptr(),
+                1 if unique else 0, stream_ptr(),
+            ),
+            "nvt_encode_build",
+        )
+
+    def fill_vocab_desc(self, d: "_lib.VocabCol", counts: torch.Tensor, max_count: int):
+        """One nvt_vocab_col: order (self vocab keys, counts) in place, then build the table."""
+        n = self.n_vocab
+        d.keys = self._vk.data_ptr()
+        d.counts = counts.data_ptr()
+        d.n = n
+        d.max_count = int(max_count)
+        d.key_bytes = self.key_bytes
+        d.unique_keys = 1 if self.unique else 0
+        small = self.key_bytes == 4 and 2 <= n <= 16384 and 0 < int(max_count) < (1 << 32)
+        if n > 1 and not small:
+            key = (self.key_bytes, n)
+            nbytes = _SORT_BYTES.get(key)
+            if nbytes is None:
+                out = C.c_uint64()
+                check(self.lib.nvt_vocab_sort_tmp_bytes(self.key_bytes, n, C.byref(out)))
+                nbytes = _SORT_BYTES[key] = out.value
+            self.sort_tmp = torch.empty(nbytes + 16, dtype=torch.uint8, device=self._vk.device)
+            d.sort_tmp = self.sort_tmp.data_ptr()
+        else:
+            d.sort_tmp = None
+        d.first_label = self.first_label
+        d.table = ptr(self.table)
+        d.capacity = self.capacity
+        d.sentinel_label = ptr(self.sentinel_label)
+
+    def fill_encode_desc(self, d: "_lib.EncodeCol", keys, valid, null_label, oov_label,
+                         num_buckets, out):
+        d.keys = keys.data_ptr()
+        d.valid = ptr(valid)
+        d.n = keys.numel()
+        d.table = ptr(self.table)
+        d.capacity = self.capacity
+        d.sentinel_label = ptr(self.sentinel_label)
+        d.null_label = int(null_label)
+        d.oov_label = int(oov_label)
+        d.num_buckets = int(num_buckets or 0)
+        d.key_bytes = self.key_bytes
+        d.out_bytes = out.element_size()
+        d.out = out.data_ptr()
+        d.vocab_keys = ptr(self.vocab_keys) if self.n_vocab else None
+        d.n_vocab = self.n_vocab if self.vocab_keys is not None else 0
+        d.first_label = self.first_label
 
     def encode(
         self,
@@ -556,6 +682,26 @@ class EncodeTable:
                 "nvt_encode",
             )
         return out
+
+
+def encode_many(items, out_dtype: torch.dtype = torch.int64):
+    """items: [(EncodeTable, keys, valid, null_label, oov_label, num_buckets)] -> [labels];
+    every column of a Categorify.transform enqueued by ONE C call (nvt_encode_many)."""
+    if out_dtype not in (torch.int32, torch.int64):
+        raise TypeError("Categorify output dtype must be int32 or int64")
+    descs = (_lib.EncodeCol * max(1, len(items)))()
+    outs, keep = [], []
+    for d, (tab, keys, valid, null_label, oov_label, nb) in zip(descs, items):
+        if keys.dtype != tab.key_dtype:
+            keys = keys.to(tab.key_dtype)
+        keys = aligned(keys)
+        out = torch.empty(keys.numel(), dtype=out_dtype, device=keys.device)
+        tab.fill_encode_desc(d, keys, valid, null_label, oov_label, nb, out)
+        outs.append(out)
+        keep.append(keys)
+    if items:
+        check(_lib.load().nvt_encode_many(descs, len(items), stream_ptr()), "nvt_encode_many")
+    return outs
 
 
 def hash_bucket(
@@ -612,6 +758,66 @@ def moments_accumulate(
             ),
             "nvt_moments",
         )
+
+
+def moments_many(items):
+    """items: [(x, valid, fill or None, out3)]: out3 (float64[3] on device) += {count, sum,
+    sum of squares}; one launch for all columns (nvt_moments_many)."""
+    if not items:
+        return
+    _lib.require_gpu()
+    lib = _lib.load()
+    descs = (_lib.MomentsCol * len(items))()
+    keep = []
+    for d, (x, valid, fill, out3) in zip(descs, items):
+        x = aligned(x.view(torch.uint8) if x.dtype == torch.bool else x)
+        keep.append(x)
+        d.x = x.data_ptr()
+        d.valid = ptr(valid)
+        d.n = x.numel()
+        d.dtype = dtype_code(x.dtype)
+        d.has_fill = 0 if fill is None else 1
+        d.fill_val = 0.0 if fill is None else float(fill)
+        d.out3 = out3.data_ptr()
+    dev = keep[0].device
+    key = ("many", dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    per = lib.nvt_moments_scratch_bytes() // 8
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < per * len(items):
+        buf = _scratch[key] = torch.empty(per * len(items), dtype=torch.float64, device=dev)
+    check(lib.nvt_moments_many(descs, len(items), buf.data_ptr(), stream_ptr()), "nvt_moments_many")
+
+
+def fill_normalize_many(items):
+    """items: [(x, valid, fill, do_norm, shift, scale, out_dtype, want_filled_mask)] ->
+    [(out, filled or None)]; one launch per dtype combination (nvt_fill_normalize_many)."""
+    if not items:
+        return []
+    _lib.require_gpu()
+    descs = (_lib.FillNormCol * len(items))()
+    outs, keep = [], []
+    for d, (x, valid, fill, do_norm, shift, scale, out_dtype, want_mask) in zip(descs, items):
+        x = aligned(x)
+        keep.append(x)
+        n = x.numel()
+        out = torch.empty(n, dtype=out_dtype, device=x.device)
+        filled = torch.empty(n, dtype=torch.uint8, device=x.device) if want_mask else None
+        d.x = x.data_ptr()
+        d.valid = ptr(valid)
+        d.n = n
+        d.dtype = dtype_code(x.dtype)
+        d.has_fill = 0 if fill is None else 1
+        d.fill_val = 0.0 if fill is None else float(fill)
+        d.do_norm = 1 if do_norm else 0
+        d.out_dtype = dtype_code(out_dtype)
+        d.shift = float(shift)
+        d.scale = float(scale)
+        d.out = out.data_ptr()
+        d.filled = ptr(filled)
+        outs.append((out, filled.view(torch.bool) if filled is not None else None))
+    check(_lib.load().nvt_fill_normalize_many(descs, len(items), stream_ptr()),
+          "nvt_fill_normalize_many")
+    return outs
 
 
 def minmax_accumulate(x: torch.Tensor, valid: Optional[torch.Tensor], out2: torch.Tensor, first: bool):

@@ -50,6 +50,11 @@ class Operator:
     def label(self):
         return self.__class__.__name__
 
+    def range_name(self, kind: str) -> str:
+        """roctx range name = the reference's @annotate string for this operator
+        (e.g. normalize.py:61,70 "Normalize_fit" / "Normalize_op")."""
+        return f"{self.label}_{'fit' if kind == 'fit' else 'op'}"
+
     def column_mapping(self, col_selector: ColumnSelector) -> Dict[str, List[str]]:
         return {name: [name] for name in col_selector.names}
 

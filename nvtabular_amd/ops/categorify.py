@@ -11,7 +11,6 @@ Index layout (categorify.py:53-71): 0 pad, 1 null, [2, 2+nb) OOV / hash buckets,
 """
 from __future__ import annotations
 
-import contextlib
 import os
 import warnings
 from copy import deepcopy
@@ -155,6 +154,7 @@ class Categorify(StatOperator):
         # device-side state: storage_name -> encoder (built at fit_end or lazily from parquet)
         self._encoders: Dict[str, object] = {}
         self._cap_hints: Dict[str, int] = {}
+        self._pending_counts: Dict[int, tuple] = {}  # id(fit state) -> (CountBatch, owners)
         # Engine extension (not in the reference): with defer_artifacts=True the
         # unique.*/meta.*.parquet files are written by flush_artifacts() /
         # Workflow.save() instead of inside fit, so a device-resident fit does no
@@ -165,6 +165,11 @@ class Categorify(StatOperator):
         if vocabs is not None:
             self.vocabs = self.process_vocabs(vocabs)
         self.categories = deepcopy(self.vocabs)
+
+    fit_end_priority = 1  # after the operators whose fit_end is a scalar read-back (workflow.py)
+
+    def range_name(self, kind: str) -> str:
+        return "Categorify_fit" if kind == "fit" else "Categorify_transform"  # categorify.py:345,477
 
     # ------------------------------------------------------------------ fit --
     def _groups(self, col_selector: ColumnSelector):
@@ -208,6 +213,9 @@ class Categorify(StatOperator):
 
     def fit_partition(self, state, col_selector, frame):
         frame, _ = as_device_frame(frame)
+        # the previous partition's counts are read back only now: its kernels (and whatever
+        # other operators queued behind them) ran while the host prepared this partition
+        self._absorb_pending(state)
         jobs, owners = [], []
         for g in state.values():
             keys, valids = self._group_keys(g, frame)
@@ -222,10 +230,20 @@ class Categorify(StatOperator):
                 hkey = f"{g.name}#{ci}"
                 jobs.append(K.DenseCountJob(k, v, None, hint=self._cap_hints.get(hkey, 0)))
                 owners.append((g, hkey))
-        # every column's count kernels are queued before the one readback of all state words
-        results = K.dense_count_many(jobs)
+        if jobs:
+            # every column's count kernels are enqueued by ONE C call (top_level_groupby,
+            # categorify.py:955); the one readback of all state words happens in
+            # _absorb_pending (next partition / fit_end)
+            with K.annotate("top_level_groupby"):
+                self._pending_counts[id(state)] = (K.CountBatch(jobs), owners)
+
+    def _absorb_pending(self, state):
+        item = self._pending_counts.pop(id(state), None)
+        if item is None:
+            return
+        batch, owners = item
         per_group = {}
-        for (g, hkey), (dk, dc, nulls, info) in zip(owners, results):
+        for (g, hkey), (dk, dc, nulls, info) in zip(owners, batch.results()):
             self._cap_hints[hkey] = max(64, info["distinct"])
             g.nulls += nulls
             g.valid_rows += info["rows"] - nulls
@@ -272,23 +290,15 @@ class Categorify(StatOperator):
     def fit_end(self, state, col_selector):
         from .. import dist
 
+        self._absorb_pending(state)
         base = os.path.join(self.out_path, "categories")
         os.makedirs(base, exist_ok=True)
         paths = {}
         groups = list(state.values())
         for g in groups:
             if not g.combo and g.parts:
-                self._merge_parts(g)
-        if dist.world_size() == 1:
-            # largest vocabularies first: their sorts / table builds keep the stream busy while
-            # the host runs ahead enqueueing the small ones (whose kernels are shorter than the
-            # ~60 us of Python per column).  Multi-rank keeps column order: the merge
-            # collectives must be issued in the same order on every rank.
-            def _size(g):
-                t = g.table
-                return int(t[0].numel()) if isinstance(t, tuple) else 0
-
-            groups.sort(key=_size, reverse=True)
+                with K.annotate("mid_level_groupby"):
+                    self._merge_parts(g)
         if dist.world_size() > 1:
             # ONE exchange for every single-vocabulary group of this fit (dist.merge_counts_many)
             singles = [g for g in groups if not g.combo]
@@ -307,18 +317,8 @@ class Categorify(StatOperator):
                     g.table = (k, c, sc[2])  # the sum of the per-rank maxima bounds the max count
                     g.nulls, g.valid_rows = sc[0], sc[1]
                     g.merged = True
-        # Independent vocabularies are finalised on a few HIP streams: the 13 small Criteo
-        # vocabularies are one-workgroup kernels (LDS bitonic sort, table clear / build) that
-        # leave 255 CUs idle when they run back to back behind each other.
-        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
-        side = self._finalize_streams() if (main is not None and dist.world_size() == 1
-                                            and len(groups) > 1) else []
-        if side:
-            ready = torch.cuda.Event()
-            ready.record(main)
-            for st in side:
-                st.wait_event(ready)
-        for gi, g in enumerate(groups):
+        opts = {}
+        for g in groups:
             nb = _pick(self.num_buckets, g.name) if self.num_buckets else None
             oov_count = nb or 1
             max_emb = _pick(self.max_size, g.name) if self.max_size else 0
@@ -328,11 +328,18 @@ class Categorify(StatOperator):
                     "`max_size` can never be less than the maximum of `num_buckets + 2` and `3`, "
                     "because we must always reserve pad, null and at least 1 oov-bucket index."
                 )
-            st = side[gi % len(side)] if side and not g.combo else None
-            if st is not None and isinstance(g.table, tuple):
-                for t in g.table[:2]:  # allocated on the main stream, consumed on `st`
-                    t.record_stream(st)
-            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            opts[g.name] = (oov_count, max_emb, freq)
+        # device-only vocabularies (no strings, nothing to trim) are ordered and get their
+        # encode tables in ONE C call (write_uniques, categorify.py:1149): nvt_vocab_finalize_many
+        fast = [g for g in groups if self._fast_finalizable(g, opts[g.name], dist)]
+        if fast:
+            with K.annotate("write_uniques"):
+                self._finalize_fast(fast, opts, base, paths)
+        for g in groups:
+            if g.name in paths:
+                continue
+            oov_count, max_emb, freq = opts[g.name]
+            with K.annotate("write_uniques"):
                 if g.combo:
                     vocab = self._finalize_combo(g, dist)
                 else:
@@ -340,19 +347,46 @@ class Categorify(StatOperator):
                 paths[g.name] = self._save_encodings(
                     g, vocab, base, first_n=max_emb, freq_threshold=freq, oov_count=oov_count
                 )
-            if st is not None:
-                _record_vocab_streams(self._encoders.get(g.name), self._pending.get(g.name), main)
-        for st in side:
-            main.wait_stream(st)
         return {name: paths[name] for name in state if name in paths}
 
-    def _finalize_streams(self):
-        dev = torch.cuda.current_device()
-        cache = getattr(self, "_fin_streams", None)
-        if cache is None or cache[0] != dev:
-            cache = (dev, [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("NVT_FINALIZE_STREAMS", "3")))])
-            self._fin_streams = cache
-        return cache[1]
+    @staticmethod
+    def _fast_finalizable(g, opt, dist):
+        _, max_emb, freq = opt
+        if g.combo or g.table is None or max_emb or freq:
+            return False
+        if any(c in g.strings for c in g.cols):
+            return False
+        if dist.world_size() > 1 and not getattr(g, "merged", False):
+            return False
+        return int(g.table[0].numel()) > 0
+
+    def _finalize_fast(self, groups, opts, base, paths):
+        descs = (K._lib.VocabCol * len(groups))()
+        built = []
+        for d, g in zip(descs, groups):
+            keys, counts, max_count = g.table
+            keys, counts = keys.contiguous(), counts.contiguous()
+            start = opts[g.name][0] + OOV_OFFSET
+            tab = K.EncodeTable(keys, start, unique=True, defer_build=True)
+            tab.fill_vocab_desc(d, counts, max_count)
+            built.append((g, keys, counts, tab, start))
+        K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
+                "nvt_vocab_finalize_many")
+        for g, keys, counts, tab, start in built:
+            tab.sort_tmp = None  # scratch: consumed by the calls enqueued above (stream-ordered)
+            self._encoders[g.name] = _SingleEncoder(tab, start)
+            n = int(counts.numel())
+            final = dict(
+                name=g.name, cols=list(g.cols), combo=False, keys=[keys], null_mask=None,
+                counts=counts, strings=None, start=start, oov_count=opts[g.name][0], oov_size=0,
+                unique_count=n, unique_size=int(g.valid_rows), null_size=g.nulls,
+                empty_input=False, base=str(base),
+            )
+            if self.defer_artifacts:
+                self._pending[g.name] = final
+            else:
+                _write_artifacts(final)
+            paths[g.name] = "/".join([str(base), f"unique.{g.name}.parquet"])
 
     # -- vocabulary finalisation ------------------------------------------------
     def _finalize_single(self, g: _GroupFit, dist):
@@ -608,6 +642,7 @@ class Categorify(StatOperator):
             assert all(x in self.freq_threshold for x in col_selector.names)
         column_mapping = self.column_mapping(col_selector)
         out_dtype = torch.int32 if np.dtype(self.output_dtype) == np.dtype("int32") else torch.int64
+        batch = []  # single-vocabulary columns: encoded by ONE C call (nvt_encode_many)
         for name in column_mapping:
             try:
                 use_name = column_mapping.get(name, name)
@@ -621,9 +656,25 @@ class Categorify(StatOperator):
                 nb = _pick(self.num_buckets, storage_name) if self.num_buckets else None
                 enc = self._encoder_for(storage_name, cols, frame)
                 null_off = enc.first_label_in_file if self.single_table else NULL_OFFSET
-                new[name] = enc.encode(frame, cols, null_off, null_off + 1, nb or 0, out_dtype)
+                if isinstance(enc, _SingleEncoder):
+                    col = frame[cols[0]]
+                    if col.fill is not None:
+                        col = col.materialize()
+                    keys, valid = key_view(col)
+                    batch.append((name, col, (enc.table, keys, valid, null_off, null_off + 1,
+                                              nb or 0)))
+                else:
+                    new[name] = enc.encode(frame, cols, null_off, null_off + 1, nb or 0, out_dtype)
             except Exception as e:
                 raise RuntimeError(f"Failed to categorical encode column {name}") from e
+        if batch:
+            try:
+                outs = K.encode_many([item for _, _, item in batch], out_dtype)
+            except Exception as e:
+                names = [n for n, _, _ in batch]
+                raise RuntimeError(f"Failed to categorical encode column {names[0]}") from e
+            for (name, col, _), out in zip(batch, outs):
+                new[name] = DeviceColumn(out, None, col.offsets, None, None)
         return new.to_pandas() if was_pandas else new
 
     # --------------------------------------------------------------- schema --
@@ -799,19 +850,6 @@ class _ComboEncoder:
             all_null = isnull if all_null is None else (all_null & isnull)
         labels = torch.where(all_null, torch.full_like(labels, null_label), labels)
         return DeviceColumn(labels.to(out_dtype))
-
-
-def _record_vocab_streams(encoder, final, stream):
-    """Tensors created on a finalisation stream are later read on the main stream."""
-    tensors = []
-    if isinstance(encoder, _SingleEncoder):
-        tab = encoder.table
-        tensors += [tab.table, tab.sentinel_label, tab.vocab_keys]
-    if final:
-        tensors += list(final.get("keys") or []) + [final.get("counts"), final.get("null_mask")]
-    for t in tensors:
-        if isinstance(t, torch.Tensor) and t.is_cuda:
-            t.record_stream(stream)
 
 
 def _build_encoder(keys, null_mask, first_label, combo, unique=True):

@@ -48,13 +48,11 @@ def moments_begin(names):
 
 
 def moments_partition(state: _MomentState, frame):
-    dev = None
-    for i, name in enumerate(state.names):
-        col = frame[name]
-        if state.acc is None:
-            dev = col.data.device
-            state.acc = torch.zeros(len(state.names), 3, dtype=torch.float64, device=dev)
-        K.moments_accumulate(col.data, col.valid, state.acc[i], fill=col.fill)
+    cols = [frame[name] for name in state.names]
+    if state.acc is None and cols:
+        state.acc = torch.zeros(len(state.names), 3, dtype=torch.float64, device=cols[0].data.device)
+    # every column of the partition in ONE launch (nvt_moments_many)
+    K.moments_many([(c.data, c.valid, c.fill, state.acc[i]) for i, c in enumerate(cols)])
 
 
 def moments_end(state: _MomentState):
@@ -104,12 +102,16 @@ class Normalize(StatOperator):
 
         new = DeviceFrame()
         out_dt = torch_dtype(self.output_dtype)
+        items, cols = [], []
         for name in col_selector.names:
             col = frame[name]
             std = self.stds[name]
             scale = std if std > 0 else 0.0  # normalize.py:79-82: std == 0 -> x - mean
             data = col.data.view(torch.uint8) if col.data.dtype == torch.bool else col.data
-            out, _ = K.fill_normalize(data, col.valid, col.fill, True, self.means[name], scale, out_dt)
+            items.append((data, col.valid, col.fill, True, self.means[name], scale, out_dt, False))
+            cols.append((name, col))
+        # FillMissing + Normalize of every column in ONE launch (nvt_fill_normalize_many)
+        for (name, col), (out, _) in zip(cols, K.fill_normalize_many(items)):
             new[name] = DeviceColumn(out, None, col.offsets)
         return new.to_pandas() if was_pandas else new
 

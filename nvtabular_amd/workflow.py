@@ -22,6 +22,7 @@ import pandas as pd
 
 from . import dist
 from .device import DeviceFrame, as_device_frame
+from .kernels import annotate
 from .io import Dataset
 from .node import Node, iter_nodes
 from .ops.base import StatOperator
@@ -84,7 +85,8 @@ class Workflow:
             out = root[node.output_schema.column_names]
         else:
             inp = self._node_input(node, root, cache)
-            out = node.op.transform(node.input_columns, inp)
+            with annotate(node.op.range_name("transform")):
+                out = node.op.transform(node.input_columns, inp)
             out, _ = as_device_frame(out)
             names = node.output_schema.column_names
             if all(n in out for n in names):
@@ -187,9 +189,16 @@ class Workflow:
                 cache: Dict[int, DeviceFrame] = {}
                 for n in phase:
                     inp = self._node_input(n, part, cache)
-                    n.op.fit_partition(states[id(n)], n.input_columns, inp)
-            for n in phase:
-                n.op.fit_finalize(n.op.fit_end(states[id(n)], n.input_columns))
+                    with annotate(n.op.range_name("fit")):
+                        n.op.fit_partition(states[id(n)], n.input_columns, inp)
+            # operators whose fit_end only reads a few scalars back (Normalize) go first: their
+            # read-back is the step's one host synchronisation, and Categorify's fit_end (which
+            # finds its counts already complete) then enqueues the vocabulary sorts and table
+            # builds with nothing between them and the transform kernels that follow.
+            # (stable sort: the order is the same on every rank, as the collectives need)
+            for n in sorted(phase, key=lambda n: getattr(n.op, "fit_end_priority", 0)):
+                with annotate(n.op.range_name("fit")):
+                    n.op.fit_finalize(n.op.fit_end(states[id(n)], n.input_columns))
                 fitted.add(id(n))
         # properties such as embedding sizes depend on the fitted state: refreshed lazily
         self._stale_schema_root = dataset.schema
