@@ -242,6 +242,21 @@ def pmc_traffic(name):
         return None
 
 
+def _host_timeline(marks):
+    """min / median / max over the timed steps of: step period, time inside fit (includes the
+    step's host synchronisation) and time to enqueue transform."""
+    if len(marks) < 2:
+        return None
+
+    def stats(v):
+        v = sorted(v)
+        return [round(1e3 * v[0], 3), round(1e3 * v[len(v) // 2], 3), round(1e3 * v[-1], 3)]
+
+    period = [marks[i + 1][0] - marks[i][0] for i in range(len(marks) - 1)]
+    return {"step_period": stats(period), "fit": stats([b - a for a, b, _ in marks]),
+            "transform_enqueue": stats([c - b for _, b, c in marks])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,9 +328,15 @@ def main():
     wf = build_workflow(cat_names, cont_names, os.path.join(tmp, f"gpu{rank}"))
     ds = nvt.Dataset(frame)
 
+    marks = []  # host clock at (step start, fit returned, transform enqueued): where a slow
+                # step spends its time (fit contains the step's one host synchronisation)
+
     def step():
+        t_a = time.perf_counter()
         wf.fit(ds)
+        t_b = time.perf_counter()
         out = wf.transform(frame)
+        marks.append((t_a, t_b, time.perf_counter()))
         return out
 
     def barrier():
@@ -339,11 +360,13 @@ def main():
     gc.disable()  # no collector pauses inside the timed region
     # ---- timed region: exactly `steps` steps, no per-kernel instrumentation ----
     barrier()
+    del marks[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    timed_marks = list(marks)
     # ---- second pass, same steps, HIP events on every kernel family (inside the library,
     # on the launch streams): per-kernel durations, GPU-busy time.  Not the number of record.
     barrier()
@@ -401,6 +424,7 @@ def main():
         "gpu_busy_ms_per_step": round(rep["busy_ms"] / args.steps, 3),
         "profiled_pass_ms_per_step": round(1e3 * dt_prof / args.steps, 3),
         "cold_step_ms": round(cold_ms, 2),
+        "host_timeline_ms": _host_timeline(timed_marks),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

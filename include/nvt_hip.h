@@ -332,6 +332,10 @@ typedef struct nvt_vocab_col {
   void *table;              /* encode table to build, or NULL                    */
   uint64_t capacity;
   int64_t *sentinel_label;
+  void *ready_event;        /* optional nvt_event: recorded behind this vocabulary's last
+                             * kernel INSTEAD of joining its stream into `stream`; whoever
+                             * reads the vocabulary / table next waits on it
+                             * (nvt_encode_col.wait_event, nvt_stream_wait_event)        */
 } nvt_vocab_col;
 int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, void *stream);
 
@@ -350,8 +354,38 @@ typedef struct nvt_encode_col {
   const void *vocab_keys;
   uint64_t n_vocab;
   int64_t first_label;
+  void *wait_event;         /* optional nvt_event the launch waits for (stream-side)     */
 } nvt_encode_col;
 int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream);
+
+/* Stream-ordered hand-off between nvt_vocab_finalize_many (which orders the large
+ * vocabularies on internal streams) and the calls that consume a vocabulary: with a
+ * ready_event per vocabulary the caller's stream is NOT blocked until every sort and table
+ * build has finished -- FillMissing + Normalize.transform and the encodes of the small
+ * vocabularies run underneath the radix passes of the large ones.  An nvt_event is an
+ * opaque handle (a hipEvent_t without timing). */
+int nvt_event_create(void **event);
+void nvt_event_destroy(void *event);
+int nvt_stream_wait_event(void *stream, void *event);
+
+/* ---- device -> host read-back of a few words without a blocking runtime wait ----------
+ * The fit needs two tiny read-backs per partition (the counting kernels' state words, the
+ * moments).  A hipMemcpy + stream synchronise blocks the host thread in an interrupt-driven
+ * wait; on some hosts that wake-up was observed to cost ~10 ms per wait (a 20 ms step became
+ * 39 ms with identical kernel times).  A mailbox is coherent, device-mapped pinned host
+ * memory: nvt_mailbox_post enqueues ONE small kernel that copies `bytes` (multiple of 8) from
+ * device memory into the mailbox and then stores a sequence number with system scope;
+ * nvt_mailbox_wait spins on that word on the host (no interrupt, no runtime call) and returns
+ * NVT_OK when it reaches `seq` (NVT_EHIP after timeout_s seconds).  nvt_mailbox_data is the
+ * host pointer of the payload. */
+typedef struct nvt_mailbox nvt_mailbox;
+int nvt_mailbox_create(uint64_t bytes, nvt_mailbox **out);
+void nvt_mailbox_destroy(nvt_mailbox *mb);
+void *nvt_mailbox_data(nvt_mailbox *mb);
+uint64_t nvt_mailbox_capacity(nvt_mailbox *mb);
+int nvt_mailbox_post(nvt_mailbox *mb, const void *src_device, uint64_t bytes, void *stream,
+                     uint64_t *seq_out);
+int nvt_mailbox_wait(nvt_mailbox *mb, uint64_t seq, double timeout_s);
 
 /* ---- instrumentation ------------------------------------------------------------------
  * HIP-event timing of every kernel family, recorded on the stream the kernels are launched

@@ -104,14 +104,15 @@ class VocabCol(C.Structure):
     _fields_ = [("keys", _vp), ("counts", _vp), ("n", _u64), ("max_count", _i64),
                 ("key_bytes", C.c_int32), ("unique_keys", C.c_int32), ("sort_tmp", _vp),
                 ("first_label", _i64), ("table", _vp), ("capacity", _u64),
-                ("sentinel_label", _vp)]
+                ("sentinel_label", _vp), ("ready_event", _vp)]
 
 
 class EncodeCol(C.Structure):
     _fields_ = [("keys", _vp), ("valid", _vp), ("n", _u64), ("table", _vp), ("capacity", _u64),
                 ("sentinel_label", _vp), ("null_label", _i64), ("oov_label", _i64),
                 ("num_buckets", _u32), ("key_bytes", C.c_int32), ("out_bytes", C.c_int32),
-                ("out", _vp), ("vocab_keys", _vp), ("n_vocab", _u64), ("first_label", _i64)]
+                ("out", _vp), ("vocab_keys", _vp), ("n_vocab", _u64), ("first_label", _i64),
+                ("wait_event", _vp)]
 
 
 SIGNATURES.update({
@@ -120,6 +121,15 @@ SIGNATURES.update({
     "nvt_dense_count_many": [C.POINTER(CountCol), _i32, _vp],
     "nvt_vocab_finalize_many": [C.POINTER(VocabCol), _i32, _vp],
     "nvt_encode_many": [C.POINTER(EncodeCol), _i32, _vp],
+    "nvt_event_create": [_pp],
+    "nvt_event_destroy": [_vp],
+    "nvt_stream_wait_event": [_vp, _vp],
+    "nvt_mailbox_create": [_u64, _pp],
+    "nvt_mailbox_destroy": [_vp],
+    "nvt_mailbox_data": [_vp],
+    "nvt_mailbox_capacity": [_vp],
+    "nvt_mailbox_post": [_vp, _vp, _u64, _vp, C.POINTER(_u64)],
+    "nvt_mailbox_wait": [_vp, _u64, _dbl],
     "nvt_prof_begin": [],
     "nvt_prof_report": [C.c_char_p, _u64, C.POINTER(_u64)],
     "nvt_range_push": [C.c_char_p],
@@ -132,6 +142,10 @@ _RESTYPES = {
     "nvt_gb_destroy": None,
     "nvt_range_push": None,
     "nvt_range_pop": None,
+    "nvt_event_destroy": None,
+    "nvt_mailbox_destroy": None,
+    "nvt_mailbox_data": C.c_void_p,
+    "nvt_mailbox_capacity": C.c_uint64,
 }
 
 _lock = threading.Lock()

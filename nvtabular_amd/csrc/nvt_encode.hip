@@ -630,6 +630,8 @@ int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
   for (int i = 0; i < ncols; ++i) {
     const nvt_encode_col &c = cols[i];
     int rc;
+    if (c.wait_event)
+      NVT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)c.wait_event, 0));
     if (c.key_bytes == 4)
       rc = encode_launch<int32_t>((const int32_t *)c.keys, c.valid, c.n, c.table, c.capacity,
                                   c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,

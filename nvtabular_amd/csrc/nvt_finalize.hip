@@ -12,6 +12,7 @@
 //     joined into the caller's stream, so their short tail kernels overlap;
 //   * every table build follows its sort on the same stream.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -79,22 +80,24 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
     NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
     for (int i = 0; i < kSide; ++i) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[i], pool->fork, 0));
   }
+  // with a ready_event the vocabulary's stream is not joined into `stream`: the event is
+  // recorded behind its last kernel and the consumer waits on it
+  bool need_join = false;
   auto finish = [&](const nvt_vocab_col &c, hipStream_t s) -> int {
-    if (c.table == nullptr) return NVT_OK;
-    return encode_build_any(c.key_bytes, c.keys, c.n, c.first_label, c.table, c.capacity,
-                            c.sentinel_label, c.unique_keys, s);
-  };
-  for (size_t j = 0; j < big.size(); ++j) {
-    const nvt_vocab_col &c = cols[big[j]];
-    hipStream_t s = fork ? pool->s[j % kSide] : main_s;
-    if (c.n > 1) {
-      NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
-      int rc = vocab_sort_any(c.key_bytes, c.keys, c.counts, c.n, c.max_count, c.sort_tmp, s);
+    if (c.table != nullptr) {
+      int rc = encode_build_any(c.key_bytes, c.keys, c.n, c.first_label, c.table, c.capacity,
+                                c.sentinel_label, c.unique_keys, s);
       if (rc) return rc;
     }
-    int rc = finish(c, s);
-    if (rc) return rc;
-  }
+    if (c.ready_event) {
+      NVT_CHECK_HIP(hipEventRecord((hipEvent_t)c.ready_event, s));
+      if (s != main_s && getenv("NVT_FLUSH_QUERY")) (void)hipStreamQuery(s);
+    } else if (s != main_s)
+      need_join = true;
+    return NVT_OK;
+  };
+  // the small vocabularies first, on the caller's stream: their one-workgroup-per-vocabulary
+  // kernel needs a whole CU's LDS and would otherwise wait until the radix passes drain
   if (!small.empty()) {
     std::vector<SmallSortDesc> d(small.size());
     for (size_t j = 0; j < small.size(); ++j) {
@@ -110,11 +113,39 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
       if (rc) return rc;
     }
   }
-  if (fork) {
+  for (size_t j = 0; j < big.size(); ++j) {
+    const nvt_vocab_col &c = cols[big[j]];
+    hipStream_t s = fork ? pool->s[j % kSide] : main_s;
+    if (c.n > 1) {
+      NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
+      int rc = vocab_sort_any(c.key_bytes, c.keys, c.counts, c.n, c.max_count, c.sort_tmp, s);
+      if (rc) return rc;
+    }
+    int rc = finish(c, s);
+    if (rc) return rc;
+  }
+  if (fork && need_join) {
     for (int i = 0; i < kSide; ++i) {
       NVT_CHECK_HIP(hipEventRecord(pool->join[i], pool->s[i]));
       NVT_CHECK_HIP(hipStreamWaitEvent(main_s, pool->join[i], 0));
     }
   }
+  return NVT_OK;
+}
+
+extern "C" int nvt_event_create(void **event) {
+  NVT_CHECK_ARG(event, "null out pointer");
+  hipEvent_t e = nullptr;
+  NVT_CHECK_HIP(hipEventCreateWithFlags(&e, getenv("NVT_EVENT_TIMING") ? hipEventDefault
+                                                                        : hipEventDisableTiming));
+  *event = (void *)e;
+  return NVT_OK;
+}
+extern "C" void nvt_event_destroy(void *event) {
+  if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+extern "C" int nvt_stream_wait_event(void *stream, void *event) {
+  NVT_CHECK_ARG(event, "null event");
+  NVT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
   return NVT_OK;
 }

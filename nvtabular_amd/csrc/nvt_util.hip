@@ -1,6 +1,7 @@
 // Error reporting, version, and launch-side instrumentation (HIP-event profiler + roctx
 // ranges) of the C ABI (include/nvt_hip.h).
 #include <dlfcn.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -102,9 +103,83 @@ void roctx_pop() {
 }
 }  // namespace nvt
 
+// ---- mailbox: device -> host read-back through coherent pinned memory + host spin ---------
+struct nvt_mailbox {
+  char *host;        // [64-byte header: seq word | payload]
+  uint64_t bytes;    // payload capacity
+  uint64_t next_seq;
+};
+
+namespace nvt {
+__global__ __launch_bounds__(256) void mailbox_post_kernel(const uint64_t *__restrict__ src,
+                                                           uint64_t *dst, uint64_t nwords,
+                                                           uint64_t *flag, uint64_t seq) {
+  for (uint64_t i = threadIdx.x; i < nwords; i += 256) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace nvt
+
 using namespace nvt;
 
 extern "C" {
+int nvt_mailbox_create(uint64_t bytes, nvt_mailbox **out) {
+  NVT_CHECK_ARG(out, "null out pointer");
+  bytes = (bytes + 7) & ~7ull;
+  void *p = nullptr;
+  NVT_CHECK_HIP(hipHostMalloc(&p, bytes + 64, hipHostMallocCoherent | hipHostMallocMapped));
+  memset(p, 0, bytes + 64);
+  nvt_mailbox *mb = new nvt_mailbox{(char *)p, bytes, 1};
+  *out = mb;
+  return NVT_OK;
+}
+void nvt_mailbox_destroy(nvt_mailbox *mb) {
+  if (!mb) return;
+  (void)hipHostFree(mb->host);
+  delete mb;
+}
+void *nvt_mailbox_data(nvt_mailbox *mb) { return mb ? mb->host + 64 : nullptr; }
+uint64_t nvt_mailbox_capacity(nvt_mailbox *mb) { return mb ? mb->bytes : 0; }
+int nvt_mailbox_post(nvt_mailbox *mb, const void *src_device, uint64_t bytes, void *stream,
+                     uint64_t *seq_out) {
+  NVT_CHECK_ARG(mb && src_device && seq_out, "null pointer");
+  NVT_CHECK_ARG(bytes % 8 == 0 && bytes <= mb->bytes, "bytes must be a multiple of 8 within capacity");
+  NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(src_device) & 7) == 0, "source must be 8-byte aligned");
+  const uint64_t seq = mb->next_seq++;
+  void *dev = nullptr;  // device-side address of the mapped host buffer
+  NVT_CHECK_HIP(hipHostGetDevicePointer(&dev, mb->host, 0));
+  mailbox_post_kernel<<<1, 256, 0, (hipStream_t)stream>>>(
+      (const uint64_t *)src_device, (uint64_t *)((char *)dev + 64), bytes / 8, (uint64_t *)dev, seq);
+  NVT_CHECK_LAUNCH();
+  *seq_out = seq;
+  return NVT_OK;
+}
+int nvt_mailbox_wait(nvt_mailbox *mb, uint64_t seq, double timeout_s) {
+  NVT_CHECK_ARG(mb, "null mailbox");
+  const volatile uint64_t *flag = reinterpret_cast<const volatile uint64_t *>(mb->host);
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (uint64_t spins = 0;; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq) return NVT_OK;
+    if ((spins & 0xFFF) == 0xFFF) {
+      timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+      if (dt > timeout_s) {
+        // a failed launch never writes the word: report it instead of spinning forever
+        hipError_t e = hipPeekAtLastError();
+        set_error("nvt_mailbox_wait: sequence %llu not reached after %.1f s (%s)",
+                  (unsigned long long)seq, dt, hipGetErrorString(e));
+        return NVT_EHIP;
+      }
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
+
 int nvt_version(void) { return 200; }  // 0.2.0
 const char *nvt_last_error(void) { return nvt::g_err; }
 

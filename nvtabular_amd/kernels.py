@@ -78,6 +78,65 @@ class annotate:
         return False
 
 
+class Event:
+    """Opaque nvt_event (a HIP event without timing): recorded by the library behind the last
+    kernel that produces an object on one of its internal streams, waited for -- on the stream,
+    never on the host -- by whoever consumes the object next."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(_lib.load().nvt_event_create(C.byref(h)), "nvt_event_create")
+        self.handle = h
+
+    def wait(self, stream: Optional[int] = None):
+        check(_lib.load().nvt_stream_wait_event(stream_ptr() if stream is None else stream,
+                                                self.handle), "nvt_stream_wait_event")
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                _lib.load().nvt_event_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+
+_mailboxes = {}
+
+
+def read_back(t: torch.Tensor):
+    """Small device tensor (int64 / float64) -> numpy array on the host WITHOUT a blocking
+    runtime wait: one tiny kernel copies it into coherent pinned memory and the host spins on
+    a sequence word (nvt_mailbox_*; include/nvt_hip.h explains why).  Stream-ordered behind
+    everything queued on the current stream, like ``t.cpu()``."""
+    import numpy as np
+
+    assert t.is_cuda and t.element_size() == 8
+    if os.environ.get("NVT_READBACK", "mailbox") == "memcpy":
+        return t.cpu().numpy()
+    lib = _lib.load()
+    t = t.contiguous()
+    nbytes = t.numel() * 8
+    key = (t.device.index, stream_ptr())
+    mb = _mailboxes.get(key)
+    if mb is None or lib.nvt_mailbox_capacity(mb) < nbytes:
+        if mb is not None:
+            lib.nvt_mailbox_destroy(mb)
+        h = C.c_void_p()
+        check(lib.nvt_mailbox_create(max(1 << 16, 2 * nbytes), C.byref(h)), "nvt_mailbox_create")
+        mb = _mailboxes[key] = h
+    if nbytes == 0:
+        return np.empty(t.shape, dtype=np.int64 if t.dtype == torch.int64 else np.float64)
+    seq = C.c_uint64()
+    check(lib.nvt_mailbox_post(mb, t.data_ptr(), nbytes, stream_ptr(), C.byref(seq)),
+          "nvt_mailbox_post")
+    check(lib.nvt_mailbox_wait(mb, seq.value, 120.0), "nvt_mailbox_wait")
+    np_dt = {torch.int64: np.int64, torch.float64: np.float64}[t.dtype]
+    buf = (C.c_char * nbytes).from_address(lib.nvt_mailbox_data(mb))
+    return np.frombuffer(buf, dtype=np_dt).reshape(tuple(t.shape)).copy()
+
+
 class _timed:
     """Former Python-side event bracket; timing now lives in the library (NVT_PROF scopes)."""
 
@@ -474,7 +533,7 @@ class CountBatch:
     def results(self):
         if self._results is None:
             while self.pending:
-                host = self.states.cpu().tolist()  # the single synchronisation point
+                host = read_back(self.states).tolist()  # the single synchronisation point
                 self.pending = [j for i, j in enumerate(self.pending) if not j.resolve(host[i])]
                 self._launch()
             self._results = [j.result for j in self.jobs]
@@ -562,6 +621,7 @@ def vocab_sort(keys: torch.Tensor, counts: torch.Tensor, max_count: int = 0):
 # --------------------------------------------------------------------------
 ENCODE_RESIDENT_I32, ENCODE_RESIDENT_I64 = 12288, 6144  # include/nvt_hip.h
 _ENC_BYTES = {}   # (key_bytes, capacity) -> nvt_encode_table_bytes
+ASYNC_FINALIZE = os.environ.get("NVT_ASYNC_FINALIZE", "1") != "0"
 _SORT_BYTES = {}  # (key_bytes, n) -> nvt_vocab_sort_tmp_bytes
 
 
@@ -589,6 +649,8 @@ class EncodeTable:
         resident = ENCODE_RESIDENT_I32 if self.key_bytes == 4 else ENCODE_RESIDENT_I64
         self.table = self.sentinel_label = None
         self.sort_tmp = None
+        self.ready = None      # Event recorded behind the sort / build on an internal stream
+        self.pending = False   # True until the current stream has been made to wait for it
         if unique and 0 < self.n_vocab <= resident:
             return
         key = (self.key_bytes, self.capacity)
@@ -635,6 +697,31 @@ class EncodeTable:
         d.table = ptr(self.table)
         d.capacity = self.capacity
         d.sentinel_label = ptr(self.sentinel_label)
+        if n > 1 and not small and ASYNC_FINALIZE:
+            # ordered on an internal stream: hand-off by event instead of a stream join, so the
+            # caller's stream keeps working (fill + normalize, encodes of the small vocabularies)
+            # underneath this vocabulary's radix passes and table build
+            if self.ready is None:
+                self.ready = Event()
+            d.ready_event = self.ready.handle
+            self.pending = True
+        else:
+            d.ready_event = None
+
+    def wait_ready(self):
+        """Order the CURRENT stream behind this vocabulary's sort / table build (no host
+        synchronisation).  Every consumer of the vocabulary or the table calls this first."""
+        if self.pending:
+            self.ready.wait()
+            self.pending = False
+            self.sort_tmp = None  # scratch of the finished sort: safe to recycle from here on
+
+    def __del__(self):
+        try:
+            if getattr(self, "pending", False):
+                self.wait_ready()  # the buffers are about to be recycled on this stream
+        except Exception:
+            pass
 
     def fill_encode_desc(self, d: "_lib.EncodeCol", keys, valid, null_label, oov_label,
                          num_buckets, out):
@@ -653,6 +740,12 @@ class EncodeTable:
         d.vocab_keys = ptr(self.vocab_keys) if self.n_vocab else None
         d.n_vocab = self.n_vocab if self.vocab_keys is not None else 0
         d.first_label = self.first_label
+        if self.pending:
+            d.wait_event = self.ready.handle  # nvt_encode_many waits on the launch stream
+            self.pending = False
+            self.sort_tmp = None
+        else:
+            d.wait_event = None
 
     def encode(
         self,
@@ -663,6 +756,7 @@ class EncodeTable:
         num_buckets: int = 0,
         out_dtype: torch.dtype = torch.int64,
     ) -> torch.Tensor:
+        self.wait_ready()
         if keys.dtype != self.key_dtype:
             keys = keys.to(self.key_dtype)
         keys = aligned(keys)
@@ -689,15 +783,20 @@ def encode_many(items, out_dtype: torch.dtype = torch.int64):
     every column of a Categorify.transform enqueued by ONE C call (nvt_encode_many)."""
     if out_dtype not in (torch.int32, torch.int64):
         raise TypeError("Categorify output dtype must be int32 or int64")
+    # vocabularies still being ordered on an internal stream go last, largest first (the order
+    # nvt_vocab_finalize_many works through them): everything that is ready runs underneath
+    order = sorted(range(len(items)),
+                   key=lambda i: (1, -items[i][0].n_vocab) if items[i][0].pending else (0, 0))
     descs = (_lib.EncodeCol * max(1, len(items)))()
-    outs, keep = [], []
-    for d, (tab, keys, valid, null_label, oov_label, nb) in zip(descs, items):
+    outs, keep = [None] * len(items), []
+    for d, i in zip(descs, order):
+        tab, keys, valid, null_label, oov_label, nb = items[i]
         if keys.dtype != tab.key_dtype:
             keys = keys.to(tab.key_dtype)
         keys = aligned(keys)
         out = torch.empty(keys.numel(), dtype=out_dtype, device=keys.device)
         tab.fill_encode_desc(d, keys, valid, null_label, oov_label, nb, out)
-        outs.append(out)
+        outs[i] = out
         keep.append(keys)
     if items:
         check(_lib.load().nvt_encode_many(descs, len(items), stream_ptr()), "nvt_encode_many")

@@ -50,6 +50,12 @@ class Operator:
     def label(self):
         return self.__class__.__name__
 
+    @property
+    def async_pending(self) -> bool:
+        """True while results of this operator's fit are still being produced on the library's
+        internal streams (Categorify): the executor schedules independent branches first."""
+        return False
+
     def range_name(self, kind: str) -> str:
         """roctx range name = the reference's @annotate string for this operator
         (e.g. normalize.py:61,70 "Normalize_fit" / "Normalize_op")."""

@@ -373,14 +373,15 @@ class Categorify(StatOperator):
         K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
                 "nvt_vocab_finalize_many")
         for g, keys, counts, tab, start in built:
-            tab.sort_tmp = None  # scratch: consumed by the calls enqueued above (stream-ordered)
+            if not tab.pending:
+                tab.sort_tmp = None  # scratch of work already ordered on this stream
             self._encoders[g.name] = _SingleEncoder(tab, start)
             n = int(counts.numel())
             final = dict(
                 name=g.name, cols=list(g.cols), combo=False, keys=[keys], null_mask=None,
                 counts=counts, strings=None, start=start, oov_count=opts[g.name][0], oov_size=0,
                 unique_count=n, unique_size=int(g.valid_rows), null_size=g.nulls,
-                empty_input=False, base=str(base),
+                empty_input=False, base=str(base), table=tab,
             )
             if self.defer_artifacts:
                 self._pending[g.name] = final
@@ -521,8 +522,29 @@ class Categorify(StatOperator):
 
     def clear(self):
         self.categories = deepcopy(self.vocabs)
+        for enc in self._encoders.values():
+            tab = getattr(enc, "table", None)
+            if tab is not None:
+                tab.wait_ready()  # its buffers are recycled on this stream from here on
         self._encoders = {}
         self._pending = {}
+
+    def fitted_vocabulary(self, name: str):
+        """(keys: list of device tensors, counts: device tensor) of a fitted vocabulary, in label
+        order, safe to read on the current stream (waits for work still in flight on the
+        library's internal streams).  Only available while the fit's device state is kept
+        (``defer_artifacts=True`` or before the next ``clear``)."""
+        final = self._pending[name]
+        if final.get("table") is not None:
+            final["table"].wait_ready()
+        return final["keys"], final["counts"]
+
+    @property
+    def async_pending(self) -> bool:
+        """Vocabularies still being ordered on the library's internal streams: the executor
+        runs the other branches of the graph first (workflow.py)."""
+        return any(getattr(getattr(e, "table", None), "pending", False)
+                   for e in self._encoders.values())
 
     def process_vocabs(self, vocabs):
         """categorify.py:421-454"""
@@ -734,6 +756,8 @@ def _write_artifacts(final):
     <name>_size; RangeIndex = label) and meta.<name>.parquet."""
     name, base, start = final["name"], final["base"], final["start"]
     keys, nm, counts = final["keys"], final["null_mask"], final["counts"]
+    if final.get("table") is not None:
+        final["table"].wait_ready()  # ordered on an internal stream: wait before reading back
     unique_path = "/".join([base, f"unique.{name}.parquet"])
     meta_path = "/".join([base, f"meta.{name}.parquet"])
     combo = final["combo"]

@@ -64,7 +64,7 @@ def moments_end(state: _MomentState):
         acc = torch.zeros(len(state.names), 3, dtype=torch.float64,
                           device=torch.device("cuda", torch.cuda.current_device()))
     acc = dist.all_reduce_sum(acc)
-    host = acc.cpu().tolist()
+    host = K.read_back(acc).tolist()
     out = {}
     for name, (n, s, s2) in zip(state.names, host):
         mean, var, std = finalize_moments(n, s, s2)

@@ -98,7 +98,12 @@ class Workflow:
         upstream = node.parents_with_dependencies
         lanes = self._branch_streams(upstream, cache)
         if lanes is None:
-            ups = [self._run(u, root, cache) for u in upstream]
+            # branches whose operators still have fit results in flight on internal streams
+            # (Categorify's large vocabularies) are evaluated last: the kernels of the other
+            # branches run underneath that work.  The column order of the result is unchanged.
+            order = sorted(range(len(upstream)), key=lambda i: _async_pending(upstream[i]))
+            done = {i: self._run(upstream[i], root, cache) for i in order}
+            ups = [done[i] for i in range(len(upstream))]
         else:
             # Independent branches (e.g. the Categorify and the FillMissing >> Normalize halves
             # of the Criteo workflow) run on different HIP streams: an encode workgroup holds
@@ -302,6 +307,10 @@ class Workflow:
         for node in iter_nodes(self.output_node):
             if isinstance(node.op, StatOperator):
                 node.op.clear()
+
+
+def _async_pending(node: Node) -> bool:
+    return any(n.op is not None and n.op.async_pending for n in iter_nodes(node))
 
 
 def _stat_ancestors(node: Node) -> List[Node]:

@@ -50,7 +50,8 @@ def test_criteo_day0_full_size_properties(tmp_path):
     vocabs = {}
     for c in cats:
         final = cat_op._pending[c]
-        keys, counts = final["keys"][0], final["counts"]
+        ks, counts = cat_op.fitted_vocabulary(c)  # waits for sorts still on internal streams
+        keys = ks[0]
         vocabs[c] = (keys.clone(), counts.clone())
         col = frame[c]
         ok = _valid_mask(col, ROWS)
@@ -89,9 +90,9 @@ def test_criteo_day0_full_size_properties(tmp_path):
     # idempotence: a refit (now with learned cardinality hints -> other kernel paths) agrees
     wf.fit(ds)
     for c in cats:
-        final = cat_op._pending[c]
-        assert torch.equal(final["keys"][0], vocabs[c][0]), c
-        assert torch.equal(final["counts"], vocabs[c][1]), c
+        ks, counts = cat_op.fitted_vocabulary(c)
+        assert torch.equal(ks[0], vocabs[c][0]), c
+        assert torch.equal(counts, vocabs[c][1]), c
 
 
 @pytest.mark.timeout(600)
@@ -157,8 +158,8 @@ def test_cfg5_multihot_lists_categorify_hashbucket(tmp_path):
     out = wf.transform(frame)
     assert torch.equal(out["tags"].offsets, offsets) and torch.equal(out["tags_h"].offsets, offsets)
     lab = out["tags"].data
-    final = cat._pending["tags"]
-    keys, counts = final["keys"][0], final["counts"]
+    ks, counts = cat.fitted_vocabulary("tags")
+    keys = ks[0]
     true_cnt = torch.zeros(card, dtype=torch.int64, device=dev).index_add_(
         0, raw, torch.ones(total, dtype=torch.int64, device=dev))
     frequent = true_cnt[raw] >= thr
