@@ -172,13 +172,15 @@ int nvt_encode_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, const 
                    const int64_t *vocab_keys, uint64_t n_vocab, int64_t first_label, void *stream);
 
 /* ---- HashBucket / hashed OOV buckets: out[i] = h32(key) % num_buckets (int32);
+ * a null row (valid bit clear) hashes as key 0 whatever bytes its slot holds (Arrow leaves the
+ * values under a null undefined; the pandas path hashes fillna(0)).
  * xor_in (optional, uint64 per row) is XORed into the 64-bit hash first and
  * xor_out (optional) receives the 64-bit hash -- the "combo" XOR chain of
  * categorify.py:1846-1851 */
-int nvt_hash_bucket_i32(const int32_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
-                        const uint64_t *xor_in, uint64_t *xor_out, void *stream);
-int nvt_hash_bucket_i64(const int64_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
-                        const uint64_t *xor_in, uint64_t *xor_out, void *stream);
+int nvt_hash_bucket_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, uint32_t num_buckets,
+                        int32_t *out, const uint64_t *xor_in, uint64_t *xor_out, void *stream);
+int nvt_hash_bucket_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, uint32_t num_buckets,
+                        int32_t *out, const uint64_t *xor_in, uint64_t *xor_out, void *stream);
 
 /* ---- Normalize.fit (_chunkwise_moments): out[3] (double, device) += {count, sum, sum of
  * squares} over non-null rows; with has_fill, nulls count as fill_val (FillMissing

@@ -58,8 +58,8 @@ SIGNATURES = {
                        _vp],
     "nvt_encode_i64": [_vp, _vp, _u64, _vp, _u64, _vp, _i64, _i64, _u32, _vp, _i32, _vp, _u64, _i64,
                        _vp],
-    "nvt_hash_bucket_i32": [_vp, _u64, _u32, _vp, _vp, _vp, _vp],
-    "nvt_hash_bucket_i64": [_vp, _u64, _u32, _vp, _vp, _vp, _vp],
+    "nvt_hash_bucket_i32": [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp],
+    "nvt_hash_bucket_i64": [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp],
     "nvt_moments_scratch_bytes": [],
     "nvt_moments": [_vp, _i32, _vp, _u64, _i32, _dbl, _vp, _vp, _vp],
     "nvt_minmax": [_vp, _i32, _vp, _u64, _i32, _vp, _vp, _vp],

@@ -429,13 +429,16 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
 }
 
 template <typename K>
-__global__ __launch_bounds__(kBlock) void hash_bucket_kernel(const K *__restrict__ keys, uint64_t n,
-                                                             uint32_t nb, int32_t *__restrict__ out,
+__global__ __launch_bounds__(kBlock) void hash_bucket_kernel(const K *__restrict__ keys,
+                                                             const uint8_t *__restrict__ valid,
+                                                             uint64_t n, uint32_t nb,
+                                                             int32_t *__restrict__ out,
                                                              const uint64_t *__restrict__ xor_in,
                                                              uint64_t *__restrict__ xor_out) {
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    uint64_t h = key_hash64((int64_t)keys[i]);
+    // a null row hashes as key 0 whatever bytes its slot holds (Arrow leaves them undefined)
+    uint64_t h = key_hash64(bit_valid(valid, i) ? (int64_t)keys[i] : 0);
     if (xor_in) h ^= xor_in[i];
     if (xor_out) xor_out[i] = h;
     if (out) out[i] = (int32_t)((uint32_t)(h >> 32) % nb);
@@ -445,6 +448,7 @@ __global__ __launch_bounds__(kBlock) void hash_bucket_kernel(const K *__restrict
 // fast path: no XOR chain, vectorised
 template <typename K>
 __global__ __launch_bounds__(kBlock) void hash_bucket_vec_kernel(const K *__restrict__ keys,
+                                                                 const uint8_t *__restrict__ valid,
                                                                  uint64_t n, uint32_t nb,
                                                                  int32_t *__restrict__ out) {
   constexpr int VEC = EncTraits<K>::vec;
@@ -454,6 +458,16 @@ __global__ __launch_bounds__(kBlock) void hash_bucket_vec_kernel(const K *__rest
   const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
   for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
     VecT pack = vkeys[v];
+    if (valid != nullptr) {  // null rows hash as key 0
+      const uint64_t row = v * VEC;
+      const unsigned vb = (unsigned)valid[row >> 3] >> (row & 7);
+      if (!(vb & 1)) pack.x = 0;
+      if (!(vb & 2)) pack.y = 0;
+      if constexpr (sizeof(K) == 4) {
+        if (!(vb & 4)) pack.z = 0;
+        if (!(vb & 8)) pack.w = 0;
+      }
+    }
     if constexpr (sizeof(K) == 4) {
       int4 r;
       r.x = (int32_t)(key_hash32(pack.x) % nb);
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void hash_bucket_vec_kernel(const K *__rest
     }
   }
   for (uint64_t i = nvec * VEC + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
-    out[i] = (int32_t)(key_hash32((int64_t)keys[i]) % nb);
+    out[i] = (int32_t)(key_hash32(bit_valid(valid, i) ? (int64_t)keys[i] : 0) % nb);
 }
 
 template <typename K>
@@ -557,8 +571,8 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
 }
 
 template <typename K>
-int hash_bucket_launch(const K *keys, uint64_t n, uint32_t nb, int32_t *out, const uint64_t *xor_in,
-                       uint64_t *xor_out, hipStream_t s) {
+int hash_bucket_launch(const K *keys, const uint8_t *valid, uint64_t n, uint32_t nb, int32_t *out,
+                       const uint64_t *xor_in, uint64_t *xor_out, hipStream_t s) {
   NVT_CHECK_ARG(nb >= 1 && nb < (1u << 31), "num_buckets must be in [1, 2^31)");
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(keys && (out || xor_out), "null keys/out");
@@ -567,10 +581,10 @@ int hash_bucket_launch(const K *keys, uint64_t n, uint32_t nb, int32_t *out, con
   NVT_PROF("hash_bucket", n * (sizeof(K) + 4), s);
   if (!xor_in && !xor_out && aligned)
     hash_bucket_vec_kernel<K><<<stream_grid(n / EncTraits<K>::vec + 1, kBlock * 2), kBlock, 0, s>>>(
-        keys, n, nb, out);
+        keys, valid, n, nb, out);
   else
-    hash_bucket_kernel<K><<<stream_grid(n, kBlock * 4), kBlock, 0, s>>>(keys, n, nb, out, xor_in,
-                                                                       xor_out);
+    hash_bucket_kernel<K><<<stream_grid(n, kBlock * 4), kBlock, 0, s>>>(keys, valid, n, nb, out,
+                                                                       xor_in, xor_out);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
@@ -650,14 +664,14 @@ int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
   }
   return NVT_OK;
 }
-int nvt_hash_bucket_i32(const int32_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
-                        const uint64_t *xor_in, uint64_t *xor_out, void *stream) {
-  return hash_bucket_launch<int32_t>(keys, n, num_buckets, out, xor_in, xor_out,
+int nvt_hash_bucket_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, uint32_t num_buckets,
+                        int32_t *out, const uint64_t *xor_in, uint64_t *xor_out, void *stream) {
+  return hash_bucket_launch<int32_t>(keys, valid, n, num_buckets, out, xor_in, xor_out,
                                      (hipStream_t)stream);
 }
-int nvt_hash_bucket_i64(const int64_t *keys, uint64_t n, uint32_t num_buckets, int32_t *out,
-                        const uint64_t *xor_in, uint64_t *xor_out, void *stream) {
-  return hash_bucket_launch<int64_t>(keys, n, num_buckets, out, xor_in, xor_out,
+int nvt_hash_bucket_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, uint32_t num_buckets,
+                        int32_t *out, const uint64_t *xor_in, uint64_t *xor_out, void *stream) {
+  return hash_bucket_launch<int64_t>(keys, valid, n, num_buckets, out, xor_in, xor_out,
                                      (hipStream_t)stream);
 }
 

@@ -335,12 +335,33 @@ def merge_groups(comp: Dict, nkeys: int, nvals: int, sumsq=False, minmax=False) 
 
 
 def merge_string_luts(lut: Optional[dict]) -> Optional[dict]:
-    """Union of the per-rank {surrogate -> string} dictionaries (host objects)."""
-    if world_size() == 1 or lut is None:
+    """Union of the per-rank {surrogate -> string} dictionaries (host objects).
+
+    COLLECTIVE: with more than one rank every rank must call it for the same column, also a
+    rank whose shard was empty (lut None) -- it contributes an empty dictionary.  Returns None
+    only when no rank had strings."""
+    if world_size() == 1:
         return lut
     gathered = [None] * world_size()
     td.all_gather_object(gathered, lut)
+    if all(d is None for d in gathered):
+        return None
     out = {}
     for d in gathered:
         out.update(d or {})
     return out
+
+
+def barrier():
+    if world_size() > 1:
+        td.barrier()
+
+
+def is_first_rank_with(value) -> bool:
+    """True on the lowest rank among those that passed an equal ``value`` (host object;
+    collective).  Used to elect ONE writer per shared output directory."""
+    if world_size() == 1:
+        return True
+    gathered = [None] * world_size()
+    td.all_gather_object(gathered, value)
+    return gathered.index(value) == rank()

@@ -293,8 +293,8 @@ class Dataset:
             if dtypes:
                 for c, t in dtypes.items():
                     if c in table.column_names:
-                        i = table.column_names.index(c)
-                        table = table.set_column(i, c, table.column(c).cast(pa.from_numpy_dtype(np.dtype(t))))
+                        ci = table.column_names.index(c)  # NOT `i`: that is the partition index
+                        table = table.set_column(ci, c, table.column(c).cast(pa.from_numpy_dtype(np.dtype(t))))
             if k is None:
                 emit(i, table)
                 continue
@@ -394,38 +394,62 @@ def _prefetch_frames(host_parts, cols, depth: int = 2):
     side = torch.cuda.Stream(device=dev)
     q: "queue.Queue" = queue.Queue(maxsize=depth)
     _END = object()
+    stop = threading.Event()  # set when the consumer abandons the generator early
+
+    def put(item) -> bool:
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def producer():
         try:
             torch.cuda.set_device(dev)
             for part in host_parts:
+                if stop.is_set():
+                    return
                 with torch.cuda.stream(side):
                     frame, _ = as_device_frame(part, dev)
                     if cols is not None:
                         frame = frame[[c for c in cols if c in frame]]
                     ev = torch.cuda.Event()
                     ev.record(side)
-                q.put((frame, ev))
-            q.put(_END)
+                if not put((frame, ev)):
+                    return
+            put(_END)
         except BaseException as e:  # surface decode / copy errors in the consumer
-            q.put(e)
+            put(e)
 
     t = threading.Thread(target=producer, daemon=True)
     t.start()
-    while True:
-        item = q.get()
-        if item is _END:
-            break
-        if isinstance(item, BaseException):
-            raise item
-        frame, ev = item
-        torch.cuda.current_stream().wait_event(ev)
-        for _, col in frame.items():  # the buffers were allocated on the side stream
-            for tns in (col.data, col.valid, col.offsets):
-                if tns is not None:
-                    tns.record_stream(torch.cuda.current_stream())
-        yield frame
-    t.join()
+    try:
+        while True:
+            item = q.get()
+            if item is _END:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            frame, ev = item
+            torch.cuda.current_stream().wait_event(ev)
+            for _, col in frame.items():  # the buffers were allocated on the side stream
+                for tns in (col.data, col.valid, col.offsets):
+                    if tns is not None:
+                        tns.record_stream(torch.cuda.current_stream())
+            yield frame
+    finally:
+        # early exit (Dataset.head(), Workflow._capture_dtypes break after one partition, an
+        # exception in the consumer): release the producer, drop the device-resident
+        # partitions it still holds and join it -- it used to stay blocked in q.put forever
+        stop.set()
+        try:
+            while True:
+                q.get_nowait()
+        except queue.Empty:
+            pass
+        t.join(timeout=30)
 
 
 def _is_arrow_table(x) -> bool:

@@ -809,8 +809,10 @@ def hash_bucket(
     xor_in: Optional[torch.Tensor] = None,
     want_hash: bool = False,
     want_bucket: bool = True,
+    valid: Optional[torch.Tensor] = None,
 ):
-    """(bucket int32 or None, hash64 or None).  hash64 is carried as int64 bits."""
+    """(bucket int32 or None, hash64 or None).  hash64 is carried as int64 bits.  Rows whose
+    ``valid`` bit is clear hash as key 0 (the slot under a null holds arbitrary bytes)."""
     lib = _lib.load()
     _lib.require_gpu()
     keys = aligned(keys)
@@ -819,7 +821,8 @@ def hash_bucket(
     xo = torch.empty(n, dtype=torch.int64, device=keys.device) if want_hash else None
     check(
         getattr(lib, f"nvt_hash_bucket_{_key_suffix(keys)}")(
-            keys.data_ptr(), n, int(num_buckets), ptr(out), ptr(xor_in), ptr(xo), stream_ptr()
+            keys.data_ptr(), ptr(valid), n, int(num_buckets), ptr(out), ptr(xor_in), ptr(xo),
+            stream_ptr()
         ),
         "nvt_hash_bucket",
     )
@@ -1006,6 +1009,14 @@ def widen_i64(x: torch.Tensor) -> torch.Tensor:
         "nvt_widen_i64",
     )
     return out
+
+
+def unpack_bitmap(valid: torch.Tensor, n: int) -> torch.Tensor:
+    """Arrow validity bitmap -> bool[n] on the device (torch plumbing for rare paths: combo
+    Categorify null rows).  Replaces a device -> host -> device round trip per column."""
+    shifts = torch.arange(8, device=valid.device, dtype=torch.uint8)
+    bits = (valid[: (n + 7) // 8].unsqueeze(1) >> shifts) & 1
+    return bits.reshape(-1)[:n].to(torch.bool)
 
 
 def popcount(valid: Optional[torch.Tensor], n: int) -> int:

@@ -88,6 +88,7 @@ class Categorify(StatOperator):
         split_out=1,
         split_every=8,
         defer_artifacts=False,
+        tie_break="value",
         **kwargs,
     ):
         # categorify.py:226-241
@@ -160,6 +161,14 @@ class Categorify(StatOperator):
         # Workflow.save() instead of inside fit, so a device-resident fit does no
         # host I/O.  Default False = reference behaviour (files exist after fit).
         self.defer_artifacts = defer_artifacts
+        # Engine extension: order of categories with EQUAL counts.  "value" (default): count
+        # descending, value ascending, sorted on the device -- deterministic.  "reference": the
+        # (value, count) table is copied to the host and ordered by the reference's literal two
+        # pandas sort_values calls (categorify.py:1300,1316; the second is pandas' default
+        # unstable sort), so labels equal a reference run on the same host tie for tie.
+        if tie_break not in ("value", "reference"):
+            raise ValueError("tie_break must be 'value' or 'reference'")
+        self.tie_break = tie_break
         self._pending: Dict[str, dict] = {}
         self.vocabs = {}
         if vocabs is not None:
@@ -293,6 +302,9 @@ class Categorify(StatOperator):
         self._absorb_pending(state)
         base = os.path.join(self.out_path, "categories")
         os.makedirs(base, exist_ok=True)
+        # ranks that share an output directory (the default './') elect ONE writer: they all
+        # hold the same merged vocabularies and used to race remove-then-write on the same files
+        self._is_writer = dist.is_first_rank_with(os.path.abspath(str(base)))
         paths = {}
         groups = list(state.values())
         for g in groups:
@@ -347,12 +359,13 @@ class Categorify(StatOperator):
                 paths[g.name] = self._save_encodings(
                     g, vocab, base, first_n=max_emb, freq_threshold=freq, oov_count=oov_count
                 )
+        if not self.defer_artifacts:
+            dist.barrier()  # the elected writer's files exist before any rank reads them
         return {name: paths[name] for name in state if name in paths}
 
-    @staticmethod
-    def _fast_finalizable(g, opt, dist):
+    def _fast_finalizable(self, g, opt, dist):
         _, max_emb, freq = opt
-        if g.combo or g.table is None or max_emb or freq:
+        if g.combo or g.table is None or max_emb or freq or self.tie_break == "reference":
             return False
         if any(c in g.strings for c in g.cols):
             return False
@@ -385,7 +398,7 @@ class Categorify(StatOperator):
             )
             if self.defer_artifacts:
                 self._pending[g.name] = final
-            else:
+            elif self._is_writer:
                 _write_artifacts(final)
             paths[g.name] = "/".join([str(base), f"unique.{g.name}.parquet"])
 
@@ -408,8 +421,19 @@ class Categorify(StatOperator):
         for c in g.cols:
             if c in g.strings:
                 strings = {**(strings or {}), **g.strings[c]}
-        if strings is not None:
-            strings = dist.merge_string_luts(strings)
+        # collective on every rank (a rank whose shard was empty has no LUT of its own and
+        # used to skip the all_gather_object: the other ranks then hung)
+        strings = dist.merge_string_luts(strings)
+        if self.tie_break == "reference" and keys.numel():
+            # the reference's literal ordering (categorify.py:1300,1316) on the host
+            hk, hc = K.read_back(keys.to(torch.int64)), K.read_back(counts)
+            vals = np.array([strings[int(k)] for k in hk], dtype=object) if strings is not None else hk
+            df = pd.DataFrame({"v": vals, "k": hk, "s": hc})
+            df = df.sort_values(["v"], na_position="first", ignore_index=True)
+            df = df.sort_values("s", ascending=False, ignore_index=True)
+            keys = torch.from_numpy(df["k"].to_numpy().astype(hk.dtype)).to(keys.device).to(keys.dtype)
+            counts = torch.from_numpy(df["s"].to_numpy().astype(np.int64)).to(counts.device)
+        elif strings is not None:
             # string columns: order ties by the string value on the host (O(#uniques))
             hk, hc = keys.cpu().numpy(), counts.cpu().numpy()
             vals = np.array([strings[int(k)] for k in hk], dtype=object)
@@ -423,9 +447,17 @@ class Categorify(StatOperator):
                     total=g.valid_rows)
 
     def _finalize_combo(self, g: _GroupFit, dist):
+        if g.table is None:  # this rank (or the whole dataset) had no rows
+            g.table = K.GroupbyTable(len(g.cols), 0, 64)
         comp = g.table.compact()
         if dist.world_size() > 1:
             comp = dist.merge_groups(comp, len(g.cols), 0)
+            # keys seen only on other ranks need their strings too (ordering and artifacts);
+            # collective per column, in column order, on every rank
+            for c in g.cols:
+                merged = dist.merge_string_luts(g.strings.get(c))
+                if merged is not None:
+                    g.strings[c] = merged
         keys, nm, size = comp["keys"], comp["null_mask"], comp["size"]
         all_null = (1 << len(g.cols)) - 1
         is_all_null = nm == all_null
@@ -495,14 +527,17 @@ class Categorify(StatOperator):
         unique_path = "/".join([str(base), f"unique.{g.name}.parquet"])
         if self.defer_artifacts:
             self._pending[g.name] = final
-        else:
+        elif getattr(self, "_is_writer", True):
             _write_artifacts(final)
         return unique_path
 
     def flush_artifacts(self):
         """Write any deferred unique.*/meta.*.parquet files (defer_artifacts=True)."""
+        # not a collective (Workflow.save may run on one rank only): the writer elected at
+        # fit_end writes, everybody drops the device copies
         for final in self._pending.values():
-            _write_artifacts(final)
+            if getattr(self, "_is_writer", True):
+                _write_artifacts(final)
         self._pending = {}
 
     def fit_finalize(self, categories):
@@ -857,20 +892,22 @@ class _ComboEncoder:
         labels = grp + self.first_label_in_file
         if num_buckets and num_buckets > 1:
             acc = None
-            for k in keys:  # XOR chain of categorify.py:1846-1851
-                _, acc = K.hash_bucket(k, num_buckets, xor_in=acc, want_hash=True, want_bucket=False)
+            for k, v in zip(keys, valids):  # XOR chain of categorify.py:1846-1851, nulls as key 0
+                _, acc = K.hash_bucket(k, num_buckets, xor_in=acc, want_hash=True, want_bucket=False,
+                                       valid=v)
             h32 = (acc >> 32) & 0xFFFFFFFF
             oov = oov_label + (h32 % num_buckets)
         else:
             oov = torch.full_like(labels, oov_label)
         labels = torch.where(grp >= 0, labels, oov)
-        # a row is null only when every component is null (categorify.py:1689-1692)
+        # a row is null only when every component is null (categorify.py:1689-1692); the
+        # validity used is key_view's, which also covers float-NaN nulls of pandas columns
         all_null = None
-        for c in cols:
-            col = frame[c]
-            host = col.valid_mask_host()
-            isnull = torch.zeros(len(col), dtype=torch.bool, device=labels.device) if host is None \
-                else torch.from_numpy(~host).to(labels.device)
+        for v in valids:
+            if v is None:
+                all_null = torch.zeros(labels.numel(), dtype=torch.bool, device=labels.device)
+                break
+            isnull = ~K.unpack_bitmap(v, labels.numel())
             all_null = isnull if all_null is None else (all_null & isnull)
         labels = torch.where(all_null, torch.full_like(labels, null_label), labels)
         return DeviceColumn(labels.to(out_dtype))

@@ -38,8 +38,8 @@ class HashBucket(Operator):
             num_buckets = self.num_buckets
         for col, nb in num_buckets.items():
             c = frame[col]
-            keys, _ = key_view(c)  # nulls hash as key 0 (the reference hashes them too)
-            out, _ = K.hash_bucket(keys, nb)
+            keys, valid = key_view(c)  # nulls hash as key 0 (the reference hashes fillna(0))
+            out, _ = K.hash_bucket(keys, nb, valid=valid)
             frame[col] = DeviceColumn(out, None, c.offsets)
         return frame.to_pandas() if was_pandas else frame
 

@@ -29,9 +29,10 @@ class HashedCross(Operator):
             nb = self.num_buckets[cross] if isinstance(self.num_buckets, dict) else self.num_buckets
             acc, val = None, None
             for i, column in enumerate(cross):
-                keys, _ = key_view(frame[column].materialize())
+                keys, valid = key_view(frame[column].materialize())
                 last = i == len(cross) - 1
-                val, acc = K.hash_bucket(keys, nb, xor_in=acc, want_hash=not last, want_bucket=last)
+                val, acc = K.hash_bucket(keys, nb, xor_in=acc, want_hash=not last, want_bucket=last,
+                                         valid=valid)
             out["_X_".join(cross)] = DeviceColumn(val, None, None)
         return out.to_pandas() if was_pandas else out
 

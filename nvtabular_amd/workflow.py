@@ -14,7 +14,6 @@ from __future__ import annotations
 import json
 import logging
 import os
-import pickle
 import time
 from typing import Dict, List, Optional
 
@@ -235,7 +234,7 @@ class Workflow:
                 for part in data.to_iter(columns=roots, shard=shard):
                     yield self._run(self.output_node, part, {})
 
-            out = Dataset(gen, schema=self._output_schema, npartitions=data.npartitions)
+            out = Dataset(gen, schema=self.output_schema, npartitions=data.npartitions)  # property: fitted
             out._forwards_shard = True  # rank sharding is decided by the source dataset
             return out
         if isinstance(data, pd.DataFrame):
@@ -278,7 +277,9 @@ class Workflow:
     def load(cls, path, client=None) -> "Workflow":
         path = str(path)
         if not os.path.exists(os.path.join(path, "graph.json")):
-            return cls._load_pickle(path, client)
+            # workflow.pkl files of the first revision are not read: unpickling runs arbitrary
+            # code (the reference ships a restricted unpickler for the same reason)
+            raise FileNotFoundError(f"{path} holds no graph.json (pickled workflows are not loaded)")
         from .graph_json import deserialize_graph
 
         wf = cls(deserialize_graph(path), client=client)
@@ -290,17 +291,6 @@ class Workflow:
             if node.op is None and node.input_schema is not None:
                 roots += [c for c in node.input_schema if c.name not in {r.name for r in roots}]
         wf.input_schema = Schema(roots) if roots else None
-        return wf
-
-    @classmethod
-    def _load_pickle(cls, path, client=None) -> "Workflow":
-        """Workflows saved by the first revision of this package (workflow.pkl)."""
-        with open(os.path.join(path, "workflow.pkl"), "rb") as f:
-            wf = pickle.load(f)
-        wf.client = client
-        for i, node in enumerate(iter_nodes(wf.output_node)):
-            if isinstance(node.op, StatOperator):
-                node.op.set_storage_path(os.path.join(path, "artifacts", f"node_{i}"), copy=False)
         return wf
 
     def clear_stats(self):
