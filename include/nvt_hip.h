@@ -231,6 +231,20 @@ typedef struct nvt_gb_table nvt_gb_table;
 /* The table object owns its device arrays (hipMalloc'ed on the current device). */
 int nvt_gb_create(int nkeys, int nvals, int flags, uint64_t capacity, nvt_gb_table **out);
 void nvt_gb_destroy(nvt_gb_table *t);
+/* The same table in CALLER-provided device memory (nvt_gb_table_bytes() bytes): hipMalloc and
+ * hipFree synchronise the device, which a fit that builds a table per partition cannot
+ * afford.  nvt_gb_destroy then only frees the handle. */
+int nvt_gb_table_bytes(int nkeys, int nvals, int flags, uint64_t capacity, uint64_t *bytes);
+int nvt_gb_create_in(int nkeys, int nvals, int flags, uint64_t capacity, void *memory,
+                     uint64_t bytes, nvt_gb_table **out);
+/* device address of the table's uint64[NVT_STATE_WORDS] state block (read it back with
+ * nvt_mailbox_post instead of the blocking nvt_gb_state) */
+uint64_t *nvt_gb_state_ptr(nvt_gb_table *t);
+/* nvt_gb_update orders the rows by group (assign slot -> radix sort -> segmented reduce; no
+ * per-row accumulator atomics) and needs nvt_gb_update_ws_bytes(n) bytes of scratch: owned and
+ * grown by the table unless the caller hands one over with nvt_gb_set_workspace. */
+int nvt_gb_update_ws_bytes(uint64_t n, uint64_t *bytes);
+int nvt_gb_set_workspace(nvt_gb_table *t, void *ws, uint64_t bytes);
 int nvt_gb_clear(nvt_gb_table *t, void *stream);
 /* keys[k]: int64 device column, key_valid[k]: bitmap or NULL; vals[j]: column of vdtype[j] */
 int nvt_gb_update(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *const *key_valid,

@@ -68,6 +68,11 @@ SIGNATURES = {
     "nvt_bucketize": [_vp, _i32, _vp, _u64, _vp, _i32, _vp, _vp],
     "nvt_gb_create": [_i32, _i32, _i32, _u64, _pp],
     "nvt_gb_destroy": [_vp],
+    "nvt_gb_table_bytes": [_i32, _i32, _i32, _u64, C.POINTER(_u64)],
+    "nvt_gb_create_in": [_i32, _i32, _i32, _u64, _vp, _u64, _pp],
+    "nvt_gb_state_ptr": [_vp],
+    "nvt_gb_update_ws_bytes": [_u64, C.POINTER(_u64)],
+    "nvt_gb_set_workspace": [_vp, _vp, _u64],
     "nvt_gb_clear": [_vp, _vp],
     "nvt_gb_update": [_vp, _pp, _pp, _pp, C.POINTER(C.c_int), _pp, _u64, _vp],
     "nvt_gb_merge": [_vp, _pp, _vp, _vp, _vp, _pp, _pp, _pp, _pp, _u64, _vp],
@@ -145,6 +150,7 @@ _RESTYPES = {
     "nvt_event_destroy": None,
     "nvt_mailbox_destroy": None,
     "nvt_mailbox_data": C.c_void_p,
+    "nvt_gb_state_ptr": C.c_void_p,
     "nvt_mailbox_capacity": C.c_uint64,
 }
 

@@ -13,9 +13,12 @@
 // not coherent, so every protocol word goes through agent-scope atomics;
 // accumulators are only ever touched by atomic RMWs, which execute at the
 // memory side.  (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility".)
+#include <cstdlib>
 #include <limits>
 
 #include "nvt_common.hpp"
+#include "nvt_internal.hpp"
+#include "nvt_prof.hpp"
 
 struct nvt_gb_table {
   int nkeys;
@@ -34,6 +37,10 @@ struct nvt_gb_table {
   long long *index;            // [cap] slot -> compact group id (lookup tables)
   uint64_t *state;             // [NVT_STATE_WORDS]
   void *ptr_scratch;           // device copy of per-call pointer tables
+  void *scratch;               // sort workspace of nvt_gb_update (grown on demand)
+  uint64_t scratch_bytes;
+  int external;                // arrays live in caller-provided memory (nvt_gb_create_in)
+  int external_scratch;        // scratch set by nvt_gb_set_workspace
 };
 
 namespace nvt {
@@ -236,6 +243,112 @@ __global__ __launch_bounds__(kBlock) void gb_update_kernel(GbView t, GbRowArgs a
     atomicAdd((unsigned long long *)&t.state[NVT_ST_ROWS], (unsigned long long)n);
 }
 
+// ---- update without per-row accumulator atomics (JoinGroupby / TargetEncoding fit) -----------
+// The kernel above does up to 2 + 4 * nvals device atomics per row on the row's group; with the
+// skewed keys these operators see, thousands of rows hit the same few slots and serialise at
+// the memory side (20 M rows, 5 M keys, one float target: 5.5 s per fit + transform).  Instead:
+//   gb_assign_kernel     row -> slot (find-or-insert: reads only once a key exists), written as
+//                        the packed word (slot << 32 | row)
+//   sort_words_bits      onesweep LSD radix on the slot bits: every group's rows become ONE run,
+//                        in row order (stable)
+//   gb_segreduce_kernel  wave-level segmented reduction over the sorted words (values gathered
+//                        by row); one add per (wave, run) into the group's accumulators -- a hot
+//                        group of a million rows costs 16 k adds instead of a million, and runs of
+//                        cold groups touch distinct addresses.
+__global__ __launch_bounds__(kBlock) void gb_assign_kernel(GbView t, GbRowArgs a, uint64_t n,
+                                                           uint64_t *__restrict__ words) {
+  unsigned n_new = 0, ovf = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    long long k[kMaxKeys];
+    unsigned nm = read_tuple(a, t.nkeys, i, k);
+    int64_t slot = find_slot(t, k, nm, true, &n_new, &ovf);
+    // rows that found no slot (overflow: the call fails) sort behind everything else
+    words[i] = ((uint64_t)(slot < 0 ? t.cap : (uint64_t)slot) << 32) | (uint64_t)(uint32_t)i;
+  }
+  if (n_new) atomicAdd((unsigned long long *)&t.state[NVT_ST_OCCUPIED], (unsigned long long)n_new);
+  if (ovf) atomicOr((unsigned long long *)&t.state[NVT_ST_OVERFLOW], 1ull);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd((unsigned long long *)&t.state[NVT_ST_ROWS], (unsigned long long)n);
+}
+
+struct SegAcc {
+  double cnt, sum, sq, mn, mx;
+};
+
+__global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArgs a, uint64_t n,
+                                                              const uint64_t *__restrict__ words) {
+  const double inf = std::numeric_limits<double>::infinity();
+  const unsigned lane = lane_id();
+  const uint64_t nwaves = (uint64_t)gridDim.x * (kBlock / kWave);
+  const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  // waves walk the sorted words in 64-element steps (fixed trip count: every lane of a wave
+  // takes part in the shuffles)
+  for (uint64_t base = wave0 * kWave; base < n; base += nwaves * kWave) {
+    const uint64_t i = base + lane;
+    const bool act = i < n;
+    const uint64_t w = act ? words[i] : ~0ull;
+    const uint32_t slot = (uint32_t)(w >> 32);
+    const uint32_t row = (uint32_t)w;
+    const bool live = act && slot < t.cap;
+    const uint32_t prev = __shfl_up(slot, 1, 64);
+    const bool head = lane == 0 || prev != slot;
+    const uint32_t next = __shfl_down(slot, 1, 64);
+    const bool tail = lane == 63 || next != slot;
+    // size / count (rows whose FIRST key component is non-null, categorify.py:995-999)
+    {
+      double sz = live ? 1.0 : 0.0;
+      double ct = (live && bit_valid(a.key_valid[0], row)) ? 1.0 : 0.0;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double osz = __shfl_up(sz, off, 64), oct = __shfl_up(ct, off, 64);
+        const uint32_t os = __shfl_up(slot, off, 64);
+        if (lane >= (unsigned)off && os == slot) {
+          sz += osz;
+          ct += oct;
+        }
+      }
+      if (live && tail) {
+        atomicAdd(&t.size[slot], (unsigned long long)sz);
+        if (ct > 0) atomicAdd(&t.count[slot], (unsigned long long)ct);
+      }
+    }
+    for (int j = 0; j < t.nvals; ++j) {
+      double v = 0;
+      const bool ok = live && load_val(a.vals[j], a.vdtype[j], row, &v) &&
+                      bit_valid(a.val_valid[j], row);
+      double sum = ok ? v : 0.0, sq = ok ? v * v : 0.0, mn = ok ? v : inf, mx = ok ? v : -inf;
+      double any = ok ? 1.0 : 0.0;
+      // inclusive segmented scan in row order: equal slots are contiguous, so "same slot as the
+      // lane `off` below" means that lane belongs to this run
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double osum = __shfl_up(sum, off, 64), osq = __shfl_up(sq, off, 64);
+        const double omn = __shfl_up(mn, off, 64), omx = __shfl_up(mx, off, 64);
+        const double oany = __shfl_up(any, off, 64);
+        const uint32_t os = __shfl_up(slot, off, 64);
+        if (lane >= (unsigned)off && os == slot) {
+          sum = osum + sum;  // earlier rows first
+          sq = osq + sq;
+          mn = omn < mn ? omn : mn;
+          mx = omx > mx ? omx : mx;
+          any += oany;
+        }
+      }
+      if (live && tail && any > 0) {
+        const uint64_t o = (uint64_t)j * t.cap + slot;
+        atomicAdd(&t.sum[o], sum);
+        if (t.sumsq) atomicAdd(&t.sumsq[o], sq);
+        if (t.vmin) {
+          atomic_min_f64(&t.vmin[o], mn);
+          atomic_max_f64(&t.vmax[o], mx);
+        }
+      }
+    }
+    (void)head;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void gb_merge_kernel(GbView t, GbMergeArgs a, uint64_t n) {
   unsigned n_new = 0, ovf = 0;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -355,11 +468,88 @@ extern "C" {
 
 void nvt_gb_destroy(nvt_gb_table *t) {
   if (!t) return;
-  void *ptrs[] = {t->slot_state, t->keys, t->nullmask, t->size, t->count, t->sum,
-                  t->sumsq,      t->vmin, t->vmax,     t->index, t->state};
-  for (void *p : ptrs)
-    if (p) (void)hipFree(p);
+  if (!t->external) {
+    void *ptrs[] = {t->slot_state, t->keys, t->nullmask, t->size, t->count, t->sum,
+                    t->sumsq,      t->vmin, t->vmax,     t->index, t->state};
+    for (void *p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  if (t->scratch && !t->external_scratch) (void)hipFree(t->scratch);
   delete t;
+}
+
+static uint64_t gb_align(uint64_t x) { return (x + 255) & ~255ull; }
+
+int nvt_gb_table_bytes(int nkeys, int nvals, int flags, uint64_t capacity, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes, "null out");
+  NVT_CHECK_ARG(nkeys >= 1 && nkeys <= kMaxKeys && nvals >= 0 && nvals <= kMaxVals, "bad shape");
+  uint64_t b = gb_align(capacity * 4) * 2 + gb_align(capacity * 8 * nkeys) +
+               gb_align(capacity * 8) * 3 + gb_align(capacity * 8 * nvals) +
+               gb_align(NVT_STATE_WORDS * 8);
+  if (nvals && (flags & NVT_GB_SUMSQ)) b += gb_align(capacity * 8 * nvals);
+  if (nvals && (flags & NVT_GB_MINMAX)) b += 2 * gb_align(capacity * 8 * nvals);
+  *bytes = b + 256;
+  return NVT_OK;
+}
+
+// Table whose arrays live in caller-provided device memory (nvt_gb_table_bytes() bytes, 256-byte
+// aligned): no hipMalloc / hipFree -- both synchronise the device -- on the fit path.
+int nvt_gb_create_in(int nkeys, int nvals, int flags, uint64_t capacity, void *memory,
+                     uint64_t bytes, nvt_gb_table **out) {
+  NVT_CHECK_ARG(out && memory, "null out/memory");
+  NVT_CHECK_ARG(nkeys >= 1 && nkeys <= kMaxKeys, "nkeys must be 1..3");
+  NVT_CHECK_ARG(nvals >= 0 && nvals <= kMaxVals, "nvals must be 0..8");
+  NVT_CHECK_ARG(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be 2^k >= 64");
+  uint64_t need = 0;
+  nvt_gb_table_bytes(nkeys, nvals, flags, capacity, &need);
+  NVT_CHECK_ARG(bytes >= need, "memory block too small (nvt_gb_table_bytes)");
+  nvt_gb_table *t = new nvt_gb_table();
+  memset(t, 0, sizeof(*t));
+  t->nkeys = nkeys;
+  t->nvals = nvals;
+  t->flags = flags;
+  t->capacity = capacity;
+  t->external = 1;
+  char *p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(memory) + 255) & ~(uintptr_t)255);
+  auto take = [&](uint64_t b) {
+    char *r = p;
+    p += gb_align(b);
+    return (void *)r;
+  };
+  t->slot_state = (unsigned *)take(capacity * 4);
+  t->nullmask = (unsigned *)take(capacity * 4);
+  t->keys = (long long *)take(capacity * 8 * nkeys);
+  t->size = (unsigned long long *)take(capacity * 8);
+  t->count = (unsigned long long *)take(capacity * 8);
+  t->index = (long long *)take(capacity * 8);
+  if (nvals) t->sum = (double *)take(capacity * 8 * nvals);
+  t->state = (uint64_t *)take(NVT_STATE_WORDS * 8);
+  if (nvals && (flags & NVT_GB_SUMSQ)) t->sumsq = (double *)take(capacity * 8 * nvals);
+  if (nvals && (flags & NVT_GB_MINMAX)) {
+    t->vmin = (double *)take(capacity * 8 * nvals);
+    t->vmax = (double *)take(capacity * 8 * nvals);
+  }
+  *out = t;
+  return NVT_OK;
+}
+
+// device address of the table's uint64[NVT_STATE_WORDS] state block (for nvt_mailbox_post)
+uint64_t *nvt_gb_state_ptr(nvt_gb_table *t) { return t ? t->state : nullptr; }
+
+int nvt_gb_update_ws_bytes(uint64_t n, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes, "null out");
+  *bytes = ((n * 8 + 255) & ~255ull) + sort_words_tmp_bytes(n) + 512;
+  return NVT_OK;
+}
+// caller-owned scratch for nvt_gb_update (nvt_gb_update_ws_bytes(n)); NULL returns to the
+// table-owned, grown-on-demand buffer
+int nvt_gb_set_workspace(nvt_gb_table *t, void *ws, uint64_t bytes) {
+  NVT_CHECK_ARG(t, "null table");
+  if (t->scratch && !t->external_scratch) (void)hipFree(t->scratch);
+  t->scratch = ws;
+  t->scratch_bytes = ws ? bytes : 0;
+  t->external_scratch = ws ? 1 : 0;
+  return NVT_OK;
 }
 
 int nvt_gb_create(int nkeys, int nvals, int flags, uint64_t capacity, nvt_gb_table **out) {
@@ -424,8 +614,41 @@ int nvt_gb_update(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *co
     a.vdtype[j] = vdtypes[j];
     a.val_valid[j] = val_valid ? val_valid[j] : nullptr;
   }
-  gb_update_kernel<<<stream_grid(n, kBlock * 2), kBlock, 0, (hipStream_t)stream>>>(view_of(t), a,
-                                                                                    n);
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_update", 0, s);
+  if (n < (1ull << 15) || n >= (1ull << 30) || t->capacity > (1ull << 31) || getenv("NVT_GB_ATOMIC")) {
+    // tiny inputs (the sort would be launch latency) and > 2^30 rows per call: per-row atomics
+    gb_update_kernel<<<stream_grid(n, kBlock * 2), kBlock, 0, s>>>(view_of(t), a, n);
+    NVT_CHECK_LAUNCH();
+    return NVT_OK;
+  }
+  // scratch: words[n] + sort workspace
+  const uint64_t need = ((n * 8 + 255) & ~255ull) + sort_words_tmp_bytes(n) + 256;
+  if (t->scratch_bytes < need) {
+    NVT_CHECK_ARG(!t->external_scratch, "workspace set by nvt_gb_set_workspace is too small");
+    if (t->scratch) {
+      NVT_CHECK_HIP(hipStreamSynchronize(s));
+      NVT_CHECK_HIP(hipFree(t->scratch));
+      t->scratch = nullptr;
+      t->scratch_bytes = 0;
+    }
+    const uint64_t grow = need + need / 4;
+    if (hipMalloc(&t->scratch, grow) != hipSuccess) {
+      set_error("nvt_gb_update: hipMalloc of %llu scratch bytes failed", (unsigned long long)grow);
+      return NVT_ENOMEM;
+    }
+    t->scratch_bytes = grow;
+  }
+  uint64_t *words = reinterpret_cast<uint64_t *>(t->scratch);
+  void *sort_tmp = reinterpret_cast<char *>(t->scratch) + ((n * 8 + 255) & ~255ull);
+  gb_assign_kernel<<<stream_grid(n, kBlock * 2), kBlock, 0, s>>>(view_of(t), a, n, words);
+  NVT_CHECK_LAUNCH();
+  int cap_bits = 1;  // slots are < capacity; the overflow marker `capacity` needs one more bit
+  while ((1ull << cap_bits) <= t->capacity) ++cap_bits;
+  uint64_t *sorted = nullptr;
+  int rc = sort_words_bits(words, n, 32, 32 + cap_bits, sort_tmp, &sorted, s);
+  if (rc) return rc;
+  gb_segreduce_kernel<<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(view_of(t), a, n, sorted);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

@@ -17,6 +17,12 @@ struct SmallSortDesc {
 bool vocab_sort_small_eligible(int key_bytes, uint64_t n, int64_t max_count);
 int vocab_sort_small_batch(const SmallSortDesc *cols, int ncols, hipStream_t s);
 
+// stable LSD radix sort of packed 64-bit words on the bit range [bit_lo, bit_hi); *result is
+// `data` or a buffer inside tmp (sort_words_tmp_bytes(n) bytes)
+uint64_t sort_words_tmp_bytes(uint64_t n);
+int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tmp, uint64_t **result,
+                    hipStream_t s);
+
 // nvt_encode.hip
 int encode_build_any(int key_bytes, const void *vocab, uint64_t n, int64_t first_label, void *table,
                      uint64_t capacity, int64_t *sentinel_label, int unique_keys, hipStream_t s);

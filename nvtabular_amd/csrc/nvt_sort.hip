@@ -608,6 +608,85 @@ inline int vocab_sort_onesweep(int32_t *keys, int64_t *counts, uint64_t n, int64
   return NVT_OK;
 }
 
+// ---- generic: stable LSD radix sort of packed 64-bit words on the bit range [bit_lo, bit_hi) ----
+// (the onesweep scatter above with FIRST = LAST = false).  Used by the multi-key groupby update:
+// words are (slot << 32 | row), sorted by slot, so that every group's rows become one run in
+// row order.
+__global__ __launch_bounds__(kS2BS) void os_hist_words_kernel(const uint64_t *__restrict__ w,
+                                                              uint64_t n, int bit_lo, int npass,
+                                                              unsigned *__restrict__ block_hist) {
+  __shared__ unsigned h[kOsMaxPass * 256];
+  for (int i = threadIdx.x; i < npass * 256; i += kS2BS) h[i] = 0;
+  __syncthreads();
+  const unsigned l = lane_id();
+  const uint64_t stride = (uint64_t)gridDim.x * kS2BS;
+  const uint64_t iters = (n + stride - 1) / stride;
+  for (uint64_t it = 0; it < iters; ++it) {
+    const uint64_t i = it * stride + (uint64_t)blockIdx.x * kS2BS + threadIdx.x;
+    const bool act = i < n;
+    const uint64_t c = act ? w[i] >> bit_lo : 0ull;
+#pragma unroll
+    for (int p = 0; p < kOsMaxPass; ++p) {
+      if (p < npass) {
+        // sorted-by-group inputs are heavily skewed (one hot group = one digit value):
+        // aggregate equal digits per wave before touching the LDS histogram
+        const unsigned d = (unsigned)(c >> (8 * p)) & 0xFF;
+        const unsigned long long peers = match_digit(d, act);
+        if (act && (peers & ((1ull << l) - 1ull)) == 0)
+          atomicAdd(&h[p * 256 + d], (unsigned)__popcll(peers));
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < npass * 256; i += kS2BS)
+    block_hist[(uint64_t)blockIdx.x * (kOsMaxPass * 256) + i] = h[i];
+}
+
+uint64_t sort_words_tmp_bytes(uint64_t n) { return os_tmp_bytes(n); }
+
+// Sorts data[0..n) by bits [bit_lo, bit_hi) (stable).  *result = data or a buffer inside tmp.
+int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tmp, uint64_t **result,
+                    hipStream_t stream) {
+  *result = data;
+  if (n <= 1 || bit_hi <= bit_lo) return NVT_OK;
+  NVT_CHECK_ARG(n < (1ull << 30), "at most 2^30-1 words");
+  const int npass = (bit_hi - bit_lo + 7) / 8;
+  NVT_CHECK_ARG(npass <= kOsMaxPass, "bit range too wide");
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  char *p = reinterpret_cast<char *>(tmp);
+  uint64_t *bufs[2];
+  bufs[0] = reinterpret_cast<uint64_t *>(p);
+  p += n * 8;
+  bufs[1] = reinterpret_cast<uint64_t *>(p);
+  p += n * 8;
+  unsigned *block_hist = reinterpret_cast<unsigned *>(p);
+  p += (uint64_t)kOsHistBlocks * kOsMaxPass * 256 * 4;
+  unsigned *base = reinterpret_cast<unsigned *>(p);
+  p += kOsMaxPass * 256 * 4;
+  unsigned *status = reinterpret_cast<unsigned *>(p);
+  const uint64_t status_words = (uint64_t)npass * ntiles * 256;
+  unsigned *tickets = status + status_words;
+  NVT_CHECK_HIP(hipMemsetAsync(status, 0, (status_words + kOsMaxPass) * 4, stream));
+  const unsigned hb = (unsigned)(ntiles < (uint64_t)kOsHistBlocks ? ntiles : kOsHistBlocks);
+  os_hist_words_kernel<<<hb, kS2BS, 0, stream>>>(data, n, bit_lo, npass, block_hist);
+  NVT_CHECK_LAUNCH();
+  os_base_kernel<<<npass, 256, 0, stream>>>(block_hist, (int)hb, base);
+  NVT_CHECK_LAUNCH();
+  const uint64_t *src = data;
+  int flip = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    uint64_t *dst = bufs[flip];
+    os_scatter_kernel<false, false><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
+        src, nullptr, nullptr, n, bit_lo + 8 * pass, base + pass * 256,
+        status + (uint64_t)pass * ntiles * 256, tickets + pass, dst, nullptr, nullptr);
+    NVT_CHECK_LAUNCH();
+    src = dst;
+    flip ^= 1;
+  }
+  *result = const_cast<uint64_t *>(src);
+  return NVT_OK;
+}
+
 // ---- all small vocabularies of a fit in ONE launch: workgroup b sorts vocabulary b --------
 // packed words in LDS (128 KiB for up to 16384 entries), bitonic network, ascending.
 constexpr int kSmallPackedMax = 16384;

@@ -137,6 +137,27 @@ def read_back(t: torch.Tensor):
     return np.frombuffer(buf, dtype=np_dt).reshape(tuple(t.shape)).copy()
 
 
+def read_back_ptr(ptr: int, nwords: int, device_index: int):
+    """uint64[nwords] at device address ``ptr`` -> list of ints, through the mailbox."""
+    import numpy as np
+
+    lib = _lib.load()
+    nbytes = nwords * 8
+    key = (device_index, stream_ptr())
+    mb = _mailboxes.get(key)
+    if mb is None or lib.nvt_mailbox_capacity(mb) < nbytes:
+        if mb is not None:
+            lib.nvt_mailbox_destroy(mb)
+        h = C.c_void_p()
+        check(lib.nvt_mailbox_create(max(1 << 16, 2 * nbytes), C.byref(h)), "nvt_mailbox_create")
+        mb = _mailboxes[key] = h
+    seq = C.c_uint64()
+    check(lib.nvt_mailbox_post(mb, ptr, nbytes, stream_ptr(), C.byref(seq)), "nvt_mailbox_post")
+    check(lib.nvt_mailbox_wait(mb, seq.value, 120.0), "nvt_mailbox_wait")
+    buf = (C.c_char * nbytes).from_address(lib.nvt_mailbox_data(mb))
+    return np.frombuffer(buf, dtype=np.uint64).astype(np.int64).tolist()
+
+
 class _timed:
     """Former Python-side event bracket; timing now lives in the library (NVT_PROF scopes)."""
 
@@ -312,7 +333,11 @@ PATH_P1_MAX_DISTINCT = int(os.environ.get("NVT_P1_MAX", 2_400_000))    # path 1:
 PATH_P1_MAX_SMALL = 1_100_000       #         ... 8192-slot tables (int64 keys / weighted merges)
 PATH_P2_MAX_DISTINCT = 9_000_000    # path 2: 64 x 64 buckets, 4096-slot tables
 PATH_P2_MAX_WEIGHTED = 18_000_000   #         weighted: 8192-slot tables
-PATH_P3_MAX_DISTINCT = 32_000_000   # path 3: 64 x 256 buckets, 8192-slot tables
+# path 3: 64 x 256 = 16384 buckets, 8192-slot tables that may fill to 6144: at 60 M distinct keys a
+# bucket holds 3662 +- 60 of them (Poisson), 40 % headroom -- Criteo-1TB's largest columns
+# (C1 / C10 / C20 / C22: 38.5-40.0 M uniques, dask-nvtabular-criteo-benchmark.py:360-366) stay on
+# the atomic-free path whether they arrive as one partition or as a merge of partial lists
+PATH_P3_MAX_DISTINCT = 60_000_000
 
 _ws_cache = {}
 _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
@@ -1041,9 +1066,17 @@ class GroupbyTable:
         self.flags = (_lib.NVT_GB_SUMSQ if sumsq else 0) | (_lib.NVT_GB_MINMAX if minmax else 0)
         self.capacity = next_pow2(capacity)
         self.device = torch.device("cuda", torch.cuda.current_device())
+        # arrays in a torch block (caching allocator: no hipMalloc / hipFree, which synchronise
+        # the device, on the fit path); the C handle only carves it up
+        nbytes = C.c_uint64()
+        check(self.lib.nvt_gb_table_bytes(nkeys, nvals, self.flags, self.capacity, C.byref(nbytes)),
+              "nvt_gb_table_bytes")
+        self._mem = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        self._ws = None
         h = C.c_void_p()
-        check(self.lib.nvt_gb_create(nkeys, nvals, self.flags, self.capacity, C.byref(h)),
-              "nvt_gb_create")
+        check(self.lib.nvt_gb_create_in(nkeys, nvals, self.flags, self.capacity,
+                                        self._mem.data_ptr(), nbytes.value, C.byref(h)),
+              "nvt_gb_create_in")
         self.handle = h
         self.clear()
 
@@ -1060,14 +1093,20 @@ class GroupbyTable:
         check(self.lib.nvt_gb_clear(self.handle, stream_ptr()), "nvt_gb_clear")
 
     def state(self) -> List[int]:
-        buf = (C.c_uint64 * _lib.STATE_WORDS)()
-        check(self.lib.nvt_gb_state(self.handle, buf, stream_ptr()), "nvt_gb_state")
-        return list(buf)
+        # mailbox read-back of the device state words (no blocking runtime wait)
+        return read_back_ptr(self.lib.nvt_gb_state_ptr(self.handle), _lib.STATE_WORDS,
+                             self.device.index)
 
     def update(self, keys, key_valid, vals, val_valid):
         keys = [widen_i64(k) for k in keys]
         vals = [aligned(v.view(torch.uint8) if v.dtype == torch.bool else v) for v in vals]
         n = keys[0].numel()
+        need = C.c_uint64()
+        check(self.lib.nvt_gb_update_ws_bytes(n, C.byref(need)), "nvt_gb_update_ws_bytes")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            check(self.lib.nvt_gb_set_workspace(self.handle, self._ws.data_ptr(), need.value),
+                  "nvt_gb_set_workspace")
         kp = _lib.ptr_array([k.data_ptr() for k in keys])
         kv = _lib.ptr_array([ptr(v) for v in key_valid])
         vp = _lib.ptr_array([v.data_ptr() for v in vals])

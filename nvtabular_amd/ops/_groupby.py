@@ -19,15 +19,19 @@ from ..device import DeviceFrame, key_view
 
 class GroupAgg:
     def __init__(self, name: str, key_cols: List[str], val_cols: List[str], sumsq=False,
-                 minmax=False):
+                 minmax=False, hint: int = 0):
         self.name = name
         self.key_cols = list(key_cols)
         self.val_cols = list(val_cols)
         self.sumsq, self.minmax = sumsq, minmax
         self.table = None
-        self.hint = 1 << 12
+        # expected groups per partition: carried from the operator's previous fit (hints dict);
+        # unknown -> assume half the rows are distinct (high-cardinality keys are what these
+        # operators are used on, and an undersized table costs a full extra pass per retry)
+        self.hint = int(hint)
         self.strings: Dict[str, dict] = {}
         self.key_dtypes: Dict[str, object] = {}
+        self.val_dtypes: Dict[str, object] = {}  # source dtype of every aggregated column
 
     def _inputs(self, frame: DeviceFrame):
         keys, kvalid = [], []
@@ -46,12 +50,14 @@ class GroupAgg:
             col = frame[c].materialize()
             vals.append(col.data)
             vvalid.append(col.valid)
+            self.val_dtypes.setdefault(c, col.data.dtype)
         return keys, kvalid, vals, vvalid
 
     def update(self, frame: DeviceFrame):
         keys, kvalid, vals, vvalid = self._inputs(frame)
         n = int(keys[0].numel())
-        cap = K.next_pow2(2 * min(max(self.hint, 32), max(n, 32)))
+        hint = self.hint if self.hint > 0 else max(1 << 12, n // 2)
+        cap = K.next_pow2(2 * min(max(hint, 32), max(n, 32)))
         while True:
             part = K.GroupbyTable(len(keys), len(vals), cap, sumsq=self.sumsq, minmax=self.minmax)
             part.update(keys, kvalid, vals, vvalid)
@@ -115,7 +121,10 @@ def stats_frame(agg: GroupAgg, comp, stats, name_sep="_", count_name=None) -> pd
     for j, cont in enumerate(agg.val_cols):
         for stat in ("sum", "mean", "min", "max", "var", "std"):
             if stat in stats:
-                data[f"{base}{name_sep}{cont}{name_sep}{stat}"] = derived[(j, stat)].cpu().numpy()
+                col = derived[(j, stat)].cpu().numpy()
+                if stat in ("sum", "min", "max") and agg.val_dtypes.get(cont) == torch.float32:
+                    col = col.astype(np.float32)  # pandas' groupby keeps the float32 of the source
+                data[f"{base}{name_sep}{cont}{name_sep}{stat}"] = col
     df = pd.DataFrame(data)
     return df
 

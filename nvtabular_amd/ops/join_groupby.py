@@ -21,8 +21,10 @@ AGG_DTYPES = {"count": np.int32, "std": np.float32, "var": np.float32, "mean": n
 class _Stats:
     """Device-resident stat table of one group: lookup index + stat columns."""
 
-    def __init__(self, key_cols, keys, null_mask, columns):
+    def __init__(self, key_cols, keys, null_mask, columns, f32_columns=()):
         self.key_cols = key_cols
+        # sum / min / max of a float32 column stay float32 (pandas' groupby result dtype)
+        self.f32_columns = set(f32_columns)
         self.n = int(keys[0].numel()) if keys else 0
         self.index = K.GroupbyTable(len(key_cols), 0, max(64, 2 * self.n + 1))
         self.index.index_build([k.contiguous() for k in keys], null_mask)
@@ -31,8 +33,14 @@ class _Stats:
 
 class JoinGroupby(StatOperator):
     def __init__(self, cont_cols=None, stats=("count",), split_out=None, split_every=None,
-                 cat_cache="host", out_path=None, on_host=True, name_sep="_", tree_width=None):
+                 cat_cache="host", out_path=None, on_host=True, name_sep="_", tree_width=None,
+                 defer_artifacts=False):
         super().__init__()
+        # engine extension (as on Categorify): write the cat_stats.*.parquet files at
+        # flush_artifacts() / Workflow.save() instead of inside fit
+        self.defer_artifacts = defer_artifacts
+        self._pending = {}
+        self._hints = {}
         self.storage_name = {}
         self.name_sep = name_sep
         self.stats = stats
@@ -43,6 +51,7 @@ class JoinGroupby(StatOperator):
         self.cat_cache = cat_cache
         self.categories = {}
         self._device_stats = {}
+        self._pending = {}
         self._cont_names = None
         if isinstance(cont_cols, Node):
             self.cont_cols = cont_cols
@@ -84,7 +93,8 @@ class JoinGroupby(StatOperator):
         sumsq = "std" in self.stats or "var" in self.stats
         minmax = "min" in self.stats or "max" in self.stats
         conts = list(self.cont_names.names)
-        return {name: GroupAgg(name, cols, conts, sumsq=sumsq, minmax=minmax)
+        return {name: GroupAgg(name, cols, conts, sumsq=sumsq, minmax=minmax,
+                               hint=self._hints.get(name, 0))
                 for name, cols in self._group_list(col_selector)}
 
     def fit_partition(self, state, col_selector, df):
@@ -98,10 +108,11 @@ class JoinGroupby(StatOperator):
         out = {}
         for name, agg in state.items():
             comp = agg.finalize()
-            df = stats_frame(agg, comp, list(self.stats), self.name_sep)
+            self._hints[name] = max(64, int(comp["n"]))
             d = os.path.join(base, f"cat_stats.{name}.parquet")
-            os.makedirs(d, exist_ok=True)
-            df.to_parquet(os.path.join(d, "part.0.parquet"), index=False)
+            self._pending[name] = (agg, comp, list(self.stats), d)
+            if not self.defer_artifacts:
+                self.flush_artifacts()
             out[name] = d
             # device cache for transform
             derived = derive_stats(comp, self.stats)
@@ -113,8 +124,19 @@ class JoinGroupby(StatOperator):
                 for stat in ("sum", "mean", "min", "max", "var", "std"):
                     if stat in self.stats:
                         cols[f"{name}{self.name_sep}{cont}{self.name_sep}{stat}"] = derived[(j, stat)]
-            self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols)
+            f32 = [f"{name}{self.name_sep}{cont}{self.name_sep}{stat}" for cont in agg.val_cols
+                   for stat in ("sum", "min", "max") if agg.val_dtypes.get(cont) == torch.float32]
+            self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols,
+                                              f32_columns=f32)
         return out
+
+    def flush_artifacts(self):
+        """Write any deferred cat_stats.<group>.parquet directories."""
+        for agg, comp, stats, d in self._pending.values():
+            os.makedirs(d, exist_ok=True)
+            stats_frame(agg, comp, stats, self.name_sep).to_parquet(
+                os.path.join(d, "part.0.parquet"), index=False)
+        self._pending = {}
 
     def fit_finalize(self, dask_stats):
         for col in dask_stats:
@@ -146,6 +168,8 @@ class JoinGroupby(StatOperator):
                 if cname in new:
                     continue
                 out_dt, miss = torch.float64, float("nan")
+                if cname in st.f32_columns:
+                    out_dt = torch.float32
                 for agg, npdt in AGG_DTYPES.items():
                     if cname.endswith(f"{self.name_sep}{agg}"):
                         out_dt = torch.int32 if npdt == np.int32 else torch.float32
@@ -198,6 +222,7 @@ class JoinGroupby(StatOperator):
     def set_storage_path(self, new_path, copy=False):
         import shutil
 
+        self.flush_artifacts()
         new = {}
         for col, old in self.categories.items():
             target = old.replace(str(self.out_path), str(new_path))
@@ -211,6 +236,7 @@ class JoinGroupby(StatOperator):
         self.categories = {}
         self.storage_name = {}
         self._device_stats = {}
+        self._pending = {}
 
 
 def _stats_from_frame(df: pd.DataFrame, key_cols) -> _Stats:
@@ -234,4 +260,5 @@ def _stats_from_frame(df: pd.DataFrame, key_cols) -> _Stats:
         c: torch.from_numpy(df[c].to_numpy().astype(np.float64)).to(dev)
         for c in df.columns if c not in key_cols
     }
-    return _Stats(list(key_cols), keys, torch.from_numpy(nm).to(dev), cols)
+    f32 = [c for c in cols if df[c].dtype == np.float32 and c.rsplit("_", 1)[-1] in ("sum", "min", "max")]
+    return _Stats(list(key_cols), keys, torch.from_numpy(nm).to(dev), cols, f32_columns=f32)

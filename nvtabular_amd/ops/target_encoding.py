@@ -31,17 +31,43 @@ def _add_fold(n, kfold, fold_seed=None) -> np.ndarray:
     return state.choice(np.arange(kfold, dtype=typ), n)
 
 
+_FOLD_CACHE = {}  # (kfold, fold_seed, device) -> uint8 tensor of the longest partition seen
+
+
 def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
-    f = _add_fold(n, kfold, fold_seed).astype(np.uint8)
-    return DeviceColumn(torch.from_numpy(f).to(device))
+    """Fold ids of one partition in HBM.
+
+    fold_seed None: ``arange(n) % kfold`` is generated on the device (no host traffic).
+    Seeded folds must be numpy's MT19937 stream to stay bit-identical to the reference
+    (target_encoding.py:436-439), so they are drawn on the host -- but the reference re-seeds
+    per partition, i.e. every partition gets the SAME sequence (a shorter partition a prefix of
+    it): the column is generated and uploaded once per (kfold, seed, device) and sliced
+    afterwards instead of 1 B/row over PCIe for every partition of every pass."""
+    if fold_seed is None:
+        # the reference's arange is created IN the fold dtype (min_scalar_type(kfold * 2), uint8
+        # for any sane kfold) and wraps: fold = (i mod 2^bits) mod kfold, not i mod kfold
+        bits = 8 * np.dtype(np.min_scalar_type(kfold * 2)).itemsize
+        idx = torch.arange(n, device=device, dtype=torch.int64)
+        if bits < 64:
+            idx = idx & ((1 << bits) - 1)
+        return DeviceColumn((idx % kfold).to(torch.uint8 if kfold <= 255 else torch.int32))
+    key = (int(kfold), int(fold_seed), str(device))
+    cached = _FOLD_CACHE.get(key)
+    if cached is None or cached.numel() < n:
+        f = _add_fold(n, kfold, fold_seed).astype(np.uint8)
+        cached = _FOLD_CACHE[key] = torch.from_numpy(f).to(device)
+    return DeviceColumn(cached[:n])
 
 
 class TargetEncoding(StatOperator):
     def __init__(self, target, target_mean=None, kfold=None, fold_seed=42, p_smooth=20,
                  out_col=None, out_dtype=None, split_out=None, split_every=None,
                  cat_cache="host", out_path=None, on_host=True, name_sep="_", drop_folds=True,
-                 tree_width=None):
+                 tree_width=None, defer_artifacts=False):
         super().__init__()
+        self.defer_artifacts = defer_artifacts  # engine extension, see JoinGroupby
+        self._pending = {}
+        self._hints = {}
         target = Node.construct_from(target)
         self.dependency = target
         self.target = target
@@ -77,11 +103,11 @@ class TargetEncoding(StatOperator):
             state["moments"] = moments_begin(targets)
         for cols in self._groups(col_selector):
             name = _make_name(*cols, sep=self.name_sep)
-            state["aggs"][name] = GroupAgg(name, cols, targets)
+            state["aggs"][name] = GroupAgg(name, cols, targets, hint=self._hints.get(name, 0))
             if self.kfold > 1:
                 fcols = [self.fold_name] + cols
                 fname = _make_name(*fcols, sep=self.name_sep)
-                state["aggs"][fname] = GroupAgg(fname, fcols, targets)
+                state["aggs"][fname] = GroupAgg(fname, fcols, targets, hint=self._hints.get(fname, 0))
         return state
 
     def fit_partition(self, state, col_selector, df):
@@ -101,10 +127,11 @@ class TargetEncoding(StatOperator):
         paths = {}
         for name, agg in state["aggs"].items():
             comp = agg.finalize()
-            df = stats_frame(agg, comp, ["count", "sum"], self.name_sep)
+            self._hints[name] = max(64, int(comp["n"]))
             d = os.path.join(base, f"cat_stats.{name}.parquet")
-            os.makedirs(d, exist_ok=True)
-            df.to_parquet(os.path.join(d, "part.0.parquet"), index=False)
+            self._pending[name] = (agg, comp, d)
+            if not self.defer_artifacts:
+                self.flush_artifacts()
             paths[name] = d
             cols = {"count": comp["count"]}
             for j, t in enumerate(agg.val_cols):
@@ -112,6 +139,14 @@ class TargetEncoding(StatOperator):
             self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols)
         moments = moments_end(state["moments"]) if state["moments"] is not None else None
         return paths, moments
+
+    def flush_artifacts(self):
+        """Write any deferred cat_stats.<group>.parquet directories."""
+        for agg, comp, d in self._pending.values():
+            os.makedirs(d, exist_ok=True)
+            stats_frame(agg, comp, ["count", "sum"], self.name_sep).to_parquet(
+                os.path.join(d, "part.0.parquet"), index=False)
+        self._pending = {}
 
     def fit_finalize(self, dask_stats):
         for col, value in dask_stats[0].items():
@@ -243,6 +278,7 @@ class TargetEncoding(StatOperator):
     def set_storage_path(self, new_path, copy=False):
         import shutil
 
+        self.flush_artifacts()
         new = {}
         for col, old in self.stats.items():
             target = old.replace(str(self.out_path), str(new_path))
@@ -256,3 +292,4 @@ class TargetEncoding(StatOperator):
         self.stats = {}
         self.means = {}
         self._device_stats = {}
+        self._pending = {}

@@ -172,3 +172,33 @@ def test_cfg5_multihot_lists_categorify_hashbucket(tmp_path):
     samp = leaves[:100_000].cpu().numpy()
     exp = (O.nvt_hash32(samp.astype(np.int64)) % np.uint32(2**20)).astype(np.int32)
     np.testing.assert_array_equal(hb[:100_000].cpu().numpy(), exp)
+
+
+@pytest.mark.timeout(600)
+def test_cfg3_high_cardinality_column_stays_on_partitioned_path():
+    """BASELINE.json configs[2]'s worst columns (Criteo-1TB C1/C10/C20/C22: ~4e7 uniques):
+    64 M rows of uniform draws from 4.8e7 ids -> ~3.5e7 distinct keys in one partition.  The
+    groupby-size must come from the partitioned LDS path (path 3), not the global-atomic
+    fallback, and equal torch.unique exactly; the encode round-trips."""
+    import torch
+
+    from nvtabular_amd import kernels as K
+
+    dev = torch.device("cuda", 0)
+    n, card = 64_000_000, 48_000_000
+    g = torch.Generator(device=dev).manual_seed(7)
+    keys = (torch.randint(0, card, (n,), device=dev, generator=g, dtype=torch.int64) * 2654435761 % (2**31)
+            ).to(torch.int32)
+    k, c, nulls, info = K.dense_count(keys, None, hint=40_000_000)
+    assert info["path"] == 3, info
+    uk, uc = torch.unique(keys, return_counts=True)
+    assert info["distinct"] == uk.numel() > 32_000_000
+    order = torch.argsort(k)
+    assert torch.equal(k[order], uk) and torch.equal(c[order], uc)
+    del order, uk, uc
+    # vocabulary order + encode table at this size: labels decode back to the keys
+    K.vocab_sort(k, c, info["max_count"])
+    tab = K.EncodeTable(k, 3, unique=True)
+    lab = tab.encode(keys, None, 1, 2)
+    assert int((lab < 3).sum().item()) == 0
+    assert torch.equal(k[(lab - 3)], keys)
