@@ -326,6 +326,14 @@ PATH_S_MAX_WEIGHTED = 5000          # path 0 for weighted merges / int64 keys: 8
 # column at 13-39 k distinct keys, with 4x the HBM reads), so the driver never picks them.
 # escalation order when a path's LDS tables overflow (C-ABI path ids, include/nvt_hip.h)
 PATH_ORDER = [6, 0, 7, 1, 2, 3]
+PATH_ORDER_I32 = [6, 0, 7, 8, 3]   # int32 keys, unweighted: path 8 replaces paths 1 and 2
+PATH_P8_MAX_DISTINCT = 9_000_000   # 1024 buckets x 16384-slot tables (<= ~11 k keys each)
+# Measured on MI355X (profiles/r02_notes.md): path 8's histogram is faster (40 vs 70 us) and it
+# saves path 2's second scatter, but its 1024-way scatter runs at 200 us (64-byte runs, look-back)
+# against 100 us for the 256-way one and the 1024 small buckets amortise the per-workgroup table
+# set-up / flush worse (count 165-240 vs 140-190 us): 557 us per column against 450 (path 1) /
+# 540 (path 2).  Kept in the ABI and the parity tests, off by default.
+USE_P8 = os.environ.get("NVT_P8", "0") == "1"
 _S_CLASSES = {6: 1, 0: 1, 7: 2, 4: 4, 5: 8}
 PATH_S2_FACTOR = 1.95               # path 7: path 0 with 2 key classes per row slab (column read twice)
 PATH_TINY_MAX = 64                  # path 6: path 0 with hot keys replicated per lane group
@@ -362,6 +370,8 @@ def _path_for(hint: int, small_tables: bool = False) -> int:
         return 0
     if hint <= PATH_S2_FACTOR * s_max:
         return 7
+    if USE_P8 and not small_tables and hint <= PATH_P8_MAX_DISTINCT:
+        return 8
     if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
         return 1
     if hint <= PATH_P2_MAX_DISTINCT:
@@ -426,11 +436,12 @@ class DenseCountJob:
         ovf = st[_lib.ST_OVERFLOW]
         if ovf & 1:
             # forced paths 4 / 5 (tests, probes) escalate to the partitioned path 1
-            nxt = PATH_ORDER.index(self.path) + 1 if self.path in PATH_ORDER else PATH_ORDER.index(1)
-            if nxt >= len(PATH_ORDER):
+            order = PATH_ORDER_I32 if (USE_P8 and self.kb == 4 and self.weights is None) else PATH_ORDER
+            nxt = order.index(self.path) + 1 if self.path in order else order.index(3 if self.path == 8 else 1)
+            if nxt >= len(order):
                 self._fallback()
                 return True
-            self.path = PATH_ORDER[nxt]
+            self.path = order[nxt]
             self.cap_guess = max(self.cap_guess, _PATH_MAX[self.path])
             return False
         if ovf & 2:
@@ -467,6 +478,7 @@ SAMPLE_ROWS = 1 << 18               # cold start: distinct keys of this many lea
 SAMPLE_MIN_ROWS = 8 * SAMPLE_ROWS   # ... when the column is at least this long
 # distinct keys each path is sized for (output-capacity guess when a path is entered by escalation)
 _PATH_MAX = {6: 1024, 0: 98304, 7: 196608, 4: 393216, 5: 786432, 1: PATH_P1_MAX_DISTINCT,
+             8: PATH_P8_MAX_DISTINCT,
              2: PATH_P2_MAX_DISTINCT, 3: PATH_P3_MAX_DISTINCT}
 
 

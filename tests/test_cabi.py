@@ -43,7 +43,7 @@ def test_argument_validation_needs_no_gpu():
     assert b"key_bytes" in lib.nvt_last_error()
     assert lib.nvt_count_table_bytes(4, 1 << 20, C.byref(nbytes)) == 0 and nbytes.value == 8 << 20
     assert lib.nvt_encode_table_bytes(8, 1 << 10, C.byref(nbytes)) == 0 and nbytes.value == 16 << 10
-    assert lib.nvt_dense_count_ws_bytes(4, 1000, 8, 0, C.byref(nbytes)) == -1
+    assert lib.nvt_dense_count_ws_bytes(4, 1000, 9, 0, C.byref(nbytes)) == -1
 
 
 def test_ops_fail_loudly_without_gpu():

@@ -486,7 +486,8 @@ def test_dense_count_paths_vs_numpy(dtype, card, n, weighted):
     ww = w if weighted else np.ones(n, dtype="int64")
     exp = pd.Series(ww[~mask]).groupby(ids[~mask]).sum()
     distinct = len(exp)
-    for path in K.PATH_ORDER + [4, 5]:
+    paths = K.PATH_ORDER + [4, 5] + ([8] if dtype == "int32" and not weighted else [])
+    for path in paths:
         job = K.DenseCountJob(keys, valid, wt, hint=distinct)
         job.path = path  # force every kernel path (the driver escalates along PATH_ORDER on overflow)
         k, c, nulls, info = K.dense_count_many([job])[0]
