@@ -157,10 +157,10 @@ int nvt_encode_build_i64(const int64_t *vocab_keys, uint64_t n_vocab, int64_t fi
  * vocab_keys / n_vocab / first_label (optional: pass NULL, 0, 0): the ordered, duplicate-free
  * vocabulary the table was built from.  Its head -- the most frequent keys -- is then
  * staged in LDS by every workgroup and only rows that miss it probe the table in HBM.
- * A vocabulary of at most NVT_ENCODE_RESIDENT_I32 (12288) int32 / NVT_ENCODE_RESIDENT_I64
+ * A vocabulary of at most NVT_ENCODE_RESIDENT_I32 (8192) int32 / NVT_ENCODE_RESIDENT_I64
  * (6144) int64 keys is staged in full: table and sentinel_label may then be NULL and
  * nvt_encode_build_* need not be called at all. */
-#define NVT_ENCODE_RESIDENT_I32 12288
+#define NVT_ENCODE_RESIDENT_I32 8192
 #define NVT_ENCODE_RESIDENT_I64 6144
 int nvt_encode_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, const void *table,
                    uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,

@@ -9,6 +9,7 @@
 // Bytes per row (int32 keys, int64 labels): 4 read + 8 written = 12; the table
 // probe is extra traffic that stays in L2 / Infinity Cache for all but the
 // ~4e7-key columns.
+#include <cstdlib>
 #include <limits>
 #include <type_traits>
 
@@ -239,7 +240,21 @@ struct HotCfg<int64_t> {
   static constexpr int slots = 8192;  // 128 KiB of {key,label} int64 pairs
 };
 
-template <typename K, typename OUT>
+// TWO (int32 keys, cache mode only): the staged head of the vocabulary lives in a 2-choice,
+// 2-slots-per-bucket table instead of a linear-probing one.  A lookup is exactly two
+// independent 16-byte LDS reads whatever the load (a MISS in the linear table walks ~2.5 slots
+// at 25 % load and ~8.5 at 75 %, which is why that table is only filled to a quarter), so the
+// table can be filled to 7/8: 14336 hot keys instead of 4096, 15-20 % fewer rows go on to the
+// table in HBM.  A key that finds both buckets full is simply not cached (the global table
+// holds every key).
+template <int NB>
+__device__ __forceinline__ void two_buckets(uint32_t h, uint32_t &b1, uint32_t &b2) {
+  b1 = (h >> 13) & (NB - 1);
+  b2 = (((h ^ (h >> 15)) * 0x2C1B3C6Du) >> 17) & (NB - 1);
+  b2 = b2 == b1 ? b1 ^ 1u : b2;
+}
+
+template <typename K, typename OUT, bool TWO = false>
 __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
@@ -264,6 +279,20 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
       s_sent = first_label + (long long)i;
       continue;
     }
+    if constexpr (TWO) {
+      uint32_t b1, b2;
+      two_buckets<SLOTS / 2>((uint32_t)slot_hash(key), b1, b2);
+      const uint32_t cand[4] = {2 * b1, 2 * b1 + 1, 2 * b2, 2 * b2 + 1};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        K prev = (K)atomicCAS(reinterpret_cast<C *>(&lt[cand[c]].key), (C)EMPTY, (C)key);
+        if (prev == EMPTY) {
+          lt[cand[c]].label = (L)(first_label + (int64_t)i);
+          break;
+        }
+      }
+      continue;  // all four slots taken: not cached
+    }
     uint32_t s = (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
     while (true) {
       K prev = (K)atomicCAS(reinterpret_cast<C *>(&lt[s].key), (C)EMPTY, (C)key);
@@ -280,6 +309,18 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
 
   // LDS lookup: label, or -1 when the key is not in the staged head of the vocabulary
   auto hot_lookup = [&](K key) -> int64_t {
+    if constexpr (TWO) {
+      uint32_t b1, b2;
+      two_buckets<SLOTS / 2>((uint32_t)slot_hash(key), b1, b2);
+      const int4 a = reinterpret_cast<const int4 *>(lt)[b1];
+      const int4 c = reinterpret_cast<const int4 *>(lt)[b2];
+      int lab = -1;
+      lab = a.x == (int)key ? a.y : lab;
+      lab = a.z == (int)key ? a.w : lab;
+      lab = c.x == (int)key ? c.y : lab;
+      lab = c.z == (int)key ? c.w : lab;
+      return (int64_t)lab;
+    }
     uint32_t s = (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
     while (true) {
       EncSlot<K> e = lt[s];
@@ -521,8 +562,8 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
                   const K *hot_keys, uint64_t n_vocab, int64_t first_label, hipStream_t s) {
   // a duplicate-free vocabulary that fits the LDS table is encoded without the global table
-  const bool resident = hot_keys != nullptr && n_vocab > 0 &&
-                        n_vocab <= (uint64_t)HotCfg<K>::slots / 4 * 3;
+  constexpr uint64_t kResident = sizeof(K) == 4 ? NVT_ENCODE_RESIDENT_I32 : NVT_ENCODE_RESIDENT_I64;
+  const bool resident = hot_keys != nullptr && n_vocab > 0 && n_vocab <= kResident;
   NVT_CHECK_ARG(resident || (table && sentinel_label), "null table");
   NVT_CHECK_ARG(resident || (capacity >= 64 && (capacity & (capacity - 1)) == 0),
                 "capacity must be 2^k >= 64");
@@ -541,11 +582,31 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
     // a vocabulary that fits entirely may fill the table to 75 % (every lookup is a hit);
     // otherwise most lookups of the table MISS, and an unsuccessful linear probe costs
     // ~2.5 slots at 50 % load but ~8.5 at 75 % (measured: 530 -> 1290 us on a 6 M-key column)
-    const uint64_t full_cap = (uint64_t)HotCfg<K>::slots / 4 * 3;
+    // fully staged (no global table) up to half load: linear probing of a table in which every
+    // lookup hits stays short there (a 73 %-full table made an 11.9 k-key column 229 instead
+    // of 129 us); larger vocabularies use the cache mode below
+    const uint64_t full_cap = kResident;
     const uint64_t part_cap = (uint64_t)HotCfg<K>::slots / NVT_HOT_DIV;
-    const uint32_t n_hot = (uint32_t)(n_vocab <= full_cap ? n_vocab : part_cap);
+    uint32_t n_hot = (uint32_t)(n_vocab <= full_cap ? n_vocab : part_cap);
     const int global_needed = n_vocab > n_hot;
     unsigned hgrid = stream_grid(n / VEC + 1, kEncBS * 2, 1);
+    if constexpr (sizeof(K) == 4) {
+      static const bool two = getenv("NVT_ENC_LINEAR") == nullptr;
+      if (global_needed && two) {  // cache mode: 2-choice table filled to 7/8
+        const uint64_t cap2 = (uint64_t)HotCfg<K>::slots / 8 * 7;
+        n_hot = (uint32_t)(n_vocab < cap2 ? n_vocab : cap2);
+        if (out_bytes == 8)
+          encode_hot_kernel<K, int64_t, true><<<hgrid, kEncBS, 0, s>>>(
+              keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
+              reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label, 1);
+        else
+          encode_hot_kernel<K, int32_t, true><<<hgrid, kEncBS, 0, s>>>(
+              keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
+              reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label, 1);
+        NVT_CHECK_LAUNCH();
+        return NVT_OK;
+      }
+    }
     if (out_bytes == 8)
       encode_hot_kernel<K, int64_t><<<hgrid, kEncBS, 0, s>>>(
           keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,

@@ -656,7 +656,7 @@ def vocab_sort(keys: torch.Tensor, counts: torch.Tensor, max_count: int = 0):
 # --------------------------------------------------------------------------
 # Categorify.transform: encode tables
 # --------------------------------------------------------------------------
-ENCODE_RESIDENT_I32, ENCODE_RESIDENT_I64 = 12288, 6144  # include/nvt_hip.h
+ENCODE_RESIDENT_I32, ENCODE_RESIDENT_I64 = 8192, 6144  # include/nvt_hip.h
 _ENC_BYTES = {}   # (key_bytes, capacity) -> nvt_encode_table_bytes
 ASYNC_FINALIZE = os.environ.get("NVT_ASYNC_FINALIZE", "1") != "0"
 _SORT_BYTES = {}  # (key_bytes, n) -> nvt_vocab_sort_tmp_bytes

@@ -20,7 +20,7 @@ __global__ void gen(int32_t *k, uint64_t n, double card, double s, uint32_t seed
   }
 }
 constexpr int EMPTY = INT32_MIN;
-template <int BITS, int BS, int F, int HASH>
+template <int BITS, int BS, int F, int HASH, int REP = 8>
 __global__ __launch_bounds__(BS) void stage(const int32_t *__restrict__ keys, const uint8_t *__restrict__ valid,
                                             uint64_t n, unsigned long long *out) {
   constexpr int SLOTS = 1 << BITS;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(BS) void stage(const int32_t *__restrict__ keys, co
   const uint64_t lo = blockIdx.x * per, hi = lo + per < nv ? lo + per : nv;
   const int iters = hi > lo ? (int)((hi - lo + (uint64_t)BS * 4 - 1) / ((uint64_t)BS * 4)) : 0;
   const uint64_t last = hi ? hi - 1 : 0;
-  const uint32_t rep = (F & 8) ? (lane & 7u) * 2053u : 0u;
+  const uint32_t rep = (F & 8) ? (lane & (unsigned)(REP - 1)) * 2053u : 0u;
   unsigned my_nulls = 0, my_sent = 0;
   bool failed = false;
   for (int it = 0; it < iters; ++it) {
@@ -488,6 +488,10 @@ int main() {
     printf("        kl2 morph: V0 %.1f  V1 %.1f  V2(=V1) -  V3 %.1f  V4 %.1f\n",
            timeit([&] { kl2<0><<<256, 1024>>>(k, n, out); }), timeit([&] { kl2<1><<<256, 1024>>>(k, n, out); }),
            timeit([&] { kl2<3><<<256, 1024>>>(k, n, out); }), timeit([&] { kl2<4><<<256, 1024>>>(k, n, out); }));
+    printf("        replication (v+s+f): x1 %.1f  x2 %.1f  x4 %.1f  x8 %.1f | 512thr x2 %.1f x4 %.1f\n",
+           run(stage<14, 1024, 7, 1>, 256, 1024), run(stage<14, 1024, 15, 1, 2>, 256, 1024),
+           run(stage<14, 1024, 15, 1, 4>, 256, 1024), run(stage<14, 1024, 15, 1, 8>, 256, 1024),
+           run(stage<14, 512, 15, 1, 2>, 256, 512), run(stage<14, 512, 15, 1, 4>, 256, 512));
     CK(hipMemset(out, 0, 8));
     stage<14, 1024, 7, 1><<<256, 1024>>>(k, valid, n, out);
     unsigned long long tot; CK(hipMemcpy(&tot, out, 8, hipMemcpyDeviceToHost));
