@@ -271,6 +271,25 @@ int nvt_gb_index_build(nvt_gb_table *t, const int64_t *const *keys, const uint8_
                        uint64_t n_groups, void *stream);
 int nvt_gb_lookup(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *const *key_valid,
                   uint64_t n, int64_t *out_group, void *stream);
+/* ---- Groupby operator (groupby.py:236-263): row order by (group, sort columns) + aggregates.
+ * nvt_sort_key_u64: order-preserving 64-bit image of a column (nulls / NaN last in either
+ * direction, pandas na_position="last").  nvt_order_rows: stable refinement of a row order by
+ * such a key (two 32-bit radix passes) or by group id (-1 = null key, sorted last); perm
+ * entries are 64-bit words whose LOW 32 bits are the row index (after a gid refinement the high
+ * half is the group id: exactly the `words` nvt_seg_aggregate takes).  nvt_seg_aggregate:
+ * out_size uint64[ngroups] rows per group, out_count uint64[nvals][ngroups] non-null values per
+ * column, out_sum / out_sumsq / out_min / out_max double[nvals][ngroups] (any of the last
+ * three pairs may be NULL) in one wave-level segmented reduction; outputs pre-initialised by
+ * the caller (0 / 0 / 0 / 0 / +inf / -inf). */
+int nvt_sort_key_u64(const void *x, int dtype, const uint8_t *valid, uint64_t n, int ascending,
+                     uint64_t *out, void *stream);
+int nvt_order_rows_ws_bytes(uint64_t n, uint64_t *bytes);
+int nvt_order_rows(const uint64_t *key64, const int64_t *gid, uint64_t ngroups,
+                   const uint64_t *perm_in, uint64_t n, uint64_t *perm_out, void *ws, void *stream);
+int nvt_seg_aggregate(const uint64_t *words, uint64_t n, uint64_t ngroups, const void *const *vals,
+                      const int *vdtypes, const uint8_t *const *val_valid, int nvals,
+                      uint64_t *out_size, uint64_t *out_count, double *out_sum, double *out_sumsq,
+                      double *out_min, double *out_max, void *stream);
 /* out[i] = group[i] >= 0 ? src[group[i]] : miss   (stat columns joined back onto rows) */
 int nvt_gather_f64(const double *src, const int64_t *group, uint64_t n, double miss, void *out,
                    int out_dtype, void *stream);

@@ -80,6 +80,11 @@ SIGNATURES = {
     "nvt_gb_compact": [_vp, _pp, _vp, _vp, _vp, _pp, _pp, _pp, _pp, _vp, _vp],
     "nvt_gb_index_build": [_vp, _pp, _vp, _u64, _vp],
     "nvt_gb_lookup": [_vp, _pp, _pp, _u64, _vp, _vp],
+    "nvt_sort_key_u64": [_vp, _i32, _vp, _u64, _i32, _vp, _vp],
+    "nvt_order_rows_ws_bytes": [_u64, C.POINTER(_u64)],
+    "nvt_order_rows": [_vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp],
+    "nvt_seg_aggregate": [_vp, _u64, _u64, _pp, C.POINTER(C.c_int), _pp, _i32, _vp, _vp, _vp, _vp,
+                          _vp, _vp, _vp],
     "nvt_gather_f64": [_vp, _vp, _u64, _dbl, _vp, _i32, _vp],
     "nvt_te_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _dbl, _dbl, _vp, _i32, _vp],
     "nvt_widen_i64": [_vp, _i32, _u64, _vp, _vp],

@@ -60,6 +60,7 @@ struct GbView {
   double *sum, *sumsq, *vmin, *vmax;
   long long *index;
   uint64_t *state;
+  unsigned long long *vcount;  // [nvals][cap] non-null values per column (nvt_seg_aggregate only)
 };
 
 struct GbRowArgs {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
       }
       if (live && tail) {
         atomicAdd(&t.size[slot], (unsigned long long)sz);
-        if (ct > 0) atomicAdd(&t.count[slot], (unsigned long long)ct);
+        if (t.count && ct > 0) atomicAdd(&t.count[slot], (unsigned long long)ct);
       }
     }
     for (int j = 0; j < t.nvals; ++j) {
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
       if (live && tail && any > 0) {
         const uint64_t o = (uint64_t)j * t.cap + slot;
         atomicAdd(&t.sum[o], sum);
+        if (t.vcount) atomicAdd(&t.vcount[o], (unsigned long long)any);
         if (t.sumsq) atomicAdd(&t.sumsq[o], sq);
         if (t.vmin) {
           atomic_min_f64(&t.vmin[o], mn);
@@ -346,6 +348,74 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
       }
     }
     (void)head;
+  }
+}
+
+// ---- Groupby operator (groupby.py:236-263): row order + per-group aggregates ----------------
+// rows are ordered by (group id, sort columns) with the stable radix sort of nvt_sort.hip over
+// packed (key32 << 32 | row) words -- a 64-bit sort key takes two passes of 32 bits -- and every
+// conventional aggregate comes from ONE wave-level segmented reduction over the ordered rows
+// (gb_segreduce_kernel above, writing straight into the output arrays).
+template <typename T>
+__device__ __forceinline__ uint64_t sortable_bits(T v);
+template <>
+__device__ __forceinline__ uint64_t sortable_bits<int64_t>(int64_t v) {
+  return (uint64_t)v ^ 0x8000000000000000ull;
+}
+template <>
+__device__ __forceinline__ uint64_t sortable_bits<int32_t>(int32_t v) {
+  return sortable_bits<int64_t>((int64_t)v);
+}
+template <>
+__device__ __forceinline__ uint64_t sortable_bits<uint8_t>(uint8_t v) {
+  return sortable_bits<int64_t>((int64_t)v);
+}
+template <>
+__device__ __forceinline__ uint64_t sortable_bits<double>(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+template <>
+__device__ __forceinline__ uint64_t sortable_bits<float>(float v) {
+  return sortable_bits<double>((double)v);
+}
+
+// out[i] = order-preserving 64-bit image of x[i]; nulls / NaN sort LAST for either direction
+// (pandas sort_values na_position="last"); descending = complemented image
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sort_key_kernel(const T *__restrict__ x,
+                                                          const uint8_t *__restrict__ valid,
+                                                          uint64_t n, int ascending,
+                                                          uint64_t *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const T v = x[i];
+    const bool ok = bit_valid(valid, i) && !is_nan(v);
+    uint64_t b = sortable_bits<T>(v);
+    if (!ascending) b = ~b;
+    out[i] = ok ? (b == ~0ull ? b - 1 : b) : ~0ull;
+  }
+}
+
+// words[i] = (hi32(i) << 32) | row(i) with row(i) = perm ? low 32 bits of perm[i] : i and
+// hi32 = 32-bit chunk `chunk` (0 = low, 1 = high) of src64[row] -- or, for group ids, the id
+// itself with -1 (null key) mapped to `null_hi` so that those rows sort last
+__global__ __launch_bounds__(kBlock) void pack_words_kernel(const uint64_t *__restrict__ src64,
+                                                            const int64_t *__restrict__ gid,
+                                                            const uint64_t *__restrict__ perm,
+                                                            uint64_t n, int chunk, uint32_t null_hi,
+                                                            uint64_t *__restrict__ words) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const uint32_t row = perm ? (uint32_t)perm[i] : (uint32_t)i;
+    uint32_t hi;
+    if (gid) {
+      const int64_t g = gid[row];
+      hi = g < 0 ? null_hi : (uint32_t)g;
+    } else {
+      hi = (uint32_t)(src64[row] >> (32 * chunk));
+    }
+    words[i] = ((uint64_t)hi << 32) | row;
   }
 }
 
@@ -457,6 +527,7 @@ inline GbView view_of(nvt_gb_table *t) {
   v.vmax = t->vmax;
   v.index = t->index;
   v.state = t->state;
+  v.vcount = nullptr;
   return v;
 }
 
@@ -685,6 +756,108 @@ int nvt_gb_merge(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *key
   int rc = fill_merge_args(t, a, keys, key_null_mask, size, count, sum, sumsq, vmin, vmax);
   if (rc) return rc;
   gb_merge_kernel<<<stream_grid(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(view_of(t), a, n);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_sort_key_u64(const void *x, int dtype, const uint8_t *valid, uint64_t n, int ascending,
+                     uint64_t *out, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(x && out, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = stream_grid(n, kBlock * 4);
+  switch (dtype) {
+    case NVT_F32: sort_key_kernel<float><<<grid, kBlock, 0, s>>>((const float *)x, valid, n, ascending, out); break;
+    case NVT_F64: sort_key_kernel<double><<<grid, kBlock, 0, s>>>((const double *)x, valid, n, ascending, out); break;
+    case NVT_I32: sort_key_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)x, valid, n, ascending, out); break;
+    case NVT_I64: sort_key_kernel<int64_t><<<grid, kBlock, 0, s>>>((const int64_t *)x, valid, n, ascending, out); break;
+    case NVT_U8: sort_key_kernel<uint8_t><<<grid, kBlock, 0, s>>>((const uint8_t *)x, valid, n, ascending, out); break;
+    default:
+      set_error("nvt_sort_key_u64: unsupported dtype %d", dtype);
+      return NVT_EINVAL;
+  }
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_order_rows_ws_bytes(uint64_t n, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes, "null out");
+  *bytes = ((n * 8 + 255) & ~255ull) + sort_words_tmp_bytes(n) + 512;
+  return NVT_OK;
+}
+
+// Stable refinement of a row order: perm_out = rows of perm_in (NULL: 0..n-1) re-ordered by
+//   key64 (both 32-bit halves, two radix sorts)                  when key64 != NULL
+//   group id (ids in [0, ngroups), -1 = null key -> sorted last)  when gid != NULL
+// perm_in / perm_out: uint64 row indices (may alias).  ws: nvt_order_rows_ws_bytes(n).
+int nvt_order_rows(const uint64_t *key64, const int64_t *gid, uint64_t ngroups,
+                   const uint64_t *perm_in, uint64_t n, uint64_t *perm_out, void *ws, void *stream) {
+  NVT_CHECK_ARG((key64 != nullptr) != (gid != nullptr), "exactly one of key64 / gid");
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(perm_out && ws, "null pointer");
+  NVT_CHECK_ARG(n < (1ull << 30) && ngroups < (1ull << 31), "at most 2^30-1 rows");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_order", 0, s);
+  uint64_t *words = reinterpret_cast<uint64_t *>(ws);
+  void *sort_tmp = reinterpret_cast<char *>(ws) + ((n * 8 + 255) & ~255ull);
+  const unsigned grid = stream_grid(n, kBlock * 4);
+  const uint64_t *cur = perm_in;
+  const int rounds = key64 ? 2 : 1;
+  for (int r = 0; r < rounds; ++r) {
+    int hi_bits = 32;
+    if (gid) {
+      hi_bits = 1;
+      while ((1ull << hi_bits) <= ngroups) ++hi_bits;  // ids 0..ngroups (ngroups = null marker)
+    }
+    pack_words_kernel<<<grid, kBlock, 0, s>>>(key64, gid, cur, n, r, (uint32_t)ngroups, words);
+    NVT_CHECK_LAUNCH();
+    uint64_t *sorted = nullptr;
+    int rc = sort_words_bits(words, n, 32, 32 + hi_bits, sort_tmp, &sorted, s);
+    if (rc) return rc;
+    // the low halves are the new row order (kept as the 64-bit words: consumers mask them)
+    NVT_CHECK_HIP(hipMemcpyAsync(perm_out, sorted, n * 8, hipMemcpyDeviceToDevice, s));
+    cur = perm_out;
+  }
+  return NVT_OK;
+}
+
+// Per-group aggregates over rows ordered by group: words[i] = (group << 32 | row), groups
+// ascending (the output of nvt_order_rows with gid; rows of null keys carry group >= ngroups and
+// are ignored).  out_size / out_count: uint64[ngroups] (rows / non-null values of column 0);
+// out_sum / out_sumsq / out_min / out_max: double[nvals][ngroups] or NULL.  All outputs must be
+// initialised by the caller (0, 0, 0, 0, +inf, -inf).
+int nvt_seg_aggregate(const uint64_t *words, uint64_t n, uint64_t ngroups, const void *const *vals,
+                      const int *vdtypes, const uint8_t *const *val_valid, int nvals,
+                      uint64_t *out_size, uint64_t *out_count, double *out_sum, double *out_sumsq,
+                      double *out_min, double *out_max, void *stream) {
+  if (n == 0 || ngroups == 0) return NVT_OK;
+  NVT_CHECK_ARG(words && out_size && (out_count || nvals == 0), "null pointer");
+  NVT_CHECK_ARG(nvals >= 0 && nvals <= kMaxVals, "nvals must be 0..8");
+  NVT_CHECK_ARG((out_min == nullptr) == (out_max == nullptr), "min/max come in pairs");
+  GbView t;
+  memset(&t, 0, sizeof(t));
+  t.nkeys = 1;
+  t.nvals = nvals;
+  t.cap = ngroups;
+  t.size = reinterpret_cast<unsigned long long *>(out_size);
+  t.count = nullptr;
+  t.vcount = reinterpret_cast<unsigned long long *>(out_count);
+  t.sum = out_sum;
+  t.sumsq = out_sumsq;
+  t.vmin = out_min;
+  t.vmax = out_max;
+  GbRowArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int j = 0; j < nvals; ++j) {
+    NVT_CHECK_ARG(vals && vals[j] && vdtypes, "null value column");
+    a.vals[j] = vals[j];
+    a.vdtype[j] = vdtypes[j];
+    a.val_valid[j] = val_valid ? val_valid[j] : nullptr;
+  }
+  NVT_CHECK_ARG(nvals == 0 || out_sum, "null out_sum");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_aggregate", 0, s);
+  gb_segreduce_kernel<<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, words);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

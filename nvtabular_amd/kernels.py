@@ -1190,6 +1190,60 @@ class GroupbyTable:
         return out
 
 
+def _order_ws(n: int, device) -> torch.Tensor:
+    need = C.c_uint64()
+    check(_lib.load().nvt_order_rows_ws_bytes(n, C.byref(need)), "nvt_order_rows_ws_bytes")
+    return torch.empty(need.value, dtype=torch.uint8, device=device)
+
+
+def order_rows(n: int, device, sort_keys=(), gid: Optional[torch.Tensor] = None, ngroups: int = 0):
+    """Row order for the Groupby operator: stable by ``sort_keys`` (most significant first; each a
+    (column tensor, validity, ascending) triple), then by group id (-1 = null key, last).
+    Returns int64 words: low 32 bits = row index, high half = group id (when gid is given)."""
+    lib = _lib.load()
+    ws = _order_ws(n, device)
+    perm = torch.empty(n, dtype=torch.int64, device=device)
+    cur = None
+    key64 = torch.empty(n, dtype=torch.int64, device=device) if sort_keys else None
+    for data, valid, ascending in reversed(list(sort_keys)):  # LSD: least significant key first
+        data = data.view(torch.uint8) if data.dtype == torch.bool else data.contiguous()
+        check(lib.nvt_sort_key_u64(data.data_ptr(), dtype_code(data.dtype), ptr(valid), n,
+                                   1 if ascending else 0, key64.data_ptr(), stream_ptr()),
+              "nvt_sort_key_u64")
+        check(lib.nvt_order_rows(key64.data_ptr(), None, 0, ptr(cur), n, perm.data_ptr(),
+                                 ws.data_ptr(), stream_ptr()), "nvt_order_rows")
+        cur = perm
+    if gid is not None:
+        gid = gid.contiguous()
+        check(lib.nvt_order_rows(None, gid.data_ptr(), int(ngroups), ptr(cur), n, perm.data_ptr(),
+                                 ws.data_ptr(), stream_ptr()), "nvt_order_rows")
+    elif cur is None:
+        perm = torch.arange(n, dtype=torch.int64, device=device)
+    return perm
+
+
+def seg_aggregate(words: torch.Tensor, ngroups: int, vals, val_valid, sumsq=False, minmax=False):
+    """(size int64[G], count int64[V, G], sum, sumsq or None, min or None, max or None) over rows
+    ordered by group (``words`` from order_rows with gid): ONE segmented-reduction launch."""
+    lib = _lib.load()
+    dev = words.device
+    nv = len(vals)
+    vals = [aligned(v.view(torch.uint8) if v.dtype == torch.bool else v) for v in vals]
+    size = torch.zeros(ngroups, dtype=torch.int64, device=dev)
+    count = torch.zeros(max(nv, 1), ngroups, dtype=torch.int64, device=dev)
+    sm = torch.zeros(max(nv, 1), ngroups, dtype=torch.float64, device=dev)
+    sq = torch.zeros(nv, ngroups, dtype=torch.float64, device=dev) if (sumsq and nv) else None
+    mn = torch.full((nv, ngroups), float("inf"), dtype=torch.float64, device=dev) if (minmax and nv) else None
+    mx = torch.full((nv, ngroups), float("-inf"), dtype=torch.float64, device=dev) if (minmax and nv) else None
+    vd = (C.c_int * max(1, nv))(*[dtype_code(v.dtype) for v in vals])
+    check(lib.nvt_seg_aggregate(words.data_ptr(), words.numel(), int(ngroups),
+                                _lib.ptr_array([v.data_ptr() for v in vals]), vd,
+                                _lib.ptr_array([ptr(v) for v in val_valid]), nv, size.data_ptr(),
+                                count.data_ptr(), sm.data_ptr(), ptr(sq), ptr(mn), ptr(mx),
+                                stream_ptr()), "nvt_seg_aggregate")
+    return size, count, sm, sq, mn, mx
+
+
 def gather(src: torch.Tensor, group: torch.Tensor, miss: float, out_dtype: torch.dtype):
     _lib.require_gpu()
     src = src.to(torch.float64).contiguous()

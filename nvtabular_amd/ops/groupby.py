@@ -144,34 +144,42 @@ class Groupby(Operator):
             keys.append(k)
             valids.append(v)
         gid = index.lookup(keys, valids)  # row -> rank of its group, -1 for a null key
-        # 2. row order: sort_cols (stable, nulls last), then stable by group
-        perm = torch.arange(n, device=dev)
-        for c in reversed(self.sort_cols):
-            v = _sortable(frame[c].materialize(), self.ascending)
-            perm = perm[torch.argsort(v[perm], stable=True, descending=not self.ascending)]
-        g_sorted = gid[perm]
-        by_group = torch.argsort(g_sorted, stable=True)
-        perm = perm[by_group]
-        g_sorted = g_sorted[by_group]
-        first_valid = int((g_sorted < 0).sum().item())
-        perm, g_sorted = perm[first_valid:], g_sorted[first_valid:]
-        sizes = torch.bincount(g_sorted, minlength=ngroups)
+        # 2. row order: sort_cols (stable, nulls last), then stable by group -- the stable radix
+        #    sort of nvt_sort.hip over (key32 << 32 | row) words (nvt_order_rows); rows of null
+        #    keys sort behind the last group and are cut off
+        sort_keys = []
+        for c in self.sort_cols:
+            col = frame[c].materialize()
+            sort_keys.append((col.data, col.valid, bool(self.ascending)))
+        words = K.order_rows(n, dev, sort_keys, gid, ngroups)
+        conts = [c for c in dict.fromkeys(list(lst) + list(conv))]
+        cols = {c: frame[c].materialize() for c in conts}
+        for c, col in cols.items():
+            if col.is_list:
+                raise NotImplementedError("Groupby over list columns")
+        want = {a for c in conv for a in conv[c]}
+        # 3. every conventional aggregate from ONE segmented reduction over the ordered rows
+        size, count, sm, sq, mn, mx = K.seg_aggregate(
+            words, ngroups, [cols[c].data for c in conts], [cols[c].valid for c in conts],
+            sumsq=bool(want & {"std", "var"}), minmax=bool(want & {"min", "max"}))
         offsets = torch.zeros(ngroups + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(sizes, 0, out=offsets[1:])
-        # 3. outputs
+        torch.cumsum(size, 0, out=offsets[1:])
+        n_valid = int(offsets[-1].item())
+        perm = (words[:n_valid] & 0xFFFFFFFF)
+        # 4. outputs
         out = DeviceFrame()
         for j, c in enumerate(self.groupby_cols):
             if c in col_selector.names:
                 src = frame[c]
                 data = gkeys[j].to(src.data.dtype) if src.strings is None else gkeys[j]
                 out[c] = DeviceColumn(data, None, None, None, src.strings)
-        for c in dict.fromkeys(list(lst) + list(conv)):
-            col = frame[c].materialize()
-            if col.is_list:
-                raise NotImplementedError("Groupby over list columns")
-            vals = col.data[perm]
-            ok = _valid_bool(col, n)[perm]
+        for ci, c in enumerate(conts):
+            col = cols[c]
+            vals = ok = None
             for a in lst.get(c, []):
+                if vals is None:
+                    vals = col.data[perm]
+                    ok = _valid_bool(col, n)[perm]
                 name = self.name_sep.join([c, a])
                 if a == "list":
                     vb = None if bool(ok.all()) else pack_bitmap_device(ok)
@@ -183,7 +191,10 @@ class Groupby(Operator):
                     vb = None if bool(sel_ok.all()) else pack_bitmap_device(sel_ok)
                     out[name] = DeviceColumn(vals[pos].contiguous(), vb, None, None, col.strings)
             for a in conv.get(c, []):
-                out[self.name_sep.join([c, a])] = _segment_agg(a, vals, ok, g_sorted, ngroups)
+                out[self.name_sep.join([c, a])] = _finish_agg(
+                    a, col.data.dtype, count[ci].to(torch.float64), sm[ci],
+                    sq[ci] if sq is not None else None, mn[ci] if mn is not None else None,
+                    mx[ci] if mx is not None else None)
         return out
 
     @property
@@ -234,32 +245,25 @@ def _lexsort(gkeys, agg: GroupAgg, cols) -> torch.Tensor:
     return order
 
 
-def _segment_agg(agg: str, vals, ok, gid, ngroups) -> DeviceColumn:
-    """pandas semantics: nulls are skipped; count -> int32; sum / mean / std / var -> float32."""
-    dev = vals.device
-    x = torch.where(ok, vals.to(torch.float64), torch.zeros((), dtype=torch.float64, device=dev))
-    cnt = torch.zeros(ngroups, dtype=torch.float64, device=dev).index_add_(0, gid, ok.to(torch.float64))
+def _finish_agg(agg: str, src_dtype, cnt, s, s2, mn, mx) -> DeviceColumn:
+    """Per-group finishing arithmetic on the O(#groups) outputs of nvt_seg_aggregate -- pandas
+    semantics: nulls are skipped; count -> int32; sum / mean / std / var -> float32."""
     if agg == "count":
         return DeviceColumn(cnt.to(torch.int32))
-    s = torch.zeros(ngroups, dtype=torch.float64, device=dev).index_add_(0, gid, x)
     if agg == "sum":
         return DeviceColumn(s.to(torch.float32))
     if agg == "mean":
         return DeviceColumn((s / cnt).to(torch.float32))
     if agg in ("std", "var"):
-        s2 = torch.zeros(ngroups, dtype=torch.float64, device=dev).index_add_(0, gid, x * x)
         var = (s2 - s * s / cnt) / (cnt - 1)
         var = torch.where(cnt > 1, var.clamp_min(0), torch.full_like(var, float("nan")))
         return DeviceColumn((var.sqrt() if agg == "std" else var).to(torch.float32))
     if agg in ("min", "max"):
-        big = float("inf") if agg == "min" else float("-inf")
-        src = torch.where(ok, vals.to(torch.float64), torch.full((), big, dtype=torch.float64, device=dev))
-        red = torch.full((ngroups,), big, dtype=torch.float64, device=dev)
-        red = red.scatter_reduce(0, gid, src, reduce="amin" if agg == "min" else "amax")
+        red = mn if agg == "min" else mx
         none = cnt == 0
-        if vals.dtype.is_floating_point:
+        if src_dtype.is_floating_point:
             red = torch.where(none, torch.full_like(red, float("nan")), red)
-            return DeviceColumn(red.to(vals.dtype))
+            return DeviceColumn(red.to(src_dtype))
         vb = None if not bool(none.any()) else pack_bitmap_device(~none)
-        return DeviceColumn(torch.where(none, torch.zeros_like(red), red).to(vals.dtype), vb)
+        return DeviceColumn(torch.where(none, torch.zeros_like(red), red).to(src_dtype), vb)
     raise NotImplementedError(agg)
