@@ -466,26 +466,36 @@ class Categorify(StatOperator):
         keys = [k[keep] for k in keys]
         nm, size = nm[keep], size[keep]
         # order: size desc, then key columns ascending with nulls first (categorify.py:1300,1316)
-        hk = [k.cpu().numpy() for k in keys]
-        hnm, hs = nm.cpu().numpy(), size.cpu().numpy()
-        sort_cols = []
-        for j, c in enumerate(g.cols):
-            isnull = (hnm >> j) & 1
-            if c in g.strings:
-                lut = g.strings[c]
-                vals = np.array([lut.get(int(k), "") for k in hk[j]], dtype=object)
-            else:
-                vals = hk[j]
-            sort_cols.append((isnull, vals))
-        lex = []
-        for isnull, vals in reversed(sort_cols):
-            lex += [vals, 1 - isnull]
-        lex.append(-hs)
-        order = np.lexsort(tuple(lex)) if len(hs) else np.array([], dtype=np.int64)
-        dev = size.device
-        keys = [torch.from_numpy(k[order]).to(dev) for k in hk]
-        nm = torch.from_numpy(hnm[order]).to(dev)
-        size = torch.from_numpy(hs[order]).to(dev)
+        if not any(c in g.strings for c in g.cols) and self.tie_break == "value":
+            # on the device: stable radix refinements, least significant key first (nvt_order_rows)
+            sort_keys = [(size, None, False)]
+            for j in range(len(g.cols)):
+                notnull = (((nm >> j) & 1) ^ 1).to(torch.uint8)
+                sort_keys += [(notnull, None, True), (keys[j], None, True)]
+            order = K.order_rows(int(size.numel()), size.device, sort_keys) & 0xFFFFFFFF
+            keys = [k[order] for k in keys]
+            nm, size = nm[order], size[order]
+        else:
+            hk = [k.cpu().numpy() for k in keys]
+            hnm, hs = nm.cpu().numpy(), size.cpu().numpy()
+            sort_cols = []
+            for j, c in enumerate(g.cols):
+                isnull = (hnm >> j) & 1
+                if c in g.strings:
+                    lut = g.strings[c]
+                    vals = np.array([lut.get(int(k), "") for k in hk[j]], dtype=object)
+                else:
+                    vals = hk[j]
+                sort_cols.append((isnull, vals))
+            lex = []
+            for isnull, vals in reversed(sort_cols):
+                lex += [vals, 1 - isnull]
+            lex.append(-hs)
+            order = np.lexsort(tuple(lex)) if len(hs) else np.array([], dtype=np.int64)
+            dev = size.device
+            keys = [torch.from_numpy(k[order]).to(dev) for k in hk]
+            nm = torch.from_numpy(hnm[order]).to(dev)
+            size = torch.from_numpy(hs[order]).to(dev)
         strings = {c: g.strings[c] for c in g.cols if c in g.strings} or None
         return dict(keys=keys, null_mask=nm, counts=size, null_size=null_size, strings=strings,
                     combo=True)
