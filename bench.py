@@ -216,28 +216,16 @@ def parity_check(frame, cat_names, cont_names, rows, oracle_out, tmp):
             "normalize_max_rel_err": worst}
 
 
-_PMC_KERNEL = {"encode_i32": "nvt::encode_hot_kernel<int, long>",
-               "dense_count_p1": "nvt::part_scatter_kernel<int, 1, false>",
-               "dense_count_p2": "nvt::part_scatter_kernel<int, 1, false>",
-               "dense_count_p0": "nvt::lds_stage_kernel<int, unsigned int, 16384>",
-               "dense_count_p6": "nvt::lds_stage_kernel<int, unsigned int, 16384>",
-               "vocab_sort": "nvt::sort2_scatter_kernel<false, false>",
-               "fill_normalize": "nvt::fill_norm_kernel<int, double>",
-               "moments": "nvt::moments_kernel<int>"}
-
-
 def pmc_traffic(name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected separately with
-    rocprofv3 --pmc and corrected per MI355X_MICROARCH.md).  PMC cannot be sampled from
-    inside the timed run, so this is the figure of the same command at the same size."""
+    """HBM bytes per launch of the dominant kernel family from the committed PMC passes
+    (profiles/r02_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate
+    `rocprofv3 --pmc` passes over this command and corrected per MI355X_MICROARCH.md; made by
+    tools/pmc_bench.sh + tools/pmc_summarize.py).  PMC cannot be sampled from inside the timed
+    run, so this is the figure of the same command at the same size."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"][_PMC_KERNEL[name]]
-        return k["hbm_bytes_corrected"]
+            return json.load(f)["scopes"][name]["hbm_bytes_per_launch"]
     except Exception:
         return None
 

@@ -32,7 +32,24 @@ for name in sorted(set(fetch) | set(write)):
     wa = w / nw if nw else 0.0
     kernels[name] = {"launches": max(nf, nw), "fetch_size_bytes_raw": int(fa),
                      "write_size_bytes": int(wa), "hbm_bytes_corrected": int(2 * fa + wa)}
+# bench.py's profiler scopes (kernel families) -> the kernels they cover; per-LAUNCH traffic of a
+# scope = sum over its kernels of (bytes per kernel launch x kernel launches) / scope launches
+SCOPES = {
+    "encode_i32": (["nvt::encode_hot_kernel<int, long"], 1),       # one kernel launch per scope
+    "fill_normalize": (["nvt::fill_norm_many_kernel<int, double>"], 1),
+    "moments": (["nvt::moments_many_kernel"], 1),
+}
+scopes = {}
+for scope, (prefixes, _) in SCOPES.items():
+    tot, launches = 0.0, 0
+    for name, v in kernels.items():
+        if any(name.startswith(p) for p in prefixes):
+            tot += v["hbm_bytes_corrected"] * v["launches"]
+            launches += v["launches"]
+    if launches:
+        scopes[scope] = {"launches": launches, "hbm_bytes_per_launch": int(tot / launches)}
 out = {
+    "scopes": scopes,
     "_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 2 "
              "--warmup 2` (45 M rows); per-launch averages over all launches of the run. gfx950 "
              "correction from MI355X_MICROARCH.md section HBM: FETCH_SIZE counts half the bytes of a "
