@@ -47,6 +47,7 @@ def _pick(opt, name, default=None):
 
 
 MERGE_FAN_IN = 8
+LAZY_FINALIZE = os.environ.get("NVT_LAZY_FINALIZE", "1") != "0"
 
 
 class _GroupFit:
@@ -170,6 +171,8 @@ class Categorify(StatOperator):
             raise ValueError("tie_break must be 'value' or 'reference'")
         self.tie_break = tie_break
         self._pending: Dict[str, dict] = {}
+        self._lazy_finalize = None  # (groups, options, base) of a fit whose ordering is deferred
+        self._writer_cache: Dict[str, bool] = {}
         self.vocabs = {}
         if vocabs is not None:
             self.vocabs = self.process_vocabs(vocabs)
@@ -304,7 +307,11 @@ class Categorify(StatOperator):
         os.makedirs(base, exist_ok=True)
         # ranks that share an output directory (the default './') elect ONE writer: they all
         # hold the same merged vocabularies and used to race remove-then-write on the same files
-        self._is_writer = dist.is_first_rank_with(os.path.abspath(str(base)))
+        # (a host collective: done once per output directory, every rank takes the same branch)
+        key = os.path.abspath(str(base))
+        if key not in self._writer_cache:
+            self._writer_cache[key] = dist.is_first_rank_with(key)
+        self._is_writer = self._writer_cache[key]
         paths = {}
         groups = list(state.values())
         for g in groups:
@@ -345,8 +352,18 @@ class Categorify(StatOperator):
         # encode tables in ONE C call (write_uniques, categorify.py:1149): nvt_vocab_finalize_many
         fast = [g for g in groups if self._fast_finalizable(g, opts[g.name], dist)]
         if fast:
-            with K.annotate("write_uniques"):
-                self._finalize_fast(fast, opts, base, paths)
+            for g in fast:
+                paths[g.name] = "/".join([str(base), f"unique.{g.name}.parquet"])
+            if self.defer_artifacts and LAZY_FINALIZE:
+                # nothing reads the ordered vocabularies inside fit when the artifacts are
+                # deferred: the sorts / table builds are enqueued by the first consumer
+                # (transform, flush_artifacts, fitted_vocabulary ...).  In fit -> transform the
+                # executor then starts the branches that do not need them (fill + normalize)
+                # first, and the ~130 launches below are issued while those kernels already run.
+                self._lazy_finalize = (fast, opts, base)
+            else:
+                with K.annotate("write_uniques"):
+                    self._finalize_fast(fast, opts, base)
         for g in groups:
             if g.name in paths:
                 continue
@@ -373,7 +390,13 @@ class Categorify(StatOperator):
             return False
         return int(g.table[0].numel()) > 0
 
-    def _finalize_fast(self, groups, opts, base, paths):
+    def _ensure_finalized(self):
+        lazy, self._lazy_finalize = self._lazy_finalize, None
+        if lazy is not None:
+            with K.annotate("write_uniques"):
+                self._finalize_fast(*lazy)
+
+    def _finalize_fast(self, groups, opts, base):
         descs = (K._lib.VocabCol * len(groups))()
         built = []
         for d, g in zip(descs, groups):
@@ -400,7 +423,6 @@ class Categorify(StatOperator):
                 self._pending[g.name] = final
             elif self._is_writer:
                 _write_artifacts(final)
-            paths[g.name] = "/".join([str(base), f"unique.{g.name}.parquet"])
 
     # -- vocabulary finalisation ------------------------------------------------
     def _finalize_single(self, g: _GroupFit, dist):
@@ -545,6 +567,7 @@ class Categorify(StatOperator):
         """Write any deferred unique.*/meta.*.parquet files (defer_artifacts=True)."""
         # not a collective (Workflow.save may run on one rank only): the writer elected at
         # fit_end writes, everybody drops the device copies
+        self._ensure_finalized()
         for final in self._pending.values():
             if getattr(self, "_is_writer", True):
                 _write_artifacts(final)
@@ -567,6 +590,7 @@ class Categorify(StatOperator):
 
     def clear(self):
         self.categories = deepcopy(self.vocabs)
+        self._lazy_finalize = None  # a fit nobody consumed: its ordering is never enqueued
         for enc in self._encoders.values():
             tab = getattr(enc, "table", None)
             if tab is not None:
@@ -579,6 +603,7 @@ class Categorify(StatOperator):
         order, safe to read on the current stream (waits for work still in flight on the
         library's internal streams).  Only available while the fit's device state is kept
         (``defer_artifacts=True`` or before the next ``clear``)."""
+        self._ensure_finalized()
         final = self._pending[name]
         if final.get("table") is not None:
             final["table"].wait_ready()
@@ -588,8 +613,8 @@ class Categorify(StatOperator):
     def async_pending(self) -> bool:
         """Vocabularies still being ordered on the library's internal streams: the executor
         runs the other branches of the graph first (workflow.py)."""
-        return any(getattr(getattr(e, "table", None), "pending", False)
-                   for e in self._encoders.values())
+        return self._lazy_finalize is not None or any(
+            getattr(getattr(e, "table", None), "pending", False) for e in self._encoders.values())
 
     def process_vocabs(self, vocabs):
         """categorify.py:421-454"""
@@ -650,6 +675,7 @@ class Categorify(StatOperator):
 
     # ------------------------------------------------------------ transform --
     def _encoder_for(self, storage_name: str, cols: List[str], frame: DeviceFrame):
+        self._ensure_finalized()
         enc = self._encoders.get(storage_name)
         if enc is not None:
             return enc
@@ -791,6 +817,7 @@ class Categorify(StatOperator):
         return self.dtype or np.int64
 
     def get_embedding_sizes(self, columns):
+        self._ensure_finalized()
         pending = {n: f["unique_count"] for n, f in self._pending.items()}
         return _get_embeddings(self.categories, columns, self.num_buckets, pending)
 
