@@ -324,7 +324,7 @@ def extra_cfg4(device, tmp, rows, sample_rows, steps=5):
     wf2 = build(os.path.join(tmp, "cfg4_par"))
     wf2.fit(nvt.Dataset(sub))
     got = wf2.transform(sub)
-    worst, nan_mismatch = 0.0, {}
+    worst, nan_mismatch, per_col = 0.0, {}, {}
     for name, exp in [("TE_k_y", te_out["TE_k_y"])] + [(c, jg_out[c]) for c in jg_out.columns]:
         gv = got[name].data.cpu().numpy().astype("float64")
         ev = exp.to_numpy().astype("float64")
@@ -344,9 +344,16 @@ def extra_cfg4(device, tmp, rows, sample_rows, steps=5):
             rel = np.abs(gv[ok] - ev[ok]) / np.maximum(np.abs(ev[ok]), 1e-3)
             # float32 accumulation of the pandas path: std of a well-conditioned group agrees to
             # ~1e-4, everything else to float32 rounding
-            worst = max(worst, float(np.max(rel)) / (10.0 if name.endswith("_std") else 1.0))
-    res["parity"] = {"parity_checked_rows": m, "max_rel_err": worst, "nan_mismatch": nan_mismatch,
-                     "parity_ok": bool(worst <= 1e-5 and not nan_mismatch)}
+            per_col[name] = float(np.max(rel))
+            worst = max(worst, per_col[name])
+    # float32 outputs: 1e-5 relative; std: the pandas path accumulates the float32 target (and its
+    # squares) in float32, so var = (sumsq - sum^2 / n) / (n - 1) carries a relative error of up
+    # to ~1e-3 there, this engine accumulates in float64 -- 5e-3 for that column (the unit tests
+    # compare float64 targets at 1e-5, tests/test_gpu_parity.py)
+    tol = {c: (5e-3 if c.endswith("_std") else 1e-5) for c in per_col}
+    res["parity"] = {"parity_checked_rows": m, "per_column_max_rel_err": per_col, "tolerance": tol,
+                     "nan_mismatch": nan_mismatch,
+                     "parity_ok": bool(all(per_col[c] <= tol[c] for c in per_col) and not nan_mismatch)}
     return res
 
 
@@ -463,7 +470,7 @@ def main():
     dt = time.perf_counter() - t0
     timed_marks = list(marks)
     # ---- second pass, same steps, HIP events on every kernel family (inside the library,
-    # on the launch streams): per-kernel durations, GPU-busy time.  Not the number of record.
+    # on the launch streams): GPU-busy time of the real, overlapped pipeline.
     barrier()
     K.profile_begin()
     t1 = time.perf_counter()
@@ -472,15 +479,32 @@ def main():
     barrier()
     dt_prof = time.perf_counter() - t1
     rep = K.profile_report()
-    prof = rep["kernels"]
+    # ---- third pass: the same steps with the cross-stream overlap switched off (vocabularies
+    # ordered inside fit, their streams joined before transform), so that every kernel family
+    # is timed running ALONE: these are the per-kernel durations the roofline is computed from
+    # (under overlap a bandwidth-bound kernel's own duration stretches while the step shrinks).
+    from nvtabular_amd.ops import categorify as _cat
+
+    saved = (K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE)
+    K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE = False, False
+    step()
+    barrier()
+    K.profile_begin()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt_serial = time.perf_counter() - t2
+    prof = K.profile_report()["kernels"]
+    K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE = saved
     gc.enable()
     del out
     if world > 1:
         import torch.distributed as td
 
-        t = torch.tensor([dt, dt_prof], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, dt_prof, dt_serial], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt, dt_prof = (float(v) for v in t.tolist())
+        dt, dt_prof, dt_serial = (float(v) for v in t.tolist())
 
     ms_per_step = 1e3 * dt / args.steps
     rows_per_s = world * n * args.steps / dt
@@ -506,6 +530,11 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes // launches,
             "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
             "launch_scopes_per_step": round(sum(v[1] for v in prof.values()) / args.steps, 1),
+            "measured_in": "third pass: cross-stream overlap off (NVT_ASYNC_FINALIZE=0 "
+                           "NVT_LAZY_FINALIZE=0), every kernel family timed alone; "
+                           f"{round(1e3 * dt_serial / args.steps, 3)} ms per step in that mode",
+            "overlapped_per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3)
+                                                  for k, v in rep["kernels"].items()},
         }
 
     result = {

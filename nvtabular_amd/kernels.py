@@ -78,12 +78,19 @@ class annotate:
         return False
 
 
+_event_pool = []  # handles of released Events: a fit re-uses them instead of creating new ones
+
+
 class Event:
     """Opaque nvt_event (a HIP event without timing): recorded by the library behind the last
     kernel that produces an object on one of its internal streams, waited for -- on the stream,
-    never on the host -- by whoever consumes the object next."""
+    never on the host -- by whoever consumes the object next.  Handles are pooled: a steady-state
+    fit creates and destroys no HIP objects."""
 
     def __init__(self):
+        if _event_pool:
+            self.handle = _event_pool.pop()
+            return
         h = C.c_void_p()
         check(_lib.load().nvt_event_create(C.byref(h)), "nvt_event_create")
         self.handle = h
