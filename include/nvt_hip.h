@@ -343,7 +343,10 @@ typedef struct nvt_count_col {
   const int64_t *weights;
   uint64_t n;
   int32_t key_bytes, path;
-  void *ws;                 /* nvt_dense_count_ws_bytes(); may be shared by columns of a call */
+  void *ws;                 /* nvt_dense_count_ws_bytes().  Columns of a call that SHARE a workspace
+                               run in order; columns given different workspaces (at most 3
+                               distinct pointers per call) run concurrently on internal streams
+                               forked from / joined into `stream`                          */
   void *out_keys;
   int64_t *out_counts;
   uint64_t out_capacity;

@@ -29,9 +29,12 @@
 //   only atomics left are LDS ones plus one reservation per tile / workgroup.
 //   HBM traffic: 6 x 4 B per row (3 reads + 2 writes + hist read) against 4 B
 //   algorithmic -- the price of removing 90 M random device atomics.
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "nvt_common.hpp"
+#include "nvt_internal.hpp"
 #include "nvt_prof.hpp"
 #include "nvt_scan.hpp"
 
@@ -1963,23 +1966,50 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
   if (contiguous)
     NVT_CHECK_HIP(hipMemsetAsync(cols[0].state, 0, (uint64_t)ncols * NVT_STATE_WORDS * 8,
                                  (hipStream_t)stream));
+  // columns that were given DIFFERENT workspaces may run concurrently: each distinct ws pointer
+  // (up to kSideStreams of them) gets an internal stream forked from / joined into `stream`, so
+  // one column's short serial kernels (reduce / scan / offsets) hide under another's wide ones.
+  // Columns sharing a workspace stay ordered on one stream.
+  hipStream_t main_s = (hipStream_t)stream;
+  std::vector<void *> wss;
+  for (int i = 0; i < ncols; ++i)
+    if (std::find(wss.begin(), wss.end(), cols[i].ws) == wss.end()) wss.push_back(cols[i].ws);
+  SidePool *pool = nullptr;
+  const bool fork = wss.size() > 1 && wss.size() <= (size_t)kSideStreams;
+  if (wss.size() > (size_t)kSideStreams) {
+    set_error("nvt_dense_count_many: at most %d distinct workspaces per call", kSideStreams);
+    return NVT_EINVAL;
+  }
+  if (fork) {
+    int rc = side_pool(1, &pool);
+    if (rc) return rc;
+    NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
+    for (size_t k = 0; k < wss.size(); ++k) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[k], pool->fork, 0));
+  }
   for (int i = 0; i < ncols; ++i) {
     const nvt_count_col &c = cols[i];
+    hipStream_t cs = main_s;
+    if (fork) cs = pool->s[std::find(wss.begin(), wss.end(), c.ws) - wss.begin()];
     int rc;
     if (c.key_bytes == 4)
       rc = dense_count<int32_t>((const int32_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,
-                                (int32_t *)c.out_keys, c.out_counts, c.out_capacity, c.state,
-                                (hipStream_t)stream, !contiguous);
+                                (int32_t *)c.out_keys, c.out_counts, c.out_capacity, c.state, cs,
+                                !contiguous);
     else if (c.key_bytes == 8)
       rc = dense_count<int64_t>((const int64_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,
-                                (int64_t *)c.out_keys, c.out_counts, c.out_capacity, c.state,
-                                (hipStream_t)stream, !contiguous);
+                                (int64_t *)c.out_keys, c.out_counts, c.out_capacity, c.state, cs,
+                                !contiguous);
     else {
       set_error("nvt_dense_count_many: key_bytes must be 4 or 8 (column %d)", i);
       return NVT_EINVAL;
     }
     if (rc) return rc;
   }
+  if (fork)
+    for (size_t k = 0; k < wss.size(); ++k) {
+      NVT_CHECK_HIP(hipEventRecord(pool->join[k], pool->s[k]));
+      NVT_CHECK_HIP(hipStreamWaitEvent(main_s, pool->join[k], 0));
+    }
   return NVT_OK;
 }
 int nvt_dense_count_i32(const int32_t *keys, const uint8_t *valid, const int64_t *weights,

@@ -702,27 +702,52 @@ int nvt_encode_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, const 
 }
 int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
   NVT_CHECK_ARG(ncols == 0 || cols, "null descriptors");
+  // the columns are independent (own output, own tables): with NVT_ENCODE_STREAMS=2|3 they go
+  // round-robin onto internal streams forked from / joined into `stream`.  Off by default:
+  // measured 15.42 / 15.40 / 15.31 ms per Criteo step with 1 / 2 / 3 streams against 15.30 on
+  // the repeat of 1 -- every encode kernel already fills the chip with one 128 KiB-LDS
+  // workgroup per CU for its whole duration, there is no tail to hide (profiles/r02_notes.md)
+  static const int n_side = [] {
+    const char *e = getenv("NVT_ENCODE_STREAMS");
+    int v = e ? atoi(e) : 1;
+    return v < 1 ? 1 : v > kSideStreams ? kSideStreams : v;
+  }();
+  hipStream_t main_s = (hipStream_t)stream;
+  SidePool *pool = nullptr;
+  const int lanes = ncols < n_side ? ncols : n_side;
+  const bool fork = lanes > 1;
+  if (fork) {
+    int rc = side_pool(2, &pool);
+    if (rc) return rc;
+    NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
+    for (int k = 0; k < lanes; ++k) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[k], pool->fork, 0));
+  }
   for (int i = 0; i < ncols; ++i) {
     const nvt_encode_col &c = cols[i];
+    hipStream_t cs = fork ? pool->s[i % lanes] : main_s;
     int rc;
-    if (c.wait_event)
-      NVT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)c.wait_event, 0));
+    if (c.wait_event) NVT_CHECK_HIP(hipStreamWaitEvent(cs, (hipEvent_t)c.wait_event, 0));
     if (c.key_bytes == 4)
       rc = encode_launch<int32_t>((const int32_t *)c.keys, c.valid, c.n, c.table, c.capacity,
                                   c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,
                                   c.out_bytes, (const int32_t *)c.vocab_keys, c.n_vocab,
-                                  c.first_label, (hipStream_t)stream);
+                                  c.first_label, cs);
     else if (c.key_bytes == 8)
       rc = encode_launch<int64_t>((const int64_t *)c.keys, c.valid, c.n, c.table, c.capacity,
                                   c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,
                                   c.out_bytes, (const int64_t *)c.vocab_keys, c.n_vocab,
-                                  c.first_label, (hipStream_t)stream);
+                                  c.first_label, cs);
     else {
       set_error("nvt_encode_many: key_bytes must be 4 or 8 (column %d)", i);
       return NVT_EINVAL;
     }
     if (rc) return rc;
   }
+  if (fork)
+    for (int k = 0; k < lanes; ++k) {
+      NVT_CHECK_HIP(hipEventRecord(pool->join[k], pool->s[k]));
+      NVT_CHECK_HIP(hipStreamWaitEvent(main_s, pool->join[k], 0));
+    }
   return NVT_OK;
 }
 int nvt_hash_bucket_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, uint32_t num_buckets,

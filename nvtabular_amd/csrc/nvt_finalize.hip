@@ -22,35 +22,7 @@
 
 namespace nvt {
 namespace {
-constexpr int kSide = 3;
-struct SidePool {
-  int dev = -1;
-  hipStream_t s[kSide];
-  hipEvent_t fork, join[kSide];
-};
-std::mutex g_pool_mu;
-std::vector<SidePool *> g_pools;
-
-int side_pool(SidePool **out) {
-  int dev = 0;
-  NVT_CHECK_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(g_pool_mu);
-  for (SidePool *p : g_pools)
-    if (p->dev == dev) {
-      *out = p;
-      return NVT_OK;
-    }
-  SidePool *p = new SidePool();
-  p->dev = dev;
-  for (int i = 0; i < kSide; ++i) {
-    NVT_CHECK_HIP(hipStreamCreateWithFlags(&p->s[i], hipStreamNonBlocking));
-    NVT_CHECK_HIP(hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming));
-  }
-  NVT_CHECK_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
-  g_pools.push_back(p);
-  *out = p;
-  return NVT_OK;
-}
+constexpr int kSide = kSideStreams;
 }  // namespace
 }  // namespace nvt
 
@@ -75,7 +47,7 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
   const bool fork = big.size() + (small.empty() ? 0 : 1) > 1 && !getenv("NVT_FINALIZE_SERIAL");
   SidePool *pool = nullptr;
   if (fork) {
-    int rc = side_pool(&pool);
+    int rc = side_pool(0, &pool);
     if (rc) return rc;
     NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
     for (int i = 0; i < kSide; ++i) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[i], pool->fork, 0));

@@ -5,6 +5,16 @@
 
 namespace nvt {
 
+// nvt_util.hip: per-device pools of internal streams that batched calls fork onto from / join
+// into the caller's stream (`which` 0: vocabulary finalisation, 1: counting)
+constexpr int kSideStreams = 3;
+struct SidePool {
+  int dev = -1, which = 0;
+  hipStream_t s[kSideStreams];
+  hipEvent_t fork, join[kSideStreams];
+};
+int side_pool(int which, SidePool **out);
+
 // nvt_sort.hip
 int vocab_sort_any(int key_bytes, void *keys, int64_t *counts, uint64_t n, int64_t max_count,
                    void *tmp, hipStream_t s);

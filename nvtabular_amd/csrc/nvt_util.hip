@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "nvt_common.hpp"
+#include "nvt_internal.hpp"
 #include "nvt_prof.hpp"
 
 namespace nvt {
@@ -22,6 +23,33 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---- internal stream pools ------------------------------------------------------
+namespace {
+std::mutex g_pool_mu;
+std::vector<SidePool *> g_pools;
+}  // namespace
+int side_pool(int which, SidePool **out) {
+  int dev = 0;
+  NVT_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (SidePool *p : g_pools)
+    if (p->dev == dev && p->which == which) {
+      *out = p;
+      return NVT_OK;
+    }
+  SidePool *p = new SidePool();
+  p->dev = dev;
+  p->which = which;
+  for (int i = 0; i < kSideStreams; ++i) {
+    NVT_CHECK_HIP(hipStreamCreateWithFlags(&p->s[i], hipStreamNonBlocking));
+    NVT_CHECK_HIP(hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming));
+  }
+  NVT_CHECK_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+  g_pools.push_back(p);
+  *out = p;
+  return NVT_OK;
 }
 
 // ---- HIP-event profiler ---------------------------------------------------------

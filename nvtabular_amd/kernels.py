@@ -358,8 +358,14 @@ _ws_cache = {}
 _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (device.type, device.index)
+# Columns of one nvt_dense_count_many call that are given different workspaces run on different
+# internal streams (include/nvt_hip.h); COUNT_STREAMS workspaces are kept per device.
+COUNT_STREAMS = max(1, min(3, int(os.environ.get("NVT_COUNT_STREAMS", "3"))))
+_PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 4: 3.0, 5: 5.0, 1: 2.5, 8: 2.5, 2: 3.2, 3: 3.5}
+
+
+def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    key = (device.type, device.index, slot)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
@@ -567,10 +573,20 @@ class CountBatch:
         for i, j in enumerate(pending):
             j.state = self.states[i]
             need = max(need, j.prepare(descs[i]))
-        ws = _workspace(need, dev)  # shared: the columns of a call are ordered on one stream
-        wp = ws.data_ptr()
-        for d in descs:
-            d.ws = wp
+        if COUNT_STREAMS == 1 or len(pending) < 2:
+            wp = _workspace(need, dev).data_ptr()  # shared: the columns are ordered on one stream
+            for d in descs:
+                d.ws = wp
+        else:
+            # longest-processing-time assignment of the columns to COUNT_STREAMS workspaces
+            load = [0.0] * COUNT_STREAMS
+            wps = [_workspace(need, dev, k).data_ptr() for k in range(COUNT_STREAMS)]
+            order = sorted(range(len(pending)),
+                           key=lambda i: -_PATH_COST.get(pending[i].path, 1.0) * pending[i].n)
+            for i in order:
+                k = load.index(min(load))
+                load[k] += _PATH_COST.get(pending[i].path, 1.0) * pending[i].n
+                descs[i].ws = wps[k]
         check(_lib.load().nvt_dense_count_many(descs, len(pending), stream_ptr()),
               "nvt_dense_count_many")
 

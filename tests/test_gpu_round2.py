@@ -211,3 +211,29 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["collective_backend"] == "gloo"
     assert rec["value"] > 0 and rec["scaling"] == "weak"
+
+
+def test_fully_staged_encode_with_unseen_keys_and_nulls(tmp_path):
+    """int32 vocabularies <= NVT_ENCODE_RESIDENT_I32 are encoded from the LDS table alone (no
+    table in HBM): labels incl. out-of-vocabulary rows and nulls must equal the oracle's."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(5)
+    n = 400_000
+    df = pd.DataFrame({
+        "a": (rng.zipf(1.2, n) % 8000).astype("int32") * 7919 - 12345,   # ~6-8 k distinct
+        "b": pd.array(rng.integers(0, 3000, n), dtype="Int32"),
+    })
+    df.loc[rng.random(n) < 0.03, "b"] = pd.NA
+    cols = ["a", "b"]
+    wf = nvt.Workflow(cols >> ops.Categorify(out_path=str(tmp_path / "gpu")))
+    wf.fit(nvt.Dataset(df))
+    df2 = df.copy()
+    df2.loc[::97, "a"] = 2_000_000_001   # never seen by fit
+    out = wf.transform(nvt.Dataset(df2)).to_ddf().compute()
+    host = _host_view(df)
+    paths = O.categorify_fit([host], cols, str(tmp_path / "cpu"), tie_break="stable")
+    exp = O.categorify_transform(_host_view(df2), cols, paths)
+    for c in cols:
+        np.testing.assert_array_equal(out[c].to_numpy(), exp[c].to_numpy(), err_msg=c)
