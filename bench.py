@@ -485,8 +485,9 @@ def main():
     # (under overlap a bandwidth-bound kernel's own duration stretches while the step shrinks).
     from nvtabular_amd.ops import categorify as _cat
 
-    saved = (K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE)
-    K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE = False, False
+    saved = (K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE, K.COUNT_STREAMS)
+    K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE, K.COUNT_STREAMS = False, False, 1
+    os.environ["NVT_FINALIZE_SERIAL"] = "1"  # read by the library at every finalize call
     step()
     barrier()
     K.profile_begin()
@@ -496,7 +497,8 @@ def main():
     barrier()
     dt_serial = time.perf_counter() - t2
     prof = K.profile_report()["kernels"]
-    K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE = saved
+    K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE, K.COUNT_STREAMS = saved
+    os.environ.pop("NVT_FINALIZE_SERIAL", None)
     gc.enable()
     del out
     if world > 1:
@@ -531,7 +533,8 @@ def main():
             "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
             "launch_scopes_per_step": round(sum(v[1] for v in prof.values()) / args.steps, 1),
             "measured_in": "third pass: cross-stream overlap off (NVT_ASYNC_FINALIZE=0 "
-                           "NVT_LAZY_FINALIZE=0), every kernel family timed alone; "
+                           "NVT_LAZY_FINALIZE=0 NVT_COUNT_STREAMS=1 NVT_FINALIZE_SERIAL=1), "
+                           "every kernel family timed alone; "
                            f"{round(1e3 * dt_serial / args.steps, 3)} ms per step in that mode",
             "overlapped_per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3)
                                                   for k, v in rep["kernels"].items()},
