@@ -453,21 +453,33 @@ def main():
     # cold step: a fresh workflow with no cardinality hints (reported, never `value`)
     barrier()
     t0 = time.perf_counter()
-    step()
+    out = step()
     barrier()
     cold_ms = 1e3 * (time.perf_counter() - t0)
+    # The timed loop keeps the previous step's output frame alive while the next one is
+    # produced (`out = step()`), so TWO 14 GB output sets coexist.  If the caching allocator
+    # first meets that during the timed region it has to hipMalloc 39 x 360 MB blocks with the
+    # GPU busy: one 28-40 ms step (100-180 ms on a box's first process), i.e. +2 ms on the mean
+    # of 15-20 steps -- the "outlier" of earlier rounds (profiles/r02_notes.md).  The warm-up
+    # therefore runs with the same ownership pattern, and one spare block per output column is
+    # cached up front so that this also holds for --warmup 1.
+    spare = [torch.empty_like(t) for _, col in out.items() for t in (col.data, col.valid)
+             if t is not None]
+    del spare
     for _ in range(max(args.warmup - 1, 0)):
-        step()
+        out = step()
     gc.collect()
     gc.disable()  # no collector pauses inside the timed region
     # ---- timed region: exactly `steps` steps, no per-kernel instrumentation ----
     barrier()
     del marks[:]
+    n_alloc0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    n_alloc = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - n_alloc0
     timed_marks = list(marks)
     # ---- second pass, same steps, HIP events on every kernel family (inside the library,
     # on the launch streams): GPU-busy time of the real, overlapped pipeline.
@@ -552,6 +564,9 @@ def main():
         "profiled_pass_ms_per_step": round(1e3 * dt_prof / args.steps, 3),
         "cold_step_ms": round(cold_ms, 2),
         "host_timeline_ms": _host_timeline(timed_marks),
+        # hipMalloc calls the caching allocator had to make inside the timed region (0 = the
+        # warm-up reached the steady-state footprint)
+        "device_allocs_in_timed_region": int(n_alloc),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -102,11 +102,14 @@ class Event:
     def __del__(self):
         h = getattr(self, "handle", None)
         if h:
+            self.handle = None
             try:
-                _lib.load().nvt_event_destroy(h)
+                if len(_event_pool) < 256:
+                    _event_pool.append(h)  # waits already enqueued captured the event's state
+                else:
+                    _lib.load().nvt_event_destroy(h)
             except Exception:
                 pass
-            self.handle = None
 
 
 _mailboxes = {}
