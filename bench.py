@@ -463,11 +463,18 @@ def main():
     # of 15-20 steps -- the "outlier" of earlier rounds (profiles/r02_notes.md).  The warm-up
     # therefore runs with the same ownership pattern, and one spare block per output column is
     # cached up front so that this also holds for --warmup 1.
-    spare = [torch.empty_like(t) for _, col in out.items() for t in (col.data, col.valid)
-             if t is not None]
-    del spare
+    cold_allocator = os.environ.get("NVT_BENCH_COLD_ALLOCATOR") == "1"  # diagnostic: old warm-up
+    if cold_allocator:
+        del out
+    else:
+        spare = [torch.empty_like(t) for _, col in out.items() for t in (col.data, col.valid)
+                 if t is not None]
+        del spare
     for _ in range(max(args.warmup - 1, 0)):
-        out = step()
+        if cold_allocator:
+            step()
+        else:
+            out = step()
     gc.collect()
     gc.disable()  # no collector pauses inside the timed region
     # ---- timed region: exactly `steps` steps, no per-kernel instrumentation ----
