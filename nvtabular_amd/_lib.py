@@ -107,7 +107,7 @@ class FillNormCol(C.Structure):
 class CountCol(C.Structure):
     _fields_ = [("keys", _vp), ("valid", _vp), ("weights", _vp), ("n", _u64),
                 ("key_bytes", C.c_int32), ("path", C.c_int32), ("ws", _vp), ("out_keys", _vp),
-                ("out_counts", _vp), ("out_capacity", _u64), ("state", _vp)]
+                ("out_counts", _vp), ("out_capacity", _u64), ("state", _vp), ("hot_image", _vp)]
 
 
 class VocabCol(C.Structure):

@@ -364,6 +364,8 @@ _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 # Columns of one nvt_dense_count_many call that are given different workspaces run on different
 # internal streams (include/nvt_hip.h); COUNT_STREAMS workspaces are kept per device.
 COUNT_STREAMS = max(1, min(3, int(os.environ.get("NVT_COUNT_STREAMS", "3"))))
+PATH_HOT, HOT_IMAGE_WORDS = 16, 8192   # include/nvt_hip.h NVT_PATH_HOT, NVT_HOT_IMAGE_WORDS
+HOT_FILTER = os.environ.get("NVT_HOT_FILTER", "1") != "0"
 _PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 4: 3.0, 5: 5.0, 1: 2.5, 8: 2.5, 2: 3.2, 3: 3.5}
 
 
@@ -417,6 +419,14 @@ class DenseCountJob:
         self.cap_guess = max(1 << 16, 2 * max(hint, 1))
         self.state = None  # device uint64[STATE_WORDS] view, assigned by dense_count_many
         self.result = None
+        self.hot = None    # None: HOT_FILTER decides; True / False: forced (tests, probes)
+
+    def _launch_path(self) -> int:
+        """The `path` argument of the C call: partitioned paths of int32 keys without weights
+        get the hot-key filter in front (include/nvt_hip.h, NVT_PATH_HOT)."""
+        eligible = self.path in (1, 2, 3) and self.kb == 4 and self.weights is None
+        hot = HOT_FILTER if self.hot is None else self.hot
+        return self.path | PATH_HOT if (eligible and hot) else self.path
 
     def prepare(self, desc: "_lib.CountCol") -> int:
         """Allocate this attempt's output list and fill one nvt_count_col descriptor; returns
@@ -428,11 +438,12 @@ class DenseCountJob:
             out_cap = min(out_cap, _S_CLASSES[path] * 256 * 384 + 1)
         self.out_k = torch.empty(out_cap + 1, dtype=self.keys.dtype, device=self.dev)
         self.out_c = torch.empty(out_cap + 1, dtype=torch.int64, device=self.dev)
-        key = (self.kb, n, path, self.weights is not None)
+        lpath = self._launch_path()
+        key = (self.kb, n, lpath, self.weights is not None)
         nbytes = _WS_BYTES.get(key)
         if nbytes is None:
             out = C.c_uint64()
-            check(self.lib.nvt_dense_count_ws_bytes(self.kb, n, path,
+            check(self.lib.nvt_dense_count_ws_bytes(self.kb, n, lpath,
                                                     0 if self.weights is None else 1, C.byref(out)))
             nbytes = _WS_BYTES[key] = out.value
         desc.keys = self.keys.data_ptr()
@@ -440,11 +451,16 @@ class DenseCountJob:
         desc.weights = ptr(self.weights)
         desc.n = n
         desc.key_bytes = self.kb
-        desc.path = path
+        desc.path = lpath
         desc.out_keys = self.out_k.data_ptr()
         desc.out_counts = self.out_c.data_ptr()
         desc.out_capacity = out_cap
         desc.state = self.state.data_ptr()
+        desc.hot_image = None
+        if lpath & PATH_HOT:
+            # the column's own hot-key table image: sampled for all columns by one launch
+            self.hot_image = torch.empty(HOT_IMAGE_WORDS, dtype=torch.int32, device=self.dev)
+            desc.hot_image = self.hot_image.data_ptr()
         return nbytes
 
     def resolve(self, st) -> bool:

@@ -486,10 +486,13 @@ def test_dense_count_paths_vs_numpy(dtype, card, n, weighted):
     ww = w if weighted else np.ones(n, dtype="int64")
     exp = pd.Series(ww[~mask]).groupby(ids[~mask]).sum()
     distinct = len(exp)
-    paths = K.PATH_ORDER + [4, 5] + ([8] if dtype == "int32" and not weighted else [])
-    for path in paths:
+    paths = [(p, False) for p in K.PATH_ORDER + [4, 5]]
+    if dtype == "int32" and not weighted:
+        paths += [(8, False)] + [(p, True) for p in (1, 2, 3)]  # path 8; hot-key filter variants
+    for path, hot in paths:
         job = K.DenseCountJob(keys, valid, wt, hint=distinct)
         job.path = path  # force every kernel path (the driver escalates along PATH_ORDER on overflow)
+        job.hot = hot
         k, c, nulls, info = K.dense_count_many([job])[0]
         assert info["path"] == path or path in (6, 0, 4, 5)  # LDS-table paths may escalate
         got = pd.Series(c.cpu().numpy(), index=k.cpu().numpy()).sort_index()
@@ -654,3 +657,41 @@ def test_hashed_cross_and_bucketize_vs_oracle():
     assert wf.output_schema["x"].tags == (nvt.Tags.CATEGORICAL,) or nvt.Tags.CATEGORICAL in wf.output_schema["x"].tags
     with pytest.raises(TypeError):
         ops.Bucketize(3)
+
+
+@pytest.mark.parametrize("path", [1, 2, 3])
+@pytest.mark.parametrize("shape", ["powerlaw", "uniform", "sorted", "one_key"])
+def test_hot_filter_counts_exact_for_any_hot_set(path, shape):
+    """NVT_PATH_HOT: the rows of the sampled hot keys are counted in LDS, the others are
+    partitioned -- exact whatever the sample saw: power law (most rows hot), uniform (the
+    sample finds nothing worth keeping: filter switched off), sorted input (the sample's hot
+    keys are local), a single key (everything hot, empty partition)."""
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.device import pack_bitmap
+
+    rng = np.random.default_rng(path * 7 + len(shape))
+    n = 3_000_001
+    if shape == "powerlaw":
+        ids = (rng.zipf(1.15, n) % 2_000_000).astype("int32") * 3 - 1000
+    elif shape == "uniform":
+        ids = rng.integers(-2**31, 2**31 - 1, n).astype("int32")
+    elif shape == "sorted":
+        ids = np.sort((rng.zipf(1.3, n) % 500_000).astype("int32"))
+    else:
+        ids = np.full(n, 77, dtype="int32")
+    ids[123] = np.iinfo("int32").min  # the empty-slot sentinel as a key
+    mask = rng.random(n) < 0.07
+    keys = torch.from_numpy(ids).cuda()
+    valid = torch.from_numpy(pack_bitmap(~mask)).cuda()
+    exp = pd.Series(np.ones(n, dtype="int64")[~mask]).groupby(ids[~mask]).sum()
+    for v in (valid, None):
+        e = exp if v is not None else pd.Series(np.ones(n, dtype="int64")).groupby(ids).sum()
+        job = K.DenseCountJob(keys, v, None, hint=len(e))
+        job.path, job.hot = path, True
+        k, c, nulls, info = K.dense_count_many([job])[0]
+        got = pd.Series(c.cpu().numpy(), index=k.cpu().numpy()).sort_index()
+        assert got.index.is_unique
+        np.testing.assert_array_equal(got.index.to_numpy(), e.index.to_numpy())
+        np.testing.assert_array_equal(got.to_numpy(), e.to_numpy())
+        assert nulls == (int(mask.sum()) if v is not None else 0)
+        assert info["max_count"] >= int(e.max()) and info["rows"] == n
