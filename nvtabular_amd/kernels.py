@@ -386,8 +386,8 @@ def _path_for(hint: int, small_tables: bool = False) -> int:
         return 6
     if hint <= s_max:
         return 0
-    if hint <= PATH_S2_FACTOR * s_max:
-        return 7
+    if hint <= PATH_S2_FACTOR * s_max and (small_tables or not HOT_FILTER):
+        return 7  # (with the hot-key filter path 1 is faster there: 241 against 307 us)
     if USE_P8 and not small_tables and hint <= PATH_P8_MAX_DISTINCT:
         return 8
     if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
@@ -421,12 +421,15 @@ class DenseCountJob:
         self.result = None
         self.hot = None    # None: HOT_FILTER decides; True / False: forced (tests, probes)
 
+    def _launch_path_of(self, path: int) -> int:
+        eligible = path in (1, 2, 3) and self.kb == 4 and self.weights is None
+        hot = HOT_FILTER if self.hot is None else self.hot
+        return path | PATH_HOT if (eligible and hot) else path
+
     def _launch_path(self) -> int:
         """The `path` argument of the C call: partitioned paths of int32 keys without weights
         get the hot-key filter in front (include/nvt_hip.h, NVT_PATH_HOT)."""
-        eligible = self.path in (1, 2, 3) and self.kb == 4 and self.weights is None
-        hot = HOT_FILTER if self.hot is None else self.hot
-        return self.path | PATH_HOT if (eligible and hot) else self.path
+        return self._launch_path_of(self.path)
 
     def prepare(self, desc: "_lib.CountCol") -> int:
         """Allocate this attempt's output list and fill one nvt_count_col descriptor; returns
@@ -474,6 +477,8 @@ class DenseCountJob:
                 self._fallback()
                 return True
             self.path = order[nxt]
+            if self.path == 7 and self._launch_path_of(1) & PATH_HOT:
+                self.path = 1  # the filtered path 1 beats two key classes (see _path_for)
             self.cap_guess = max(self.cap_guess, _PATH_MAX[self.path])
             return False
         if ovf & 2:

@@ -45,7 +45,8 @@ def test_path_selection_thresholds():
     assert K._path_for(0) == 0                      # unknown: start on the plain LDS-table path
     assert K._path_for(3) == 6 and K._path_for(64) == 6
     assert K._path_for(65) == 0 and K._path_for(K.PATH_S_MAX_DISTINCT) == 0
-    assert K._path_for(K.PATH_S_MAX_DISTINCT + 1) == 7
+    # 11-21 k int32 keys: two key classes (path 7) only without the hot-key filter
+    assert K._path_for(K.PATH_S_MAX_DISTINCT + 1) == (1 if K.HOT_FILTER and not K.USE_P8 else 7 if not K.HOT_FILTER else 8)
     if K.USE_P8:  # opt-in: ONE 1024-bucket level (path 8) for int32 keys without weights
         assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_DISTINCT) + 1) == 8
         assert K._path_for(K.PATH_P8_MAX_DISTINCT) == 8 and K._path_for(K.PATH_P8_MAX_DISTINCT + 1) == 3
