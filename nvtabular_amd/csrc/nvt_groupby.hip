@@ -445,40 +445,72 @@ __global__ __launch_bounds__(kBlock) void gb_merge_kernel(GbView t, GbMergeArgs 
   if (ovf) atomicOr((unsigned long long *)&t.state[NVT_ST_OVERFLOW], 1ull);
 }
 
+// table -> dense group arrays, arbitrary order.  Each workgroup takes tiles of kBlock *
+// kGbCompactItems consecutive slots, ranks the READY ones with a wave scan + LDS and reserves
+// its output range with ONE atomic per tile (an atomic per wave on the single cursor
+// serialises at the memory side: 4.5 ms for a 16 M-slot table, 39 % of the cfg4 step).
+constexpr int kGbCompactItems = 8;
 __global__ __launch_bounds__(kBlock) void gb_compact_kernel(GbView t, GbOutArgs o,
                                                             uint64_t *out_n) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  const uint64_t rounds = (t.cap + stride - 1) / stride;
+  constexpr uint64_t TILE = (uint64_t)kBlock * kGbCompactItems;
+  __shared__ unsigned wsum[kBlock / kWave];
+  __shared__ unsigned long long tile_base;
   const double qnan = std::numeric_limits<double>::quiet_NaN();
-  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  for (uint64_t r = 0; r < rounds; ++r, i += stride) {
-    bool occ = i < t.cap && t.slot_state[i] == ST_READY;
-    unsigned long long m = __ballot(occ);
-    if (m == 0) continue;
-    unsigned lane = lane_id();
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd((unsigned long long *)out_n, (unsigned long long)__popcll(m));
-    base = __shfl(base, 0, 64);
-    if (!occ) continue;
-    uint64_t g = base + __popcll(m & ((1ull << lane) - 1ull));
-    for (int j = 0; j < t.nkeys; ++j)
-      if (o.keys[j]) o.keys[j][g] = t.keys[(uint64_t)j * t.cap + i];
-    if (o.null_mask) o.null_mask[g] = (uint8_t)t.nullmask[i];
-    if (o.size) o.size[g] = (int64_t)t.size[i];
-    if (o.count) o.count[g] = (int64_t)t.count[i];
-    for (int j = 0; j < t.nvals; ++j) {
-      uint64_t s = (uint64_t)j * t.cap + i;
-      if (o.sum[j]) o.sum[j][g] = t.sum[s];
-      if (o.sumsq[j]) o.sumsq[j][g] = t.sumsq ? t.sumsq[s] : qnan;
-      if (o.vmin[j]) {
-        double v = t.vmin ? t.vmin[s] : qnan;
-        o.vmin[j][g] = (v == std::numeric_limits<double>::infinity()) ? qnan : v;
-      }
-      if (o.vmax[j]) {
-        double v = t.vmax ? t.vmax[s] : qnan;
-        o.vmax[j][g] = (v == -std::numeric_limits<double>::infinity()) ? qnan : v;
+  const unsigned lane = lane_id(), w = threadIdx.x / kWave;
+  const uint64_t ntiles = (t.cap + TILE - 1) / TILE;
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // item q of the tile's round r is slot tile * TILE + r * kBlock + threadIdx.x (coalesced)
+    unsigned occ = 0, mine = 0;
+#pragma unroll
+    for (int r = 0; r < kGbCompactItems; ++r) {
+      const uint64_t i = tile * TILE + (uint64_t)r * kBlock + threadIdx.x;
+      if (i < t.cap && t.slot_state[i] == ST_READY) {
+        occ |= 1u << r;
+        ++mine;
       }
     }
+    unsigned inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned o2 = __shfl_up(inc, off, 64);
+      if (lane >= (unsigned)off) inc += o2;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned wbase = 0, total = 0;
+    for (unsigned q = 0; q < kBlock / kWave; ++q) {
+      if (q < w) wbase += wsum[q];
+      total += wsum[q];
+    }
+    if (threadIdx.x == 0)
+      tile_base = total ? atomicAdd((unsigned long long *)out_n, (unsigned long long)total) : 0;
+    __syncthreads();
+    uint64_t g = tile_base + wbase + inc - mine;
+#pragma unroll
+    for (int r = 0; r < kGbCompactItems; ++r) {
+      if (!((occ >> r) & 1)) continue;
+      const uint64_t i = tile * TILE + (uint64_t)r * kBlock + threadIdx.x;
+      for (int j = 0; j < t.nkeys; ++j)
+        if (o.keys[j]) o.keys[j][g] = t.keys[(uint64_t)j * t.cap + i];
+      if (o.null_mask) o.null_mask[g] = (uint8_t)t.nullmask[i];
+      if (o.size) o.size[g] = (int64_t)t.size[i];
+      if (o.count) o.count[g] = (int64_t)t.count[i];
+      for (int j = 0; j < t.nvals; ++j) {
+        uint64_t s = (uint64_t)j * t.cap + i;
+        if (o.sum[j]) o.sum[j][g] = t.sum[s];
+        if (o.sumsq[j]) o.sumsq[j][g] = t.sumsq ? t.sumsq[s] : qnan;
+        if (o.vmin[j]) {
+          double v = t.vmin ? t.vmin[s] : qnan;
+          o.vmin[j][g] = (v == std::numeric_limits<double>::infinity()) ? qnan : v;
+        }
+        if (o.vmax[j]) {
+          double v = t.vmax ? t.vmax[s] : qnan;
+          o.vmax[j][g] = (v == -std::numeric_limits<double>::infinity()) ? qnan : v;
+        }
+      }
+      ++g;
+    }
+    __syncthreads();
   }
 }
 
@@ -889,7 +921,7 @@ int nvt_gb_compact(nvt_gb_table *t, int64_t *const *out_keys, uint8_t *out_null_
   }
   hipStream_t s = (hipStream_t)stream;
   NVT_CHECK_HIP(hipMemsetAsync(out_n, 0, sizeof(uint64_t), s));
-  gb_compact_kernel<<<stream_grid(t->capacity, kBlock), kBlock, 0, s>>>(view_of(t), o, out_n);
+  gb_compact_kernel<<<stream_grid(t->capacity, kBlock * kGbCompactItems), kBlock, 0, s>>>(view_of(t), o, out_n);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
