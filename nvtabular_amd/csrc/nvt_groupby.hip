@@ -20,21 +20,28 @@
 #include "nvt_internal.hpp"
 #include "nvt_prof.hpp"
 
+// One 16-byte header per slot: a probe of a single-key table (the common JoinGroupby /
+// TargetEncoding group) touches ONE 64-byte sector instead of four arrays (state, null mask,
+// key, group id: gb_lookup 1.78 -> ms per 20 M rows, profiles/r02_notes.md).
+struct nvt_gb_head {
+  long long key0;
+  unsigned meta;   // bits 0-7 slot state, bits 8-15 null mask of the key tuple
+  unsigned index;  // slot -> compact group id (lookup tables), 0xFFFFFFFF = none
+};
+
 struct nvt_gb_table {
   int nkeys;
   int nvals;
   int flags;
   uint64_t capacity;
-  unsigned *slot_state;        // [cap]
-  long long *keys;             // [nkeys][cap]
-  unsigned *nullmask;          // [cap]
+  struct nvt_gb_head *head;    // [cap] {first key component, state | null mask, group id}
+  long long *keys;             // [nkeys - 1][cap] the further key components
   unsigned long long *size;    // [cap]
   unsigned long long *count;   // [cap]
   double *sum;                 // [nvals][cap]
   double *sumsq;               // [nvals][cap] or null
   double *vmin;                // [nvals][cap] or null
   double *vmax;                // [nvals][cap] or null
-  long long *index;            // [cap] slot -> compact group id (lookup tables)
   uint64_t *state;             // [NVT_STATE_WORDS]
   void *ptr_scratch;           // device copy of per-call pointer tables
   void *scratch;               // sort workspace of nvt_gb_update (grown on demand)
@@ -53,12 +60,10 @@ constexpr int kGbMaxProbe = 1024;
 struct GbView {
   int nkeys, nvals, flags;
   uint64_t mask, cap;
-  unsigned *slot_state;
-  long long *keys;
-  unsigned *nullmask;
+  nvt_gb_head *head;
+  long long *keys;  // components 1 .. nkeys-1
   unsigned long long *size, *count;
   double *sum, *sumsq, *vmin, *vmax;
-  long long *index;
   uint64_t *state;
   unsigned long long *vcount;  // [nvals][cap] non-null values per column (nvt_seg_aggregate only)
 };
@@ -101,17 +106,18 @@ __device__ __forceinline__ int64_t find_slot(const GbView &t, const long long (&
   int probe = 0;
   unsigned spins = 0;  // bounded wait on a LOCKED slot: report overflow rather than hang the GPU
   while (probe < kGbMaxProbe) {
-    unsigned st = __hip_atomic_load(&t.slot_state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nvt_gb_head *hd = &t.head[slot];
+    unsigned st = __hip_atomic_load(&hd->meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st == ST_EMPTY) {
       if (!insert) return -1;
-      unsigned prev = atomicCAS(&t.slot_state[slot], ST_EMPTY, ST_LOCKED);
+      unsigned prev = atomicCAS(&hd->meta, ST_EMPTY, ST_LOCKED);
       if (prev == ST_EMPTY) {
-        for (int j = 0; j < t.nkeys; ++j)
-          __hip_atomic_store(&t.keys[(uint64_t)j * t.cap + slot], k[j], __ATOMIC_RELAXED,
+        __hip_atomic_store(&hd->key0, k[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 1; j < t.nkeys; ++j)
+          __hip_atomic_store(&t.keys[(uint64_t)(j - 1) * t.cap + slot], k[j], __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&t.nullmask[slot], nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&t.slot_state[slot], ST_READY, __ATOMIC_RELAXED,
+        __hip_atomic_store(&hd->meta, ST_READY | (nm << 8), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         *n_new += 1;
         return (int64_t)slot;
@@ -123,10 +129,11 @@ __device__ __forceinline__ int64_t find_slot(const GbView &t, const long long (&
       *ovf = 1;
       return -1;
     }
-    // READY: compare
-    bool same = __hip_atomic_load(&t.nullmask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nm;
-    for (int j = 0; same && j < t.nkeys; ++j)
-      same = __hip_atomic_load(&t.keys[(uint64_t)j * t.cap + slot], __ATOMIC_RELAXED,
+    // READY: compare (the null mask travels with the state word)
+    bool same = (st >> 8) == nm &&
+                __hip_atomic_load(&hd->key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k[0];
+    for (int j = 1; same && j < t.nkeys; ++j)
+      same = __hip_atomic_load(&t.keys[(uint64_t)(j - 1) * t.cap + slot], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT) == k[j];
     if (same) return (int64_t)slot;
     slot = (slot + 1) & t.mask;
@@ -184,12 +191,14 @@ __global__ __launch_bounds__(kBlock) void gb_clear_kernel(GbView t) {
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   const double inf = std::numeric_limits<double>::infinity();
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < t.cap; i += stride) {
-    t.slot_state[i] = ST_EMPTY;
-    t.nullmask[i] = 0;
+    nvt_gb_head e;
+    e.key0 = 0;
+    e.meta = ST_EMPTY;
+    e.index = 0xFFFFFFFFu;
+    t.head[i] = e;
     t.size[i] = 0;
     t.count[i] = 0;
-    t.index[i] = -1;
-    for (int j = 0; j < t.nkeys; ++j) t.keys[(uint64_t)j * t.cap + i] = 0;
+    for (int j = 1; j < t.nkeys; ++j) t.keys[(uint64_t)(j - 1) * t.cap + i] = 0;
     for (int j = 0; j < t.nvals; ++j) {
       t.sum[(uint64_t)j * t.cap + i] = 0.0;
       if (t.sumsq) t.sumsq[(uint64_t)j * t.cap + i] = 0.0;
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void gb_compact_kernel(GbView t, GbOutArgs 
 #pragma unroll
     for (int r = 0; r < kGbCompactItems; ++r) {
       const uint64_t i = tile * TILE + (uint64_t)r * kBlock + threadIdx.x;
-      if (i < t.cap && t.slot_state[i] == ST_READY) {
+      if (i < t.cap && (t.head[i].meta & 0xFFu) == ST_READY) {
         occ |= 1u << r;
         ++mine;
       }
@@ -490,9 +499,11 @@ __global__ __launch_bounds__(kBlock) void gb_compact_kernel(GbView t, GbOutArgs 
     for (int r = 0; r < kGbCompactItems; ++r) {
       if (!((occ >> r) & 1)) continue;
       const uint64_t i = tile * TILE + (uint64_t)r * kBlock + threadIdx.x;
-      for (int j = 0; j < t.nkeys; ++j)
-        if (o.keys[j]) o.keys[j][g] = t.keys[(uint64_t)j * t.cap + i];
-      if (o.null_mask) o.null_mask[g] = (uint8_t)t.nullmask[i];
+      const nvt_gb_head hd = t.head[i];
+      if (o.keys[0]) o.keys[0][g] = hd.key0;
+      for (int j = 1; j < t.nkeys; ++j)
+        if (o.keys[j]) o.keys[j][g] = t.keys[(uint64_t)(j - 1) * t.cap + i];
+      if (o.null_mask) o.null_mask[g] = (uint8_t)(hd.meta >> 8);
       if (o.size) o.size[g] = (int64_t)t.size[i];
       if (o.count) o.count[g] = (int64_t)t.count[i];
       for (int j = 0; j < t.nvals; ++j) {
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void gb_index_build_kernel(GbView t, GbMerg
     unsigned nm = a.null_mask ? a.null_mask[i] : 0;
     for (int j = 0; j < t.nkeys; ++j) k[j] = ((nm >> j) & 1) ? 0 : a.keys[j][i];
     int64_t slot = find_slot(t, k, nm, true, &n_new, &ovf);
-    if (slot >= 0) t.index[slot] = (long long)i;
+    if (slot >= 0) t.head[slot].index = (unsigned)i;
   }
   if (n_new) atomicAdd((unsigned long long *)&t.state[NVT_ST_OCCUPIED], (unsigned long long)n_new);
   if (ovf) atomicOr((unsigned long long *)&t.state[NVT_ST_OVERFLOW], 1ull);
@@ -537,7 +548,9 @@ __global__ __launch_bounds__(kBlock) void gb_lookup_kernel(GbView t, GbRowArgs a
     long long k[kMaxKeys];
     unsigned nm = read_tuple(a, t.nkeys, i, k);
     int64_t slot = find_slot(t, k, nm, false, &n_new, &ovf);
-    out[i] = slot >= 0 ? (int64_t)t.index[slot] : -1;
+    unsigned g = 0xFFFFFFFFu;
+    if (slot >= 0) g = t.head[slot].index;
+    out[i] = g == 0xFFFFFFFFu ? -1 : (int64_t)g;
   }
 }
 
@@ -548,16 +561,14 @@ inline GbView view_of(nvt_gb_table *t) {
   v.flags = t->flags;
   v.cap = t->capacity;
   v.mask = t->capacity - 1;
-  v.slot_state = t->slot_state;
+  v.head = t->head;
   v.keys = t->keys;
-  v.nullmask = t->nullmask;
   v.size = t->size;
   v.count = t->count;
   v.sum = t->sum;
   v.sumsq = t->sumsq;
   v.vmin = t->vmin;
   v.vmax = t->vmax;
-  v.index = t->index;
   v.state = t->state;
   v.vcount = nullptr;
   return v;
@@ -572,8 +583,8 @@ extern "C" {
 void nvt_gb_destroy(nvt_gb_table *t) {
   if (!t) return;
   if (!t->external) {
-    void *ptrs[] = {t->slot_state, t->keys, t->nullmask, t->size, t->count, t->sum,
-                    t->sumsq,      t->vmin, t->vmax,     t->index, t->state};
+    void *ptrs[] = {t->head, t->keys, t->size, t->count, t->sum,
+                    t->sumsq, t->vmin, t->vmax, t->state};
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
   }
@@ -586,8 +597,8 @@ static uint64_t gb_align(uint64_t x) { return (x + 255) & ~255ull; }
 int nvt_gb_table_bytes(int nkeys, int nvals, int flags, uint64_t capacity, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes, "null out");
   NVT_CHECK_ARG(nkeys >= 1 && nkeys <= kMaxKeys && nvals >= 0 && nvals <= kMaxVals, "bad shape");
-  uint64_t b = gb_align(capacity * 4) * 2 + gb_align(capacity * 8 * nkeys) +
-               gb_align(capacity * 8) * 3 + gb_align(capacity * 8 * nvals) +
+  uint64_t b = gb_align(capacity * 16) + gb_align(capacity * 8 * (nkeys - 1)) +
+               gb_align(capacity * 8) * 2 + gb_align(capacity * 8 * nvals) +
                gb_align(NVT_STATE_WORDS * 8);
   if (nvals && (flags & NVT_GB_SUMSQ)) b += gb_align(capacity * 8 * nvals);
   if (nvals && (flags & NVT_GB_MINMAX)) b += 2 * gb_align(capacity * 8 * nvals);
@@ -619,12 +630,10 @@ int nvt_gb_create_in(int nkeys, int nvals, int flags, uint64_t capacity, void *m
     p += gb_align(b);
     return (void *)r;
   };
-  t->slot_state = (unsigned *)take(capacity * 4);
-  t->nullmask = (unsigned *)take(capacity * 4);
-  t->keys = (long long *)take(capacity * 8 * nkeys);
+  t->head = (nvt_gb_head *)take(capacity * 16);
+  if (nkeys > 1) t->keys = (long long *)take(capacity * 8 * (nkeys - 1));
   t->size = (unsigned long long *)take(capacity * 8);
   t->count = (unsigned long long *)take(capacity * 8);
-  t->index = (long long *)take(capacity * 8);
   if (nvals) t->sum = (double *)take(capacity * 8 * nvals);
   t->state = (uint64_t *)take(NVT_STATE_WORDS * 8);
   if (nvals && (flags & NVT_GB_SUMSQ)) t->sumsq = (double *)take(capacity * 8 * nvals);
@@ -670,12 +679,10 @@ int nvt_gb_create(int nkeys, int nvals, int flags, uint64_t capacity, nvt_gb_tab
     if (bytes == 0) return true;
     return hipMalloc(p, bytes) == hipSuccess;
   };
-  bool ok = alloc((void **)&t->slot_state, capacity * 4) &&
-            alloc((void **)&t->keys, capacity * 8 * nkeys) &&
-            alloc((void **)&t->nullmask, capacity * 4) && alloc((void **)&t->size, capacity * 8) &&
-            alloc((void **)&t->count, capacity * 8) &&
+  bool ok = alloc((void **)&t->head, capacity * 16) &&
+            alloc((void **)&t->keys, capacity * 8 * (nkeys - 1)) &&
+            alloc((void **)&t->size, capacity * 8) && alloc((void **)&t->count, capacity * 8) &&
             alloc((void **)&t->sum, capacity * 8 * nvals) &&
-            alloc((void **)&t->index, capacity * 8) &&
             alloc((void **)&t->state, NVT_STATE_WORDS * 8);
   if (ok && nvals && (flags & NVT_GB_SUMSQ)) ok = alloc((void **)&t->sumsq, capacity * 8 * nvals);
   if (ok && nvals && (flags & NVT_GB_MINMAX))
