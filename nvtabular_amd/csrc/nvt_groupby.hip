@@ -500,6 +500,9 @@ __global__ __launch_bounds__(kBlock) void gb_compact_kernel(GbView t, GbOutArgs 
       if (!((occ >> r) & 1)) continue;
       const uint64_t i = tile * TILE + (uint64_t)r * kBlock + threadIdx.x;
       const nvt_gb_head hd = t.head[i];
+      // the table now also maps its keys to the compact group ids (nvt_gb_lookup works on it
+      // without a second table built by nvt_gb_index_build)
+      t.head[i].index = (unsigned)g;
       if (o.keys[0]) o.keys[0][g] = hd.key0;
       for (int j = 1; j < t.nkeys; ++j)
         if (o.keys[j]) o.keys[j][g] = t.keys[(uint64_t)(j - 1) * t.cap + i];

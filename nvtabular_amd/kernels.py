@@ -1210,8 +1210,10 @@ class GroupbyTable:
             ),
             "nvt_gb_compact",
         )
+        # index_table: nvt_gb_compact also stored every group's position in its slot, so this
+        # table answers lookups for exactly these groups (no nvt_gb_index_build of a second one)
         return dict(keys=keys, null_mask=nm, size=size, count=count, sum=sums, sumsq=sumsqs,
-                    min=mins, max=maxs, n=g)
+                    min=mins, max=maxs, n=g, index_table=self)
 
     def index_build(self, keys, null_mask):
         n = keys[0].numel() if keys else 0

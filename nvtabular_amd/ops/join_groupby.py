@@ -21,13 +21,17 @@ AGG_DTYPES = {"count": np.int32, "std": np.float32, "var": np.float32, "mean": n
 class _Stats:
     """Device-resident stat table of one group: lookup index + stat columns."""
 
-    def __init__(self, key_cols, keys, null_mask, columns, f32_columns=()):
+    def __init__(self, key_cols, keys, null_mask, columns, f32_columns=(), index_table=None):
         self.key_cols = key_cols
         # sum / min / max of a float32 column stay float32 (pandas' groupby result dtype)
         self.f32_columns = set(f32_columns)
         self.n = int(keys[0].numel()) if keys else 0
-        self.index = K.GroupbyTable(len(key_cols), 0, max(64, 2 * self.n + 1))
-        self.index.index_build([k.contiguous() for k in keys], null_mask)
+        if index_table is not None:
+            # the fit table itself: compaction left every group's row number in its slot
+            self.index = index_table
+        else:
+            self.index = K.GroupbyTable(len(key_cols), 0, max(64, 2 * self.n + 1))
+            self.index.index_build([k.contiguous() for k in keys], null_mask)
         self.columns = columns  # name -> float64/int64 tensor [groups]
 
 
@@ -127,7 +131,7 @@ class JoinGroupby(StatOperator):
             f32 = [f"{name}{self.name_sep}{cont}{self.name_sep}{stat}" for cont in agg.val_cols
                    for stat in ("sum", "min", "max") if agg.val_dtypes.get(cont) == torch.float32]
             self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols,
-                                              f32_columns=f32)
+                                              f32_columns=f32, index_table=comp.get("index_table"))
         return out
 
     def flush_artifacts(self):

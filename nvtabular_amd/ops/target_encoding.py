@@ -136,7 +136,8 @@ class TargetEncoding(StatOperator):
             cols = {"count": comp["count"]}
             for j, t in enumerate(agg.val_cols):
                 cols[f"sum:{t}"] = comp["sum"][j]
-            self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols)
+            self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols,
+                                              index_table=comp.get("index_table"))
         moments = moments_end(state["moments"]) if state["moments"] is not None else None
         return paths, moments
 
