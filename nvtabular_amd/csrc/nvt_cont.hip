@@ -819,6 +819,7 @@ int nvt_gather_f64(const double *src, const int64_t *group, uint64_t n, double m
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(src && group && out, "null pointer");
   hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("gather", 0, s);
   unsigned grid = stream_grid(n, kBlock * 4);
   switch (out_dtype) {
     case NVT_F64:
@@ -849,6 +850,7 @@ int nvt_te_apply(const int64_t *group_all, const int64_t *group_fold, const doub
   NVT_CHECK_ARG(group_all && sum_all && cnt_all && out, "null pointer");
   NVT_CHECK_ARG(!group_fold || (sum_fold && cnt_fold), "fold stats missing");
   hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("te_apply", 0, s);
   unsigned grid = stream_grid(n, kBlock * 4);
   if (out_dtype == NVT_F32)
     te_kernel<float><<<grid, kBlock, 0, s>>>(group_all, group_fold, sum_all, cnt_all, sum_fold,

@@ -702,6 +702,7 @@ int nvt_gb_create(int nkeys, int nvals, int flags, uint64_t capacity, nvt_gb_tab
 
 int nvt_gb_clear(nvt_gb_table *t, void *stream) {
   NVT_CHECK_ARG(t, "null table");
+  NVT_PROF("groupby_clear", 0, (hipStream_t)stream);
   gb_clear_kernel<<<stream_grid(t->capacity, kBlock * 2), kBlock, 0, (hipStream_t)stream>>>(
       view_of(t));
   NVT_CHECK_LAUNCH();
@@ -930,6 +931,7 @@ int nvt_gb_compact(nvt_gb_table *t, int64_t *const *out_keys, uint8_t *out_null_
     o.vmax[j] = out_max ? out_max[j] : nullptr;
   }
   hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_compact", 0, s);
   NVT_CHECK_HIP(hipMemsetAsync(out_n, 0, sizeof(uint64_t), s));
   gb_compact_kernel<<<stream_grid(t->capacity, kBlock * kGbCompactItems), kBlock, 0, s>>>(view_of(t), o, out_n);
   NVT_CHECK_LAUNCH();
@@ -964,6 +966,7 @@ int nvt_gb_lookup(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *co
     a.keys[j] = keys[j];
     a.key_valid[j] = key_valid ? key_valid[j] : nullptr;
   }
+  NVT_PROF("groupby_lookup", n * 8ull * (uint64_t)t->nkeys, (hipStream_t)stream);
   gb_lookup_kernel<<<stream_grid(n, kBlock * 2), kBlock, 0, (hipStream_t)stream>>>(view_of(t), a,
                                                                                     n, out_group);
   NVT_CHECK_LAUNCH();
