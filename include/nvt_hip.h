@@ -112,7 +112,7 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
  *      bucket inflated by a hot key is cut into a primary chunk plus small excess chunks
  *      (dispatched last) whose partial lists are merged per bucket.
  *   path | NVT_PATH_HOT (paths 1 / 2 / 3, int32 keys, no weights): a hot-key filter in front
- *      of the partition -- the histogram pass also counts the rows of up to ~7000 frequent
+ *      of the partition -- the histogram pass also counts the rows of a few thousand frequent
  *      keys (picked from a sample of the column) in LDS and switches them off for the
  *      scatter / count stages, which then handle only the remaining rows (60-95 % fewer on
  *      power-law columns).  Exact for any hot set.

@@ -802,15 +802,34 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const K *__restrict__ k
 //                       output list behind the partition's entries
 // The hot set is a heuristic; the result is exact for ANY hot set because a key is either in
 // the image (all of its rows are counted by the counters) or not (all of them are partitioned).
-constexpr int kHotSlots = NVT_HOT_IMAGE_WORDS;  // 2-choice table, 2 slots per bucket: 32 KiB keys + 32 KiB counters
-constexpr int kHotBuckets = kHotSlots / 2;
+// The table: buckets of NVT_HOT_WIDTH slots, ONE candidate bucket per key, so a lookup is one
+// 8- or 16-byte LDS read.  A key whose bucket is full is simply not hot (2 choices x 2 slots
+// kept ~8 % more keys and cost a second read per row: 2.37 vs 2.22 ms for the nine filtered
+// path-1 columns).
+#ifndef NVT_HOT_WIDTH
+#define NVT_HOT_WIDTH 2
+#endif
+constexpr int kHotSlots = NVT_HOT_IMAGE_WORDS;  // 32 KiB of keys + 32 KiB of counters
+constexpr int kHotWidth = NVT_HOT_WIDTH;
+constexpr int kHotBuckets = kHotSlots / kHotWidth;
 constexpr int kHotBlocks = 256;         // histogram workgroups (one per CU: 130 KiB of LDS each)
 constexpr int kHotSampleBlocks = 64;    // x 1024 rows
 
-__device__ __forceinline__ void hot_buckets(uint32_t h, uint32_t &b1, uint32_t &b2) {
-  b1 = (h >> 13) & (kHotBuckets - 1);
-  b2 = (((h ^ (h >> 15)) * 0x2C1B3C6Du) >> 17) & (kHotBuckets - 1);
-  b2 = b2 == b1 ? b1 ^ 1u : b2;
+__device__ __forceinline__ uint32_t hot_bucket(uint32_t h) { return (h >> 13) & (kHotBuckets - 1); }
+// slot of `key` in its bucket (already loaded), or -1
+__device__ __forceinline__ int hot_find(const int2 &b, int32_t key, uint32_t base) {
+  int slot = -1;
+  slot = b.x == key ? (int)base : slot;
+  slot = b.y == key ? (int)base + 1 : slot;
+  return slot;
+}
+__device__ __forceinline__ int hot_find(const int4 &b, int32_t key, uint32_t base) {
+  int slot = -1;
+  slot = b.x == key ? (int)base : slot;
+  slot = b.y == key ? (int)base + 1 : slot;
+  slot = b.z == key ? (int)base + 2 : slot;
+  slot = b.w == key ? (int)base + 3 : slot;
+  return slot;
 }
 
 struct HotSampleCol {
@@ -842,12 +861,10 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
   const unsigned S = (unsigned)(nblk < (uint64_t)kHotSampleBlocks ? nblk : kHotSampleBlocks);
   const uint64_t step = (S ? nblk / S : 1) * 1024;  // rows between the starts of sampled blocks
   auto insert = [&](int32_t key, uint32_t h) -> bool {
-    uint32_t b1, b2;
-    hot_buckets(h, b1, b2);
-    const uint32_t cand[4] = {2 * b1, 2 * b1 + 1, 2 * b2, 2 * b2 + 1};
+    const uint32_t b = hot_bucket(h) * kHotWidth;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int32_t prev = atomicCAS(&tk[cand[c]], EMPTY, key);
+    for (int c = 0; c < kHotWidth; ++c) {
+      const int32_t prev = atomicCAS(&tk[b + c], EMPTY, key);
       if (prev == EMPTY || prev == key) return true;
     }
     return false;
@@ -903,10 +920,10 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
       const int32_t key = kreg[q];
       if (key != EMPTY) {
         const uint32_t h = slot_hash(key);
-        uint32_t b1, b2;
-        hot_buckets(h, b1, b2);
-        const bool found = tk[2 * b1] == key || tk[2 * b1 + 1] == key || tk[2 * b2] == key ||
-                           tk[2 * b2 + 1] == key;
+        const uint32_t b = hot_bucket(h) * kHotWidth;
+        bool found = false;
+#pragma unroll
+        for (int c = 0; c < kHotWidth; ++c) found = found || tk[b + c] == key;
         if (!found) insert(key, h);
         hits += found;
         rows += 1;
@@ -936,14 +953,15 @@ __global__ __launch_bounds__(1024) void part_hist_hot_kernel(
   using K = int32_t;
   constexpr K EMPTY = DKey<K>::empty;
   __shared__ unsigned h[kMaxFine];
-  __shared__ int2 tk[kHotBuckets];
+  using BucketT = std::conditional<kHotWidth == 4, int4, int2>::type;
+  __shared__ BucketT tk[kHotBuckets];
   __shared__ unsigned tc[kHotSlots];
   __shared__ unsigned ht[256];
   __shared__ unsigned long long s_nulls;
   const int nb = 1 << bits, nc = 1 << b1;
   for (int i = threadIdx.x; i < nb; i += 1024) h[i] = 0;
   for (int i = threadIdx.x; i < kHotBuckets; i += 1024)
-    tk[i] = reinterpret_cast<const int2 *>(image)[i];
+    tk[i] = reinterpret_cast<const BucketT *>(image)[i];
   for (int i = threadIdx.x; i < kHotSlots; i += 1024) tc[i] = 0;
   if (threadIdx.x == 0) s_nulls = 0;
   unsigned long long nulls = 0;
@@ -989,25 +1007,20 @@ __global__ __launch_bounds__(1024) void part_hist_hot_kernel(
           }
         }
       }
-      // both candidate buckets of every key are requested before any of them is used
-      int2 ba[VEC], bb[VEC];
-      uint32_t sa[VEC], sb[VEC];
+      // the buckets of all keys of the vector are requested before any of them is used
+      BucketT bk[VEC];
+      uint32_t sa[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        hot_buckets(slot_hash(kv[j]), sa[j], sb[j]);
-        ba[j] = tk[sa[j]];
-        bb[j] = tk[sb[j]];
+        sa[j] = hot_bucket(slot_hash(kv[j]));
+        bk[j] = tk[sa[j]];
       }
       unsigned cold_bits = 0;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if ((bits_ok >> j) & 1) {
           const K key = kv[j];
-          int slot = -1;
-          slot = ba[j].x == key ? (int)(2 * sa[j]) : slot;
-          slot = ba[j].y == key ? (int)(2 * sa[j] + 1) : slot;
-          slot = bb[j].x == key ? (int)(2 * sb[j]) : slot;
-          slot = bb[j].y == key ? (int)(2 * sb[j] + 1) : slot;
+          const int slot = hot_find(bk[j], key, kHotWidth * sa[j]);
           if (slot >= 0 && key != EMPTY) {
             atomicAdd(&tc[slot], 1u);
           } else {
