@@ -254,12 +254,16 @@ __device__ __forceinline__ void two_buckets(uint32_t h, uint32_t &b1, uint32_t &
   b2 = b2 == b1 ? b1 ^ 1u : b2;
 }
 
-template <typename K, typename OUT, bool TWO = false>
+// GLOBAL = false: the whole vocabulary is staged (no table in HBM): the probe phases and their
+// registers disappear.  (UU = 3 / 4 key vectors per lane in flight, and a 2048-slot table with
+// two workgroups per CU for vocabularies <= 1024 keys, were each ~2 % slower: profiles/r02_notes.md)
+template <typename K, typename OUT, bool TWO = false, bool GLOBAL = true, int UU = 2>
 __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
     int64_t null_label, int64_t oov_label, uint32_t num_buckets, OUT *__restrict__ out,
-    const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label, int global_needed) {
+    const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label) {
+  constexpr bool global_needed = GLOBAL;
   constexpr K EMPTY = EncTraits<K>::empty;
   constexpr int VEC = EncTraits<K>::vec;
   constexpr int SLOTS = HotCfg<K>::slots;
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
   const uint64_t stride = (uint64_t)gridDim.x * kEncBS;
   using VecT = typename std::conditional<sizeof(K) == 4, int4, longlong2>::type;
   const VecT *vkeys = reinterpret_cast<const VecT *>(keys);
-  constexpr int U = 2;
+  constexpr int U = UU;
   constexpr int NK = U * VEC;
   // software pipeline: the key vectors (and bitmap bytes) of iteration i+1 are requested
   // before iteration i is processed -- with one 1024-thread workgroup per CU the stream
@@ -408,24 +412,26 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     }
     // phase 2: first probe of every miss issued back to back (independent loads), so the
     // HBM / Infinity-Cache latency is paid once per batch, not once per key
-    uint64_t slot[NK];
-    EncSlot<K> e[NK];
+    if constexpr (GLOBAL) {
+      uint64_t slot[NK];
+      EncSlot<K> e[NK];
 #pragma unroll
-    for (int q = 0; q < NK; ++q) {
-      slot[q] = (uint64_t)slot_hash(k[q]) & mask;
-      if (need[q]) e[q] = table[slot[q]];
-    }
+      for (int q = 0; q < NK; ++q) {
+        slot[q] = (uint64_t)slot_hash(k[q]) & mask;
+        if (need[q]) e[q] = table[slot[q]];
+      }
 #pragma unroll
-    for (int q = 0; q < NK; ++q) {
-      if (!need[q]) continue;
-      while (true) {  // collisions continue here (load factor <= 0.5: short chains)
-        if (e[q].key == k[q]) {
-          lab[q] = (int64_t)e[q].label;
-          break;
+      for (int q = 0; q < NK; ++q) {
+        if (!need[q]) continue;
+        while (true) {  // collisions continue here (load factor <= 0.5: short chains)
+          if (e[q].key == k[q]) {
+            lab[q] = (int64_t)e[q].label;
+            break;
+          }
+          if (e[q].key == EMPTY) break;
+          slot[q] = (slot[q] + 1) & mask;
+          e[q] = table[slot[q]];
         }
-        if (e[q].key == EMPTY) break;
-        slot[q] = (slot[q] + 1) & mask;
-        e[q] = table[slot[q]];
       }
     }
 #pragma unroll
@@ -598,23 +604,25 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
         if (out_bytes == 8)
           encode_hot_kernel<K, int64_t, true><<<hgrid, kEncBS, 0, s>>>(
               keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
-              reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label, 1);
+              reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label);
         else
           encode_hot_kernel<K, int32_t, true><<<hgrid, kEncBS, 0, s>>>(
               keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
-              reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label, 1);
+              reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label);
         NVT_CHECK_LAUNCH();
         return NVT_OK;
       }
     }
-    if (out_bytes == 8)
-      encode_hot_kernel<K, int64_t><<<hgrid, kEncBS, 0, s>>>(
-          keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
-          reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label, global_needed);
-    else
-      encode_hot_kernel<K, int32_t><<<hgrid, kEncBS, 0, s>>>(
-          keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
-          reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label, global_needed);
+#define NVT_ENC_HOT(OUTT, GL, UUU)                                                               \
+  encode_hot_kernel<K, OUTT, false, GL, UUU><<<hgrid, kEncBS, 0, s>>>(                            \
+      keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,        \
+      reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label)
+    if (global_needed) {
+      if (out_bytes == 8) NVT_ENC_HOT(int64_t, true, 2); else NVT_ENC_HOT(int32_t, true, 2);
+    } else {
+      if (out_bytes == 8) NVT_ENC_HOT(int64_t, false, 2); else NVT_ENC_HOT(int32_t, false, 2);
+    }
+#undef NVT_ENC_HOT
     NVT_CHECK_LAUNCH();
     return NVT_OK;
   }
