@@ -116,3 +116,39 @@ def test_row_limit_is_reported_not_silently_wrapped():
     rc = lib.nvt_dense_count_i32(k.data_ptr(), None, None, C.c_uint64(1 << 32), 0, ws.data_ptr(),
                                  k.data_ptr(), o.data_ptr(), 16, state.data_ptr(), None)
     assert rc == -1 and b"2^32" in lib.nvt_last_error()
+
+
+def test_single_column_abi_call_with_hot_filter_samples_inline():
+    """nvt_dense_count_i32(path | NVT_PATH_HOT) without the batched call's per-column image:
+    the hot-key sample is taken inside the column's pipeline and kept in the workspace."""
+    import ctypes as C
+
+    from nvtabular_amd import _lib
+    from nvtabular_amd import kernels as K
+
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n = 1_200_000
+    ids = (rng.zipf(1.2, n) % 300_000).astype("int32") * 11 - 7
+    keys = torch.from_numpy(ids).cuda()
+    path = 1 | K.PATH_HOT
+    need = C.c_uint64()
+    K.check(lib.nvt_dense_count_ws_bytes(4, n, path, 0, C.byref(need)))
+    ws = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+    out_k = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    out_c = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    state = torch.zeros(_lib.STATE_WORDS, dtype=torch.int64, device="cuda")
+    K.check(lib.nvt_dense_count_i32(keys.data_ptr(), None, None, n, path, ws.data_ptr(),
+                                    out_k.data_ptr(), out_c.data_ptr(), n + 1, state.data_ptr(),
+                                    K.stream_ptr()))
+    st = state.cpu().tolist()
+    assert st[_lib.ST_OVERFLOW] == 0 and st[_lib.ST_ROWS] == n
+    m = st[_lib.ST_OCCUPIED]
+    got = pd.Series(out_c[:m].cpu().numpy(), index=out_k[:m].cpu().numpy()).sort_index()
+    exp = pd.Series(np.ones(n, dtype="int64")).groupby(ids).sum()
+    assert got.index.is_unique
+    np.testing.assert_array_equal(got.index.to_numpy(), exp.index.to_numpy())
+    np.testing.assert_array_equal(got.to_numpy(), exp.to_numpy())
+    # the filter is refused where it does not apply
+    assert lib.nvt_dense_count_ws_bytes(8, n, path, 0, C.byref(need)) == -1
+    assert lib.nvt_dense_count_ws_bytes(4, n, 0 | K.PATH_HOT, 0, C.byref(need)) == -1
