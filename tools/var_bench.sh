@@ -1,6 +1,10 @@
-cp nvtabular_amd/libnvt_hip.so /tmp/orig.so
-for v in orig hot2 hot3; do
-  if [ $v != orig ]; then cp nvtabular_amd/libnvt_v_$v.so nvtabular_amd/libnvt_hip.so; fi
-  echo "== $v"; python bench.py --no-cpu-baseline --steps 10 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['per_kernel_ms_per_step']['encode_i32'])"
+#!/bin/bash
+# run-to-run spread of the driver-style command inside one box: tools/var_bench.sh <outdir> [runs]
+cd /root/repo; out=gpurun_out/$1; mkdir -p $out
+for i in $(seq 1 ${2:-3}); do
+  python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $out/run$i.json 2> $out/run$i.err
+  python - <<PY
+import json
+r=json.load(open("$out/run$i.json")); print("run $i", round(r["ms_per_step"],3), round(r["gpu_busy_ms_per_step"],3), r["host_timeline_ms"]["step_period"], r["device_allocs_in_timed_region"], r["roofline"]["frac"])
+PY
 done
-cp /tmp/orig.so nvtabular_amd/libnvt_hip.so
