@@ -191,15 +191,27 @@ def _hip_merge_counts(keys: torch.Tensor, counts: torch.Tensor):
     return k, c
 
 
+def _hip_merge_counts_many(parts):
+    """Owner-side merge of every column's received (key, count) rows: ONE batched launch and ONE
+    read-back for all columns (the per-column form synchronised 26 times per Criteo fit)."""
+    from . import kernels as K
+
+    jobs = [K.DenseCountJob(k, None, c, hint=int(k.numel())) for k, c in parts]
+    return [(k, c) for k, c, _, _ in K.dense_count_many(jobs)]
+
+
 _owner_fn: Callable = _hip_owner
 _merge_counts_fn: Callable = _hip_merge_counts
+_merge_counts_many_fn: Optional[Callable] = _hip_merge_counts_many
 
 
 def set_backend_fns(owner_fn=None, merge_counts_fn=None):
     """Test hook: replace the HIP owner-hash / owner-merge steps (gloo CPU tests)."""
-    global _owner_fn, _merge_counts_fn
+    global _owner_fn, _merge_counts_fn, _merge_counts_many_fn
     _owner_fn = owner_fn or _hip_owner
     _merge_counts_fn = merge_counts_fn or _hip_merge_counts
+    # an injected per-column merge (host stand-in of the CPU tests) replaces the batched one too
+    _merge_counts_many_fn = None if merge_counts_fn else _hip_merge_counts_many
 
 
 # --------------------------------------------------------------------------
@@ -267,12 +279,20 @@ def merge_counts_many(tables):
     off = torch.zeros(G * ncol + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
     off = off.tolist()
-    merged = []
+    parts = []
     for j in range(ncol):
         pieces = [recv[off[src * ncol + j] : off[src * ncol + j + 1]] for src in range(G)]
         part = torch.cat(pieces) if G > 1 else pieces[0]
-        if part.shape[0]:
-            mk, mc = _merge_counts_fn(part[:, 0].contiguous().to(dtypes[j]), part[:, 1].contiguous())
+        parts.append((part[:, 0].contiguous().to(dtypes[j]), part[:, 1].contiguous()))
+    live = [j for j in range(ncol) if parts[j][0].numel()]
+    if _merge_counts_many_fn is not None:
+        results = dict(zip(live, _merge_counts_many_fn([parts[j] for j in live])))
+    else:
+        results = {j: _merge_counts_fn(*parts[j]) for j in live}
+    merged = []
+    for j in range(ncol):
+        if j in results:
+            mk, mc = results[j]
             merged.append(torch.stack([mk.to(torch.int64), mc.to(torch.int64)], dim=1))
         else:
             merged.append(torch.empty((0, 2), dtype=torch.int64, device=dev))
