@@ -262,10 +262,17 @@ def merge_counts_many(tables):
     dest = torch.cat(dest_parts)
     rows = torch.stack([torch.cat([k.to(torch.int64) for k, _, _ in tables]),
                         torch.cat([c.to(torch.int64) for _, c, _ in tables])], dim=1)
-    # rows are concatenated column by column, so the ascending row indices of one owner are
-    # already grouped by column: G compactions give the (owner, column) order -- a full
-    # argsort of ~3e7 destinations was the most expensive step of the whole exchange
-    order = torch.cat([torch.nonzero(owner_all == g).squeeze(1) for g in range(G)])
+    # (owner, column) order of the rows.  (Host stand-in: rows are concatenated column by
+    # column, so the ascending row indices of one owner are already grouped by column and G
+    # compactions do; a full torch argsort of ~3e7 destinations was the most expensive step.)
+    if dest.is_cuda:
+        # stable radix sort of (destination << 32 | row) words on the destination bits
+        from . import kernels as K
+
+        words = K.order_rows(int(dest.numel()), dev, gid=dest, ngroups=G * ncol)
+        order = words & 0xFFFFFFFF
+    else:  # host stand-in of the CPU tests
+        order = torch.cat([torch.nonzero(owner_all == g).squeeze(1) for g in range(G)])
     send_mat = torch.bincount(dest, minlength=G * ncol).to(torch.int64).view(G, ncol)
     # ---- count matrix: row g of mine goes to rank g ------------------------------------
     if _backend() == "nccl":
