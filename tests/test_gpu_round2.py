@@ -237,3 +237,32 @@ def test_fully_staged_encode_with_unseen_keys_and_nulls(tmp_path):
     exp = O.categorify_transform(_host_view(df2), cols, paths)
     for c in cols:
         np.testing.assert_array_equal(out[c].to_numpy(), exp[c].to_numpy(), err_msg=c)
+
+
+def test_multi_partition_fit_on_the_filtered_partitioned_path(tmp_path):
+    """Three partitions of a 150 k-key power-law column: every partition is counted on path
+    1 | NVT_PATH_HOT (its own sampled hot set), the per-partition lists are merged by the
+    weighted count -- vocabulary and labels equal the oracle's on the whole frame."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K, ops
+
+    rng = np.random.default_rng(21)
+    n = 1_200_000
+    df = pd.DataFrame({
+        "c": pd.array((rng.zipf(1.08, n) % 150_000).astype("int32") * 13 - 99, dtype="Int32"),
+    })
+    df.loc[rng.random(n) < 0.02, "c"] = pd.NA
+    parts = [df.iloc[i * 400_000:(i + 1) * 400_000].reset_index(drop=True) for i in range(3)]
+    host = _host_view(df)
+    assert K._path_for(host["c"].nunique()) == 1 and K.HOT_FILTER
+    wf = nvt.Workflow(["c"] >> ops.Categorify(out_path=str(tmp_path / "gpu")))
+    wf.fit(nvt.Dataset(parts))
+    out = wf.transform(nvt.Dataset(df)).to_ddf().compute()
+    paths = O.categorify_fit([_host_view(p) for p in parts], ["c"], str(tmp_path / "cpu"),
+                             tie_break="stable")
+    exp = O.categorify_transform(host, ["c"], paths)
+    np.testing.assert_array_equal(out["c"].to_numpy(), exp["c"].to_numpy())
+    a = pd.read_parquet(tmp_path / "gpu" / "categories" / "unique.c.parquet")
+    b = pd.read_parquet(paths["c"])
+    np.testing.assert_array_equal(a["c"].to_numpy(), b["c"].to_numpy())
+    np.testing.assert_array_equal(a["c_size"].to_numpy(), b["c_size"].to_numpy())
