@@ -2342,8 +2342,25 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
   // one column's short serial kernels (reduce / scan / offsets) hide under another's wide ones.
   // Columns sharing a workspace stay ordered on one stream.
   hipStream_t main_s = (hipStream_t)stream;
+  std::vector<void *> wss;
+  for (int i = 0; i < ncols; ++i)
+    if (std::find(wss.begin(), wss.end(), cols[i].ws) == wss.end()) wss.push_back(cols[i].ws);
+  SidePool *pool = nullptr;
+  const bool fork = wss.size() > 1 && wss.size() <= (size_t)kSideStreams;
+  if (wss.size() > (size_t)kSideStreams) {
+    set_error("nvt_dense_count_many: at most %d distinct workspaces per call", kSideStreams);
+    return NVT_EINVAL;
+  }
+  if (fork) {
+    int rc = side_pool(1, &pool);
+    if (rc) return rc;
+    NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
+    for (size_t k = 0; k < wss.size(); ++k) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[k], pool->fork, 0));
+  }
   // hot-key samples of every filtered column: ONE launch (a workgroup per column) on the
-  // caller's stream, ahead of the per-column pipelines
+  // caller's stream.  The internal streams were forked before it: columns that need no sample
+  // start at once, a stream waits for the samples only in front of its first filtered column.
+  bool sampled = false;
   {
     HotSampleBatch hb;
     int nh = 0;
@@ -2352,6 +2369,7 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
         NVT_PROF("dense_count_sample", 0, main_s);
         hot_sample_kernel<<<nh, 1024, 0, main_s>>>(hb);
         NVT_CHECK_LAUNCH();
+        sampled = true;
       }
       nh = 0;
       return NVT_OK;
@@ -2368,25 +2386,19 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
     int rc = flush();
     if (rc) return rc;
   }
-  std::vector<void *> wss;
-  for (int i = 0; i < ncols; ++i)
-    if (std::find(wss.begin(), wss.end(), cols[i].ws) == wss.end()) wss.push_back(cols[i].ws);
-  SidePool *pool = nullptr;
-  const bool fork = wss.size() > 1 && wss.size() <= (size_t)kSideStreams;
-  if (wss.size() > (size_t)kSideStreams) {
-    set_error("nvt_dense_count_many: at most %d distinct workspaces per call", kSideStreams);
-    return NVT_EINVAL;
-  }
-  if (fork) {
-    int rc = side_pool(1, &pool);
-    if (rc) return rc;
-    NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
-    for (size_t k = 0; k < wss.size(); ++k) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[k], pool->fork, 0));
-  }
+  bool waited[kSideStreams] = {false, false, false};
+  if (fork && sampled) NVT_CHECK_HIP(hipEventRecord(pool->aux, main_s));
   for (int i = 0; i < ncols; ++i) {
     const nvt_count_col &c = cols[i];
     hipStream_t cs = main_s;
-    if (fork) cs = pool->s[std::find(wss.begin(), wss.end(), c.ws) - wss.begin()];
+    if (fork) {
+      const size_t k = std::find(wss.begin(), wss.end(), c.ws) - wss.begin();
+      cs = pool->s[k];
+      if (sampled && (c.path & NVT_PATH_HOT) && c.hot_image && !waited[k]) {
+        NVT_CHECK_HIP(hipStreamWaitEvent(cs, pool->aux, 0));
+        waited[k] = true;
+      }
+    }
     int rc;
     if (c.key_bytes == 4)
       rc = dense_count<int32_t>((const int32_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,

@@ -11,7 +11,7 @@ constexpr int kSideStreams = 3;
 struct SidePool {
   int dev = -1, which = 0;
   hipStream_t s[kSideStreams];
-  hipEvent_t fork, join[kSideStreams];
+  hipEvent_t fork, join[kSideStreams], aux;
 };
 int side_pool(int which, SidePool **out);
 

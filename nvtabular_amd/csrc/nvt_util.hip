@@ -47,6 +47,7 @@ int side_pool(int which, SidePool **out) {
     NVT_CHECK_HIP(hipEventCreateWithFlags(&p->join[i], hipEventDisableTiming));
   }
   NVT_CHECK_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+  NVT_CHECK_HIP(hipEventCreateWithFlags(&p->aux, hipEventDisableTiming));
   g_pools.push_back(p);
   *out = p;
   return NVT_OK;
