@@ -105,8 +105,6 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
  *      LDS atomics serialise);
  *   7  path 0 with 2 key classes per row slab: each LDS table keeps the keys of one class,
  *      the column is read twice (<= ~21000 distinct keys; 350 us against 420 us on path 1);
- *   4 / 5  the same with 4 / 8 classes (column read 4x / 8x) -- exact, tested, but not faster
- *      than path 1 on MI355X;
  *   1 / 2 / 3  hash-partition the rows into 256 / 64 x 64 / 64 x 256 buckets (exact
  *      per-tile histograms + scan, no cursor atomics), then one LDS table per bucket; a
  *      bucket inflated by a hot key is cut into a primary chunk plus small excess chunks

@@ -252,6 +252,15 @@ __device__ __forceinline__ void fill_norm_body(
       }
       return (OUT)raw;
     }
+    if constexpr (std::is_same<T, float>::value) {
+      // a float32 column stays float32 through pandas' `(values - mean) / std` (the Python
+      // float operands are weak scalars, normalize.py:79-84) and is widened afterwards: the
+      // same two correctly rounded fp32 operations here give the reference's bits
+      float v = isnull ? (has_fill ? (float)fill_val : std::numeric_limits<float>::quiet_NaN()) : raw;
+      v = v - (float)shift;
+      if (inv_is_div != 0.0) v = v / (float)scale;
+      return (OUT)v;
+    }
     double v = isnull ? (has_fill ? fill_val : qnan) : (double)raw;
     v -= shift;
     if (inv_is_div != 0.0) v /= scale;

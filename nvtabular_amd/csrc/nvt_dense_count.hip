@@ -1789,202 +1789,6 @@ __global__ __launch_bounds__(kStageBS) void part_merge_kernel(
   lds_flush<K, C, kStageBS, SLOTS>(lkeys, lcnt, out_keys, out_cnt, out_cap, cursor, state);
 }
 
-// ---------------------------------------------------------------------------
-// Path 8: ONE partition level of 1024 buckets (int32 keys, unweighted) for 21 k .. ~9 M distinct
-// keys.  Against paths 1 / 2 it drops the per-tile histograms and their device scan (the
-// scatter finds each (tile, bucket) offset by a decoupled look-back over the tiles before it,
-// like the onesweep passes of nvt_sort.hip) and path 2's second scatter level: the column is
-// read by the histogram, read + written once by the scatter, read once by the per-bucket count.
-//   hist1k     512 workgroups: 4-way replicated LDS histogram of the top 10 hash bits
-//   reduce / scan (shared with paths 1-3) -> exact bucket starts, P3 work list
-//   scatter1k  16384-row tiles, 512 threads: ranks by LDS atomics, tile staged in bucket order
-//              (64-byte runs on average), global offsets by look-back, ticketed tile ids
-//   P3 / offsets / copy / merge as in path 1 (16384-slot tables, one workgroup per bucket chunk)
-// ---------------------------------------------------------------------------
-constexpr int kP8Bits = 10, kP8Buckets = 1 << kP8Bits;
-constexpr int kP8Tile = 16384, kP8BS = 512;
-constexpr unsigned kP8Agg = 1u << 30, kP8Prefix = 2u << 30, kP8Mask = (1u << 30) - 1u;
-
-__global__ __launch_bounds__(1024) void part_hist1k_kernel(const int32_t *__restrict__ keys,
-                                                            const uint8_t *__restrict__ valid,
-                                                            uint64_t n, unsigned *block_hist,
-                                                            uint64_t *state) {
-  __shared__ unsigned h[4][kP8Buckets];
-  __shared__ unsigned long long s_nulls;
-  for (int i = threadIdx.x; i < 4 * kP8Buckets; i += 1024) (&h[0][0])[i] = 0;
-  if (threadIdx.x == 0) s_nulls = 0;
-  __syncthreads();
-  // hot keys put most lanes of a wave on ONE bucket: 4 copies (by lane quarter) cut the
-  // same-address LDS atomics four-fold
-  unsigned *my = h[(threadIdx.x >> 4) & 3];
-  unsigned long long nulls = 0;
-  const uint64_t nvec = n / 4;
-  const int4 *vk = reinterpret_cast<const int4 *>(keys);
-  const uint64_t stride = (uint64_t)gridDim.x * 1024;
-  constexpr int U = 4;
-  for (uint64_t v0 = (uint64_t)blockIdx.x * 1024 + threadIdx.x; v0 < nvec; v0 += stride * U) {
-    int4 p[U];
-    unsigned vb[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t v = v0 + (uint64_t)u * stride;
-      const uint64_t vc = v < nvec ? v : nvec - 1;  // clamped, masked below (no branch around loads)
-      p[u] = vk[vc];
-      vb[u] = valid ? (unsigned)valid[(vc * 4) >> 3] : 0xFFu;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t v = v0 + (uint64_t)u * stride;
-      const unsigned inr = v < nvec ? 15u : 0u;
-      const unsigned bits = (vb[u] >> ((v * 4) & 7)) & inr;
-      nulls += __popc(inr & ~bits);
-      const int kk[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if ((bits >> j) & 1) atomicAdd(&my[part_hash<int32_t>(kk[j]) >> (32 - kP8Bits)], 1u);
-    }
-  }
-  for (uint64_t i = nvec * 4 + (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) {
-    if (bit_valid(valid, i))
-      atomicAdd(&my[part_hash<int32_t>(keys[i]) >> (32 - kP8Bits)], 1u);
-    else
-      ++nulls;
-  }
-  if (nulls) atomicAdd(&s_nulls, nulls);
-  __syncthreads();
-  for (int i = threadIdx.x; i < kP8Buckets; i += 1024)
-    block_hist[(uint64_t)blockIdx.x * kP8Buckets + i] = h[0][i] + h[1][i] + h[2][i] + h[3][i];
-  if (threadIdx.x == 0 && s_nulls) atomicAdd((unsigned long long *)&state[DS_NULLS], s_nulls);
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    atomicAdd((unsigned long long *)&state[DS_ROWS], (unsigned long long)n);
-}
-
-__global__ __launch_bounds__(kP8BS) void part_scatter1k_kernel(
-    const int32_t *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
-    const unsigned long long *__restrict__ fine_start, unsigned *status, unsigned *ticket,
-    int32_t *__restrict__ out_keys) {
-  constexpr int ROWS = kP8Tile / kP8BS;  // 32 rows = 8 vectors per thread
-  constexpr int NV = ROWS / 4;
-  __shared__ int32_t stage[kP8Tile];
-  __shared__ unsigned cnt[kP8Buckets], off[kP8Buckets];
-  __shared__ unsigned gbase[kP8Buckets];  // n < 2^32; 76 KiB of LDS in all: two workgroups per CU
-  __shared__ unsigned wsum[kP8BS / kWave];
-  __shared__ unsigned s_tile;
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-  cnt[threadIdx.x] = 0;
-  cnt[threadIdx.x + kP8BS] = 0;
-  __syncthreads();
-  const unsigned tile = s_tile;
-  const uint64_t lo = (uint64_t)tile * kP8Tile;
-  const uint64_t hi = lo + kP8Tile < n ? lo + kP8Tile : n;
-  const uint64_t nvec_all = (n + 3) / 4;
-  int32_t k[ROWS];
-  unsigned short pos[ROWS], bk[ROWS];
-  int4 pack[NV];
-  unsigned vraw[NV];
-  const int4 *vk = reinterpret_cast<const int4 *>(keys);
-#pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const uint64_t i0 = lo + ((uint64_t)u * kP8BS + threadIdx.x) * 4;
-    const bool full = i0 + 4 <= n;
-    const uint64_t vc = full ? i0 / 4 : 0;  // clamped: rows outside the column are masked below
-    pack[u] = vk[vc < nvec_all ? vc : 0];
-    vraw[u] = valid ? (unsigned)valid[(full ? i0 : 0) >> 3] : 0xFFu;
-  }
-#pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const uint64_t i0 = lo + ((uint64_t)u * kP8BS + threadIdx.x) * 4;
-    int32_t kv[4] = {pack[u].x, pack[u].y, pack[u].z, pack[u].w};
-    unsigned vb;
-    if (i0 + 4 <= n) {
-      vb = (vraw[u] >> (i0 & 7)) & 15u;
-    } else {  // the column's last, partial vector
-      vb = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        kv[j] = 0;
-        if (i0 + j < n && bit_valid(valid, i0 + j)) {
-          kv[j] = keys[i0 + j];
-          vb |= 1u << j;
-        }
-      }
-    }
-    if (i0 >= hi) vb = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = u * 4 + j;
-      k[r] = kv[j];
-      bk[r] = 0xFFFF;
-      pos[r] = 0;
-      if ((vb >> j) & 1) {
-        const unsigned b = part_hash<int32_t>(kv[j]) >> (32 - kP8Bits);
-        bk[r] = (unsigned short)b;
-        pos[r] = (unsigned short)atomicAdd(&cnt[b], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  {  // thread t owns buckets 2t, 2t+1: tile-local starts, look-back for the global offsets
-    const unsigned b0 = threadIdx.x * 2;
-    const unsigned c0 = cnt[b0], c1 = cnt[b0 + 1];
-    unsigned *st0 = status + (uint64_t)tile * kP8Buckets + b0;
-    // publish the aggregates first: the tiles behind this one only need these words
-    __hip_atomic_store(st0, (tile == 0 ? kP8Prefix : kP8Agg) | c0, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(st0 + 1, (tile == 0 ? kP8Prefix : kP8Agg) | c1, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned tot = c0 + c1;
-    unsigned inc = tot;
-    const unsigned lane = lane_id(), w = threadIdx.x / kWave;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      unsigned x = __shfl_up(inc, o, 64);
-      if (lane >= (unsigned)o) inc += x;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    unsigned wb = 0;
-    for (unsigned q = 0; q < w; ++q) wb += wsum[q];
-    const unsigned start = wb + inc - tot;
-    off[b0] = start;
-    off[b0 + 1] = start + c0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const unsigned b = b0 + q, mine = q ? c1 : c0;
-      unsigned excl = 0;
-      if (tile > 0) {
-        unsigned tb = tile - 1;
-        while (true) {
-          const unsigned v = __hip_atomic_load(status + (uint64_t)tb * kP8Buckets + b,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned f = v >> 30;
-          if (f == 0) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-          }
-          excl += v & kP8Mask;
-          if (f == 2) break;
-          --tb;  // tile 0 always publishes a prefix
-        }
-        __hip_atomic_store(status + (uint64_t)tile * kP8Buckets + b, kP8Prefix | (excl + mine),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      gbase[b] = (unsigned)fine_start[b] + excl;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r)
-    if (bk[r] != 0xFFFF) stage[off[bk[r]] + pos[r]] = k[r];
-  __syncthreads();
-  const unsigned total = off[kP8Buckets - 1] + cnt[kP8Buckets - 1];
-  for (unsigned i = threadIdx.x; i < total; i += kP8BS) {
-    const int32_t key = stage[i];
-    const unsigned b = part_hash<int32_t>(key) >> (32 - kP8Bits);
-    out_keys[(uint64_t)gbase[b] + (i - off[b])] = key;
-  }
-}
-
 inline uint64_t align16(uint64_t x) { return (x + 15) & ~15ull; }
 
 // Partitioned paths:
@@ -2016,12 +1820,6 @@ inline PathCfg path_cfg(int path, int key_bytes, int weighted, uint64_t n) {
     uint64_t small_rows = chunk / NVT_SMALL_DIV < 16384 ? 16384 : chunk / NVT_SMALL_DIV;
     return {8, 0, small ? kLdsSlots : kLdsSlotsBig, chunk, small_rows};
   }
-  if (path == 8) {
-    uint64_t chunk = (n / kP8Buckets) + (n / kP8Buckets) / 7 + 1;
-    chunk = chunk < 32768 ? 32768 : (chunk > (1ull << 20) ? (1ull << 20) : chunk);
-    uint64_t small_rows = chunk / NVT_SMALL_DIV < 8192 ? 8192 : chunk / NVT_SMALL_DIV;
-    return {kP8Bits, 0, kLdsSlotsBig, chunk, small_rows};
-  }
   if (path == 2) return {6, 6, weighted ? kLdsSlots : 4096, (uint64_t)kChunk, (uint64_t)kChunk};
   return {6, 8, kLdsSlots, (uint64_t)kChunk, (uint64_t)kChunk};
 }
@@ -2045,7 +1843,6 @@ struct DenseWs {
   int64_t *tmp_cnt;    // [n]
   unsigned *blk_cnt;   // [t3 max]
   unsigned long long *blk_off, *blk_lo;
-  unsigned *p8_status;  // path 8: [tiles][1024] look-back words + ticket
   // hot filter (path | NVT_PATH_HOT)
   int32_t *hot_image;   // [kHotSlots] 2-choice table image of the hot keys
   unsigned *hot_cnt;    // [kHotBlocks][kHotSlots] per-workgroup counters
@@ -2054,7 +1851,7 @@ struct DenseWs {
 
 // path argument -> stage-1 key-class bits (-1: a partitioned path)
 inline int split_bits_of(int path) {
-  return (path == 0 || path == 6) ? 0 : path == 7 ? 1 : path == 4 ? 2 : path == 5 ? 3 : -1;
+  return (path == 0 || path == 6) ? 0 : path == 7 ? 1 : -1;
 }
 inline int stage_slots(int key_bytes, int weighted) {
   return (weighted || key_bytes == 8) ? kLdsSlots : kLdsSlotsBig;
@@ -2109,8 +1906,6 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
     w.blk_cnt = (unsigned *)take(t3max * 4);
     w.blk_off = (unsigned long long *)take(t3max * 8);
     w.blk_lo = (unsigned long long *)take(t3max * 8);
-    if (path == 8)
-      w.p8_status = (unsigned *)take(((n + kP8Tile - 1) / kP8Tile * kP8Buckets + 16) * 4);
     if (hot) {
       w.hot_image = (int32_t *)take(kHotSlots * 4);
       w.hot_cnt = (unsigned *)take((uint64_t)kHotBlocks * kHotSlots * 4);
@@ -2129,13 +1924,11 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
   const int path_arg = path;
   const bool hot = (path & NVT_PATH_HOT) != 0;
   path &= ~NVT_PATH_HOT;
-  NVT_CHECK_ARG(path >= 0 && path <= 8,
-                "path must be 0 / 7 / 4 / 5 / 6 (LDS tables: 1 / 2 / 4 / 8 key classes / tiny) or "
-                "1 / 2 / 3 / 8 (partitioned)");
+  NVT_CHECK_ARG(path == 0 || path == 6 || path == 7 || (path >= 1 && path <= 3),
+                "path must be 0 / 6 / 7 (LDS tables: one key class / tiny / two key classes) or "
+                "1 / 2 / 3 (partitioned)");
   NVT_CHECK_ARG(!hot || (path >= 1 && path <= 3 && sizeof(K) == 4 && weights == nullptr),
                 "the hot filter takes int32 keys without weights on paths 1 / 2 / 3");
-  NVT_CHECK_ARG(path != 8 || (sizeof(K) == 4 && weights == nullptr),
-                "path 8 takes int32 keys without weights");
   NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
   NVT_CHECK_ARG(n == 0 || (keys && out_keys && out_cnt), "null keys/out");
   NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 rows per call (32-bit LDS counters)");
@@ -2181,26 +1974,6 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
     const K *fine_keys = nullptr;
     const int64_t *fine_w = nullptr;
     const unsigned t3 = (unsigned)max_units_of(cfg, n, 1 << bits);  // upper bound on P3 units
-    if (path == 8) {
-      if constexpr (sizeof(K) == 4) {
-        const unsigned tiles = (unsigned)((n + kP8Tile - 1) / kP8Tile);
-        NVT_CHECK_HIP(hipMemsetAsync(w.p8_status, 0, ((uint64_t)tiles * kP8Buckets + 16) * 4, s));
-        part_hist1k_kernel<<<kHistBlocks, 1024, 0, s>>>(keys, valid, n, w.block_hist, state);
-        NVT_CHECK_LAUNCH();
-        part_reduce_kernel<<<kP8Buckets / 64, 64 * kReduceGroups, 0, s>>>(w.block_hist, kHistBlocks,
-                                                                         kP8Buckets, w.totals);
-        NVT_CHECK_LAUNCH();
-        part_scan_kernel<<<1, 1024, 0, s>>>(w.totals, kP8Bits, 0, w.fine_start, w.fine_cursor,
-                                            w.coarse_cursor, w.tile_start, w.chunk_start,
-                                            w.pchunk_start, chunk_rows, cfg.small_rows);
-        NVT_CHECK_LAUNCH();
-        part_scatter1k_kernel<<<tiles, kP8BS, 0, s>>>(keys, valid, n, w.fine_start, w.p8_status,
-                                                      w.p8_status + (uint64_t)tiles * kP8Buckets,
-                                                      (int32_t *)w.bufA);
-        NVT_CHECK_LAUNCH();
-        fine_keys = (const K *)w.bufA;
-      }
-    } else {
     int hist_blocks = kHistBlocks;
     if (hot) {
       if constexpr (sizeof(K) == 4) {
@@ -2271,7 +2044,6 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
         fine_keys = (const K *)w.bufB;
       }
     }
-    }  // paths 1 / 2 / 3
 #define NVT_P3P4(WEIGHTED, C, SLOTS, BS)                                                          \
   do {                                                                                            \
     part_count_kernel<K, WEIGHTED, SLOTS, BS><<<t3, BS, 0, s>>>(                                  \
@@ -2320,7 +2092,7 @@ extern "C" {
 
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
-  NVT_CHECK_ARG((path & ~NVT_PATH_HOT) >= 0 && (path & ~NVT_PATH_HOT) <= 8, "path must be 0..8");
+  NVT_CHECK_ARG((path & ~NVT_PATH_HOT) >= 0 && (path & ~NVT_PATH_HOT) <= 7, "path must be 0..7");
   NVT_CHECK_ARG(!(path & NVT_PATH_HOT) || ((path & ~NVT_PATH_HOT) >= 1 && (path & ~NVT_PATH_HOT) <= 3 &&
                                           key_bytes == 4 && !weighted),
                 "the hot filter takes int32 keys without weights on paths 1 / 2 / 3");

@@ -330,21 +330,9 @@ PATH_S_MAX_DISTINCT = 11000         # path 0 (int32 keys, unweighted): 16384-slo
 PATH_S_MAX_WEIGHTED = 5000          # path 0 for weighted merges / int64 keys: 8192 slots
 # Path 7 = path 0 with 2 key classes per row slab (column read twice): 350 us against 420 us on
 # path 1 for 12-21 k distinct keys.
-# Paths 4 / 5 (path 0 with 4 / 8 key classes per row slab: the column is read 4x / 8x, each
-# LDS table holds a quarter / an eighth of the vocabulary) are exposed by the C ABI and covered
-# by the parity tests, but measured no faster than path 1 on MI355X (490 vs 530 us per 45 M-row
-# column at 13-39 k distinct keys, with 4x the HBM reads), so the driver never picks them.
 # escalation order when a path's LDS tables overflow (C-ABI path ids, include/nvt_hip.h)
 PATH_ORDER = [6, 0, 7, 1, 2, 3]
-PATH_ORDER_I32 = [6, 0, 7, 8, 3]   # int32 keys, unweighted: path 8 replaces paths 1 and 2
-PATH_P8_MAX_DISTINCT = 9_000_000   # 1024 buckets x 16384-slot tables (<= ~11 k keys each)
-# Measured on MI355X (profiles/r02_notes.md): path 8's histogram is faster (40 vs 70 us) and it
-# saves path 2's second scatter, but its 1024-way scatter runs at 200 us (64-byte runs, look-back)
-# against 100 us for the 256-way one and the 1024 small buckets amortise the per-workgroup table
-# set-up / flush worse (count 165-240 vs 140-190 us): 557 us per column against 450 (path 1) /
-# 540 (path 2).  Kept in the ABI and the parity tests, off by default.
-USE_P8 = os.environ.get("NVT_P8", "0") == "1"
-_S_CLASSES = {6: 1, 0: 1, 7: 2, 4: 4, 5: 8}
+_S_CLASSES = {6: 1, 0: 1, 7: 2}
 PATH_S2_FACTOR = 1.95               # path 7: path 0 with 2 key classes per row slab (column read twice)
 PATH_TINY_MAX = 64                  # path 6: path 0 with hot keys replicated per lane group
 PATH_P1_MAX_DISTINCT = int(os.environ.get("NVT_P1_MAX", 2_400_000))    # path 1: ONE level, 256 buckets x 16384-slot tables (int32)
@@ -366,7 +354,7 @@ _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 COUNT_STREAMS = max(1, min(3, int(os.environ.get("NVT_COUNT_STREAMS", "3"))))
 PATH_HOT, HOT_IMAGE_WORDS = 16, 8192   # include/nvt_hip.h NVT_PATH_HOT, NVT_HOT_IMAGE_WORDS
 HOT_FILTER = os.environ.get("NVT_HOT_FILTER", "1") != "0"
-_PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 4: 3.0, 5: 5.0, 1: 2.5, 8: 2.5, 2: 3.2, 3: 3.5}
+_PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 1: 2.5, 2: 3.2, 3: 3.5}
 
 
 def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
@@ -388,8 +376,6 @@ def _path_for(hint: int, small_tables: bool = False) -> int:
         return 0
     if hint <= PATH_S2_FACTOR * s_max and (small_tables or not HOT_FILTER):
         return 7  # (with the hot-key filter path 1 is faster there: 241 against 307 us)
-    if USE_P8 and not small_tables and hint <= PATH_P8_MAX_DISTINCT:
-        return 8
     if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
         return 1
     if hint <= PATH_P2_MAX_DISTINCT:
@@ -470,9 +456,8 @@ class DenseCountJob:
         """Inspect the state words read back for this job; False = relaunch needed."""
         ovf = st[_lib.ST_OVERFLOW]
         if ovf & 1:
-            # forced paths 4 / 5 (tests, probes) escalate to the partitioned path 1
-            order = PATH_ORDER_I32 if (USE_P8 and self.kb == 4 and self.weights is None) else PATH_ORDER
-            nxt = order.index(self.path) + 1 if self.path in order else order.index(3 if self.path == 8 else 1)
+            order = PATH_ORDER
+            nxt = order.index(self.path) + 1
             if nxt >= len(order):
                 self._fallback()
                 return True
@@ -514,8 +499,7 @@ class DenseCountJob:
 SAMPLE_ROWS = 1 << 18               # cold start: distinct keys of this many leading rows ...
 SAMPLE_MIN_ROWS = 8 * SAMPLE_ROWS   # ... when the column is at least this long
 # distinct keys each path is sized for (output-capacity guess when a path is entered by escalation)
-_PATH_MAX = {6: 1024, 0: 98304, 7: 196608, 4: 393216, 5: 786432, 1: PATH_P1_MAX_DISTINCT,
-             8: PATH_P8_MAX_DISTINCT,
+_PATH_MAX = {6: 1024, 0: 98304, 7: 196608, 1: PATH_P1_MAX_DISTINCT,
              2: PATH_P2_MAX_DISTINCT, 3: PATH_P3_MAX_DISTINCT}
 
 
@@ -733,6 +717,7 @@ class EncodeTable:
         resident = ENCODE_RESIDENT_I32 if self.key_bytes == 4 else ENCODE_RESIDENT_I64
         self.table = self.sentinel_label = None
         self.sort_tmp = None
+        self._counts = None    # the counts tensor while an internal stream still orders it
         self.ready = None      # Event recorded behind the sort / build on an internal stream
         self.pending = False   # True until the current stream has been made to wait for it
         if unique and 0 < self.n_vocab <= resident:
@@ -759,6 +744,10 @@ class EncodeTable:
     def fill_vocab_desc(self, d: "_lib.VocabCol", counts: torch.Tensor, max_count: int):
         """One nvt_vocab_col: order (self vocab keys, counts) in place, then build the table."""
         n = self.n_vocab
+        # the counts are ordered in place on the same internal stream as the keys: they must
+        # outlive the hand-off event exactly like keys / table / sort_tmp (a rank that writes
+        # no artifacts used to drop its only reference right after the launch)
+        self._counts = counts
         d.keys = self._vk.data_ptr()
         d.counts = counts.data_ptr()
         d.n = n
@@ -799,6 +788,7 @@ class EncodeTable:
             self.ready.wait()
             self.pending = False
             self.sort_tmp = None  # scratch of the finished sort: safe to recycle from here on
+            self._counts = None
 
     def __del__(self):
         try:
@@ -828,6 +818,7 @@ class EncodeTable:
             d.wait_event = self.ready.handle  # nvt_encode_many waits on the launch stream
             self.pending = False
             self.sort_tmp = None
+            self._counts = None
         else:
             d.wait_event = None
 

@@ -308,7 +308,11 @@ class Categorify(StatOperator):
         # ranks that share an output directory (the default './') elect ONE writer: they all
         # hold the same merged vocabularies and used to race remove-then-write on the same files
         # (a host collective: done once per output directory, every rank takes the same branch)
-        key = os.path.abspath(str(base))
+        # (keyed by host too: on a multi-node run with node-local output directories every node
+        # needs its own copy of the artifacts)
+        import socket
+
+        key = (socket.gethostname(), os.path.abspath(str(base)))
         if key not in self._writer_cache:
             self._writer_cache[key] = dist.is_first_rank_with(key)
         self._is_writer = self._writer_cache[key]
@@ -330,11 +334,17 @@ class Categorify(StatOperator):
                     mx = 0
                 else:
                     k, c, mx = g.table
-                tabs.append((k, c, [int(g.nulls), int(g.valid_rows), int(mx)]))
+                # has-strings travels with the summed scalars: whether a group needs the
+                # collective string-LUT merge must be the SAME decision on every rank (a rank
+                # whose shard was empty has no strings of its own and used to take the
+                # non-collective fast path while the others waited in all_gather_object)
+                has_str = int(any(c_ in g.strings for c_ in g.cols))
+                tabs.append((k, c, [int(g.nulls), int(g.valid_rows), int(mx), has_str]))
             if tabs:
                 for g, (k, c, sc) in zip(singles, dist.merge_counts_many(tabs)):
                     g.table = (k, c, sc[2])  # the sum of the per-rank maxima bounds the max count
                     g.nulls, g.valid_rows = sc[0], sc[1]
+                    g.any_rank_strings = sc[3] > 0
                     g.merged = True
         opts = {}
         for g in groups:
@@ -384,7 +394,7 @@ class Categorify(StatOperator):
         _, max_emb, freq = opt
         if g.combo or g.table is None or max_emb or freq or self.tie_break == "reference":
             return False
-        if any(c in g.strings for c in g.cols):
+        if any(c in g.strings for c in g.cols) or getattr(g, "any_rank_strings", False):
             return False
         if dist.world_size() > 1 and not getattr(g, "merged", False):
             return False
@@ -423,6 +433,8 @@ class Categorify(StatOperator):
                 self._pending[g.name] = final
             elif self._is_writer:
                 _write_artifacts(final)
+            else:
+                tab.wait_ready()  # `final` (and the counts it holds) dies here: order the stream first
 
     # -- vocabulary finalisation ------------------------------------------------
     def _finalize_single(self, g: _GroupFit, dist):
@@ -569,8 +581,13 @@ class Categorify(StatOperator):
         # fit_end writes, everybody drops the device copies
         self._ensure_finalized()
         for final in self._pending.values():
-            if getattr(self, "_is_writer", True):
-                _write_artifacts(final)
+            path = "/".join([final["base"], f"unique.{final['name']}.parquet"])
+            if getattr(self, "_is_writer", True) or not os.path.exists(path):
+                _write_artifacts(final)  # (a non-writer whose writer never flushed writes itself)
+            elif final.get("table") is not None:
+                # dropping the device copies: their buffers go back to the allocator on THIS
+                # stream, which must first be ordered behind the internal stream that sorts them
+                final["table"].wait_ready()
         self._pending = {}
 
     def fit_finalize(self, categories):

@@ -63,6 +63,9 @@ class LambdaOp(Operator):
                 self.last_path = "device"
                 return out
             except HostFallback:
+                # the UDF is re-run from scratch on pandas: columns already evaluated on the
+                # device are evaluated again, so a UDF with side effects sees them twice
+                # (the reference calls a UDF once per column; pure functions cannot tell)
                 host, was_pandas = frame.to_pandas(), False
         new = pd.DataFrame(index=host.index)
         for col in col_selector.names:

@@ -115,8 +115,27 @@ class DeviceSeries:
     def __rtruediv__(self, o):
         return self._bin(o, lambda a, b: torch.div(torch.as_tensor(self._f64(a), device=b.device), self._f64(b)), True)
 
-    def __floordiv__(self, o): return self._bin(o, lambda a, b: torch.div(a, b, rounding_mode="floor"))
-    def __mod__(self, o): return self._bin(o, torch.remainder)
+    def _int_divisor_guard(self, o):
+        """pandas turns integer // 0 and integer % 0 into inf / NaN (float64); integer division
+        by zero on the device is undefined.  A zero scalar, or a whole integer column as the
+        divisor (it may hold zeros; checking would be a host synchronisation), goes to the
+        host path."""
+        b = self._raw(o)
+        if self._t.is_floating_point():
+            return
+        if isinstance(b, torch.Tensor):
+            if not b.is_floating_point():
+                raise HostFallback("integer // or % by an integer column")
+        elif not isinstance(b, float) and b == 0:
+            raise HostFallback("integer // or % by zero")
+
+    def __floordiv__(self, o):
+        self._int_divisor_guard(o)
+        return self._bin(o, lambda a, b: torch.div(a, b, rounding_mode="floor"))
+
+    def __mod__(self, o):
+        self._int_divisor_guard(o)
+        return self._bin(o, torch.remainder)
     def __pow__(self, o): return self._bin(o, torch.pow)
     def __neg__(self): return self._wrap(-self._t)
     def __abs__(self): return self._wrap(self._t.abs())

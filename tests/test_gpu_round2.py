@@ -107,9 +107,10 @@ def test_normalize_minmax_vs_oracle_incl_constant_column():
         "v": rng.integers(-50, 50, n).astype("int32"),
         "const": np.full(n, 7.0),          # max == min -> x / (2x) = 0.5 (normalize.py:155-160)
         "zero": np.zeros(n),               # max == min == 0 -> 0 / 0 = NaN
+        "w": rng.normal(0, 3, n).astype("float32"),   # float32 stays float32 in pandas
     })
     df.loc[rng.random(n) < 0.1, "u"] = np.nan
-    cols = ["u", "v", "const", "zero"]
+    cols = ["u", "v", "const", "zero", "w"]
     parts = [df.iloc[: n // 2].reset_index(drop=True), df.iloc[n // 2:].reset_index(drop=True)]
     op = ops.NormalizeMinMax()
     wf = nvt.Workflow(cols >> op)
@@ -121,6 +122,8 @@ def test_normalize_minmax_vs_oracle_incl_constant_column():
     exp = O.minmax_transform(df, cols, mins, maxs)
     for c in cols:
         np.testing.assert_allclose(out[c].to_numpy(), exp[c].to_numpy(), rtol=1e-12, atol=0, equal_nan=True)
+    # float32 input: (x - min) / dif is two float32 operations in pandas and in the kernel
+    np.testing.assert_array_equal(out["w"].to_numpy(), exp["w"].to_numpy())
 
 
 def test_tie_break_reference_equals_literal_pandas_order(tmp_path):

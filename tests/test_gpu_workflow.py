@@ -75,8 +75,9 @@ def test_parquet_dataset_fit_transform_vs_oracle(tmp_path):
     ofull = O.fill_missing(odf[["I1", "I2"]].copy(), ["I1", "I2"], 0)
     ref = O.normalize_transform(ofull, ["I1", "I2"], mom["mean"].to_dict(), mom["std"].to_dict())
     np.testing.assert_allclose(got["I1"].to_numpy(), ref["I1"].to_numpy(), rtol=1e-6, atol=1e-9)
-    # float32 input: the reference subtracts in float32 (pandas), the kernel in fp64
-    np.testing.assert_allclose(got["I2"].to_numpy(), ref["I2"].to_numpy(), rtol=1e-4, atol=1e-5)
+    # float32 input: pandas subtracts and divides in float32 (normalize.py:79-84), and so does
+    # the kernel -- the same two correctly rounded operations, bit for bit
+    np.testing.assert_array_equal(got["I2"].to_numpy(), ref["I2"].to_numpy())
     np.testing.assert_array_equal(got["label"].to_numpy(), df["label"].to_numpy())
     # schema: test_categorify.py:532-540 / categorify.py:564-577
     props = wf.output_schema["C2"].properties
@@ -150,6 +151,61 @@ def test_user_vocabs_and_single_table(tmp_path):
     for name in ["Authors", "Engaging_User"]:
         assert old_max <= new[name].min()
         old_max += new[name].max()
+
+
+def test_vocabs_dict_of_paths_reuses_fitted_files(tmp_path):
+    """categorify.py:441-446: `vocabs={col: "path/to/unique.col.parquet"}` -- the files of an
+    earlier fit are taken as they are (no fit for those columns), labels equal the fit's."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    df = _criteo_like(20_000, seed=7)
+    wf1 = nvt.Workflow(["C1", "C2"] >> ops.Categorify(out_path=str(tmp_path / "first")))
+    exp = wf1.fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    paths = {c: str(tmp_path / "first" / "categories" / f"unique.{c}.parquet") for c in ("C1", "C2")}
+    assert all(os.path.exists(p) for p in paths.values())
+    op = ops.Categorify(out_path=str(tmp_path / "second"), vocabs=paths)
+    assert op.categories == paths
+    wf2 = nvt.Workflow(["C1", "C2"] >> op)
+    got = wf2.fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    for c in ("C1", "C2"):
+        np.testing.assert_array_equal(got[c].to_numpy(), exp[c].to_numpy())
+    # nothing was fitted or rewritten for the supplied columns
+    assert not os.path.exists(tmp_path / "second" / "categories" / "unique.C1.parquet")
+    # a vocabulary for one column only: the other one is fitted as usual
+    op3 = ops.Categorify(out_path=str(tmp_path / "third"), vocabs={"C1": paths["C1"]})
+    got3 = nvt.Workflow(["C1", "C2"] >> op3).fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    for c in ("C1", "C2"):
+        np.testing.assert_array_equal(got3[c].to_numpy(), exp[c].to_numpy())
+    with pytest.raises(ValueError, match="Unrecognized vocab type"):
+        ops.Categorify(vocabs={"C1": 3})
+
+
+@pytest.mark.parametrize("max_size", [0, 6])
+@pytest.mark.parametrize("buckets", [None, 3])
+def test_placement_knobs_do_not_change_the_result(tmp_path, max_size, buckets):
+    """test_categorify.py:668-704 (split_out) and categorify.py:152-173: split_out / on_host /
+    cat_cache / search_sorted steer where the reference keeps and how it searches the
+    categories; labels and the unique.*.parquet contents must not depend on them."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    df = pd.DataFrame({"user_id": np.array([1, 2, 3, 4, 6, 8, 5, 3] * 10, dtype="int64")})
+    kw = dict(max_size=max_size, num_buckets=buckets)
+    wf1 = nvt.Workflow(["user_id"] >> ops.Categorify(out_path=str(tmp_path / "a"), split_out=1, **kw))
+    r1 = wf1.fit_transform(nvt.Dataset(df)).to_ddf().compute()
+    wfn = nvt.Workflow(["user_id"] >> ops.Categorify(
+        out_path=str(tmp_path / "b"), split_out=2, split_every=4, on_host=False,
+        cat_cache="device", search_sorted=True, **kw))
+    rn = wfn.fit_transform(nvt.Dataset(df, npartitions=3)).to_ddf().compute()
+    np.testing.assert_array_equal(rn["user_id"].to_numpy(), r1["user_id"].to_numpy())
+    c1 = pd.read_parquet(tmp_path / "a" / "categories" / "unique.user_id.parquet")
+    cn = pd.read_parquet(tmp_path / "b" / "categories" / "unique.user_id.parquet")
+    pd.testing.assert_frame_equal(c1, cn)
+    with pytest.warns(FutureWarning):
+        ops.Categorify(tree_width=8)
+    with pytest.raises(ValueError):
+        ops.Categorify(search_sorted=True, freq_threshold=2)
 
 
 def test_save_load_roundtrip_and_eager_artifacts(tmp_path):

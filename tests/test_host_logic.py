@@ -46,14 +46,10 @@ def test_path_selection_thresholds():
     assert K._path_for(3) == 6 and K._path_for(64) == 6
     assert K._path_for(65) == 0 and K._path_for(K.PATH_S_MAX_DISTINCT) == 0
     # 11-21 k int32 keys: two key classes (path 7) only without the hot-key filter
-    assert K._path_for(K.PATH_S_MAX_DISTINCT + 1) == (1 if K.HOT_FILTER and not K.USE_P8 else 7 if not K.HOT_FILTER else 8)
-    if K.USE_P8:  # opt-in: ONE 1024-bucket level (path 8) for int32 keys without weights
-        assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_DISTINCT) + 1) == 8
-        assert K._path_for(K.PATH_P8_MAX_DISTINCT) == 8 and K._path_for(K.PATH_P8_MAX_DISTINCT + 1) == 3
-    else:
-        assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_DISTINCT) + 1) == 1
-        assert K._path_for(K.PATH_P1_MAX_DISTINCT + 1) == 2
-        assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1) == 3
+    assert K._path_for(K.PATH_S_MAX_DISTINCT + 1) == (1 if K.HOT_FILTER else 7)
+    assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_DISTINCT) + 1) == 1
+    assert K._path_for(K.PATH_P1_MAX_DISTINCT + 1) == 2
+    assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1) == 3
     assert K._path_for(K.PATH_P3_MAX_DISTINCT + 1) == -1   # global-table fallback
     # int64 keys / weighted merges use the smaller tables
     assert K._path_for(K.PATH_S_MAX_WEIGHTED + 1, small_tables=True) == 7
@@ -62,7 +58,6 @@ def test_path_selection_thresholds():
     assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1, small_tables=True) == 3
     # escalation order covers every automatic path exactly once
     assert sorted(K.PATH_ORDER) == [0, 1, 2, 3, 6, 7] and set(K._PATH_MAX) >= set(K.PATH_ORDER)
-    assert sorted(K.PATH_ORDER_I32) == [0, 3, 6, 7, 8] and set(K._PATH_MAX) >= set(K.PATH_ORDER_I32)
 
 
 def test_shuffle_option_coercion():
