@@ -68,6 +68,7 @@ extern "C" {
 #define NVT_ST_ROWS 4      /* rows consumed (nulls included)                 */
 /* words 5..7: scratch cursors of nvt_dense_count_*                                  */
 #define NVT_ST_MAXCOUNT 8  /* nvt_dense_count_*: largest count in the output list    */
+#define NVT_ST_BIG 9       /* range path: entries whose count is >= 255            */
 #define NVT_STATE_WORDS 16
 
 int nvt_version(void);
@@ -114,6 +115,18 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
  *      keys (picked from a sample of the column) in LDS and switches them off for the
  *      scatter / count stages, which then handle only the remaining rows (60-95 % fewer on
  *      power-law columns).  Exact for any hot set.
+ *   NVT_PATH_RANGE | (log2(buckets) << 8)  (int32 keys, no weights, 64 .. 1024 buckets of
+ *      <= ~6000 distinct keys each): ONE pass partitions the rows that the hot-key filter does
+ *      not absorb by KEY RANGE through per-workgroup write-combining bins in LDS (64-byte lines
+ *      into a private region per (bucket, workgroup): no histogram pre-pass, no cursors); one
+ *      workgroup per bucket then counts its rows in an LDS table addressed by a monotone
+ *      function of the key and emits it in key order.  The output list is SORTED BY KEY
+ *      (sentinel key first), and hot_image[NVT_RANGE_AUX_HIST + c] receives the number of
+ *      entries with min(count, 255) == c -- what nvt_vocab_finalize_many needs to order the
+ *      vocabulary by (count desc, key asc) in ONE stable counting pass (nvt_vocab_col.src_keys).
+ *      hot_image must then be the column's own int32[NVT_RANGE_AUX_WORDS].  Ranges are derived
+ *      from the sampled min / max: keys that are not spread over their range overflow a region
+ *      or a table (overflow bit0) and the column is rerun on a hash path.
  * weights (optional, int64 per row) turns the count into a weighted sum -- the tree-merge
  * of (key,count) lists (_mid_level_groupby).  ws: device scratch of
  * nvt_dense_count_ws_bytes().  state (device uint64[NVT_STATE_WORDS], written):
@@ -123,6 +136,14 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
  * bit1: out_capacity too small.  The output list is in no particular order. */
 #define NVT_PATH_HOT 16
 #define NVT_HOT_IMAGE_WORDS 8192
+#define NVT_PATH_RANGE 9
+#define NVT_RANGE_WGS 256           /* partition workgroups = runs per bucket                 */
+#define NVT_RANGE_AUX_LO 8192       /* aux words behind the hot image: range origin (biased),
+                                       span, multiplier (2 words), shift of the monotone map   */
+#define NVT_RANGE_AUX_HIST 8208     /*   uint32[256] histogram of min(count, 255)             */
+#define NVT_RANGE_AUX_HOTSTART 8464 /*   uint32[1025]: hot image slots by bucket (CSR offsets) */
+#define NVT_RANGE_AUX_HOTORDER 9504 /*   uint16[8192]: the image slots in bucket order         */
+#define NVT_RANGE_AUX_WORDS (9504 + 4096)
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes);
 int nvt_dense_count_i32(const int32_t *keys, const uint8_t *valid, const int64_t *weights,
                         uint64_t n, int path, void *ws, int32_t *out_keys, int64_t *out_counts,
@@ -360,7 +381,15 @@ typedef struct nvt_count_col {
                                own (workspaces may be shared): the hot-key samples of all columns
                                are then taken by ONE launch ahead of the pipelines.  NULL: sampled
                                inside the column's pipeline, image kept in ws                 */
+  void *range_table;        /* NVT_PATH_RANGE, optional: nvt_range_table_bytes(buckets) bytes.  The
+                               per-bucket count tables are written out as they are: an encode table
+                               addressed by the same monotone map, slot = {key, position in the
+                               key-ordered output list}.  nvt_vocab_finalize_many turns the positions
+                               into labels (nvt_vocab_col.range_table), nvt_encode_many probes it
+                               (nvt_encode_col.range_aux).                                        */
 } nvt_count_col;
+/* bytes of the range table of a column counted with 2^nb_log2 buckets */
+int nvt_range_table_bytes(int nb_log2, uint64_t *bytes);
 int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream);
 
 /* one vocabulary of Categorify.fit_end: sort (count desc, key asc) in place, then build its
@@ -383,7 +412,23 @@ typedef struct nvt_vocab_col {
                              * kernel INSTEAD of joining its stream into `stream`; whoever
                              * reads the vocabulary / table next waits on it
                              * (nvt_encode_col.wait_event, nvt_stream_wait_event)        */
+  /* KEY-SORTED source list (range path of nvt_dense_count_many; int32 keys): when src_keys is
+   * set, (keys, counts) are OUTPUT arrays of n entries -- the list is ordered out of place by
+   * ONE stable counting pass on min(count, 255), the n_big entries with count >= 255 are sorted
+   * on their own, and the encode table is filled by the same pass.  sort_tmp then needs
+   * nvt_vocab_order_tmp_bytes(n, n_big) bytes. */
+  const void *src_keys;
+  const int64_t *src_counts;
+  const uint32_t *cls_hist;  /* device uint32[256]: entries per min(count, 255)           */
+  uint64_t n_big;            /* entries with count >= 255 (state[NVT_ST_BIG])             */
+  /* with a key-sorted source: `table` is the RANGE TABLE the counting pass dumped
+   * (nvt_count_col.range_table; slots {key, position in the source list}): its positions are
+   * replaced by labels in one streaming pass -- no clear, no random inserts.  range_aux = the
+   * column's aux block (nvt_count_col.hot_image) that holds the map parameters. */
+  const int32_t *range_aux;
+  int32_t range_nb_log2;
 } nvt_vocab_col;
+int nvt_vocab_order_tmp_bytes(uint64_t n, uint64_t n_big, uint64_t *bytes);
 int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, void *stream);
 
 /* one column of Categorify.transform; fields as the arguments of nvt_encode_* */
@@ -402,6 +447,8 @@ typedef struct nvt_encode_col {
   uint64_t n_vocab;
   int64_t first_label;
   void *wait_event;         /* optional nvt_event the launch waits for (stream-side)     */
+  const int32_t *range_aux; /* `table` is a range table (nvt_count_col.range_table): probed by
+                               the monotone map whose parameters sit in this aux block      */
 } nvt_encode_col;
 int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream);
 

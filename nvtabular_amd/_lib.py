@@ -14,13 +14,15 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnvt_hip.so")
+# NVT_HIP_LIB: an alternative build of the same library (A / B measurements of kernel variants)
+LIB_PATH = os.environ.get("NVT_HIP_LIB") or os.path.join(_HERE, "libnvt_hip.so")
 
 # dtype codes (include/nvt_hip.h)
 NVT_F32, NVT_F64, NVT_I32, NVT_I64, NVT_U8 = 0, 1, 2, 3, 4
 NVT_GB_SUMSQ, NVT_GB_MINMAX = 1, 2
 ST_NULLS, ST_SENTINEL, ST_OCCUPIED, ST_OVERFLOW, ST_ROWS = 0, 1, 2, 3, 4
 ST_MAXCOUNT = 8
+ST_BIG = 9
 STATE_WORDS = 16
 
 _vp, _u64, _i64, _i32, _u32, _dbl = (
@@ -46,9 +48,11 @@ SIGNATURES = {
     "nvt_count_compact_i32": [_vp, _u64, _vp, _vp, _vp, _vp],
     "nvt_count_compact_i64": [_vp, _u64, _vp, _vp, _vp, _vp],
     "nvt_dense_count_ws_bytes": [_i32, _u64, _i32, _i32, C.POINTER(_u64)],
+    "nvt_range_table_bytes": [_i32, C.POINTER(_u64)],
     "nvt_dense_count_i32": [_vp, _vp, _vp, _u64, _i32, _vp, _vp, _vp, _u64, _vp, _vp],
     "nvt_dense_count_i64": [_vp, _vp, _vp, _u64, _i32, _vp, _vp, _vp, _u64, _vp, _vp],
     "nvt_vocab_sort_tmp_bytes": [_i32, _u64, C.POINTER(_u64)],
+    "nvt_vocab_order_tmp_bytes": [_u64, _u64, C.POINTER(_u64)],
     "nvt_vocab_sort_i32": [_vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_vocab_sort_i64": [_vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_encode_table_bytes": [_i32, _u64, C.POINTER(_u64)],
@@ -107,14 +111,17 @@ class FillNormCol(C.Structure):
 class CountCol(C.Structure):
     _fields_ = [("keys", _vp), ("valid", _vp), ("weights", _vp), ("n", _u64),
                 ("key_bytes", C.c_int32), ("path", C.c_int32), ("ws", _vp), ("out_keys", _vp),
-                ("out_counts", _vp), ("out_capacity", _u64), ("state", _vp), ("hot_image", _vp)]
+                ("out_counts", _vp), ("out_capacity", _u64), ("state", _vp), ("hot_image", _vp),
+                ("range_table", _vp)]
 
 
 class VocabCol(C.Structure):
     _fields_ = [("keys", _vp), ("counts", _vp), ("n", _u64), ("max_count", _i64),
                 ("key_bytes", C.c_int32), ("unique_keys", C.c_int32), ("sort_tmp", _vp),
                 ("first_label", _i64), ("table", _vp), ("capacity", _u64),
-                ("sentinel_label", _vp), ("ready_event", _vp)]
+                ("sentinel_label", _vp), ("ready_event", _vp), ("src_keys", _vp),
+                ("src_counts", _vp), ("cls_hist", _vp), ("n_big", _u64), ("range_aux", _vp),
+                ("range_nb_log2", C.c_int32)]
 
 
 class EncodeCol(C.Structure):
@@ -122,7 +129,7 @@ class EncodeCol(C.Structure):
                 ("sentinel_label", _vp), ("null_label", _i64), ("oov_label", _i64),
                 ("num_buckets", _u32), ("key_bytes", C.c_int32), ("out_bytes", C.c_int32),
                 ("out", _vp), ("vocab_keys", _vp), ("n_vocab", _u64), ("first_label", _i64),
-                ("wait_event", _vp)]
+                ("wait_event", _vp), ("range_aux", _vp)]
 
 
 SIGNATURES.update({

@@ -36,6 +36,7 @@
 #include "nvt_common.hpp"
 #include "nvt_internal.hpp"
 #include "nvt_prof.hpp"
+#include "nvt_range.hpp"
 #include "nvt_scan.hpp"
 
 #ifndef NVT_STAGE_U
@@ -837,6 +838,7 @@ struct HotSampleCol {
   const uint8_t *valid;
   uint64_t n;
   int32_t *image;
+  int nb_log2;  // > 0: also derive the key ranges of the range path (image[NVT_RANGE_AUX_*])
 };
 constexpr int kHotBatch = 32;
 struct HotSampleBatch {
@@ -852,10 +854,16 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
   int32_t *image = batch.c[blockIdx.x].image;
   __shared__ int32_t tk[kHotSlots];
   __shared__ unsigned seen[2048];  // 64 K-bit "seen once" filter
-  __shared__ unsigned s_hits, s_rows;
+  __shared__ unsigned s_hits, s_rows, s_umin, s_umax;
+  __shared__ uint64_t s_map[4];
   for (int i = threadIdx.x; i < kHotSlots; i += 1024) tk[i] = EMPTY;
   for (int i = threadIdx.x; i < 2048; i += 1024) seen[i] = 0;
-  if (threadIdx.x == 0) s_hits = s_rows = 0;
+  if (threadIdx.x == 0) {
+    s_hits = s_rows = 0;
+    s_umin = 0xFFFFFFFFu;
+    s_umax = 0u;
+  }
+  unsigned umin = 0xFFFFFFFFu, umax = 0u;  // order-preserving unsigned images of the sampled keys
   __syncthreads();
   const uint64_t nblk = (n + 1023) / 1024;
   const unsigned S = (unsigned)(nblk < (uint64_t)kHotSampleBlocks ? nblk : kHotSampleBlocks);
@@ -927,6 +935,9 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
         if (!found) insert(key, h);
         hits += found;
         rows += 1;
+        const unsigned u = (unsigned)key ^ 0x80000000u;
+        umin = u < umin ? u : umin;
+        umax = u > umax ? u : umax;
       }
     }
   }
@@ -935,13 +946,101 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
     hits += __shfl_down(hits, off, 64);
     rows += __shfl_down(rows, off, 64);
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned a = __shfl_down(umin, off, 64), b = __shfl_down(umax, off, 64);
+    umin = a < umin ? a : umin;
+    umax = b > umax ? b : umax;
+  }
   if (lane_id() == 0) {
     atomicAdd(&s_hits, hits);
     atomicAdd(&s_rows, rows);
+    atomicMin(&s_umin, umin);
+    atomicMax(&s_umax, umax);
   }
   __syncthreads();
   const bool useful = (uint64_t)s_hits * 8 >= (uint64_t)s_rows && s_rows > 0;
   for (int i = threadIdx.x; i < kHotSlots; i += 1024) image[i] = useful ? tk[i] : EMPTY;
+  const int nb_log2 = batch.c[blockIdx.x].nb_log2;
+  if (nb_log2 > 0 && threadIdx.x == 0) {
+    // range path: fine slot = (min(u - ulo, span) * mul) >> sh over the sampled span padded by
+    // 1/64 on either side (keys outside land in the edge slots: monotone, just unbalanced);
+    // see RangeMap in nvt_range_count.hip
+    uint64_t lo = s_umin, hi = s_umax;
+    if (s_rows == 0) {
+      lo = 0;
+      hi = 0xFFFFFFFFull;
+    }
+    const uint64_t pad = ((hi - lo) >> 6) + 1;
+    lo = lo > pad ? lo - pad : 0;
+    hi = hi + pad < 0xFFFFFFFFull ? hi + pad : 0xFFFFFFFFull;
+    const uint64_t span = hi - lo, F = 1ull << (nb_log2 + 14);
+    uint64_t mul;
+    int sh;
+    if (span + 1 >= F) {
+      mul = (F << 32) / (span + 1);
+      sh = 32;
+    } else {
+      mul = F / (span + 1);
+      sh = 0;
+    }
+    image[NVT_RANGE_AUX_LO] = (int32_t)(uint32_t)lo;
+    image[NVT_RANGE_AUX_LO + 1] = (int32_t)(uint32_t)span;
+    image[NVT_RANGE_AUX_LO + 2] = (int32_t)(uint32_t)mul;
+    image[NVT_RANGE_AUX_LO + 3] = (int32_t)(uint32_t)(mul >> 32);
+    image[NVT_RANGE_AUX_LO + 4] = sh;
+    s_map[0] = lo;
+    s_map[1] = span;
+    s_map[2] = mul;
+    s_map[3] = (uint64_t)sh;
+  }
+  if (nb_log2 > 0) {
+    // the image slots indexed by range bucket (counting sort): the per-bucket count workgroup
+    // of the range path picks up its hot keys without scanning the whole image
+    unsigned *bcnt = seen;  // 2048 words, free again
+    for (int i = threadIdx.x; i < 1025; i += 1024) bcnt[i] = 0;
+    __syncthreads();
+    const uint64_t lo = s_map[0], span = s_map[1], mul = s_map[2];
+    const int sh = (int)s_map[3];
+    unsigned myb[kHotSlots / 1024], myr[kHotSlots / 1024];
+#pragma unroll
+    for (int q = 0; q < kHotSlots / 1024; ++q) {
+      const int i = q * 1024 + threadIdx.x;
+      const int32_t key = useful ? tk[i] : EMPTY;
+      myb[q] = 0xFFFFFFFFu;
+      if (key != EMPTY) {
+        const uint64_t u = (uint32_t)key ^ 0x80000000u;
+        uint64_t d = u > lo ? u - lo : 0;
+        d = d < span ? d : span;
+        myb[q] = (unsigned)(((d * mul) >> sh) >> 14);
+        myr[q] = atomicAdd(&bcnt[myb[q]], 1u);
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bucket counts (one per thread)
+    __shared__ unsigned swt[16];
+    const unsigned v = bcnt[threadIdx.x];
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(inc, off, 64);
+      if (lane_id() >= (unsigned)off) inc += o;
+    }
+    if (lane_id() == 63) swt[threadIdx.x / 64] = inc;
+    __syncthreads();
+    unsigned wb = 0;
+    for (unsigned q = 0; q < threadIdx.x / 64; ++q) wb += swt[q];
+    const unsigned start = wb + inc - v;
+    __syncthreads();
+    bcnt[threadIdx.x] = start;
+    image[NVT_RANGE_AUX_HOTSTART + threadIdx.x] = (int32_t)start;
+    if (threadIdx.x == 1023) image[NVT_RANGE_AUX_HOTSTART + 1024] = (int32_t)(start + v);
+    __syncthreads();
+    unsigned short *order = reinterpret_cast<unsigned short *>(image + NVT_RANGE_AUX_HOTORDER);
+#pragma unroll
+    for (int q = 0; q < kHotSlots / 1024; ++q)
+      if (myb[q] != 0xFFFFFFFFu) order[bcnt[myb[q]] + myr[q]] = (unsigned short)(q * 1024 + threadIdx.x);
+  }
 }
 
 // part_hist_kernel for int32 keys without weights, with the hot-key lookup (see above).
@@ -1919,8 +2018,26 @@ inline uint64_t dense_ws_layout(int key_bytes, uint64_t n, int path, int weighte
 template <typename K>
 int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uint64_t n, int path,
                 void *wsp, K *out_keys, int64_t *out_cnt, uint64_t out_cap, uint64_t *state,
-                hipStream_t s, bool clear_state = true, int32_t *hot_image_ext = nullptr) {
+                hipStream_t s, bool clear_state = true, int32_t *hot_image_ext = nullptr,
+                void *range_table = nullptr) {
   NVT_CHECK_ARG(state && wsp, "null state/workspace");
+  if ((path & 0xFF) == NVT_PATH_RANGE) {
+    if constexpr (sizeof(K) == 4) {
+      NVT_CHECK_ARG(weights == nullptr, "the range path takes int32 keys without weights");
+      NVT_CHECK_ARG(hot_image_ext != nullptr,
+                    "the range path needs the column's aux block (nvt_dense_count_many, hot_image)");
+      NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
+      NVT_CHECK_ARG(n == 0 || (keys && out_keys && out_cnt), "null keys/out");
+      NVT_CHECK_ARG(n < (1ull << 32), "at most 2^32-1 rows per call (32-bit LDS counters)");
+      if (clear_state) NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
+      if (n == 0) return NVT_OK;
+      return range_count_i32((const int32_t *)keys, valid, n, (path >> 8) & 0xFF, wsp, hot_image_ext,
+                             (int32_t *)out_keys, out_cnt, out_cap, range_table, state, s);
+    } else {
+      set_error("dense_count: the range path takes int32 keys");
+      return NVT_EINVAL;
+    }
+  }
   const int path_arg = path;
   const bool hot = (path & NVT_PATH_HOT) != 0;
   path &= ~NVT_PATH_HOT;
@@ -1981,7 +2098,7 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
           w.hot_image = hot_image_ext;  // sampled by nvt_dense_count_many ahead of the pipelines
         } else {
           HotSampleBatch hb;
-          hb.c[0] = {(const int32_t *)keys, valid, n, w.hot_image};
+          hb.c[0] = {(const int32_t *)keys, valid, n, w.hot_image, 0};
           hot_sample_kernel<<<1, 1024, 0, s>>>(hb);
           NVT_CHECK_LAUNCH();
         }
@@ -2090,8 +2207,20 @@ using namespace nvt;
 
 extern "C" {
 
+int nvt_range_table_bytes(int nb_log2, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes && nb_log2 >= 6 && nb_log2 <= 10, "64 .. 1024 buckets");
+  *bytes = (((uint64_t)1 << nb_log2) * kRpRegion + kRpGuard) * 8;
+  return NVT_OK;
+}
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
+  if ((path & 0xFF) == NVT_PATH_RANGE) {
+    const int nb_log2 = (path >> 8) & 0xFF;
+    NVT_CHECK_ARG(key_bytes == 4 && !weighted && nb_log2 >= 6 && nb_log2 <= 10,
+                  "the range path takes int32 keys without weights, 64 .. 1024 buckets");
+    *bytes = range_count_ws_bytes(n, nb_log2) + 64;
+    return NVT_OK;
+  }
   NVT_CHECK_ARG((path & ~NVT_PATH_HOT) >= 0 && (path & ~NVT_PATH_HOT) <= 7, "path must be 0..7");
   NVT_CHECK_ARG(!(path & NVT_PATH_HOT) || ((path & ~NVT_PATH_HOT) >= 1 && (path & ~NVT_PATH_HOT) <= 3 &&
                                           key_bytes == 4 && !weighted),
@@ -2148,8 +2277,11 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
     };
     for (int i = 0; i < ncols; ++i) {
       const nvt_count_col &c = cols[i];
-      if (!(c.path & NVT_PATH_HOT) || c.key_bytes != 4 || c.weights || c.n == 0 || !c.hot_image) continue;
-      hb.c[nh++] = {(const int32_t *)c.keys, c.valid, c.n, c.hot_image};
+      const bool range = (c.path & 0xFF) == NVT_PATH_RANGE;
+      if (!((c.path & NVT_PATH_HOT) || range) || c.key_bytes != 4 || c.weights || c.n == 0 ||
+          !c.hot_image)
+        continue;
+      hb.c[nh++] = {(const int32_t *)c.keys, c.valid, c.n, c.hot_image, range ? (c.path >> 8) & 0xFF : 0};
       if (nh == kHotBatch) {
         int rc = flush();
         if (rc) return rc;
@@ -2166,7 +2298,8 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
     if (fork) {
       const size_t k = std::find(wss.begin(), wss.end(), c.ws) - wss.begin();
       cs = pool->s[k];
-      if (sampled && (c.path & NVT_PATH_HOT) && c.hot_image && !waited[k]) {
+      if (sampled && ((c.path & NVT_PATH_HOT) || (c.path & 0xFF) == NVT_PATH_RANGE) && c.hot_image &&
+          !waited[k]) {
         NVT_CHECK_HIP(hipStreamWaitEvent(cs, pool->aux, 0));
         waited[k] = true;
       }
@@ -2175,7 +2308,10 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
     if (c.key_bytes == 4)
       rc = dense_count<int32_t>((const int32_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,
                                 (int32_t *)c.out_keys, c.out_counts, c.out_capacity, c.state, cs,
-                                !contiguous, (c.path & NVT_PATH_HOT) ? c.hot_image : nullptr);
+                                !contiguous,
+                                ((c.path & NVT_PATH_HOT) || (c.path & 0xFF) == NVT_PATH_RANGE) ? c.hot_image
+                                                                                            : nullptr,
+                                c.range_table);
     else if (c.key_bytes == 8)
       rc = dense_count<int64_t>((const int64_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,
                                 (int64_t *)c.out_keys, c.out_counts, c.out_capacity, c.state, cs,

@@ -16,6 +16,7 @@
 #include "nvt_common.hpp"
 #include "nvt_internal.hpp"
 #include "nvt_prof.hpp"
+#include "nvt_range.hpp"
 
 namespace nvt {
 
@@ -257,13 +258,28 @@ __device__ __forceinline__ void two_buckets(uint32_t h, uint32_t &b1, uint32_t &
 // GLOBAL = false: the whole vocabulary is staged (no table in HBM): the probe phases and their
 // registers disappear.  (UU = 3 / 4 key vectors per lane in flight, and a 2048-slot table with
 // two workgroups per CU for vocabularies <= 1024 keys, were each ~2 % slower: profiles/r02_notes.md)
-template <typename K, typename OUT, bool TWO = false, bool GLOBAL = true, int UU = 2>
+// RANGE (int32 keys): `table` is a range table (the per-bucket tables of the counting pass,
+// dumped; nvt_range.hpp): first slot from the monotone map, probing runs forward without
+// wrapping (an empty slot ends every chain).
+template <typename K, typename OUT, bool TWO = false, bool GLOBAL = true, int UU = 2,
+          bool RANGE = false>
 __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
     int64_t null_label, int64_t oov_label, uint32_t num_buckets, OUT *__restrict__ out,
-    const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label) {
+    const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label,
+    const int32_t *__restrict__ range_aux = nullptr) {
   constexpr bool global_needed = GLOBAL;
+  RangeMap rmap = {0u, 0u, 0ull, 0};
+  if constexpr (RANGE) rmap = load_map(range_aux);
+  auto first_slot = [&](K key) -> uint64_t {
+    if constexpr (RANGE) return rmap.table_slot((int32_t)key);
+    return (uint64_t)slot_hash(key) & mask;
+  };
+  auto next_slot = [&](uint64_t sl) -> uint64_t {
+    if constexpr (RANGE) return sl + 1;
+    return (sl + 1) & mask;
+  };
   constexpr K EMPTY = EncTraits<K>::empty;
   constexpr int VEC = EncTraits<K>::vec;
   constexpr int SLOTS = HotCfg<K>::slots;
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
       EncSlot<K> e[NK];
 #pragma unroll
       for (int q = 0; q < NK; ++q) {
-        slot[q] = (uint64_t)slot_hash(k[q]) & mask;
+        slot[q] = first_slot(k[q]);
         if (need[q]) e[q] = table[slot[q]];
       }
 #pragma unroll
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
             break;
           }
           if (e[q].key == EMPTY) break;
-          slot[q] = (slot[q] + 1) & mask;
+          slot[q] = next_slot(slot[q]);
           e[q] = table[slot[q]];
         }
       }
@@ -468,7 +484,18 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     OUT r = (OUT)null_label;
     if (bit_valid(valid, i)) {
       int64_t lab = key == EMPTY ? sent : hot_lookup(key);
-      if (lab < 0 && key != EMPTY && global_needed) lab = probe<K>(table, mask, key);
+      if (lab < 0 && key != EMPTY && global_needed) {
+        uint64_t sl = first_slot(key);
+        while (true) {
+          const EncSlot<K> e1 = table[sl];
+          if (e1.key == key) {
+            lab = (int64_t)e1.label;
+            break;
+          }
+          if (e1.key == EMPTY) break;
+          sl = next_slot(sl);
+        }
+      }
       r = finish(key, lab);
     }
     out[i] = r;
@@ -566,13 +593,16 @@ template <typename K>
 int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *table,
                   uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
-                  const K *hot_keys, uint64_t n_vocab, int64_t first_label, hipStream_t s) {
+                  const K *hot_keys, uint64_t n_vocab, int64_t first_label, hipStream_t s,
+                  const int32_t *range_aux = nullptr) {
   // a duplicate-free vocabulary that fits the LDS table is encoded without the global table
   constexpr uint64_t kResident = sizeof(K) == 4 ? NVT_ENCODE_RESIDENT_I32 : NVT_ENCODE_RESIDENT_I64;
   const bool resident = hot_keys != nullptr && n_vocab > 0 && n_vocab <= kResident;
   NVT_CHECK_ARG(resident || (table && sentinel_label), "null table");
-  NVT_CHECK_ARG(resident || (capacity >= 64 && (capacity & (capacity - 1)) == 0),
+  NVT_CHECK_ARG(resident || range_aux || (capacity >= 64 && (capacity & (capacity - 1)) == 0),
                 "capacity must be 2^k >= 64");
+  NVT_CHECK_ARG(range_aux == nullptr || (sizeof(K) == 4 && hot_keys != nullptr && n_vocab > 0),
+                "range tables: int32 keys with the ordered vocabulary (vocab_keys)");
   NVT_CHECK_ARG(out_bytes == 4 || out_bytes == 8, "out_bytes must be 4 or 8");
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(keys && out, "null keys/out");
@@ -598,9 +628,21 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
     unsigned hgrid = stream_grid(n / VEC + 1, kEncBS * 2, 1);
     if constexpr (sizeof(K) == 4) {
       static const bool two = getenv("NVT_ENC_LINEAR") == nullptr;
-      if (global_needed && two) {  // cache mode: 2-choice table filled to 7/8
+      if (global_needed && (two || range_aux != nullptr)) {  // cache mode: 2-choice table filled to 7/8
         const uint64_t cap2 = (uint64_t)HotCfg<K>::slots / 8 * 7;
         n_hot = (uint32_t)(n_vocab < cap2 ? n_vocab : cap2);
+        if (range_aux != nullptr) {
+          if (out_bytes == 8)
+            encode_hot_kernel<K, int64_t, true, true, 2, true><<<hgrid, kEncBS, 0, s>>>(
+                keys, valid, n, t, 0, sentinel_label, null_label, oov_label, num_buckets,
+                reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label, range_aux);
+          else
+            encode_hot_kernel<K, int32_t, true, true, 2, true><<<hgrid, kEncBS, 0, s>>>(
+                keys, valid, n, t, 0, sentinel_label, null_label, oov_label, num_buckets,
+                reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label, range_aux);
+          NVT_CHECK_LAUNCH();
+          return NVT_OK;
+        }
         if (out_bytes == 8)
           encode_hot_kernel<K, int64_t, true><<<hgrid, kEncBS, 0, s>>>(
               keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
@@ -665,6 +707,37 @@ int encode_build_any(int key_bytes, const void *vocab, uint64_t n, int64_t first
                                  sentinel_label, unique_keys, s);
   return build_launch<int64_t>((const int64_t *)vocab, n, first_label, table, capacity,
                                sentinel_label, unique_keys, s);
+}
+
+// the two halves of a build, for callers that fill most of the table themselves (the one-pass
+// vocabulary ordering, nvt_sort.hip): clear, then insert a duplicate-free int32 key range
+int encode_clear_any(int key_bytes, void *table, uint64_t capacity, int64_t *sentinel_label,
+                     hipStream_t s) {
+  NVT_CHECK_ARG(table && sentinel_label, "null table");
+  NVT_CHECK_ARG(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be 2^k >= 64");
+  NVT_PROF("encode_build", 0, s);
+  if (key_bytes == 4)
+    enc_clear_kernel<int32_t><<<stream_grid(capacity, kBlock * 4), kBlock, 0, s>>>(
+        reinterpret_cast<EncSlot<int32_t> *>(table), capacity, sentinel_label);
+  else
+    enc_clear_kernel<int64_t><<<stream_grid(capacity, kBlock * 4), kBlock, 0, s>>>(
+        reinterpret_cast<EncSlot<int64_t> *>(table), capacity, sentinel_label);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int encode_insert_any(int key_bytes, const void *vocab, uint64_t n, int64_t first_label,
+                      void *table, uint64_t capacity, int64_t *sentinel_label, hipStream_t s) {
+  NVT_CHECK_ARG(key_bytes == 4, "encode_insert_any: int32 keys");
+  NVT_CHECK_ARG(table && sentinel_label && (n == 0 || vocab), "null pointer");
+  NVT_CHECK_ARG(first_label + (int64_t)n < INT32_MAX, "labels overflow int32");
+  if (n == 0) return NVT_OK;
+  NVT_PROF("encode_build", 0, s);
+  enc_build_unique_i32_kernel<<<stream_grid(n, kBlock), kBlock, 0, s>>>(
+      (const int32_t *)vocab, n, first_label, reinterpret_cast<EncSlot<int32_t> *>(table),
+      capacity - 1, sentinel_label);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
 }
 
 }  // namespace nvt
@@ -739,7 +812,7 @@ int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
       rc = encode_launch<int32_t>((const int32_t *)c.keys, c.valid, c.n, c.table, c.capacity,
                                   c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,
                                   c.out_bytes, (const int32_t *)c.vocab_keys, c.n_vocab,
-                                  c.first_label, cs);
+                                  c.first_label, cs, c.range_aux);
     else if (c.key_bytes == 8)
       rc = encode_launch<int64_t>((const int64_t *)c.keys, c.valid, c.n, c.table, c.capacity,
                                   c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,

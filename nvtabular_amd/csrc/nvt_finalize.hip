@@ -37,7 +37,9 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
     NVT_CHECK_ARG(c.key_bytes == 4 || c.key_bytes == 8, "key_bytes must be 4 or 8");
     NVT_CHECK_ARG(c.n <= 1 || (c.keys && c.counts), "null keys/counts");
     NVT_CHECK_ARG(c.table == nullptr || c.sentinel_label, "table without sentinel_label");
-    if (vocab_sort_small_eligible(c.key_bytes, c.n, c.max_count))
+    NVT_CHECK_ARG(c.src_keys == nullptr || (c.key_bytes == 4 && c.src_counts && c.cls_hist),
+                  "key-sorted source: int32 keys with src_counts and cls_hist");
+    if (c.src_keys == nullptr && vocab_sort_small_eligible(c.key_bytes, c.n, c.max_count))
       small.push_back(i);
     else
       big.push_back(i);
@@ -56,7 +58,7 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
   // recorded behind its last kernel and the consumer waits on it
   bool need_join = false;
   auto finish = [&](const nvt_vocab_col &c, hipStream_t s) -> int {
-    if (c.table != nullptr) {
+    if (c.table != nullptr && c.src_keys == nullptr) {
       int rc = encode_build_any(c.key_bytes, c.keys, c.n, c.first_label, c.table, c.capacity,
                                 c.sentinel_label, c.unique_keys, s);
       if (rc) return rc;
@@ -88,7 +90,15 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
   for (size_t j = 0; j < big.size(); ++j) {
     const nvt_vocab_col &c = cols[big[j]];
     hipStream_t s = fork ? pool->s[j % kSide] : main_s;
-    if (c.n > 1) {
+    if (c.src_keys != nullptr) {
+      // key-sorted list of the range path: one stable counting pass orders it and fills the table
+      NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
+      int rc = vocab_order_from_sorted((const int32_t *)c.src_keys, c.src_counts, c.n, c.cls_hist,
+                                       c.n_big, c.max_count, (int32_t *)c.keys, c.counts,
+                                       c.sort_tmp, c.first_label, c.table, c.capacity,
+                                       c.sentinel_label, c.range_aux, c.range_nb_log2, s);
+      if (rc) return rc;
+    } else if (c.n > 1) {
       NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
       int rc = vocab_sort_any(c.key_bytes, c.keys, c.counts, c.n, c.max_count, c.sort_tmp, s);
       if (rc) return rc;

@@ -33,7 +33,28 @@ uint64_t sort_words_tmp_bytes(uint64_t n);
 int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tmp, uint64_t **result,
                     hipStream_t s);
 
+// nvt_range_count.hip: path NVT_PATH_RANGE of nvt_dense_count_* (aux = hot image + range
+// parameters written by hot_sample_kernel + class histogram)
+uint64_t range_count_ws_bytes(uint64_t n, int nb_log2);
+int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int nb_log2, void *ws,
+                    int32_t *aux, int32_t *out_keys, int64_t *out_cnt, uint64_t out_cap,
+                    void *range_table, uint64_t *state, hipStream_t s);
+
+// nvt_sort.hip: vocabulary order of a KEY-SORTED (key, count) list (range path) in one stable
+// counting pass on min(count, 255) + encode table filled in the same pass
+uint64_t vocab_order_tmp_bytes(uint64_t n, uint64_t n_big);
+int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, uint64_t n,
+                            const unsigned *cls_hist, uint64_t n_big, int64_t max_count,
+                            int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label,
+                            void *table, uint64_t capacity, int64_t *sentinel_label,
+                            const int32_t *range_aux, int range_nb_log2, hipStream_t s);
+
 // nvt_encode.hip
+int encode_clear_any(int key_bytes, void *table, uint64_t capacity, int64_t *sentinel_label,
+                     hipStream_t s);
+// insert vocab[0 .. n) with labels first_label + i into an already cleared / partly filled table
+int encode_insert_any(int key_bytes, const void *vocab, uint64_t n, int64_t first_label,
+                      void *table, uint64_t capacity, int64_t *sentinel_label, hipStream_t s);
 int encode_build_any(int key_bytes, const void *vocab, uint64_t n, int64_t first_label, void *table,
                      uint64_t capacity, int64_t *sentinel_label, int unique_keys, hipStream_t s);
 

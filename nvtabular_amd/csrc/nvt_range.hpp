@@ -1,0 +1,55 @@
+// Monotone key -> slot map of the range path, shared by the counting kernels
+// (nvt_range_count.hip), the vocabulary ordering (nvt_sort.hip) and the encode kernel
+// (nvt_encode.hip): the per-bucket LDS tables of the counting pass are dumped as they are and
+// BECOME the encode table ("range table"), so all three must address it the same way.
+#pragma once
+#include "nvt_common.hpp"
+
+namespace nvt {
+
+constexpr int kRpSlots = 16384;              // slots per bucket table
+constexpr int kRpTail = 128;                 // slots past the table end (no wrap-around)
+constexpr int kRpRegion = kRpSlots + kRpTail;  // slots per bucket in the dumped table
+constexpr int kRpGuard = 64;                 // empty slots behind the last bucket
+// empty slot of an int32 encode table: {key INT32_MIN, label INT32_MAX} (enc_clear_kernel)
+constexpr unsigned long long kEncEmptySlot =
+    ((unsigned long long)(uint32_t)INT32_MAX << 32) | (unsigned long long)(uint32_t)INT32_MIN;
+
+// order-preserving image of an int32 key in uint32
+__device__ __forceinline__ uint32_t ukey(int32_t k) { return (uint32_t)k ^ 0x80000000u; }
+
+// key -> "fine slot" f in [0, NB * 16384): bucket = f >> 14, home slot = f & 16383.
+// f = (min(max(u - ulo, 0), span) * mul) >> sh with (mul, sh) chosen by the sample kernel so
+// that the padded span of the sampled keys covers ALL buckets evenly (a power-of-two bucket
+// width left up to half of them empty): span + 1 >= F = NB * 16384: mul = F * 2^32 / (span + 1),
+// sh = 32; smaller spans (dense ids): mul = F / (span + 1), sh = 0 -- keys spread with gaps.
+struct RangeMap {
+  uint32_t ulo, span;
+  uint64_t mul;
+  int sh;
+  __device__ __forceinline__ uint32_t fine(int32_t key) const {
+    const uint32_t u = ukey(key);
+    uint32_t d = u > ulo ? u - ulo : 0u;
+    d = d < span ? d : span;
+    return (uint32_t)(((uint64_t)d * mul) >> sh);
+  }
+  __device__ __forceinline__ uint32_t bucket(int32_t key) const { return fine(key) >> 14; }
+  __device__ __forceinline__ uint32_t slot(int32_t key) const { return fine(key) & (kRpSlots - 1); }
+  // first slot to look at in the dumped table (bucket regions of kRpRegion slots, probing
+  // runs forward without wrapping; the counting pass guarantees an empty slot ends every chain)
+  __device__ __forceinline__ uint64_t table_slot(int32_t key) const {
+    const uint32_t f = fine(key);
+    return (uint64_t)(f >> 14) * kRpRegion + (f & (kRpSlots - 1));
+  }
+};
+
+__device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {
+  RangeMap m;
+  m.ulo = (uint32_t)aux[NVT_RANGE_AUX_LO];
+  m.span = (uint32_t)aux[NVT_RANGE_AUX_LO + 1];
+  m.mul = (uint64_t)(uint32_t)aux[NVT_RANGE_AUX_LO + 2] | ((uint64_t)(uint32_t)aux[NVT_RANGE_AUX_LO + 3] << 32);
+  m.sh = aux[NVT_RANGE_AUX_LO + 4];
+  return m;
+}
+
+}  // namespace nvt

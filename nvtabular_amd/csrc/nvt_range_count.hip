@@ -1,0 +1,719 @@
+// Categorify.fit groupby-size, path 9 ("range path"): int32 keys, unweighted, ~11 k .. ~6.5 M
+// distinct keys.  Replaces categorify.py:955-1051 (_top_level_groupby, size only) like the
+// hash-partitioned paths 1-3 of nvt_dense_count.hip, with two differences that matter:
+//
+//   * ONE pass over the column instead of histogram + scan + 1-2 scatter passes: every
+//     workgroup keeps a small write-combining bin per bucket in LDS and flushes whole 64-byte
+//     lines into its OWN region of each bucket (no cursors, no global atomics, no histogram
+//     pre-pass).  Hot keys are counted in LDS as before (hot-key image of the sample kernel)
+//     and never reach the bins.
+//   * buckets are KEY RANGES (monotone bucket function) and the per-bucket LDS table is
+//     addressed by a monotone function of the key with linear probing, so a table's clusters
+//     are in key order and only the (short) clusters themselves have to be ordered when the
+//     table is emitted: the (key, count) list leaves this path SORTED BY KEY.  The vocabulary
+//     order "count descending, key ascending" (categorify.py:1300,1316) then needs a single
+//     stable counting pass on min(count, 255) instead of a 7-pass radix sort
+//     (nvt_sort.hip: cls_scatter_kernel).
+//
+//   rp_partition_kernel  256 workgroups x 1024 threads, contiguous row slabs.  Per row: hot
+//                        lookup (one 8-byte LDS read) -> counter, or bin append (one returning
+//                        LDS atomic + one LDS write).  A bin that holds >= 16 keys is flushed
+//                        (16 lanes x 4 B = one 64-byte line) into region (bucket, workgroup).
+//   hot_totals_kernel    column sums of the per-workgroup hot counters -> total per image slot
+//   rp_count_kernel      one workgroup per bucket (ticketed, in bucket order): gathers the 256
+//                        runs of its bucket + the hot keys that fall into its range into a
+//                        monotone LDS table, ranks every entry inside its cluster, finds its
+//                        offset in the output by a decoupled look-back over the preceding
+//                        buckets and writes (key, count) in key order; also the histogram of
+//                        min(count, 255) for the ordering pass.
+//
+// The ranges come from the sample (min / max of the sampled keys, padded): balanced for keys
+// that are spread over their range (hashed ids: Criteo, the bench generator).  Badly balanced
+// ranges overflow a region or a table; the overflow bit sends the column to the hash paths,
+// which make no assumption about the key distribution.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "nvt_common.hpp"
+#include "nvt_internal.hpp"
+#include "nvt_prof.hpp"
+#include "nvt_range.hpp"
+
+namespace nvt {
+
+namespace {
+
+constexpr int32_t kEmpty = INT32_MIN;
+constexpr int kRpBS = 1024;
+constexpr int kRpG = NVT_RANGE_WGS;          // partition workgroups (row slabs)
+constexpr int kRpBinWords = 20480;           // 80 KiB of bins: CAP = kRpBinWords / NB keys per bin
+constexpr int kRpLine = 16;                  // keys per flushed line (64 bytes)
+constexpr int kRpMaxNbLog2 = 10;
+constexpr int kHotSlotsR = NVT_HOT_IMAGE_WORDS;
+constexpr int kHotBucketsR = kHotSlotsR / 2;
+constexpr int kRpProbe = 512;
+#ifndef NVT_RANGE_U
+#define NVT_RANGE_U 2
+#endif
+constexpr unsigned long long kStAgg = 1ull << 62, kStPrefix = 2ull << 62,
+                             kStMask = (1ull << 62) - 1ull;
+
+__device__ __forceinline__ uint32_t hot_bucket_r(uint32_t h) { return (h >> 13) & (kHotBucketsR - 1); }
+
+
+// ---------------------------------------------------------------------------------------------
+// pass 1: hot counters + range partition of the cold rows
+// ---------------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
+    const int32_t *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const int32_t *__restrict__ aux, int nb_log2, uint32_t region_cap, int32_t *__restrict__ regions,
+    uint32_t *__restrict__ fills, unsigned *__restrict__ hot_cnt, uint64_t *state) {
+  __shared__ int2 tk[kHotBucketsR];
+  __shared__ unsigned tc[kHotSlotsR];
+  __shared__ int32_t bins[kRpBinWords];
+  __shared__ unsigned fill[1 << kRpMaxNbLog2], flushed[1 << kRpMaxNbLog2];
+  __shared__ unsigned long long s_nulls, s_sent;
+  __shared__ unsigned s_ovf;
+  const unsigned NB = 1u << nb_log2, CAP = (unsigned)kRpBinWords >> nb_log2;
+  const unsigned g = blockIdx.x, lane = lane_id();
+  for (int i = threadIdx.x; i < kHotBucketsR; i += kRpBS)
+    tk[i] = reinterpret_cast<const int2 *>(aux)[i];
+  for (int i = threadIdx.x; i < kHotSlotsR; i += kRpBS) tc[i] = 0;
+  for (unsigned i = threadIdx.x; i < NB; i += kRpBS) {
+    fill[i] = 0;
+    flushed[i] = 0;
+  }
+  if (threadIdx.x == 0) {
+    s_nulls = 0;
+    s_sent = 0;
+    s_ovf = 0;
+  }
+  const RangeMap map = load_map(aux);
+  __syncthreads();
+
+  // flush every bin that holds >= kRpLine keys (or, with `all`, whatever it holds): one
+  // 16-lane group per bin, four bins per wave instruction; bin t is owned by thread t
+  auto flush_bins = [&](bool all) {
+    if (threadIdx.x < NB) {  // whole waves: NB is a multiple of 64
+      const unsigned t = threadIdx.x;
+      unsigned f = fill[t];
+      f = f < CAP ? f : CAP;
+      const unsigned nfl = all ? f : (f / kRpLine) * kRpLine;  // keys leaving the bin
+      unsigned long long todo = __ballot(nfl > 0);
+      const unsigned sub = lane >> 4, l16 = lane & 15;
+      const unsigned wave_base = t - lane;
+      while (todo) {
+        int sel = -1;
+#pragma unroll
+        for (unsigned q = 0; q < 4; ++q) {
+          const int bit = todo ? (int)__ffsll((long long)todo) - 1 : -1;
+          if (todo) todo &= todo - 1;
+          sel = (q == sub) ? bit : sel;
+        }
+        const unsigned src = sel >= 0 ? (unsigned)sel : 0u;
+        const unsigned fb = __shfl(f, src, 64), nb_out = __shfl(nfl, src, 64);
+        if (sel >= 0) {
+          const unsigned bin = wave_base + (unsigned)sel;
+          const unsigned done = flushed[bin];
+          const int32_t *bsrc = bins + bin * CAP;
+          if (done + nb_out > region_cap) {
+            if (l16 == 0) atomicOr(&s_ovf, 1u);
+          } else {
+            int32_t *dst = regions + ((uint64_t)bin * kRpG + g) * region_cap + done;
+#ifndef NVT_RP_NOFLUSHSTORE
+            for (unsigned u = l16; u < nb_out; u += kRpLine) dst[u] = bsrc[u];
+#else
+            if (done == 0xFFFFFFu) dst[0] = bsrc[0];
+#endif
+          }
+          // the keys that stay (< kRpLine of them) move to the front of the bin
+          const unsigned rem = fb - nb_out;
+          int32_t keep = 0;
+          if (l16 < rem) keep = bsrc[nb_out + l16];
+          if (l16 < rem) bins[bin * CAP + l16] = keep;
+        }
+      }
+      fill[t] = f - nfl;
+      flushed[t] += nfl;
+    }
+  };
+
+  // contiguous slab of 16-byte vectors per workgroup; the last vector of the column may be partial
+  const uint64_t nvec = (n + 3) / 4, nfull = n / 4;
+  const uint64_t per = (nvec + kRpG - 1) / kRpG;
+  const uint64_t v_lo = (uint64_t)g * per;
+  const uint64_t v_hi = v_lo + per < nvec ? v_lo + per : nvec;
+  unsigned long long nulls = 0, sent = 0;
+  // U vectors per thread per round: the rounds of a workgroup are separated by two barriers, so
+  // the load latency of a round is exposed unless the next round's loads are already in flight
+  int4 npack[U];
+  unsigned nvb[U];  // bit 8: vector present, bits 0-3: rows valid, bit 9: bits 4-7 rows in range
+  auto issue = [&](uint64_t v0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t v = v0 + (uint64_t)u * kRpBS;
+      nvb[u] = 0;
+      npack[u] = make_int4(0, 0, 0, 0);
+      if (v < v_hi) {
+        if (v < nfull) {
+          npack[u] = reinterpret_cast<const int4 *>(keys)[v];
+          nvb[u] = 0x100u | (valid ? (unsigned)valid[(v * 4) >> 3] << 12 : 0xFF000u);  // raw byte
+        } else {  // partial tail vector
+          int32_t kk[4] = {0, 0, 0, 0};
+          unsigned ok = 0, in = 0;
+          for (int j = 0; j < 4; ++j) {
+            const uint64_t i = v * 4 + j;
+            if (i < n) {
+              in |= 1u << j;
+              if (bit_valid(valid, i)) {
+                kk[j] = keys[i];
+                ok |= 1u << j;
+              }
+            }
+          }
+          npack[u] = make_int4(kk[0], kk[1], kk[2], kk[3]);
+          nvb[u] = 0x300u | ok | (in << 4);
+        }
+      }
+    }
+  };
+  issue(v_lo + threadIdx.x);
+  for (uint64_t v0 = v_lo; v0 < v_hi; v0 += (uint64_t)kRpBS * U) {
+    int32_t kv[4 * U];
+    unsigned vbs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      kv[4 * u + 0] = npack[u].x;
+      kv[4 * u + 1] = npack[u].y;
+      kv[4 * u + 2] = npack[u].z;
+      kv[4 * u + 3] = npack[u].w;
+      vbs[u] = nvb[u];
+    }
+    issue(v0 + (uint64_t)kRpBS * U + threadIdx.x);
+    unsigned pend = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned vb = vbs[u];
+      if (!(vb & 0x100u)) continue;
+      const uint64_t v = v0 + (uint64_t)u * kRpBS + threadIdx.x;
+      const unsigned ok = (vb & 0x200u) ? vb & 0xFu : ((vb >> 12) >> ((v * 4) & 7)) & 0xFu;
+      const unsigned in = (vb & 0x200u) ? (vb >> 4) & 0xFu : 0xFu;
+      nulls += __popc(in & ~ok);
+      // the hot buckets of the four keys are requested before any of them is used
+      int2 hb[4];
+      uint32_t sa[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sa[j] = hot_bucket_r(slot_hash(kv[4 * u + j]));
+        hb[j] = tk[sa[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = 4 * u + j;
+        if (!((ok >> j) & 1)) continue;
+        const int32_t key = kv[q];
+        if (key == kEmpty) {
+          ++sent;
+          continue;
+        }
+        int slot = -1;
+        slot = hb[j].x == key ? (int)(2 * sa[j]) : slot;
+        slot = hb[j].y == key ? (int)(2 * sa[j] + 1) : slot;
+        if (slot >= 0)
+          atomicAdd(&tc[slot], 1u);
+        else
+          pend |= 1u << q;
+      }
+    }
+    // append the cold keys; a key whose bin is full waits for the flush and tries again
+    while (true) {
+      if (s_ovf) pend = 0;  // a region overflowed: the column is rerun on a hash path anyway
+#pragma unroll
+      for (int q = 0; q < 4 * U; ++q) {
+        if ((pend >> q) & 1) {
+          const unsigned bkt = map.bucket(kv[q]);
+          const unsigned pos = atomicAdd(&fill[bkt], 1u);
+          if (pos < CAP) {
+            bins[bkt * CAP + pos] = kv[q];
+            pend &= ~(1u << q);
+          }
+        }
+      }
+      __syncthreads();
+      flush_bins(false);
+      if (!__syncthreads_or(pend != 0)) break;
+    }
+  }
+  flush_bins(true);
+  __syncthreads();
+  for (unsigned b = threadIdx.x; b < NB; b += kRpBS) fills[(uint64_t)b * kRpG + g] = flushed[b];
+  for (int i = threadIdx.x; i < kHotSlotsR; i += kRpBS) hot_cnt[(uint64_t)g * kHotSlotsR + i] = tc[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nulls += __shfl_down(nulls, off, 64);
+    sent += __shfl_down(sent, off, 64);
+  }
+  if (lane == 0) {
+    if (nulls) atomicAdd(&s_nulls, nulls);
+    if (sent) atomicAdd(&s_sent, sent);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_nulls) atomicAdd((unsigned long long *)&state[NVT_ST_NULLS], s_nulls);
+    if (s_sent) atomicAdd((unsigned long long *)&state[NVT_ST_SENTINEL], s_sent);
+    if (s_ovf) atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW], 1ull);
+    if (g == 0) atomicAdd((unsigned long long *)&state[NVT_ST_ROWS], (unsigned long long)n);
+  }
+}
+
+// totals per hot slot = column sums of the per-workgroup counters (64 slots per workgroup x 16
+// row groups, every load of a thread in flight; cf. hot_reduce_kernel of nvt_dense_count.hip)
+constexpr int kTotGroups = 16;
+__global__ __launch_bounds__(64 * kTotGroups) void hot_totals_kernel(
+    const unsigned *__restrict__ hot_cnt, int nblocks, unsigned *__restrict__ hot_tot) {
+  __shared__ unsigned part[kTotGroups][64];
+  const unsigned l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const unsigned slot = blockIdx.x * 64 + l;
+  unsigned t = 0;  // < 2^32: the column has fewer rows than that
+#pragma unroll 16
+  for (int b = (int)g; b < nblocks; b += kTotGroups) t += hot_cnt[(uint64_t)b * kHotSlotsR + slot];
+  part[g][l] = t;
+  __syncthreads();
+  if (g != 0) return;
+  unsigned tot = 0;
+#pragma unroll
+  for (int q = 0; q < kTotGroups; ++q) tot += part[q][l];
+  hot_tot[slot] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 2: one workgroup per bucket -> key-ordered (key, count) entries
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRpBS) void rp_count_kernel(
+    const int32_t *__restrict__ regions, const uint32_t *__restrict__ fills, uint32_t region_cap,
+    const int32_t *__restrict__ aux, const unsigned *__restrict__ hot_tot, int nb_log2,
+    unsigned long long *status, unsigned *ticket, int32_t *__restrict__ out_keys,
+    int64_t *__restrict__ out_cnt, uint64_t out_cap, unsigned *cls_hist,
+    unsigned long long *__restrict__ range_table, uint64_t *state) {
+  constexpr int NSL = kRpSlots + kRpTail;
+  constexpr int NW = kRpBS / kWave;
+  __shared__ int32_t lkeys[NSL];
+  __shared__ unsigned lcnt[NSL];
+  __shared__ unsigned run_len[kRpG];
+  __shared__ unsigned hist[256];
+  __shared__ unsigned wtot[NW];
+  __shared__ unsigned lovf, s_b, s_bad;
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) {
+    s_b = atomicAdd(ticket, 1u);
+    lovf = 0;
+  }
+  for (int i = threadIdx.x; i < NSL; i += kRpBS) {
+    lkeys[i] = kEmpty;
+    lcnt[i] = 0;
+  }
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned b = s_b, NB = 1u << nb_log2;
+  const unsigned lane = lane_id(), w = threadIdx.x / kWave;
+  const RangeMap map = load_map(aux);
+#ifdef NVT_RANGE_TIMING
+  long long tm[8];
+  int tmi = 0;
+#define NVT_TM() do { if (threadIdx.x == 0 && b == NB / 2 + 7) tm[tmi++] = clock64(); } while (0)
+#else
+#define NVT_TM() do {} while (0)
+#endif
+  NVT_TM();
+  // (pass 1 overflowed a region: the run lengths are not to be trusted, nothing is gathered)
+  const bool skip = (state[NVT_ST_OVERFLOW] & 1ull) != 0;
+  if (threadIdx.x < kRpG) {
+    const unsigned len = fills[(uint64_t)b * kRpG + threadIdx.x];
+    run_len[threadIdx.x] = (skip || len > region_cap) ? 0u : len;
+  }
+  __syncthreads();
+  bool failed = skip;
+  // probe chain from slot s on (the home slot has been looked at already when `first` is set)
+  auto insert_from = [&](int32_t key, unsigned wgt, uint32_t s) {
+#pragma unroll 4
+    for (int p = 0; p < kRpProbe; ++p, ++s) {
+      if (s >= (uint32_t)NSL) break;
+      int32_t cur = lkeys[s];
+      if (cur == kEmpty) {
+        cur = atomicCAS(&lkeys[s], kEmpty, key);
+        if (cur == kEmpty) cur = key;
+      }
+      if (cur == key) {
+        atomicAdd(&lcnt[s], wgt);
+        return;
+      }
+    }
+    failed = true;
+  };
+  // Wave w gathers runs w*16 .. w*16+15 (~60-700 keys each) through ONE flat index over their
+  // concatenation: every lane has a key in every step, eight loads are in flight per lane, and
+  // the home slots of a batch are read together before the (dependent) probe chains start.
+  // (One run after the other was a chain of 16 dependent global loads per wave.)
+  {
+    constexpr int RPW = kRpG / NW;  // runs per wave
+    unsigned pre[RPW + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) pre[q + 1] = pre[q] + run_len[w * RPW + q];
+    const unsigned total = pre[RPW];
+    const int32_t *rbase = regions + ((uint64_t)b * kRpG + w * RPW) * region_cap;
+    constexpr int GB = 8;
+    for (unsigned f0 = 0; f0 < total && !failed; f0 += GB * kWave) {
+      int32_t kk[GB];
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        const unsigned f = f0 + u * kWave + lane;
+        unsigned r = 0;
+#pragma unroll
+        for (int q = 1; q < RPW; ++q) r += f >= pre[q] ? 1u : 0u;
+        kk[u] = f < total ? rbase[(uint64_t)r * region_cap + (f - pre[r])] : kEmpty;
+      }
+      uint32_t hs[GB];
+      int32_t cur[GB];
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        hs[u] = map.slot(kk[u]);
+        cur[u] = lkeys[hs[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        if (kk[u] == kEmpty) continue;
+        if (cur[u] == kk[u])
+          atomicAdd(&lcnt[hs[u]], 1u);  // already at home: fire and forget
+        else
+          insert_from(kk[u], 1u, hs[u]);
+      }
+    }
+  }
+  NVT_TM();
+  // the hot keys of this range (indexed by bucket by the sample kernel), with the totals of
+  // their counters
+  {
+    const unsigned h0 = (unsigned)aux[NVT_RANGE_AUX_HOTSTART + b], h1 = (unsigned)aux[NVT_RANGE_AUX_HOTSTART + b + 1];
+    const unsigned short *order = reinterpret_cast<const unsigned short *>(aux + NVT_RANGE_AUX_HOTORDER);
+    for (unsigned jx = h0 + threadIdx.x; jx < h1; jx += kRpBS) {
+      const unsigned slot = order[jx];
+      const int32_t key = aux[slot];
+      const unsigned tot = hot_tot[slot];
+      if (key != kEmpty && tot > 0 && !failed) insert_from(key, tot, map.slot(key));
+    }
+  }
+  if (failed) atomicOr(&lovf, 1u);
+  __syncthreads();
+  NVT_TM();
+  // workgroup-uniform (the global flag may be raised by another workgroup at any moment: it is
+  // read ONCE, by one thread; threads that disagreed here used to split at the return below)
+  if (threadIdx.x == 0)
+    s_bad = (lovf != 0 ||
+             (__hip_atomic_load(&state[NVT_ST_OVERFLOW], __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT) & 1ull))
+                ? 1u : 0u;
+  __syncthreads();
+  const bool bad = s_bad != 0;
+  // ---- entries of this bucket; bucket 0 also emits the sentinel key (smallest int32) ----
+  const unsigned long long sent_rows = b == 0 ? state[NVT_ST_SENTINEL] : 0ull;
+  const unsigned extra = sent_rows > 0 ? 1u : 0u;
+  constexpr int ITER = (NSL + kRpBS - 1) / kRpBS;  // slot i = it * 1024 + thread: 17 sweeps
+  // occupied slots per (sweep, wave) are recomputed in the second sweep; first the wave totals
+  unsigned mine = 0;
+  for (int it = 0; it < ITER; ++it) {
+    const int i = it * kRpBS + (int)threadIdx.x;
+    const bool occ = i < NSL && lkeys[i] != kEmpty;
+    mine += (unsigned)__popcll(__ballot(occ));
+  }
+  if (lane == 0) wtot[w] = mine;  // (every lane of the wave holds the same sum)
+  __syncthreads();
+  unsigned E = extra;
+  for (int q = 0; q < NW; ++q) E += wtot[q];
+  // more entries than the table is meant to hold: clusters (and the ranking below) grow
+  // quadratically -- report it like a table overflow
+  const bool full = E > (unsigned)(kRpSlots / 4 * 3);
+  if (bad || full) E = 0;
+  NVT_TM();
+  // ---- decoupled look-back over the preceding buckets (wave 0) ----
+  if (w == 0) {
+    unsigned long long excl = 0;
+    if (lane == 0)
+      __hip_atomic_store(&status[b], (b == 0 ? kStPrefix : kStAgg) | (unsigned long long)E,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b > 0) {
+      int top = (int)b - 1;  // look at buckets top, top-1, ... top-63
+      while (true) {
+        const int idx = top - (int)lane;
+        unsigned long long v = kStPrefix;  // virtual bucket -1: prefix 0
+        if (idx >= 0) {
+          do {
+            v = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef NVT_RP_SLEEP
+#define NVT_RP_SLEEP 1
+#endif
+            if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(NVT_RP_SLEEP);
+          } while ((v >> 62) == 0);
+        }
+        const unsigned long long isp = __ballot((v >> 62) == 2);
+        // nearest prefix (lowest lane); everything in front of it contributes its aggregate
+        const int first = isp ? (int)__ffsll((long long)isp) - 1 : 64;
+        unsigned long long add = ((int)lane <= first) ? (v & kStMask) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) add += __shfl_down(add, off, 64);
+        excl += __shfl(add, 0, 64);
+        if (isp) break;
+        top -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&status[b], kStPrefix | (excl + E), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_base = excl;
+  }
+  __syncthreads();
+  NVT_TM();
+  const unsigned long long base = s_base;
+  if (b == NB - 1 && threadIdx.x == 0) {
+    if (base + E > out_cap)
+      atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW], 2ull);
+    else
+      state[NVT_ST_OCCUPIED] = base + E;
+  }
+  if (bad || full) {
+    if (threadIdx.x == 0 && (lovf != 0 || full))
+      atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW], 1ull);
+    return;
+  }
+  if (base + E > out_cap) return;  // reported by the last bucket
+  if (extra && threadIdx.x == 0) {
+    out_keys[base] = kEmpty;
+    out_cnt[base] = (int64_t)sent_rows;
+    const unsigned cls = sent_rows < 255 ? (unsigned)sent_rows : 255u;
+    atomicAdd(&hist[cls], 1u);
+    unsigned long long *gm = reinterpret_cast<unsigned long long *>(&state[NVT_ST_MAXCOUNT]);
+    atomicMax(gm, sent_rows);
+  }
+  // ---- ranked emission: position = occupied slots before the cluster + rank inside it ----
+  // occupied slots in front of slot i = it * 1024 + w * 64 + lane: exclusive prefix over the
+  // (sweep, wave) groups in slot order, computed once (17 x 16 groups)
+  __shared__ unsigned occ_pre[ITER * NW];
+  __shared__ unsigned occ_wsum[8];
+  for (int it = 0; it < ITER; ++it) {
+    const int i = it * kRpBS + (int)threadIdx.x;
+    const bool occ = i < NSL && lkeys[i] != kEmpty;
+    const unsigned c = (unsigned)__popcll(__ballot(occ));
+    if (lane == 0) occ_pre[it * NW + w] = c;
+  }
+  __syncthreads();
+  {
+    constexpr int NG = ITER * NW;                 // 272 groups
+    constexpr int SW = (NG + kWave - 1) / kWave;  // scanned by the first 5 waves
+    unsigned v = 0, inc = 0;
+    if (w < (unsigned)SW) {
+      v = threadIdx.x < (unsigned)NG ? occ_pre[threadIdx.x] : 0u;
+      inc = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off, 64);
+        if (lane >= (unsigned)off) inc += o;
+      }
+      if (lane == 63) occ_wsum[w] = inc;
+    }
+    __syncthreads();
+    if (w < (unsigned)SW && threadIdx.x < (unsigned)NG) {
+      unsigned wb = 0;
+      for (unsigned q = 0; q < w; ++q) wb += occ_wsum[q];
+      occ_pre[threadIdx.x] = extra + wb + inc - v;
+    }
+    __syncthreads();
+  }
+  NVT_TM();
+  unsigned mx = 0;
+  for (int it = 0; it < ITER; ++it) {
+    const int i = it * kRpBS + (int)threadIdx.x;
+    const int32_t k = i < NSL ? lkeys[i] : kEmpty;
+    const bool occ = k != kEmpty;
+    unsigned long long dump = kEncEmptySlot;
+    const unsigned long long bal = __ballot(occ);
+    const unsigned front = occ_pre[it * NW + w];
+    if (occ) {
+      const unsigned p_i = front + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+      // cluster of slot i: walk left to its first slot, right to its end, four slots per step
+      // (independent LDS reads: the one-slot-at-a-time walk was a chain of dependent reads as
+      // long as the longest cluster among the 64 lanes).  rank = smaller keys in the cluster.
+      unsigned rank = 0;
+      int s = i;
+      while (true) {
+        int32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = s - 1 - q >= 0 ? lkeys[s - 1 - q] : kEmpty;
+        int run = 0;
+        bool open = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          open = open && o[q] != kEmpty;
+          run += open ? 1 : 0;
+          rank += (open && o[q] < k) ? 1u : 0u;
+        }
+        s -= run;
+        if (run < 4) break;
+      }
+      int e = i + 1;
+      while (true) {
+        int32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = e + q < NSL ? lkeys[e + q] : kEmpty;
+        int run = 0;
+        bool open = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          open = open && o[q] != kEmpty;
+          run += open ? 1 : 0;
+          rank += (open && o[q] < k) ? 1u : 0u;
+        }
+        e += run;
+        if (run < 4) break;
+      }
+      const uint64_t pos = base + p_i - (unsigned)(i - s) + rank;
+      const unsigned c = lcnt[i];
+#ifndef NVT_RP_NOWRITE
+      out_keys[pos] = k;
+      out_cnt[pos] = (int64_t)c;
+#else
+      if (pos == 0xFFFFFFFFFFull) out_keys[0] = k;
+#endif
+      atomicAdd(&hist[c < 255u ? c : 255u], 1u);
+      mx = c > mx ? c : mx;
+      dump = ((unsigned long long)(uint32_t)pos << 32) | (uint32_t)k;
+    }
+    // the table as it stands in LDS becomes this bucket's region of the encode table: slot ->
+    // {key, position in the key-ordered list}; the ordering pass turns positions into labels
+    if (range_table != nullptr && i < NSL) range_table[(uint64_t)b * NSL + i] = dump;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0 && mx > 0) {
+    unsigned long long *gm = reinterpret_cast<unsigned long long *>(&state[NVT_ST_MAXCOUNT]);
+    if (mx > __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(gm, (unsigned long long)mx);
+  }
+  if (range_table != nullptr && b == NB - 1 && threadIdx.x < kRpGuard)
+    range_table[(uint64_t)NB * NSL + threadIdx.x] = kEncEmptySlot;
+  __syncthreads();
+  NVT_TM();
+#ifdef NVT_RANGE_TIMING
+  if (threadIdx.x == 0 && b == NB / 2 + 7)
+    for (int q = 1; q < tmi; ++q) state[9 + q] = (uint64_t)(tm[q] - tm[q - 1]);
+#endif
+  if (threadIdx.x < 256) {
+    const unsigned h = hist[threadIdx.x];
+    if (h) atomicAdd(&cls_hist[threadIdx.x], h);
+    if (threadIdx.x == 255 && h)
+      atomicAdd((unsigned long long *)&state[NVT_ST_BIG], (unsigned long long)h);
+  }
+}
+
+inline uint64_t al16(uint64_t x) { return (x + 15) & ~15ull; }
+
+}  // namespace
+
+uint32_t range_region_cap(uint64_t n, int nb_log2) {
+  const uint64_t rows_per_wg = (n + kRpG - 1) / kRpG;
+  const uint64_t c = 2 * (rows_per_wg >> nb_log2) + 64;
+  return (uint32_t)((c + kRpLine - 1) / kRpLine * kRpLine);
+}
+
+struct RangeWs {
+  int32_t *regions;
+  uint32_t *fills;
+  unsigned *hot_cnt, *hot_tot;
+  unsigned long long *status;
+  unsigned *ticket;
+};
+
+uint64_t range_ws_layout(uint64_t n, int nb_log2, char *base, RangeWs *ws) {
+  uint64_t off = 0;
+  auto take = [&](uint64_t bytes) {
+    char *p = base ? base + off : nullptr;
+    off += al16(bytes);
+    return p;
+  };
+  RangeWs w;
+  const uint64_t NB = 1ull << nb_log2;
+  w.regions = (int32_t *)take(NB * kRpG * range_region_cap(n, nb_log2) * 4);
+  w.fills = (uint32_t *)take(NB * kRpG * 4);
+  w.hot_cnt = (unsigned *)take((uint64_t)kRpG * kHotSlotsR * 4);
+  w.hot_tot = (unsigned *)take((uint64_t)kHotSlotsR * 4);
+  w.status = (unsigned long long *)take(NB * 8 + 64);  // + ticket
+  w.ticket = (unsigned *)(w.status ? (char *)w.status + NB * 8 : nullptr);
+  if (ws) *ws = w;
+  return off;
+}
+
+uint64_t range_count_ws_bytes(uint64_t n, int nb_log2) {
+  return range_ws_layout(n, nb_log2, nullptr, nullptr);
+}
+
+// aux = the column's int32[NVT_RANGE_AUX_WORDS]: hot image (sampled, with the range parameters,
+// by hot_sample_kernel ahead of this call) and the class histogram (cleared here)
+int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int nb_log2, void *wsp,
+                    int32_t *aux, int32_t *out_keys, int64_t *out_cnt, uint64_t out_cap,
+                    void *range_table, uint64_t *state, hipStream_t s) {
+  NVT_CHECK_ARG(nb_log2 >= 6 && nb_log2 <= kRpMaxNbLog2, "range path: 64 .. 1024 buckets");
+  NVT_CHECK_ARG(aux != nullptr, "range path: the column needs its aux block (hot_image)");
+  NVT_PROF("dense_count_r9", n * 4, s);
+  RangeWs w;
+  range_ws_layout(n, nb_log2, (char *)wsp, &w);
+  const unsigned NB = 1u << nb_log2;
+  const uint32_t cap = range_region_cap(n, nb_log2);
+  NVT_CHECK_HIP(hipMemsetAsync(w.status, 0, (uint64_t)NB * 8 + 64, s));
+  NVT_CHECK_HIP(hipMemsetAsync(aux + NVT_RANGE_AUX_HIST, 0, 256 * 4, s));
+  static const bool debug = getenv("NVT_RANGE_DEBUG") != nullptr;
+  auto mark = [&](const char *what) {
+    if (debug) {
+      hipError_t e = hipStreamSynchronize(s);
+      fprintf(stderr, "[range n=%llu nb=%u cap=%u] %s: %s\n", (unsigned long long)n, NB, cap, what,
+              hipGetErrorString(e));
+      fflush(stderr);
+    }
+  };
+  mark("begin");
+  if (debug) {
+    int32_t prm[5];
+    (void)hipMemcpy(prm, aux + NVT_RANGE_AUX_LO, sizeof(prm), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[range] map: ulo=%u span=%u mul=%llu sh=%d; ws=%p regions=%p fills=%p hot_cnt=%p aux=%p\n",
+            (unsigned)prm[0], (unsigned)prm[1],
+            (unsigned long long)(uint32_t)prm[2] | ((unsigned long long)(uint32_t)prm[3] << 32), prm[4],
+            wsp, (void *)w.regions, (void *)w.fills, (void *)w.hot_cnt, (void *)aux);
+  }
+  static const int upr = getenv("NVT_RANGE_U") ? atoi(getenv("NVT_RANGE_U")) : NVT_RANGE_U;
+  if (upr == 4)
+    rp_partition_kernel<4><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
+                                                  w.fills, w.hot_cnt, state);
+  else if (upr == 1)
+    rp_partition_kernel<1><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
+                                                  w.fills, w.hot_cnt, state);
+  else
+    rp_partition_kernel<2><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
+                                                  w.fills, w.hot_cnt, state);
+  NVT_CHECK_LAUNCH();
+  mark("partition");
+  hot_totals_kernel<<<kHotSlotsR / 64, 64 * kTotGroups, 0, s>>>(w.hot_cnt, kRpG, w.hot_tot);
+  NVT_CHECK_LAUNCH();
+  mark("totals");
+  rp_count_kernel<<<NB, kRpBS, 0, s>>>(w.regions, w.fills, cap, aux, w.hot_tot, nb_log2, w.status,
+                                       w.ticket, out_keys, out_cnt, out_cap,
+                                       (unsigned *)(aux + NVT_RANGE_AUX_HIST),
+                                       (unsigned long long *)range_table, state);
+  NVT_CHECK_LAUNCH();
+  mark("count");
+  return NVT_OK;
+}
+
+}  // namespace nvt

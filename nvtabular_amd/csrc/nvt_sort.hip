@@ -17,7 +17,10 @@
 #include "nvt_common.hpp"
 #include "nvt_internal.hpp"
 #include "nvt_prof.hpp"
+#include "nvt_range.hpp"
 #include "nvt_scan.hpp"
+
+extern "C" int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes);
 
 namespace nvt {
 
@@ -898,6 +901,274 @@ int vocab_sort_small_batch(const SmallSortDesc *cols, int ncols, hipStream_t s) 
   return NVT_OK;
 }
 
+// ---- vocabulary order from a KEY-SORTED (key, count) list: ONE stable counting pass ---------
+// The range path of the counting stage (nvt_range_count.hip) emits its list in key order and a
+// histogram of cls = min(count, 255).  "count descending, key ascending" (categorify.py:1300,
+// 1316) is then: class 255 (count >= 255; a few thousand entries of a 45 M-row power-law
+// column, never more than rows / 255) in front, then classes 254 .. 1, every class in the key
+// order it already has.  One stable scatter by class does that for all but the first class,
+// whose entries are sorted afterwards by the (small) generic sort; the encode table is filled
+// by the same scatter, where every entry learns its label.  Against the 7-pass radix sort +
+// separate table build: 12 B read + 12 B written per entry instead of ~120, 4 launches
+// instead of 11.
+// Same tile geometry, ballot ranking and decoupled look-back as os_scatter_kernel above.
+__device__ __forceinline__ unsigned cls_digit(uint64_t comp) {
+  const uint32_t cnt = ~(uint32_t)(comp >> 32);
+  return 255u - (cnt < 255u ? cnt : 255u);
+}
+
+__global__ __launch_bounds__(kS2BS) void cls_scatter_kernel(
+    const int32_t *__restrict__ keys, const int64_t *__restrict__ cnts, uint64_t n,
+    const unsigned *__restrict__ cls_hist, unsigned *status, unsigned *ticket, int32_t *out_keys,
+    int64_t *out_cnts, unsigned long long *table, uint64_t mask, int64_t first_label,
+    int64_t *sentinel_label, int32_t *label_of) {
+  constexpr int NW = kS2BS / kWave;
+  __shared__ unsigned wcnt[NW][256];
+  __shared__ unsigned goff[256];
+  __shared__ unsigned wtot[NW], btot[NW];
+  __shared__ unsigned s_tile;
+  __shared__ uint64_t stage[kS2Tile];
+  const unsigned w = threadIdx.x / kWave, l = lane_id();
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int q = 0; q < NW; ++q) wcnt[q][threadIdx.x] = 0;
+  // class bases: digit d = 255 - cls, base[d] = entries of the classes in front of it
+  unsigned cbase;
+  {
+    const unsigned v = cls_hist[255 - threadIdx.x];
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned o = __shfl_up(inc, off, 64);
+      if (l >= (unsigned)off) inc += o;
+    }
+    if (l == 63) btot[w] = inc;
+    __syncthreads();
+    unsigned wb = 0;
+    for (unsigned q = 0; q < w; ++q) wb += btot[q];
+    cbase = wb + inc - v;
+  }
+  const unsigned tile = s_tile;
+  uint64_t c[kS2Rows];
+  unsigned short local[kS2Rows];
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    const uint64_t i = s2_elem(tile, w, r, l);
+    c[r] = ~0ull;
+    if (i < n) c[r] = comp_make(keys[i], cnts[i]);
+  }
+  const uint64_t tile_base = (uint64_t)tile * kS2Tile;
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    const bool act = s2_elem(tile, w, r, l) < n;
+    const unsigned d = cls_digit(c[r]);
+    const unsigned long long peers = match_digit(d, act);
+    const unsigned rank = __popcll(peers & ((1ull << l) - 1ull));
+    const unsigned before = act ? wcnt[w][d] : 0;
+    __builtin_amdgcn_wave_barrier();
+    if (act && rank == 0) wcnt[w][d] = before + (unsigned)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    local[r] = (unsigned short)(before + rank);
+  }
+  __syncthreads();
+  {
+    const unsigned d = threadIdx.x;
+    unsigned t[NW], tot = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      t[q] = wcnt[q][d];
+      tot += t[q];
+    }
+    unsigned *my = status + (uint64_t)tile * 256 + d;
+    __hip_atomic_store(my, (tile == 0 ? kOsPrefix : kOsAgg) | tot, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    unsigned inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned o = __shfl_up(inc, off, 64);
+      if (l >= (unsigned)off) inc += o;
+    }
+    if (l == 63) wtot[w] = inc;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (unsigned q = 0; q < w; ++q) wbase += wtot[q];
+    const unsigned dstart = wbase + inc - tot;
+    unsigned run = dstart;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      wcnt[q][d] = run;
+      run += t[q];
+    }
+    unsigned excl = 0;
+    if (tile > 0) {
+      unsigned tb = tile - 1;
+      while (true) {
+        const unsigned v = __hip_atomic_load(status + (uint64_t)tb * 256 + d, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned f = v >> 30;
+        if (f == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += v & kOsMask;
+        if (f == 2) break;
+        --tb;
+      }
+      __hip_atomic_store(my, kOsPrefix | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    goff[d] = cbase + excl - dstart;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    const uint64_t i = s2_elem(tile, w, r, l);
+    if (i < n) {
+      const unsigned d = cls_digit(c[r]);
+      const unsigned sidx = wcnt[w][d] + local[r];
+      stage[sidx] = c[r];
+      // range table: label of the entry at position i of the key-ordered list (class 255 is
+      // labelled after its own sort: -1 here)
+      if (label_of != nullptr) label_of[i] = d != 0 ? (int32_t)(first_label + goff[d] + sidx) : -1;
+    }
+  }
+  __syncthreads();
+  const unsigned tile_n = (unsigned)(n - tile_base < (uint64_t)kS2Tile ? n - tile_base : kS2Tile);
+#pragma unroll 4
+  for (int j = 0; j < kS2Rows; ++j) {
+    const unsigned idx = j * kS2BS + threadIdx.x;
+    if (idx < tile_n) {
+      const uint64_t v = stage[idx];
+      const unsigned d = cls_digit(v);
+      const unsigned dst = goff[d] + idx;
+      const int32_t key = comp_key(v);
+      out_keys[dst] = key;
+      out_cnts[dst] = comp_cnt(v);
+      if (key == INT32_MIN && d != 0 && sentinel_label != nullptr) {
+        *sentinel_label = first_label + (int64_t)dst;
+      } else if (table != nullptr && d != 0) {  // class 255 gets its labels after its own sort
+        const int64_t label = first_label + (int64_t)dst;
+        {
+          const unsigned long long want = ((unsigned long long)(uint32_t)label << 32) | (uint32_t)key;
+          uint64_t slot = (uint64_t)slot_hash(key) & mask;
+          while (atomicCAS(&table[slot], kEncEmptySlot, want) != kEncEmptySlot) slot = (slot + 1) & mask;
+        }
+      }
+    }
+  }
+}
+
+// Range table (dumped by the counting pass: slot = {key, position in the key-ordered list}):
+// positions -> labels.  One streaming pass: the slots are in key order, so label_of[] is read
+// front to back as well.
+__global__ __launch_bounds__(kBlock) void range_patch_kernel(unsigned long long *table,
+                                                             uint64_t nslots,
+                                                             const int32_t *__restrict__ label_of) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock * 2;
+  for (uint64_t s0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 2; s0 < nslots; s0 += stride) {
+    ulonglong2 e = *reinterpret_cast<ulonglong2 *>(table + s0);  // nslots is even, 16-byte aligned
+    bool dirty = false;
+    if ((int32_t)(uint32_t)e.x != INT32_MIN) {
+      e.x = ((unsigned long long)(uint32_t)label_of[(uint32_t)(e.x >> 32)] << 32) | (uint32_t)e.x;
+      dirty = true;
+    }
+    if ((int32_t)(uint32_t)e.y != INT32_MIN) {
+      e.y = ((unsigned long long)(uint32_t)label_of[(uint32_t)(e.y >> 32)] << 32) | (uint32_t)e.y;
+      dirty = true;
+    }
+    if (dirty) *reinterpret_cast<ulonglong2 *>(table + s0) = e;
+  }
+}
+
+// labels of the (few) entries of class 255 after their own sort: vocab[j] -> first_label + j
+__global__ __launch_bounds__(kBlock) void range_fix_prefix_kernel(
+    unsigned long long *table, const int32_t *__restrict__ aux, const int32_t *__restrict__ vocab,
+    uint64_t n_big, int64_t first_label, int64_t *sentinel_label) {
+  const RangeMap map = load_map(aux);
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n_big; j += stride) {
+    const int32_t key = vocab[j];
+    const int64_t label = first_label + (int64_t)j;
+    if (key == INT32_MIN) {
+      *sentinel_label = label;
+      continue;
+    }
+    uint64_t s = map.table_slot(key);
+    while (true) {
+      const unsigned long long e = table[s];
+      if ((int32_t)(uint32_t)e == key) {
+        table[s] = ((unsigned long long)(uint32_t)label << 32) | (uint32_t)key;
+        break;
+      }
+      if ((int32_t)(uint32_t)e == INT32_MIN) break;  // cannot happen for a key of the vocabulary
+      ++s;
+    }
+  }
+}
+
+uint64_t vocab_order_tmp_bytes(uint64_t n, uint64_t n_big) {
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  uint64_t sort_bytes = 0;
+  if (n_big > 1) (void)nvt_vocab_sort_tmp_bytes(4, n_big, &sort_bytes);
+  return pad16(ntiles * 256 * 4 + 64) + sort_bytes + pad16(n * 4) + 64;  // + label_of[n]
+}
+
+int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, uint64_t n,
+                            const unsigned *cls_hist, uint64_t n_big, int64_t max_count,
+                            int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label,
+                            void *table, uint64_t capacity, int64_t *sentinel_label,
+                            const int32_t *range_aux, int range_nb_log2, hipStream_t s) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(n < (1ull << 30), "at most 2^30-1 vocabulary entries");
+  NVT_CHECK_ARG(n_big <= n, "n_big > n");
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  unsigned *status = reinterpret_cast<unsigned *>(tmp);
+  unsigned *ticket = status + ntiles * 256;
+  uint64_t sort_bytes = 0;
+  if (n_big > 1) (void)nvt_vocab_sort_tmp_bytes(4, n_big, &sort_bytes);
+  char *sort_tmp = reinterpret_cast<char *>(tmp) + pad16(ntiles * 256 * 4 + 64);
+  int32_t *label_of = reinterpret_cast<int32_t *>(sort_tmp + pad16(sort_bytes));
+  // range table (range_aux set): `table` holds {key, position} slots already (dumped by the
+  // counting pass) and only needs its positions replaced by labels -- no clear, no inserts
+  const bool ranged = table != nullptr && range_aux != nullptr;
+  if (table && !ranged) {
+    int rc = encode_clear_any(4, table, capacity, sentinel_label, s);
+    if (rc) return rc;
+  } else if (ranged) {
+    NVT_CHECK_HIP(hipMemsetAsync(sentinel_label, 0xFF, 8, s));  // -1: no sentinel key
+  }
+  {
+    NVT_PROF("vocab_order", n * 24, s);
+    NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 256 * 4 + 64, s));
+    cls_scatter_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(
+        src_keys, src_cnts, n, cls_hist, status, ticket, out_keys, out_cnts,
+        ranged ? nullptr : (unsigned long long *)table, capacity - 1, first_label, sentinel_label,
+        ranged ? label_of : nullptr);
+    NVT_CHECK_LAUNCH();
+    if (ranged) {
+      const uint64_t nslots = ((uint64_t)1 << range_nb_log2) * kRpRegion + kRpGuard;
+      range_patch_kernel<<<stream_grid(nslots / 2, kBlock, 8), kBlock, 0, s>>>(
+          (unsigned long long *)table, nslots, label_of);
+      NVT_CHECK_LAUNCH();
+    }
+  }
+  if (n_big > 1) {
+    int rc = vocab_sort_any(4, out_keys, out_cnts, n_big, max_count, sort_tmp, s);
+    if (rc) return rc;
+  }
+  if (table && n_big > 0) {
+    if (ranged) {
+      NVT_PROF("encode_build", 0, s);
+      range_fix_prefix_kernel<<<stream_grid(n_big, kBlock), kBlock, 0, s>>>(
+          (unsigned long long *)table, range_aux, out_keys, n_big, first_label, sentinel_label);
+      NVT_CHECK_LAUNCH();
+    } else {
+      int rc = encode_insert_any(4, out_keys, n_big, first_label, table, capacity, sentinel_label, s);
+      if (rc) return rc;
+    }
+  }
+  return NVT_OK;
+}
+
 }  // namespace nvt
 
 using namespace nvt;
@@ -913,6 +1184,11 @@ int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes) {
            (uint64_t)(key_bytes + 8) * 256 * 8 + 64;
   if (key_bytes == 4 && sort2_tmp_bytes(n) > *bytes) *bytes = sort2_tmp_bytes(n);
   if (key_bytes == 4 && os_tmp_bytes(n) > *bytes) *bytes = os_tmp_bytes(n);
+  return NVT_OK;
+}
+int nvt_vocab_order_tmp_bytes(uint64_t n, uint64_t n_big, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes, "null out pointer");
+  *bytes = vocab_order_tmp_bytes(n, n_big);
   return NVT_OK;
 }
 int nvt_vocab_sort_i32(int32_t *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tmp,

@@ -113,6 +113,7 @@ class Event:
 
 
 _mailboxes = {}
+READBACK_TIMEOUT_S = float(os.environ.get("NVT_READBACK_TIMEOUT", "120"))
 
 
 def read_back(t: torch.Tensor):
@@ -141,7 +142,7 @@ def read_back(t: torch.Tensor):
     seq = C.c_uint64()
     check(lib.nvt_mailbox_post(mb, t.data_ptr(), nbytes, stream_ptr(), C.byref(seq)),
           "nvt_mailbox_post")
-    check(lib.nvt_mailbox_wait(mb, seq.value, 120.0), "nvt_mailbox_wait")
+    check(lib.nvt_mailbox_wait(mb, seq.value, READBACK_TIMEOUT_S), "nvt_mailbox_wait")
     np_dt = {torch.int64: np.int64, torch.float64: np.float64}[t.dtype]
     buf = (C.c_char * nbytes).from_address(lib.nvt_mailbox_data(mb))
     return np.frombuffer(buf, dtype=np_dt).reshape(tuple(t.shape)).copy()
@@ -163,7 +164,7 @@ def read_back_ptr(ptr: int, nwords: int, device_index: int):
         mb = _mailboxes[key] = h
     seq = C.c_uint64()
     check(lib.nvt_mailbox_post(mb, ptr, nbytes, stream_ptr(), C.byref(seq)), "nvt_mailbox_post")
-    check(lib.nvt_mailbox_wait(mb, seq.value, 120.0), "nvt_mailbox_wait")
+    check(lib.nvt_mailbox_wait(mb, seq.value, READBACK_TIMEOUT_S), "nvt_mailbox_wait")
     buf = (C.c_char * nbytes).from_address(lib.nvt_mailbox_data(mb))
     return np.frombuffer(buf, dtype=np.uint64).astype(np.int64).tolist()
 
@@ -345,7 +346,17 @@ PATH_P2_MAX_WEIGHTED = 18_000_000   #         weighted: 8192-slot tables
 # the atomic-free path whether they arrive as one partition or as a merge of partial lists
 PATH_P3_MAX_DISTINCT = 60_000_000
 
+# path 9 (range path, include/nvt_hip.h NVT_PATH_RANGE): int32 keys without weights; ONE partition
+# pass by key range + per-bucket tables emitted in key order.  Buckets are sized for <= ~5000
+# distinct keys (16384-slot tables addressed by a monotone function of the key want a low load).
+PATH_RANGE = 9
+RANGE_AUX_WORDS, RANGE_AUX_HIST = 9504 + 4096, 8208   # include/nvt_hip.h NVT_RANGE_AUX_*
+RANGE_KEYS_PER_BUCKET = 5000
+PATH_RANGE_MAX_DISTINCT = int(os.environ.get("NVT_RANGE_MAX", 6_500_000))
+USE_RANGE = os.environ.get("NVT_RANGE", "1") != "0"
+
 _ws_cache = {}
+_RT_BYTES = {}   # range_bits -> nvt_range_table_bytes
 _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 
 
@@ -354,7 +365,7 @@ _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 COUNT_STREAMS = max(1, min(3, int(os.environ.get("NVT_COUNT_STREAMS", "3"))))
 PATH_HOT, HOT_IMAGE_WORDS = 16, 8192   # include/nvt_hip.h NVT_PATH_HOT, NVT_HOT_IMAGE_WORDS
 HOT_FILTER = os.environ.get("NVT_HOT_FILTER", "1") != "0"
-_PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 1: 2.5, 2: 3.2, 3: 3.5}
+_PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 9: 2.0, 1: 2.5, 2: 3.2, 3: 3.5}
 
 
 def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
@@ -368,7 +379,7 @@ def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
     return buf
 
 
-def _path_for(hint: int, small_tables: bool = False) -> int:
+def _path_for(hint: int, small_tables: bool = False, allow_range: bool = True) -> int:
     s_max = PATH_S_MAX_WEIGHTED if small_tables else PATH_S_MAX_DISTINCT
     if 0 < hint <= PATH_TINY_MAX:
         return 6
@@ -376,6 +387,8 @@ def _path_for(hint: int, small_tables: bool = False) -> int:
         return 0
     if hint <= PATH_S2_FACTOR * s_max and (small_tables or not HOT_FILTER):
         return 7  # (with the hot-key filter path 1 is faster there: 241 against 307 us)
+    if USE_RANGE and HOT_FILTER and allow_range and not small_tables and hint <= PATH_RANGE_MAX_DISTINCT:
+        return PATH_RANGE
     if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
         return 1
     if hint <= PATH_P2_MAX_DISTINCT:
@@ -389,8 +402,13 @@ class DenseCountJob:
     """One column's groupby-size, launched asynchronously; ``dense_count_many`` reads all
     jobs' state words back with a single device->host copy."""
 
-    def __init__(self, keys, valid, weights=None, hint: int = 0):
+    def __init__(self, keys, valid, weights=None, hint: int = 0, allow_range: bool = True):
         _lib.require_gpu()
+        self.want_table = True    # range path: also dump the count tables as the encode table
+        self.range_table = None
+        self.allow_range = allow_range  # False: the range path overflowed on this column before
+        self.range_failed = False
+        self.min_range_bits = 8
         self.lib = _lib.load()
         self.keys = aligned(keys)
         self.valid = valid
@@ -400,14 +418,21 @@ class DenseCountJob:
         self.suffix = _key_suffix(self.keys)
         self.kb = 4 if self.suffix == "i32" else 8
         self.hint = hint
-        self.path = _path_for(hint,
-                              small_tables=(weights is not None or self.kb == 8))
+        self.path = _path_for(hint, small_tables=(weights is not None or self.kb == 8),
+                              allow_range=allow_range)
         self.cap_guess = max(1 << 16, 2 * max(hint, 1))
         self.state = None  # device uint64[STATE_WORDS] view, assigned by dense_count_many
         self.result = None
         self.hot = None    # None: HOT_FILTER decides; True / False: forced (tests, probes)
 
+    def range_bits(self) -> int:
+        """log2 of the bucket count of the range path: 256 .. 1024 buckets."""
+        want = max(1, -(-max(self.hint, 1) // RANGE_KEYS_PER_BUCKET))
+        return max(self.min_range_bits, min(10, max(8, (want - 1).bit_length())))
+
     def _launch_path_of(self, path: int) -> int:
+        if path == PATH_RANGE:
+            return PATH_RANGE | (self.range_bits() << 8)
         eligible = path in (1, 2, 3) and self.kb == 4 and self.weights is None
         hot = HOT_FILTER if self.hot is None else self.hot
         return path | PATH_HOT if (eligible and hot) else path
@@ -446,7 +471,23 @@ class DenseCountJob:
         desc.out_capacity = out_cap
         desc.state = self.state.data_ptr()
         desc.hot_image = None
-        if lpath & PATH_HOT:
+        desc.range_table = None
+        if path == PATH_RANGE:
+            # aux block: hot image + range parameters (sample kernel) + class histogram
+            self.hot_image = torch.empty(RANGE_AUX_WORDS, dtype=torch.int32, device=self.dev)
+            desc.hot_image = self.hot_image.data_ptr()
+            if self.want_table:
+                # the per-bucket count tables, dumped: the column's encode table (range table)
+                bits = self.range_bits()
+                rt_bytes = _RT_BYTES.get(bits)
+                if rt_bytes is None:
+                    rt_out = C.c_uint64()
+                    check(self.lib.nvt_range_table_bytes(bits, C.byref(rt_out)))
+                    rt_bytes = _RT_BYTES[bits] = rt_out.value
+                self.range_table = torch.empty(rt_bytes, dtype=torch.uint8, device=self.dev)
+                self.table_bits = bits
+                desc.range_table = self.range_table.data_ptr()
+        elif lpath & PATH_HOT:
             # the column's own hot-key table image: sampled for all columns by one launch
             self.hot_image = torch.empty(HOT_IMAGE_WORDS, dtype=torch.int32, device=self.dev)
             desc.hot_image = self.hot_image.data_ptr()
@@ -457,13 +498,28 @@ class DenseCountJob:
         ovf = st[_lib.ST_OVERFLOW]
         if ovf & 1:
             order = PATH_ORDER
-            nxt = order.index(self.path) + 1
+            if self.path == PATH_RANGE and self.range_bits() < 10:
+                # more distinct keys than the hint promised (cold start): all 1024 buckets first
+                self.min_range_bits = 10
+                self.cap_guess = max(self.cap_guess, 1 << 22)
+                return False
+            # (the range path assumes keys spread over their range; a hash path does not)
+            nxt = order.index(1) if self.path == PATH_RANGE else order.index(self.path) + 1
+            self.range_failed = self.range_failed or self.path == PATH_RANGE
+            if (self.path == 0 and USE_RANGE and HOT_FILTER and self.allow_range and self.kb == 4
+                    and self.weights is None and not self.range_failed):
+                # LDS tables too small: the range path comes next for int32 keys
+                self.path = PATH_RANGE
+                self.cap_guess = max(self.cap_guess, 1 << 20)
+                return False
             if nxt >= len(order):
                 self._fallback()
                 return True
             self.path = order[nxt]
             if self.path == 7 and self._launch_path_of(1) & PATH_HOT:
                 self.path = 1  # the filtered path 1 beats two key classes (see _path_for)
+            if self.path == 1 and self.hint > PATH_P1_MAX_DISTINCT:
+                self.path = 2 if self.hint <= PATH_P2_MAX_DISTINCT else 3
             self.cap_guess = max(self.cap_guess, _PATH_MAX[self.path])
             return False
         if ovf & 2:
@@ -473,13 +529,25 @@ class DenseCountJob:
             return False
         m = st[_lib.ST_OCCUPIED]
         max_count = st[_lib.ST_MAXCOUNT]
+        if self.path == PATH_RANGE:
+            # key-ordered list (the sentinel key, smallest int32, already leads it) + what the
+            # one-pass vocabulary ordering needs: histogram of min(count, 255), entries >= 255
+            self.result = (self.out_k[:m], self.out_c[:m], st[_lib.ST_NULLS],
+                           dict(path=self.path, distinct=m, max_count=max_count,
+                                rows=st[_lib.ST_ROWS], sorted_by_key=True,
+                                cls_hist=self.hot_image[RANGE_AUX_HIST:RANGE_AUX_HIST + 256],
+                                n_big=st[_lib.ST_BIG], range_aux=self.hot_image,
+                                range_table=self.range_table,
+                                range_bits=self.table_bits if self.range_table is not None else 0))
+            return True
         if st[_lib.ST_SENTINEL] > 0:
             self.out_k[m] = INT32_MIN if self.kb == 4 else INT64_MIN
             self.out_c[m] = st[_lib.ST_SENTINEL]
             max_count = max(max_count, st[_lib.ST_SENTINEL])
             m += 1
         self.result = (self.out_k[:m], self.out_c[:m], st[_lib.ST_NULLS],
-                       dict(path=self.path, distinct=m, max_count=max_count, rows=st[_lib.ST_ROWS]))
+                       dict(path=self.path, distinct=m, max_count=max_count, rows=st[_lib.ST_ROWS],
+                            range_failed=self.range_failed))
         return True
 
     def _fallback(self):
@@ -499,7 +567,7 @@ class DenseCountJob:
 SAMPLE_ROWS = 1 << 18               # cold start: distinct keys of this many leading rows ...
 SAMPLE_MIN_ROWS = 8 * SAMPLE_ROWS   # ... when the column is at least this long
 # distinct keys each path is sized for (output-capacity guess when a path is entered by escalation)
-_PATH_MAX = {6: 1024, 0: 98304, 7: 196608, 1: PATH_P1_MAX_DISTINCT,
+_PATH_MAX = {6: 1024, 0: 98304, 7: 196608, 9: PATH_RANGE_MAX_DISTINCT, 1: PATH_P1_MAX_DISTINCT,
              2: PATH_P2_MAX_DISTINCT, 3: PATH_P3_MAX_DISTINCT}
 
 
@@ -543,7 +611,7 @@ def _presample(jobs):
     for j, (_, _, nulls, info) in zip(cand, _run_jobs(samples)):
         est = _estimate_distinct(info["distinct"], info["rows"] - nulls, j.n)
         j.hint = est
-        j.path = _path_for(est, small_tables=(j.kb == 8))
+        j.path = _path_for(est, small_tables=(j.kb == 8), allow_range=j.allow_range)
         j.cap_guess = max(1 << 16, 2 * est)
 
 
@@ -697,7 +765,10 @@ class EncodeTable:
     """key -> label probe table built from an ordered vocabulary."""
 
     def __init__(self, vocab_keys: torch.Tensor, first_label: int, unique: bool = False,
-                 defer_build: bool = False):
+                 defer_build: bool = False, range_table=None):
+        """range_table = (table, aux, bits): the table was dumped by the range path of the
+        counting stage and is addressed by the monotone map stored in ``aux``; it is completed
+        (positions -> labels) by nvt_vocab_finalize_many -- no table is allocated or built here."""
         _lib.require_gpu()
         self.lib = _lib.load()
         self.suffix = _key_suffix(vocab_keys)
@@ -716,11 +787,19 @@ class EncodeTable:
         # NVT_ENCODE_RESIDENT_*) is encoded from LDS alone: no global table, no build kernel
         resident = ENCODE_RESIDENT_I32 if self.key_bytes == 4 else ENCODE_RESIDENT_I64
         self.table = self.sentinel_label = None
+        self.range_aux, self.range_bits = None, 0
         self.sort_tmp = None
         self._counts = None    # the counts tensor while an internal stream still orders it
+        self._src = None       # key-sorted source list of the one-pass ordering, same lifetime
         self.ready = None      # Event recorded behind the sort / build on an internal stream
         self.pending = False   # True until the current stream has been made to wait for it
         if unique and 0 < self.n_vocab <= resident:
+            return
+        if range_table is not None:
+            assert defer_build and unique and self.key_bytes == 4
+            self.table, self.range_aux, self.range_bits = range_table
+            self.capacity = 0
+            self.sentinel_label = torch.empty(1, dtype=torch.int64, device=dev)
             return
         key = (self.key_bytes, self.capacity)
         nbytes = _ENC_BYTES.get(key)
@@ -741,9 +820,17 @@ class EncodeTable:
             "nvt_encode_build",
         )
 
-    def fill_vocab_desc(self, d: "_lib.VocabCol", counts: torch.Tensor, max_count: int):
-        """One nvt_vocab_col: order (self vocab keys, counts) in place, then build the table."""
+    def fill_vocab_desc(self, d: "_lib.VocabCol", counts: torch.Tensor, max_count: int, src=None):
+        """One nvt_vocab_col: order (self vocab keys, counts) in place, then build the table.
+        ``src`` = (keys, counts, cls_hist, n_big) of a KEY-SORTED list (range path): the
+        vocabulary is then written out of place into (self vocab keys, counts) by one stable
+        counting pass that also fills the table."""
         n = self.n_vocab
+        if src is not None:
+            return self._fill_vocab_desc_sorted(d, counts, max_count, src)
+        d.src_keys = d.src_counts = d.cls_hist = d.range_aux = None
+        d.n_big = 0
+        d.range_nb_log2 = 0
         # the counts are ordered in place on the same internal stream as the keys: they must
         # outlive the hand-off event exactly like keys / table / sort_tmp (a rank that writes
         # no artifacts used to drop its only reference right after the launch)
@@ -781,6 +868,44 @@ class EncodeTable:
         else:
             d.ready_event = None
 
+    def _fill_vocab_desc_sorted(self, d, counts, max_count, src):
+        src_keys, src_counts, cls_hist, n_big = src
+        n = self.n_vocab
+        assert self.key_bytes == 4 and src_keys.numel() == n and counts.numel() == n
+        self._counts = counts
+        self._src = (src_keys, src_counts, cls_hist)  # read on an internal stream until `ready`
+        d.keys = self._vk.data_ptr()
+        d.counts = counts.data_ptr()
+        d.n = n
+        d.max_count = int(max_count)
+        d.key_bytes = 4
+        d.unique_keys = 1
+        d.src_keys = src_keys.data_ptr()
+        d.src_counts = src_counts.data_ptr()
+        d.cls_hist = cls_hist.data_ptr()
+        d.n_big = int(n_big)
+        d.range_aux = ptr(self.range_aux)
+        d.range_nb_log2 = int(self.range_bits)
+        key = ("order", n, int(n_big))
+        nbytes = _SORT_BYTES.get(key)
+        if nbytes is None:
+            out = C.c_uint64()
+            check(self.lib.nvt_vocab_order_tmp_bytes(n, int(n_big), C.byref(out)))
+            nbytes = _SORT_BYTES[key] = out.value
+        self.sort_tmp = torch.empty(nbytes + 16, dtype=torch.uint8, device=self._vk.device)
+        d.sort_tmp = self.sort_tmp.data_ptr()
+        d.first_label = self.first_label
+        d.table = ptr(self.table)
+        d.capacity = self.capacity
+        d.sentinel_label = ptr(self.sentinel_label)
+        if ASYNC_FINALIZE:
+            if self.ready is None:
+                self.ready = Event()
+            d.ready_event = self.ready.handle
+            self.pending = True
+        else:
+            d.ready_event = None
+
     def wait_ready(self):
         """Order the CURRENT stream behind this vocabulary's sort / table build (no host
         synchronisation).  Every consumer of the vocabulary or the table calls this first."""
@@ -789,6 +914,7 @@ class EncodeTable:
             self.pending = False
             self.sort_tmp = None  # scratch of the finished sort: safe to recycle from here on
             self._counts = None
+            self._src = None
 
     def __del__(self):
         try:
@@ -814,11 +940,13 @@ class EncodeTable:
         d.vocab_keys = ptr(self.vocab_keys) if self.n_vocab else None
         d.n_vocab = self.n_vocab if self.vocab_keys is not None else 0
         d.first_label = self.first_label
+        d.range_aux = ptr(self.range_aux)
         if self.pending:
             d.wait_event = self.ready.handle  # nvt_encode_many waits on the launch stream
             self.pending = False
             self.sort_tmp = None
             self._counts = None
+            self._src = None
         else:
             d.wait_event = None
 
@@ -831,6 +959,8 @@ class EncodeTable:
         num_buckets: int = 0,
         out_dtype: torch.dtype = torch.int64,
     ) -> torch.Tensor:
+        if self.range_aux is not None:  # range tables go through the descriptor entry point
+            return encode_many([(self, keys, valid, null_label, oov_label, num_buckets)], out_dtype)[0]
         self.wait_ready()
         if keys.dtype != self.key_dtype:
             keys = keys.to(self.key_dtype)

@@ -59,6 +59,8 @@ class _GroupFit:
         self.combo = combo  # multi-column key tuple (nvt_gb_*) vs single key column
         self.table = None  # (keys, counts, max_count) dense list | K.GroupbyTable (combo)
         self.parts = []    # per-partition dense lists not merged into `table` yet
+        self.sorted = None  # (keys tensor, info) of a KEY-SORTED list (range path); applies to
+        #                     `table` only while table[0] is that very tensor
         self.nulls = 0
         self.valid_rows = 0  # non-null key rows seen (== sum of counts)
         self.hint = 1 << 12  # expected distinct keys per partition, learned as we go
@@ -171,6 +173,8 @@ class Categorify(StatOperator):
             raise ValueError("tie_break must be 'value' or 'reference'")
         self.tie_break = tie_break
         self._pending: Dict[str, dict] = {}
+        self._last_paths: Dict[str, int] = {}  # counting path of each column's last partition
+        self._no_range = set()                 # columns on which the range path overflowed
         self._lazy_finalize = None  # (groups, options, base) of a fit whose ordering is deferred
         self._writer_cache: Dict[str, bool] = {}
         self.vocabs = {}
@@ -240,7 +244,8 @@ class Categorify(StatOperator):
             g.key_dtype = keys[0].dtype
             for ci, (k, v) in enumerate(zip(keys, valids)):
                 hkey = f"{g.name}#{ci}"
-                jobs.append(K.DenseCountJob(k, v, None, hint=self._cap_hints.get(hkey, 0)))
+                jobs.append(K.DenseCountJob(k, v, None, hint=self._cap_hints.get(hkey, 0),
+                                            allow_range=hkey not in self._no_range))
                 owners.append((g, hkey))
         if jobs:
             # every column's count kernels are enqueued by ONE C call (top_level_groupby,
@@ -257,6 +262,11 @@ class Categorify(StatOperator):
         per_group = {}
         for (g, hkey), (dk, dc, nulls, info) in zip(owners, batch.results()):
             self._cap_hints[hkey] = max(64, info["distinct"])
+            self._last_paths[hkey] = info["path"]
+            if info.get("range_failed"):
+                self._no_range.add(hkey)  # keys not spread over their range: hash paths from now on
+            if info.get("sorted_by_key"):
+                g.sorted = (dk, info)
             g.nulls += nulls
             g.valid_rows += info["rows"] - nulls
             per_group.setdefault(g.name, (g, []))[1].append((dk, dc, info["max_count"]))
@@ -413,8 +423,17 @@ class Categorify(StatOperator):
             keys, counts, max_count = g.table
             keys, counts = keys.contiguous(), counts.contiguous()
             start = opts[g.name][0] + OOV_OFFSET
-            tab = K.EncodeTable(keys, start, unique=True, defer_build=True)
-            tab.fill_vocab_desc(d, counts, max_count)
+            src = rtab = None
+            if g.sorted is not None and g.sorted[0] is g.table[0] and keys.dtype == torch.int32:
+                # key-sorted list of the range path: ordered out of place in ONE counting pass
+                # (write_uniques' two sort_values, categorify.py:1300,1316)
+                info = g.sorted[1]
+                src = (keys, counts, info["cls_hist"], info["n_big"])
+                keys, counts = torch.empty_like(keys), torch.empty_like(counts)
+                if info.get("range_table") is not None:
+                    rtab = (info["range_table"], info["range_aux"], info["range_bits"])
+            tab = K.EncodeTable(keys, start, unique=True, defer_build=True, range_table=rtab)
+            tab.fill_vocab_desc(d, counts, max_count, src=src)
             built.append((g, keys, counts, tab, start))
         K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
                 "nvt_vocab_finalize_many")

@@ -1,0 +1,127 @@
+"""Range path (NVT_PATH_RANGE, csrc/nvt_range_count.hip) + one-pass vocabulary ordering
+(csrc/nvt_sort.hip cls_scatter): exact counts, key-ordered output, overflow fallback, and the
+(count desc, key asc) order / encode table built from it -- against numpy / the oracle.
+Reference semantics: categorify.py:955-1051 (groupby-size), :1300,1316 (order), :1558-1807."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _count_forced(keys, valid, path, hint):
+    from nvtabular_amd import kernels as K
+
+    job = K.DenseCountJob(keys, valid, None, hint=hint)
+    job.path = path
+    return K.dense_count_many([job])[0]
+
+
+def _zipf_keys(rng, n, card, s=1.15, scramble=True):
+    u = rng.random(n)
+    x = np.floor(((card ** (1.0 - s) - 1.0) * u + 1.0) ** (1.0 / (1.0 - s))).clip(1, card).astype(np.int64)
+    if scramble:
+        x = (x * 2654435761 + 12345) % (2**31)
+    return x.astype(np.int32)
+
+
+@pytest.mark.parametrize("n,card,hint", [
+    (300_000, 40_000, 30_000),        # 256 buckets, few keys per bucket
+    (2_000_000, 3_000_000, 1_500_000),  # 512 buckets
+    (3_000_000, 40_000_000, 6_000_000),  # 1024 buckets, mostly singletons
+    (1003, 500, 20_000),              # fewer rows than workgroups, ragged tail
+])
+@pytest.mark.parametrize("nulls", [False, True])
+def test_range_path_counts_exact_and_key_ordered(n, card, hint, nulls):
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.device import pack_bitmap
+
+    rng = np.random.default_rng(n + card)
+    ids = _zipf_keys(rng, n, card)
+    ids[7] = np.iinfo(np.int32).min  # the sentinel key is a legal value
+    ids[11] = np.iinfo(np.int32).max
+    ids[13] = -5
+    mask = rng.random(n) < 0.1 if nulls else np.zeros(n, dtype=bool)
+    mask[7] = False
+    keys = torch.from_numpy(ids).cuda()
+    valid = torch.from_numpy(pack_bitmap(~mask)).cuda() if nulls else None
+    k, c, nn, info = _count_forced(keys, valid, K.PATH_RANGE, hint)
+    assert info["path"] == K.PATH_RANGE and info["sorted_by_key"]
+    exp = pd.Series(np.ones(n, dtype=np.int64)[~mask]).groupby(ids[~mask]).sum()
+    hk, hc = k.cpu().numpy(), c.cpu().numpy()
+    assert nn == int(mask.sum()) and info["rows"] == n
+    np.testing.assert_array_equal(hk, exp.index.to_numpy())        # key order, sentinel first
+    np.testing.assert_array_equal(hc, exp.to_numpy())
+    assert info["max_count"] == int(hc.max())
+    hist = info["cls_hist"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    np.testing.assert_array_equal(hist, np.bincount(np.minimum(hc, 255), minlength=256))
+    assert info["n_big"] == int((hc >= 255).sum())
+
+
+def test_range_path_falls_back_when_keys_are_not_spread():
+    """Dense ids plus one far outlier: the sampled range is a poor partition (every key in one
+    bucket); the overflow bit sends the column to a hash path and the result stays exact."""
+    from nvtabular_amd import kernels as K
+
+    rng = np.random.default_rng(3)
+    n = 1_500_000
+    ids = rng.integers(0, 900_000, n).astype(np.int32)
+    ids[::1000] = 2**31 - 7
+    keys = torch.from_numpy(ids).cuda()
+    k, c, nn, info = _count_forced(keys, None, K.PATH_RANGE, 900_000)
+    assert info["path"] != K.PATH_RANGE
+    got = pd.Series(c.cpu().numpy(), index=k.cpu().numpy()).sort_index()
+    exp = pd.Series(np.ones(n, dtype=np.int64)).groupby(ids).sum()
+    np.testing.assert_array_equal(got.index.to_numpy(), exp.index.to_numpy())
+    np.testing.assert_array_equal(got.to_numpy(), exp.to_numpy())
+
+
+def test_range_path_dense_ids_stay_on_the_range_path():
+    """Dense ids 0..N-1 (the usual already-encoded column): direct-address like, no fallback."""
+    from nvtabular_amd import kernels as K
+
+    rng = np.random.default_rng(4)
+    n = 2_000_000
+    ids = rng.integers(0, 1_200_000, n).astype(np.int32)
+    k, c, nn, info = _count_forced(torch.from_numpy(ids).cuda(), None, K.PATH_RANGE, 1_000_000)
+    assert info["path"] == K.PATH_RANGE
+    exp = pd.Series(np.ones(n, dtype=np.int64)).groupby(ids).sum()
+    np.testing.assert_array_equal(k.cpu().numpy(), exp.index.to_numpy())
+    np.testing.assert_array_equal(c.cpu().numpy(), exp.to_numpy())
+
+
+@pytest.mark.parametrize("n,card", [(1_000_000, 400_000), (3_000_000, 5_000_000)])
+def test_workflow_on_the_range_path_vs_oracle(tmp_path, n, card):
+    """Categorify fit + transform where the column takes the range path and the one-pass
+    ordering: labels bit-exact against the oracle (count desc, value asc), unique.*.parquet
+    identical; a second fit (steady state: hints known) gives the same labels."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+    from nvtabular_amd.device import DeviceColumn, DeviceFrame, pack_bitmap
+
+    rng = np.random.default_rng(card)
+    ids = _zipf_keys(rng, n, card, s=1.1)
+    mask = rng.random(n) < 0.03
+    frame = DeviceFrame({"c": DeviceColumn(torch.from_numpy(ids).cuda(),
+                                           torch.from_numpy(pack_bitmap(~mask)).cuda())})
+    op = ops.Categorify(out_path=str(tmp_path / "g"))
+    wf = nvt.Workflow(["c"] >> op)
+    wf.fit(nvt.Dataset(frame))
+    got = wf.transform(frame)["c"].data.cpu().numpy()
+    assert op._last_paths["c#0"] == 9
+    vals = ids.astype("float64")
+    vals[mask] = np.nan
+    df = pd.DataFrame({"c": vals})
+    paths = O.categorify_fit([df], ["c"], str(tmp_path / "c"), tie_break="stable")
+    exp = O.categorify_transform(df, ["c"], paths)["c"].to_numpy()
+    np.testing.assert_array_equal(got, exp)
+    a = pd.read_parquet(tmp_path / "g" / "categories" / "unique.c.parquet")
+    b = pd.read_parquet(paths["c"])
+    np.testing.assert_array_equal(a["c"].to_numpy().astype(np.int64), b["c"].to_numpy().astype(np.int64))
+    np.testing.assert_array_equal(a["c_size"].to_numpy(), b["c_size"].to_numpy())
+    wf.fit(nvt.Dataset(frame))
+    again = wf.transform(frame)["c"].data.cpu().numpy()
+    np.testing.assert_array_equal(again, exp)

@@ -243,8 +243,9 @@ def test_fully_staged_encode_with_unseen_keys_and_nulls(tmp_path):
 
 
 def test_multi_partition_fit_on_the_filtered_partitioned_path(tmp_path):
-    """Three partitions of a 150 k-key power-law column: every partition is counted on path
-    1 | NVT_PATH_HOT (its own sampled hot set), the per-partition lists are merged by the
+    """Three partitions of a 150 k-key power-law column: every partition is counted on a
+    partitioned path behind its own sampled hot set (the range path, or path 1 | NVT_PATH_HOT
+    with NVT_RANGE=0), the per-partition lists are merged by the
     weighted count -- vocabulary and labels equal the oracle's on the whole frame."""
     import nvtabular_amd as nvt
     from nvtabular_amd import kernels as K, ops
@@ -257,7 +258,8 @@ def test_multi_partition_fit_on_the_filtered_partitioned_path(tmp_path):
     df.loc[rng.random(n) < 0.02, "c"] = pd.NA
     parts = [df.iloc[i * 400_000:(i + 1) * 400_000].reset_index(drop=True) for i in range(3)]
     host = _host_view(df)
-    assert K._path_for(host["c"].nunique()) == 1 and K.HOT_FILTER
+    # (a partitioned path: the range path by default, the filtered hash path 1 with NVT_RANGE=0)
+    assert K._path_for(host["c"].nunique()) in (1, K.PATH_RANGE) and K.HOT_FILTER
     wf = nvt.Workflow(["c"] >> ops.Categorify(out_path=str(tmp_path / "gpu")))
     wf.fit(nvt.Dataset(parts))
     out = wf.transform(nvt.Dataset(df)).to_ddf().compute()

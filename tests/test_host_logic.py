@@ -46,10 +46,19 @@ def test_path_selection_thresholds():
     assert K._path_for(3) == 6 and K._path_for(64) == 6
     assert K._path_for(65) == 0 and K._path_for(K.PATH_S_MAX_DISTINCT) == 0
     # 11-21 k int32 keys: two key classes (path 7) only without the hot-key filter
-    assert K._path_for(K.PATH_S_MAX_DISTINCT + 1) == (1 if K.HOT_FILTER else 7)
-    assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_DISTINCT) + 1) == 1
-    assert K._path_for(K.PATH_P1_MAX_DISTINCT + 1) == 2
+    # int32 keys without weights: the range path (9) from the end of the LDS-table path up to
+    # ~6.5 M distinct keys, hash partitions beyond
+    rng_on = K.USE_RANGE and K.HOT_FILTER
+    assert K._path_for(K.PATH_S_MAX_DISTINCT + 1) == (9 if rng_on else 1 if K.HOT_FILTER else 7)
+    assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_DISTINCT) + 1) == (9 if rng_on else 1)
+    assert K._path_for(K.PATH_P1_MAX_DISTINCT + 1) == (9 if rng_on else 2)
+    assert K._path_for(K.PATH_RANGE_MAX_DISTINCT + 1) == 2
     assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1) == 3
+    j = K.DenseCountJob.__new__(K.DenseCountJob)
+    j.min_range_bits = 8
+    for hint, bits in ((12_000, 8), (1_200_000, 8), (1_300_000, 9), (2_600_000, 10), (6_400_000, 10)):
+        j.hint = hint
+        assert j.range_bits() == bits, (hint, j.range_bits())
     assert K._path_for(K.PATH_P3_MAX_DISTINCT + 1) == -1   # global-table fallback
     # int64 keys / weighted merges use the smaller tables
     assert K._path_for(K.PATH_S_MAX_WEIGHTED + 1, small_tables=True) == 7
