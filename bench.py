@@ -216,16 +216,33 @@ def parity_check(frame, cat_names, cont_names, rows, oracle_out, tmp):
             "normalize_max_rel_err": worst}
 
 
-def pmc_traffic(name):
-    """HBM bytes per launch of the dominant kernel family from the committed PMC passes
-    (profiles/r02_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate
-    `rocprofv3 --pmc` passes over this command and corrected per MI355X_MICROARCH.md; made by
-    tools/pmc_bench.sh + tools/pmc_summarize.py).  PMC cannot be sampled from inside the timed
-    run, so this is the figure of the same command at the same size."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+FAMILIES = {
+    # kernel family -> (scope-name prefixes, algorithmic bytes per row per column, columns)
+    "count": (("dense_count_",), 4, "cat"),            # Categorify.fit: groupby-size
+    "vocab_order": (("vocab_", "encode_build"), 0, "cat"),  # write_uniques + encode tables: no column bytes
+    "encode": (("encode_i32", "encode_i64"), 12, "cat"),    # Categorify.transform
+    "moments": (("moments",), 4, "cont"),              # Normalize.fit
+    "fill_normalize": (("fill_normalize",), 12, "cont"),
+}
+
+
+def family_of(scope):
+    for fam, (prefixes, _, _) in FAMILIES.items():
+        if any(scope.startswith(p) for p in prefixes):
+            return fam
+    return scope
+
+
+def pmc_traffic():
+    """HBM bytes from the committed PMC passes (profiles/r03_pmc_traffic.json: FETCH_SIZE /
+    WRITE_SIZE collected in separate `rocprofv3 --pmc` passes over this command and corrected
+    per MI355X_MICROARCH.md; made by tools/prof_r03.sh + tools/pmc_summarize.py).  PMC cannot be
+    sampled from inside the timed run, so these are the figures of the same command at the same
+    size.  -> {"families": {family: bytes per step}, "step": bytes per step} or None."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["scopes"][name]["hbm_bytes_per_launch"]
+            return json.load(f)
     except Exception:
         return None
 
@@ -357,6 +374,174 @@ def extra_cfg4(device, tmp, rows, sample_rows, steps=5):
     return res
 
 
+def _timed_steps(step, steps):
+    """(ms per step, profile report of one more step) of a fit + transform closure."""
+    from nvtabular_amd import kernels as K
+
+    step()  # cold
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    K.profile_begin()
+    out = step()
+    rep = K.profile_report()
+    del out
+    return ms, rep
+
+
+def extra_cfg3(device, tmp, rows, ncols=4, card=100_000_000, steps=3):
+    """BASELINE.json configs[2]'s worst columns on one GPU: the Criteo-1TB `--high-cards`
+    columns (bench/examples/dask-nvtabular-criteo-benchmark.py:360-366: 38-40 M uniques).
+    `ncols` columns x `rows` rows of uniform int32 ids out of `card` (~36 M distinct per
+    column at 45 M rows): nothing is hot, every row is partitioned (path 3: 64 x 256 buckets)
+    and every encode probes a table in HBM.  Categorify fit + transform, HBM-resident."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+    from nvtabular_amd.device import DeviceColumn, DeviceFrame
+    from nvtabular_amd.node import iter_nodes
+
+    frame = DeviceFrame()
+    for j in range(ncols):
+        g = torch.Generator(device=device).manual_seed(900 + j)
+        x = torch.randint(0, card, (rows,), device=device, generator=g, dtype=torch.int64)
+        frame[f"H{j}"] = DeviceColumn(((x * 2654435761 + 17 * j) % (2**31)).to(torch.int32))
+        del x
+    names = list(frame.columns)
+    wf = nvt.Workflow(names >> ops.Categorify(out_path=os.path.join(tmp, "cfg3"), defer_artifacts=True))
+    ds = nvt.Dataset(frame)
+
+    def step():
+        wf.fit(ds)
+        return wf.transform(frame)
+
+    ms, rep = _timed_steps(step, steps)
+    op = [n.op for n in iter_nodes(wf.output_node) if type(n.op).__name__ == "Categorify"][0]
+    keys, counts = op.fitted_vocabulary(names[0])
+    bytes_per_row = ncols * (4 + 12)
+    res = {
+        "workload": f"{ncols} high-cardinality int32 columns x {rows} rows, uniform over {card} ids "
+                    f"({int(keys[0].numel())} distinct in the first), Categorify fit + transform",
+        "rows_per_s": rows / (ms / 1e3), "ms_per_step": ms,
+        "algorithmic_bytes_per_row": bytes_per_row,
+        "algorithmic_GBps": rows / (ms / 1e3) * bytes_per_row / 1e9,
+        "counting_paths": sorted(set(op._last_paths.values())),
+        "gpu_busy_ms": round(rep["busy_ms"], 3),
+        "per_kernel_ms": {k: round(v[0], 3) for k, v in rep["kernels"].items()},
+    }
+    # parity of the whole column set through properties (the oracle cannot hold 36 M-key pandas
+    # groupbys in seconds): labels are a bijection between keys and [3, 3 + distinct), counts sum
+    # to the rows, the order is (count desc, key asc)
+    out = wf.transform(frame)
+    lab = out[names[0]].data
+    n_distinct = int(keys[0].numel())
+    ok = int(lab.min().item()) == 3 and int(lab.max().item()) == 2 + n_distinct
+    ok = ok and bool(torch.equal(keys[0][(lab - 3)], frame[names[0]].data))
+    ok = ok and int(counts.sum().item()) == rows
+    c = counts
+    k64 = keys[0].to(torch.int64)
+    ok = ok and bool(((c[:-1] > c[1:]) | ((c[:-1] == c[1:]) & (k64[:-1] < k64[1:]))).all().item())
+    res["parity"] = {"property_checks": "labels <-> vocabulary bijection, counts sum to rows, "
+                                        "order (count desc, key asc)", "parity_ok": bool(ok)}
+    return res
+
+
+def extra_cfg5(device, tmp, rows=10_000_000, steps=3):
+    """BASELINE.json configs[4]: multi-hot list<int32> column (0..8 leaves per row, Zipf over
+    1 M ids) + a scalar id column: Categorify on both and HashBucket on the list column
+    (categorify.py:1696,1803; hash_bucket.py:93-96 act on the leaves and keep the offsets).
+    The list path reuses the scalar kernels on the leaves; parity against the oracle on a
+    sample."""
+    import pandas as pd
+
+    import nvtabular_amd as nvt
+    import oracle as O
+    from nvtabular_amd import ops
+    from nvtabular_amd.device import DeviceColumn, DeviceFrame
+
+    g = torch.Generator(device=device).manual_seed(55)
+    lens = torch.randint(0, 9, (rows,), device=device, generator=g, dtype=torch.int64)
+    offsets = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(lens, 0)
+    nleaf = int(offsets[-1].item())
+    u = torch.rand(nleaf, device=device, dtype=torch.float64, generator=g)
+    s, card = 1.15, 1.0e6
+    x = (((card ** (1.0 - s) - 1.0) * u + 1.0) ** (1.0 / (1.0 - s))).floor().clamp_(1, card).to(torch.int64)
+    leaves = ((x * 2654435761) % (2**31)).to(torch.int32)
+    item = torch.randint(0, 50_000, (rows,), device=device, generator=g, dtype=torch.int32)
+    frame = DeviceFrame({"tags": DeviceColumn(leaves, None, offsets), "item": DeviceColumn(item)})
+
+    def build(path):
+        cats = ["tags", "item"] >> ops.Categorify(out_path=path, defer_artifacts=True)
+        hb = ["tags"] >> ops.HashBucket(1000) >> ops.Rename(postfix="_hb")
+        return nvt.Workflow(cats + hb)
+
+    wf = build(os.path.join(tmp, "cfg5"))
+    ds = nvt.Dataset(frame)
+
+    def step():
+        wf.fit(ds)
+        return wf.transform(frame)
+
+    ms, rep = _timed_steps(step, steps)
+    bytes_per_row_leaf = 4 + 12 + 4 + 4  # categorify fit + transform, hash bucket in + out
+    res = {
+        "workload": f"{rows} rows, list<int32> column with {nleaf} leaves (Zipf over 1e6 ids) + "
+                    "scalar id column: Categorify (both) + HashBucket(1000) (list), fit + transform",
+        "rows_per_s": rows / (ms / 1e3), "leaves_per_s": nleaf / (ms / 1e3), "ms_per_step": ms,
+        "algorithmic_GBps": (nleaf * bytes_per_row_leaf + rows * 16) / (ms / 1e3) / 1e9,
+        "gpu_busy_ms": round(rep["busy_ms"], 3),
+        "per_kernel_ms": {k: round(v[0], 3) for k, v in rep["kernels"].items()},
+    }
+    # parity on the first 200 k rows against the oracle
+    m = 200_000
+    hoff = offsets[: m + 1].cpu().numpy()
+    hleaf = leaves[: int(hoff[-1])].cpu().numpy()
+    hdf = pd.DataFrame({"tags": [hleaf[a:b] for a, b in zip(hoff[:-1], hoff[1:])],
+                        "item": item[:m].cpu().numpy()})
+    sub = DeviceFrame({"tags": DeviceColumn(leaves[: int(hoff[-1])].contiguous(), None,
+                                            offsets[: m + 1].contiguous()),
+                       "item": DeviceColumn(item[:m].contiguous())})
+    wf2 = build(os.path.join(tmp, "cfg5_par"))
+    wf2.fit(nvt.Dataset(sub))
+    got = wf2.transform(sub)
+    paths = O.categorify_fit([hdf], ["tags", "item"], os.path.join(tmp, "cfg5_cpu"), tie_break="stable")
+    exp = O.categorify_transform(hdf, ["tags", "item"], paths)
+    exp_leaves = np.concatenate([np.asarray(r) for r in exp["tags"]]) if m else np.empty(0)
+    ok = bool((got["tags"].data.cpu().numpy() == exp_leaves).all())
+    ok = ok and bool((got["item"].data.cpu().numpy() == exp["item"].to_numpy()).all())
+    hb_exp = np.concatenate([np.asarray(r) for r in
+                             O.hash_bucket_op(hdf[["tags"]].copy(), 1000, cols=["tags"])["tags"]])
+    ok = ok and bool((got["tags_hb"].data.cpu().numpy() == hb_exp).all())
+    res["parity"] = {"parity_checked_rows": m, "parity_ok": ok}
+    return res
+
+
+def eager_artifacts_step_ms(frame, cat_names, cont_names, tmp, steps=2):
+    """The drop-in default: Categorify(defer_artifacts=False) writes unique.*/meta.*.parquet
+    inside fit like the reference (categorify.py:1326-1334).  ms per fit + transform step."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    cats = cat_names >> ops.Categorify(out_path=os.path.join(tmp, "eager"))
+    conts = cont_names >> ops.FillMissing() >> ops.Normalize()
+    wf = nvt.Workflow(cats + conts)
+    ds = nvt.Dataset(frame)
+    wf.fit(ds)
+    out = wf.transform(frame)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wf.fit(ds)
+        out = wf.transform(frame)
+    torch.cuda.synchronize()
+    del out
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,10 +637,21 @@ def main():
 
     # cold step: a fresh workflow with no cardinality hints (reported, never `value`)
     barrier()
+    K.STATS["count_relaunches"] = 0
+    cold_alloc0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     out = step()
+    t_enq = time.perf_counter()
     barrier()
     cold_ms = 1e3 * (time.perf_counter() - t0)
+    cold_info = {
+        "fit_ms": round(1e3 * (marks[-1][1] - marks[-1][0]), 2),
+        "transform_enqueue_ms": round(1e3 * (marks[-1][2] - marks[-1][1]), 2),
+        "drain_ms": round(cold_ms - 1e3 * (t_enq - t0), 2),
+        "device_allocs": int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - cold_alloc0),
+        "count_relaunches": int(K.STATS["count_relaunches"]),
+        "presampled_columns": int(K.STATS["presampled_columns"]),
+    }
     # The timed loop keeps the previous step's output frame alive while the next one is
     # produced (`out = step()`), so TWO 14 GB output sets coexist.  If the caching allocator
     # first meets that during the timed region it has to hipMalloc 39 x 360 MB blocks with the
@@ -534,21 +730,44 @@ def main():
     bytes_per_row = (C * 4 + Kc * 4) + (C * 12 + Kc * 12)
     gbs = rows_per_s * bytes_per_row / 1e9
 
-    # dominant kernel by summed launch time (HIP events around each kernel family, recorded by
-    # the library on the launch stream during the profiled pass), among the kernels that
-    # stream the column data (algorithmic bytes > 0)
+    # Roofline: the kernel FAMILY with the largest summed time among those that stream column
+    # data (HIP events around every launch scope, recorded by the library on the launch stream in
+    # the third pass; a family = all paths / columns of one operator stage).  achieved = the
+    # family's algorithmic bytes per step / its time per step; "launch" = one column's pass.
     roofline = None
     if prof:
-        name, (tot_ms, launches, alg_bytes) = max(
-            ((k, v) for k, v in prof.items() if v[2] > 0), key=lambda kv: kv[1][0])
-        avg_s = tot_ms / launches / 1e3
-        achieved = alg_bytes / launches / avg_s / 1e9
+        ncols = {"cat": C, "cont": Kc}
+        fam = {}
+        for scope, (tot_ms, launches, _) in prof.items():
+            f = fam.setdefault(family_of(scope), {"ms": 0.0, "launches": 0})
+            f["ms"] += tot_ms / args.steps
+            if scope != "dense_count_sample":  # (one batched launch per step, not a column pass)
+                f["launches"] += launches / args.steps
+        traffic = pmc_traffic() if world == 1 and n == 45_000_000 else None
+        per_family = {}
+        for name, f in fam.items():
+            _, bpr, kind = FAMILIES.get(name, ((), 0, "cat"))
+            fbytes = bpr * n * ncols[kind]
+            per_family[name] = {
+                "algorithmic_bytes_per_step": fbytes, "ms_per_step": round(f["ms"], 3),
+                "launches_per_step": round(f["launches"], 1),
+                "GBps": round(fbytes / (f["ms"] / 1e3) / 1e9, 1) if f["ms"] > 0 else None,
+                "frac": round(fbytes / (f["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if f["ms"] > 0 else None,
+                "hbm_traffic_bytes_per_step": (traffic or {}).get("families", {}).get(name),
+            }
+        dom = max((k for k, v in per_family.items() if v["algorithmic_bytes_per_step"] > 0),
+                  key=lambda k: per_family[k]["ms_per_step"])
+        d = per_family[dom]
+        launches = max(d["launches_per_step"], 1.0)
         roofline = {
-            "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(name),
-            "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
-            "algorithmic_bytes_per_launch": alg_bytes // launches,
+            "bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": d["frac"],
+            "traffic": (d["hbm_traffic_bytes_per_step"] / launches
+                        if d["hbm_traffic_bytes_per_step"] else None),
+            "avg_launch_us": round(1e3 * d["ms_per_step"] / launches, 2),
+            "launches": int(round(launches * args.steps)),
+            "algorithmic_bytes_per_launch": int(d["algorithmic_bytes_per_step"] / launches),
+            "per_family": per_family,
             "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
             "launch_scopes_per_step": round(sum(v[1] for v in prof.values()) / args.steps, 1),
             "measured_in": "third pass: cross-stream overlap off (NVT_ASYNC_FINALIZE=0 "
@@ -558,6 +777,9 @@ def main():
             "overlapped_per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3)
                                                   for k, v in rep["kernels"].items()},
         }
+        step_traffic = (traffic or {}).get("step")
+    else:
+        step_traffic = None
 
     result = {
         "metric": "rows/sec + GB/s (Criteo Categorify+FillMissing+Normalize fit+transform, HBM-resident)",
@@ -570,6 +792,7 @@ def main():
         "gpu_busy_ms_per_step": round(rep["busy_ms"] / args.steps, 3),
         "profiled_pass_ms_per_step": round(1e3 * dt_prof / args.steps, 3),
         "cold_step_ms": round(cold_ms, 2),
+        "cold_step": cold_info,
         "host_timeline_ms": _host_timeline(timed_marks),
         # hipMalloc calls the caching allocator had to make inside the timed region (0 = the
         # warm-up reached the steady-state footprint)
@@ -593,19 +816,37 @@ def main():
         },
         "algorithmic_GBps": gbs,
         "frac_of_hbm_peak": gbs / (HBM_PEAK_GBS * world),
+        "algorithmic_bytes_per_step": bytes_per_row * n,
+        "step_traffic_bytes": step_traffic,  # HBM bytes per step from the committed PMC passes
         "roofline": roofline,
     }
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline:
+        # (rank 0 only, also when world > 1: its own shard, a single-rank fit for the parity leg)
+        from nvtabular_amd import dist as _dist
+
         sample = min(args.cpu_sample, n) // 8 * 8
         result["cpu_baseline"], oracle_out = cpu_baseline(frame, cat_names, cont_names, sample, tmp)
-        result["parity"] = parity_check(frame, cat_names, cont_names, sample, oracle_out, tmp)
+        with _dist.local_only():
+            result["parity"] = parity_check(frame, cat_names, cont_names, sample, oracle_out, tmp)
     if rank == 0 and world == 1 and not args.no_extra and not args.no_cpu_baseline:
+        # entries beside the headline number (never `value`); none of them may break the line
+        try:
+            result["eager_artifacts_step_ms"] = round(
+                eager_artifacts_step_ms(frame, cat_names, cont_names, tmp), 1)
+        except Exception as e:
+            result["eager_artifacts_step_ms"] = {"error": repr(e)}
         del frame, ds, wf
         torch.cuda.empty_cache()
-        try:
-            result["extra_configs"] = {"cfg4_te_joingroupby": extra_cfg4(device, tmp, args.cfg4_rows, 1_000_000)}
-        except Exception as e:  # the headline line must not depend on the extra entry
-            result["extra_configs"] = {"cfg4_te_joingroupby": {"error": repr(e)}}
+        extras = {}
+        for key, fn in (("cfg4_te_joingroupby", lambda: extra_cfg4(device, tmp, args.cfg4_rows, 1_000_000)),
+                        ("cfg3_highcard_columns", lambda: extra_cfg3(device, tmp, n)),
+                        ("cfg5_multihot", lambda: extra_cfg5(device, tmp))):
+            try:
+                extras[key] = fn()
+            except Exception as e:
+                extras[key] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+        result["extra_configs"] = extras
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -1137,7 +1137,7 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
     NVT_CHECK_HIP(hipMemsetAsync(sentinel_label, 0xFF, 8, s));  // -1: no sentinel key
   }
   {
-    NVT_PROF("vocab_order", n * 24, s);
+    NVT_PROF("vocab_order", 0, s);
     NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 256 * 4 + 64, s));
     cls_scatter_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(
         src_keys, src_cnts, n, cls_hist, status, ticket, out_keys, out_cnts,

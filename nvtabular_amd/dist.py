@@ -28,11 +28,34 @@ import torch
 import torch.distributed as td
 
 
+_local_only = 0
+
+
+class local_only:
+    """Within this block the process behaves as a single-rank job although a process group
+    exists: a fit made by ONE rank alone (bench.py's parity leg on rank 0) must not enter the
+    collectives its peers are not taking part in."""
+
+    def __enter__(self):
+        global _local_only
+        _local_only += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _local_only
+        _local_only -= 1
+        return False
+
+
 def world_size() -> int:
+    if _local_only:
+        return 1
     return td.get_world_size() if td.is_available() and td.is_initialized() else 1
 
 
 def rank() -> int:
+    if _local_only:
+        return 0
     return td.get_rank() if td.is_available() and td.is_initialized() else 0
 
 

@@ -594,6 +594,9 @@ def _estimate_distinct(d: int, m: int, n: int) -> int:
     return int(min(n, 3.0 * D + 64))
 
 
+STATS = {"count_relaunches": 0, "presampled_columns": 0}  # diagnostics (bench.py cold step)
+
+
 def _presample(jobs):
     """Jobs with no cardinality hint (first partition of a fit) start on a path chosen from
     the distinct count of a 256 K-row prefix instead of climbing PATH_ORDER from the bottom:
@@ -611,6 +614,10 @@ def _presample(jobs):
     for j, (_, _, nulls, info) in zip(cand, _run_jobs(samples)):
         est = _estimate_distinct(info["distinct"], info["rows"] - nulls, j.n)
         j.hint = est
+        STATS["presampled_columns"] += 1
+        # an estimate, not a hint: the range path starts with all its buckets (a column with more
+        # keys than estimated would overflow 256 / 512 buckets and be counted twice)
+        j.min_range_bits = 10
         j.path = _path_for(est, small_tables=(j.kb == 8), allow_range=j.allow_range)
         j.cap_guess = max(1 << 16, 2 * est)
 
@@ -671,6 +678,7 @@ class CountBatch:
             while self.pending:
                 host = read_back(self.states).tolist()  # the single synchronisation point
                 self.pending = [j for i, j in enumerate(self.pending) if not j.resolve(host[i])]
+                STATS["count_relaunches"] += len(self.pending)
                 self._launch()
             self._results = [j.result for j in self.jobs]
         return self._results
