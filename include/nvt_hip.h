@@ -69,6 +69,7 @@ extern "C" {
 /* words 5..7: scratch cursors of nvt_dense_count_*                                  */
 #define NVT_ST_MAXCOUNT 8  /* nvt_dense_count_*: largest count in the output list    */
 #define NVT_ST_BIG 9       /* range path: entries whose count is >= 255            */
+#define NVT_ST_NEED 10     /* range path, overflow bit1: entries the output list needs */
 #define NVT_STATE_WORDS 16
 
 int nvt_version(void);
@@ -429,6 +430,9 @@ typedef struct nvt_vocab_col {
   int32_t range_nb_log2;
 } nvt_vocab_col;
 int nvt_vocab_order_tmp_bytes(uint64_t n, uint64_t n_big, uint64_t *bytes);
+/* hist[c] = entries with min(counts[i], 255) == c, for a key-sorted list that did not come from
+ * the range path (multi-GPU: gathered owner shards); hist[255] = n_big */
+int nvt_class_hist(const int64_t *counts, uint64_t n, uint32_t *hist, void *stream);
 int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, void *stream);
 
 /* one column of Categorify.transform; fields as the arguments of nvt_encode_* */

@@ -23,6 +23,7 @@ NVT_GB_SUMSQ, NVT_GB_MINMAX = 1, 2
 ST_NULLS, ST_SENTINEL, ST_OCCUPIED, ST_OVERFLOW, ST_ROWS = 0, 1, 2, 3, 4
 ST_MAXCOUNT = 8
 ST_BIG = 9
+ST_NEED = 10
 STATE_WORDS = 16
 
 _vp, _u64, _i64, _i32, _u32, _dbl = (
@@ -53,6 +54,7 @@ SIGNATURES = {
     "nvt_dense_count_i64": [_vp, _vp, _vp, _u64, _i32, _vp, _vp, _vp, _u64, _vp, _vp],
     "nvt_vocab_sort_tmp_bytes": [_i32, _u64, C.POINTER(_u64)],
     "nvt_vocab_order_tmp_bytes": [_u64, _u64, C.POINTER(_u64)],
+    "nvt_class_hist": [_vp, _u64, _vp, _vp],
     "nvt_vocab_sort_i32": [_vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_vocab_sort_i64": [_vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_encode_table_bytes": [_i32, _u64, C.POINTER(_u64)],

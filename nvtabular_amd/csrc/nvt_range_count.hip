@@ -477,10 +477,12 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
   NVT_TM();
   const unsigned long long base = s_base;
   if (b == NB - 1 && threadIdx.x == 0) {
-    if (base + E > out_cap)
+    if (base + E > out_cap) {
       atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW], 2ull);
-    else
+      state[NVT_ST_NEED] = base + E;  // the relaunch can be sized exactly
+    } else {
       state[NVT_ST_OCCUPIED] = base + E;
+    }
   }
   if (bad || full) {
     if (threadIdx.x == 0 && (lovf != 0 || full))

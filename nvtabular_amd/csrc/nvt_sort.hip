@@ -1105,6 +1105,29 @@ __global__ __launch_bounds__(kBlock) void range_fix_prefix_kernel(
   }
 }
 
+// histogram of min(count, 255) of a (key, count) list that did not come from the range path (the
+// multi-GPU merge gathers key-sorted owner shards): what cls_scatter_kernel needs
+__global__ __launch_bounds__(kBlock) void class_hist_kernel(const int64_t *__restrict__ cnts,
+                                                            uint64_t n, unsigned *hist) {
+  __shared__ unsigned h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  unsigned ones = 0;  // class 1 is most of a power-law vocabulary: counted in a register
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t c = cnts[i];
+    if (c == 1)
+      ++ones;
+    else
+      atomicAdd(&h[c < 255 ? (c < 0 ? 0 : (unsigned)c) : 255u], 1u);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ones += __shfl_down(ones, off, 64);
+  if (lane_id() == 0 && ones) atomicAdd(&h[1], ones);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
 uint64_t vocab_order_tmp_bytes(uint64_t n, uint64_t n_big) {
   const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
   uint64_t sort_bytes = 0;
@@ -1184,6 +1207,15 @@ int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes) {
            (uint64_t)(key_bytes + 8) * 256 * 8 + 64;
   if (key_bytes == 4 && sort2_tmp_bytes(n) > *bytes) *bytes = sort2_tmp_bytes(n);
   if (key_bytes == 4 && os_tmp_bytes(n) > *bytes) *bytes = os_tmp_bytes(n);
+  return NVT_OK;
+}
+int nvt_class_hist(const int64_t *counts, uint64_t n, uint32_t *hist, void *stream) {
+  NVT_CHECK_ARG(hist && (n == 0 || counts), "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_CHECK_HIP(hipMemsetAsync(hist, 0, 256 * 4, s));
+  if (n == 0) return NVT_OK;
+  class_hist_kernel<<<stream_grid(n, kBlock * 8, 4), kBlock, 0, s>>>(counts, n, hist);
+  NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
 int nvt_vocab_order_tmp_bytes(uint64_t n, uint64_t n_big, uint64_t *bytes) {

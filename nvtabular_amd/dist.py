@@ -176,6 +176,15 @@ def _all_gather_v(t: torch.Tensor, sizes: Optional[List[int]] = None) -> torch.T
     if sizes is None:
         n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
         sizes = [int(s.item()) for s in _all_gather_same(n)]
+    if _backend() == "nccl":
+        # exact sizes, no padding to the longest shard (key-range owners are not balanced):
+        # an all-to-all(v) in which every rank sends its whole tensor to every peer moves
+        # exactly the bytes of an all-gather(v)
+        out = torch.empty((sum(sizes),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        n = int(t.shape[0])
+        send = t.contiguous().repeat((G,) + (1,) * (t.dim() - 1))
+        td.all_to_all_single(out, send, output_split_sizes=list(sizes), input_split_sizes=[n] * G)
+        return out
     m = max(sizes) if sizes else 0
     pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
@@ -183,14 +192,50 @@ def _all_gather_v(t: torch.Tensor, sizes: Optional[List[int]] = None) -> torch.T
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
 
 
+def _pack64(columns: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Columns of one table as ONE int64 [rows, ncols] matrix (float64 bit-cast, narrower integer
+    types widened), so that a table travels in one collective instead of one per column."""
+    cols = []
+    for c in columns:
+        if c.dtype == torch.float64:
+            cols.append(c.contiguous().view(torch.int64))
+        else:
+            cols.append(c.to(torch.int64))
+    if not cols:
+        return torch.empty((0, 0), dtype=torch.int64)
+    return torch.stack(cols, dim=1)
+
+
+def _unpack64(mat: torch.Tensor, like: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    out = []
+    for j, c in enumerate(like):
+        col = mat[:, j].contiguous()
+        out.append(col.view(torch.float64) if c.dtype == torch.float64 else col.to(c.dtype))
+    return out
+
+
 def exchange_rows(columns: Sequence[torch.Tensor], owner: torch.Tensor) -> List[torch.Tensor]:
-    """Send row i of every column to rank owner[i]; returns the received columns."""
+    """Send row i of every column to rank owner[i]; returns the received columns.  ONE
+    all-to-all(v) for the whole table (it used to be one per column: >= 8 latency-bound
+    collectives per JoinGroupby / TargetEncoding table)."""
     G = world_size()
-    order = torch.argsort(owner, stable=True)
-    send_counts_t = torch.bincount(owner.to(torch.int64), minlength=G).to(torch.int64)
+    owner64 = owner.to(torch.int64)
+    if owner.is_cuda:
+        from . import kernels as K
+
+        order = K.order_rows(int(owner.numel()), owner.device, gid=owner64, ngroups=G) & 0xFFFFFFFF
+    else:
+        order = torch.argsort(owner64, stable=True)
+    send_counts_t = torch.bincount(owner64, minlength=G).to(torch.int64)
     recv_counts_t = _all_to_all_counts(send_counts_t)
     sc, rc = send_counts_t.cpu().tolist(), recv_counts_t.cpu().tolist()
-    return [_all_to_all_v(c[order].contiguous(), sc, rc) for c in columns]
+    mat = _pack64(columns)[order].contiguous()
+    return _unpack64(_all_to_all_v(mat, sc, rc), columns)
+
+
+def gather_rows(columns: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """Every rank's rows of a table, concatenated in rank order: ONE all-gather(v)."""
+    return _unpack64(_all_gather_v(_pack64(columns)), columns)
 
 
 # --------------------------------------------------------------------------
@@ -244,8 +289,42 @@ def merge_counts(keys: torch.Tensor, counts: torch.Tensor, nulls: int):
     """Global (key -> count) table from per-rank tables; identical on every rank."""
     if world_size() == 1:
         return keys, counts, nulls
-    k, c, sc = merge_counts_many([(keys, counts, [nulls])])[0]
+    k, c, sc, _ = merge_counts_many([(keys, counts, [nulls])])[0]
     return k, c, sc[0]
+
+
+def _range_owner(k64: torch.Tensor, lo: int, hi: int, G: int) -> torch.Tensor:
+    """Owner rank of every key by KEY RANGE: rank r owns [lo + r * w, lo + (r + 1) * w) with
+    w = ceil((hi - lo + 1) / G) -- monotone in the key, so the owners' key-sorted shards,
+    concatenated in rank order, are one key-sorted list.  (Plain integer arithmetic on int64
+    tensors: O(#distinct keys) plumbing, runs on host tensors in the gloo tests.)"""
+    span = hi - lo + 1
+    width = -(-span // G)
+    # (k - lo) can exceed int64 for int64 keys spanning the whole range: halve both first
+    if span >= (1 << 62):
+        return (((k64 >> 1) - (lo >> 1)) // max(width >> 1, 1)).clamp_(0, G - 1)
+    return ((k64 - lo) // width).clamp_(0, G - 1)
+
+
+def _sort_by_key_default(keys, counts):
+    if keys.is_cuda:
+        from . import kernels as K
+
+        return K.sort_by_key(keys, counts)
+    order = torch.argsort(keys, stable=True)  # host stand-in (gloo tests)
+    return keys[order].contiguous(), counts[order].contiguous()
+
+
+def _class_hist_default(counts):
+    if counts.is_cuda:
+        from . import kernels as K
+
+        return K.class_hist(counts)
+    return torch.bincount(counts.clamp(max=255), minlength=256).to(torch.int32)
+
+
+_sort_by_key_fn: Callable = _sort_by_key_default
+_class_hist_fn: Callable = _class_hist_default
 
 
 def merge_counts_many(tables):
@@ -255,39 +334,58 @@ def merge_counts_many(tables):
     summed over the ranks (null rows, valid rows, ...).  Every column's rows travel in the
     same collectives, tagged by column:
 
-        owner(key) = h32(key) % G per column
+        all-reduce of the per-column key ranges   (1 collective: min / max of the keys)
+        owner(key) = key range r of G equal ranges per column (monotone in the key)
         rows sorted by (owner, column)            -> [G x ncol] send-count matrix
-        all-to-all of the count matrix            (1 collective)
-        all-to-all(v) of the (key, count) rows    (1 collective, int64 pairs)
-        owner-side merge per column               (weighted dense count)
+        all-to-all of the count matrix            (1)
+        all-to-all(v) of the (key, count) rows    (1, int64 pairs)
+        owner-side merge per column (weighted dense count), then ordered BY KEY
         all-gather of the [ncol] merged lengths   (1)
         all-gather(v) of the merged rows          (1)
         all-reduce of the scalars                 (1)
 
-    -- 5 collectives per fit however many columns there are (the first version issued 7 per
-    column: 182 latency-bound RCCL calls and 78 host syncs for the 26 Criteo columns).
-    Returns [(keys, counts, summed_scalars)], identical on every rank, keys in the dtype of
-    the input (columns whose local table is empty come back as int64)."""
+    -- 6 collectives per fit however many columns there are.  Because owners hold key RANGES
+    and order their shards by key, the gathered list of a column is key-sorted on every rank:
+    the vocabulary order (count desc, key asc) is then ONE stable counting pass per rank
+    (nvt_vocab_col.src_keys) instead of a 7-pass radix sort of the union on every rank -- the
+    part of the finalisation that grew with the number of GPUs.  (The reference partitions the
+    uniques for the same reason: split_out, categorify.py:152-160,1214-1270.)
+    Returns [(keys, counts, summed_scalars, info)], identical on every rank; info =
+    dict(sorted_by_key=True, cls_hist=int32[256], n_big) for the ordering pass.  Keys come back
+    in the dtype of the input (columns whose local table is empty everywhere: int64)."""
     G = world_size()
     if G == 1:
-        return [(k, c, list(sc)) for k, c, sc in tables]
+        return [(k, c, list(sc), None) for k, c, sc in tables]
     ncol = len(tables)
     dev = tables[0][0].device
     dtypes = [k.dtype for k, _, _ in tables]
     lens = [int(k.numel()) for k, _, _ in tables]
+    k64s = [k.to(torch.int64) for k, _, _ in tables]
+    # ---- global key range per column ---------------------------------------------------
+    big = torch.iinfo(torch.int64).max
+    rng = torch.empty(ncol, 2, dtype=torch.int64, device=dev)  # (-min, max): one MAX reduce
+    for j, k in enumerate(k64s):
+        if lens[j]:
+            rng[j, 0] = -(k.min().clamp(min=-big))
+            rng[j, 1] = k.max()
+        else:
+            rng[j, 0] = -big
+            rng[j, 1] = -big
+    _all_reduce(rng, td.ReduceOp.MAX)
+    rng_h = rng.cpu().tolist()
     # ---- rows grouped by (owner, column) --------------------------------------------
     own_parts, dest_parts = [], []
-    for j, (k, _, _) in enumerate(tables):
-        own = _owner_fn([k], G).to(torch.int64) if lens[j] else torch.empty(0, dtype=torch.int64, device=dev)
+    for j, k in enumerate(k64s):
+        lo, hi = -rng_h[j][0], rng_h[j][1]
+        if lens[j]:
+            own = _range_owner(k, lo, hi, G)
+        else:
+            own = torch.empty(0, dtype=torch.int64, device=dev)
         own_parts.append(own)
         dest_parts.append(own * ncol + j)
     owner_all = torch.cat(own_parts)
     dest = torch.cat(dest_parts)
-    rows = torch.stack([torch.cat([k.to(torch.int64) for k, _, _ in tables]),
-                        torch.cat([c.to(torch.int64) for _, c, _ in tables])], dim=1)
-    # (owner, column) order of the rows.  (Host stand-in: rows are concatenated column by
-    # column, so the ascending row indices of one owner are already grouped by column and G
-    # compactions do; a full torch argsort of ~3e7 destinations was the most expensive step.)
+    rows = torch.stack([torch.cat(k64s), torch.cat([c.to(torch.int64) for _, c, _ in tables])], dim=1)
     if dest.is_cuda:
         # stable radix sort of (destination << 32 | row) words on the destination bits
         from . import kernels as K
@@ -295,7 +393,7 @@ def merge_counts_many(tables):
         words = K.order_rows(int(dest.numel()), dev, gid=dest, ngroups=G * ncol)
         order = words & 0xFFFFFFFF
     else:  # host stand-in of the CPU tests
-        order = torch.cat([torch.nonzero(owner_all == g).squeeze(1) for g in range(G)])
+        order = torch.argsort(dest, stable=True)
     send_mat = torch.bincount(dest, minlength=G * ncol).to(torch.int64).view(G, ncol)
     # ---- count matrix: row g of mine goes to rank g ------------------------------------
     if _backend() == "nccl":
@@ -305,7 +403,7 @@ def merge_counts_many(tables):
         recv_mat = torch.stack([m[rank()] for m in _all_gather_same(send_mat.contiguous())])
     send_h, recv_h = send_mat.cpu(), recv_mat.cpu()
     recv = _all_to_all_v(rows[order].contiguous(), send_h.sum(1).tolist(), recv_h.sum(1).tolist())
-    # ---- owner-side merge, column by column ------------------------------------------------
+    # ---- owner-side merge, column by column, then key order -----------------------------
     off = torch.zeros(G * ncol + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
     off = off.tolist()
@@ -322,11 +420,11 @@ def merge_counts_many(tables):
     merged = []
     for j in range(ncol):
         if j in results:
-            mk, mc = results[j]
+            mk, mc = _sort_by_key_fn(*results[j])
             merged.append(torch.stack([mk.to(torch.int64), mc.to(torch.int64)], dim=1))
         else:
             merged.append(torch.empty((0, 2), dtype=torch.int64, device=dev))
-    # ---- replicate: every rank gets every owner's share ---------------------------------------
+    # ---- replicate: every rank gets every owner's share, rank (= key range) order -------------
     mlen = torch.tensor([m.shape[0] for m in merged], dtype=torch.int64, device=dev)
     all_len = torch.stack(_all_gather_same(mlen)).cpu()  # [G, ncol]
     everything = _all_gather_v(torch.cat(merged), sizes=all_len.sum(1).tolist())
@@ -341,8 +439,18 @@ def merge_counts_many(tables):
     out = []
     for j in range(ncol):
         seg = torch.cat([everything[goff[r * ncol + j] : goff[r * ncol + j + 1]] for r in range(G)])
-        out.append((seg[:, 0].contiguous().to(dtypes[j]), seg[:, 1].contiguous(),
-                    scal[j][: len(tables[j][2])]))
+        keys, counts = seg[:, 0].contiguous().to(dtypes[j]), seg[:, 1].contiguous()
+        info = None
+        if keys.numel():
+            hist = _class_hist_fn(counts)
+            info = dict(sorted_by_key=True, cls_hist=hist, n_big=None, merged=True)
+        out.append((keys, counts, scal[j][: len(tables[j][2])], info))
+    # n_big of every column: ONE read-back of the 256th histogram words
+    infos = [o[3] for o in out if o[3] is not None]
+    if infos:
+        nb = torch.stack([i["cls_hist"][255] for i in infos]).to(torch.int64).cpu().tolist()
+        for i, v in zip(infos, nb):
+            i["n_big"] = int(v) & 0xFFFFFFFF
     return out
 
 
@@ -370,15 +478,18 @@ def merge_groups(comp: Dict, nkeys: int, nvals: int, sumsq=False, minmax=False) 
     tab = K.GroupbyTable(nkeys, nvals, max(64, 2 * int(rsize.numel())), sumsq=sumsq, minmax=minmax)
     tab.merge(rkeys, rnm, rsize, rcount, rsum, rsq, rmin, rmax)
     mine = tab.compact()
+    flat = (list(mine["keys"]) + [mine["null_mask"], mine["size"], mine["count"]] + list(mine["sum"])
+            + list(mine["sumsq"]) + list(mine["min"]) + list(mine["max"]))
+    it = iter(gather_rows(flat))  # the whole table in one all-gather(v)
     out = dict(
-        keys=[_all_gather_v(k) for k in mine["keys"]],
-        null_mask=_all_gather_v(mine["null_mask"]),
-        size=_all_gather_v(mine["size"]),
-        count=_all_gather_v(mine["count"]),
-        sum=[_all_gather_v(t) for t in mine["sum"]],
-        sumsq=[_all_gather_v(t) for t in mine["sumsq"]],
-        min=[_all_gather_v(t) for t in mine["min"]],
-        max=[_all_gather_v(t) for t in mine["max"]],
+        keys=[next(it) for _ in mine["keys"]],
+        null_mask=next(it),
+        size=next(it),
+        count=next(it),
+        sum=[next(it) for _ in mine["sum"]],
+        sumsq=[next(it) for _ in mine["sumsq"]],
+        min=[next(it) for _ in mine["min"]],
+        max=[next(it) for _ in mine["max"]],
     )
     out["n"] = int(out["size"].numel())
     return out

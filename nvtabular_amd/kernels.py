@@ -525,7 +525,9 @@ class DenseCountJob:
         if ovf & 2:
             if self.cap_guess > self.n:
                 raise _lib.NvtHipError("dense count: output list overflowed at full capacity")
-            self.cap_guess = max(4 * self.cap_guess, 1 << 20)
+            need = st[_lib.ST_NEED] if self.path == PATH_RANGE else 0
+            # (the range path reports the exact size; the hash paths only that it was too small)
+            self.cap_guess = need + 64 if need > self.cap_guess else max(4 * self.cap_guess, 1 << 20)
             return False
         m = st[_lib.ST_OCCUPIED]
         max_count = st[_lib.ST_MAXCOUNT]
@@ -619,7 +621,8 @@ def _presample(jobs):
         # keys than estimated would overflow 256 / 512 buckets and be counted twice)
         j.min_range_bits = 10
         j.path = _path_for(est, small_tables=(j.kb == 8), allow_range=j.allow_range)
-        j.cap_guess = max(1 << 16, 2 * est)
+        # ... and a roomy output list (a sixth of the rows): a relaunch costs a full recount
+        j.cap_guess = max(1 << 16, 2 * est, j.n // 6 if j.path not in _S_CLASSES else 0)
 
 
 class CountBatch:
@@ -737,6 +740,25 @@ def merge_dense(lists, hint: int = 0):
     k, c, _, info = dense_count(keys, None, counts,
                                 hint=hint or max(int(x[0].numel()) for x in lists))
     return k, c, info["max_count"]
+
+
+def class_hist(counts: torch.Tensor) -> torch.Tensor:
+    """int32[256] histogram of min(count, 255) on the device (nvt_class_hist): the input of the
+    one-pass ordering of a key-sorted (key, count) list."""
+    hist = torch.empty(256, dtype=torch.int32, device=counts.device)
+    counts = counts.contiguous()
+    check(_lib.load().nvt_class_hist(ptr(counts) if counts.numel() else None, counts.numel(),
+                                     hist.data_ptr(), stream_ptr()), "nvt_class_hist")
+    return hist
+
+
+def sort_by_key(keys: torch.Tensor, counts: torch.Tensor):
+    """(keys, counts) ordered by key ascending (radix sort of nvt_order_rows)."""
+    n = int(keys.numel())
+    if n <= 1:
+        return keys, counts
+    perm = order_rows(n, keys.device, sort_keys=[(keys, None, True)]) & 0xFFFFFFFF
+    return keys[perm].contiguous(), counts[perm].contiguous()
 
 
 def vocab_sort(keys: torch.Tensor, counts: torch.Tensor, max_count: int = 0):

@@ -351,11 +351,14 @@ class Categorify(StatOperator):
                 has_str = int(any(c_ in g.strings for c_ in g.cols))
                 tabs.append((k, c, [int(g.nulls), int(g.valid_rows), int(mx), has_str]))
             if tabs:
-                for g, (k, c, sc) in zip(singles, dist.merge_counts_many(tabs)):
+                for g, (k, c, sc, info) in zip(singles, dist.merge_counts_many(tabs)):
                     g.table = (k, c, sc[2])  # the sum of the per-rank maxima bounds the max count
                     g.nulls, g.valid_rows = sc[0], sc[1]
                     g.any_rank_strings = sc[3] > 0
                     g.merged = True
+                    # owners hold key ranges and gather key-sorted shards: the merged list is
+                    # key-sorted, the one-pass ordering applies on every rank (int32 keys)
+                    g.sorted = (k, info) if info is not None and info.get("sorted_by_key") else None
         opts = {}
         for g in groups:
             nb = _pick(self.num_buckets, g.name) if self.num_buckets else None

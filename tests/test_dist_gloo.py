@@ -60,13 +60,36 @@ def _worker(rank, world, port, q):
              torch.ones(7 if rank == 0 else 0, dtype=torch.int64), [rank])]
     many = dist.merge_counts_many(tabs)
     assert many[1][0].dtype == torch.int32 and many[0][0].dtype == torch.int64
-    assert many[0][2] == [3 + 4, 20] and many[1][2] == [2, 4, 6] and many[2][2] == [1]
+    tot_r = sum(range(world))
+    assert many[0][2] == [3 * world + tot_r, 10 * world] and many[1][2] == [world, 2 * world, 3 * world]
+    assert many[2][2] == [tot_r]
+    # owners hold key RANGES and gather key-sorted shards: every rank receives each column as
+    # ONE key-sorted list (no re-sort of the union), with the histogram of min(count, 255) the
+    # one-pass vocabulary ordering needs
+    for kk, cc, _, info in many:
+        assert (np.diff(kk.numpy().astype(np.int64)) > 0).all()
+        assert info["sorted_by_key"]
+        np.testing.assert_array_equal(info["cls_hist"].numpy(),
+                                      np.bincount(np.minimum(cc.numpy(), 255), minlength=256))
+        assert info["n_big"] == int((cc.numpy() >= 255).sum())
     m0 = pd.Series(many[0][1].numpy(), index=many[0][0].numpy()).sort_index()
     assert sorted(many[2][0].tolist()) == list(range(7)) and many[2][1].tolist() == [1] * 7
     q.put(("many", rank, m0.index.to_numpy(), m0.to_numpy(), many[1][0].numpy(), many[1][1].numpy(),
            k32.numpy()))
+    # a whole multi-column table (JoinGroupby / TargetEncoding merge) in ONE all-to-all(v) and
+    # ONE all-gather(v): int64 keys, uint8 null mask, float64 sums
+    tk = torch.arange(rank * 1000, rank * 1000 + 50, dtype=torch.int64)
+    tcols = [tk, (tk % 3).to(torch.uint8), tk.to(torch.float64) * 0.5 + 0.25]
+    recv = dist.exchange_rows(tcols, (tk % world).to(torch.int32))
+    assert recv[0].dtype == torch.int64 and recv[1].dtype == torch.uint8 and recv[2].dtype == torch.float64
+    assert bool((recv[0] % world == rank).all()) and recv[0].numel() > 0
+    assert torch.equal(recv[1], (recv[0] % 3).to(torch.uint8))
+    assert torch.equal(recv[2], recv[0].to(torch.float64) * 0.5 + 0.25)
+    allrows = dist.gather_rows(recv)
+    assert sorted(allrows[0].tolist()) == sorted(t for r in range(world) for t in range(r * 1000, r * 1000 + 50))
+    assert torch.equal(allrows[2], allrows[0].to(torch.float64) * 0.5 + 0.25)
     mom = dist.all_reduce_sum(torch.tensor([[1.0 + rank, 2.0, 3.0]], dtype=torch.float64))
-    mn = dist.all_reduce_min(torch.tensor([float("nan") if rank == 0 else 4.0, 2.0 + rank]))
+    mn = dist.all_reduce_min(torch.tensor([float("nan") if rank == 0 else 4.0 + rank - 1, 2.0 + rank]))
     lut = dist.merge_string_luts({rank: f"s{rank}"})
     got = pd.Series(gc.numpy(), index=gk.numpy()).sort_index()
     q.put((rank, got.index.to_numpy(), got.to_numpy(), nulls, mom.tolist(), mn.tolist(), lut, keys))
@@ -75,13 +98,14 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_merge_counts_world2_gloo():
+@pytest.mark.parametrize("world", [2, 4])
+def test_merge_counts_world2_gloo(world):
     import pandas as pd
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     items = [q.get(timeout=150) for _ in range(2 * len(procs))]
@@ -96,10 +120,10 @@ def test_merge_counts_world2_gloo():
         # every rank ends with the same, complete table
         np.testing.assert_array_equal(r[1], exp.index.to_numpy())
         np.testing.assert_array_equal(r[2], exp.to_numpy())
-        assert r[3] == 3 + 4
-        assert r[4] == [[3.0, 4.0, 6.0]]
+        assert r[3] == 3 * world + sum(range(world))
+        assert r[4] == [[float(world + sum(range(world))), 2.0 * world, 3.0 * world]]
         assert r[5] == [4.0, 2.0]
-        assert r[6] == {0: "s0", 1: "s1"}
+        assert r[6] == {i: f"s{i}" for i in range(world)}
     # the batched exchange: same int64 table, and the int32 column summed over both ranks
     exp32 = pd.Series(1, index=np.concatenate([m[5] for m in many])).groupby(level=0).sum().sort_index()
     for m in many:
