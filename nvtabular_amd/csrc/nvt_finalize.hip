@@ -87,17 +87,28 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
       if (rc) return rc;
     }
   }
+  std::vector<OrderTail> tails;   // class-255 sorts of the key-sorted vocabularies: one batch
+  std::vector<int> tail_cols;
   for (size_t j = 0; j < big.size(); ++j) {
     const nvt_vocab_col &c = cols[big[j]];
     hipStream_t s = fork ? pool->s[j % kSide] : main_s;
     if (c.src_keys != nullptr) {
       // key-sorted list of the range path: one stable counting pass orders it and fills the table
       NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
+      bool deferred = false;
+      static const bool batch_tail = getenv("NVT_NO_TAIL_BATCH") == nullptr;
       int rc = vocab_order_from_sorted((const int32_t *)c.src_keys, c.src_counts, c.n, c.cls_hist,
                                        c.n_big, c.max_count, (int32_t *)c.keys, c.counts,
                                        c.sort_tmp, c.first_label, c.table, c.capacity,
-                                       c.sentinel_label, c.range_aux, c.range_nb_log2, s);
+                                       c.sentinel_label, c.range_aux, c.range_nb_log2, s,
+                                       batch_tail ? &deferred : nullptr);
       if (rc) return rc;
+      if (deferred) {
+        tails.push_back({(int32_t *)c.keys, c.counts, c.n_big, c.first_label, c.table, c.capacity,
+                         c.sentinel_label, c.range_aux});
+        tail_cols.push_back(big[j]);
+        continue;  // its ready event is recorded behind the batched tail
+      }
     } else if (c.n > 1) {
       NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
       int rc = vocab_sort_any(c.key_bytes, c.keys, c.counts, c.n, c.max_count, c.sort_tmp, s);
@@ -105,6 +116,26 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
     }
     int rc = finish(c, s);
     if (rc) return rc;
+  }
+  if (!tails.empty()) {
+    // every scatter has to be done before the batched sort: internal stream 0 waits for the
+    // other two and runs the tail; the caller's stream is NOT joined (joining it here cost
+    // 0.3 ms per Criteo step: fill + normalize and the small encodes started later)
+    hipStream_t ts = main_s;
+    bool all_events = true;
+    for (int i : tail_cols) all_events = all_events && cols[i].ready_event != nullptr;
+    if (fork) {
+      ts = pool->s[0];
+      for (int i = 1; i < kSide; ++i) {
+        NVT_CHECK_HIP(hipEventRecord(pool->join[i], pool->s[i]));
+        NVT_CHECK_HIP(hipStreamWaitEvent(ts, pool->join[i], 0));
+      }
+      if (!all_events) need_join = true;
+    }
+    int rc = vocab_order_tail_batch(tails.data(), (int)tails.size(), ts);
+    if (rc) return rc;
+    for (int i : tail_cols)
+      if (cols[i].ready_event) NVT_CHECK_HIP(hipEventRecord((hipEvent_t)cols[i].ready_event, ts));
   }
   if (fork && need_join) {
     for (int i = 0; i < kSide; ++i) {

@@ -47,7 +47,20 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
                             const unsigned *cls_hist, uint64_t n_big, int64_t max_count,
                             int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label,
                             void *table, uint64_t capacity, int64_t *sentinel_label,
-                            const int32_t *range_aux, int range_nb_log2, hipStream_t s);
+                            const int32_t *range_aux, int range_nb_log2, hipStream_t s,
+                            bool *tail_deferred = nullptr);
+// the deferred part: sort of the n_big leading entries (class 255) + their labels
+struct OrderTail {
+  int32_t *keys;
+  int64_t *counts;
+  uint64_t n_big;
+  int64_t first_label;
+  void *table;
+  uint64_t capacity;
+  int64_t *sentinel_label;
+  const int32_t *range_aux;
+};
+int vocab_order_tail_batch(const OrderTail *t, int nt, hipStream_t s);
 
 // nvt_encode.hip
 int encode_clear_any(int key_bytes, void *table, uint64_t capacity, int64_t *sentinel_label,

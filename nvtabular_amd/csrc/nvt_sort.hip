@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include <cstdlib>
+#include <vector>
 
 #include "nvt_common.hpp"
 #include "nvt_internal.hpp"
@@ -1139,7 +1140,9 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
                             const unsigned *cls_hist, uint64_t n_big, int64_t max_count,
                             int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label,
                             void *table, uint64_t capacity, int64_t *sentinel_label,
-                            const int32_t *range_aux, int range_nb_log2, hipStream_t s) {
+                            const int32_t *range_aux, int range_nb_log2, hipStream_t s,
+                            bool *tail_deferred) {
+  if (tail_deferred) *tail_deferred = false;
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(n < (1ull << 30), "at most 2^30-1 vocabulary entries");
   NVT_CHECK_ARG(n_big <= n, "n_big > n");
@@ -1174,6 +1177,12 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
       NVT_CHECK_LAUNCH();
     }
   }
+  // the sort of class 255 and the labels of its entries: left to ONE batched launch for all the
+  // vocabularies of the call when the caller asks for it (vocab_order_tail_batch)
+  if (tail_deferred && vocab_sort_small_eligible(4, n_big, max_count)) {
+    *tail_deferred = true;
+    return NVT_OK;
+  }
   if (n_big > 1) {
     int rc = vocab_sort_any(4, out_keys, out_cnts, n_big, max_count, sort_tmp, s);
     if (rc) return rc;
@@ -1186,6 +1195,36 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
       NVT_CHECK_LAUNCH();
     } else {
       int rc = encode_insert_any(4, out_keys, n_big, first_label, table, capacity, sentinel_label, s);
+      if (rc) return rc;
+    }
+  }
+  return NVT_OK;
+}
+
+// class 255 of several vocabularies (vocab_order_from_sorted with tail_deferred): ONE batched
+// sort launch (a workgroup per vocabulary) instead of a one-workgroup launch per vocabulary,
+// then the labels of the sorted entries
+int vocab_order_tail_batch(const OrderTail *t, int nt, hipStream_t s) {
+  if (nt == 0) return NVT_OK;
+  std::vector<SmallSortDesc> d(nt);
+  for (int i = 0; i < nt; ++i) {
+    d[i].keys = t[i].keys;
+    d[i].counts = t[i].counts;
+    d[i].n = (unsigned)t[i].n_big;
+  }
+  int rc = vocab_sort_small_batch(d.data(), nt, s);
+  if (rc) return rc;
+  NVT_PROF("encode_build", 0, s);
+  for (int i = 0; i < nt; ++i) {
+    if (!t[i].table) continue;
+    if (t[i].range_aux) {
+      range_fix_prefix_kernel<<<stream_grid(t[i].n_big, kBlock), kBlock, 0, s>>>(
+          (unsigned long long *)t[i].table, t[i].range_aux, t[i].keys, t[i].n_big, t[i].first_label,
+          t[i].sentinel_label);
+      NVT_CHECK_LAUNCH();
+    } else {
+      rc = encode_insert_any(4, t[i].keys, t[i].n_big, t[i].first_label, t[i].table, t[i].capacity,
+                             t[i].sentinel_label, s);
       if (rc) return rc;
     }
   }
