@@ -138,6 +138,9 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
 #define NVT_PATH_HOT 16
 #define NVT_HOT_IMAGE_WORDS 8192
 #define NVT_PATH_RANGE 9
+#define NVT_PATH_SORT 10            /* int32 keys, no weights, any number of distinct keys: radix sort of
+                                       the rows + run lengths; key-sorted output like the range path;
+                                       hot_image = uint32[256] receiving the histogram of min(count, 255) */
 #define NVT_RANGE_WGS 256           /* partition workgroups = runs per bucket                 */
 #define NVT_RANGE_AUX_LO 8192       /* aux words behind the hot image: range origin (biased),
                                        span, multiplier (2 words), shift of the monotone map   */

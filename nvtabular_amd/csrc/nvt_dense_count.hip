@@ -2021,6 +2021,21 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
                 hipStream_t s, bool clear_state = true, int32_t *hot_image_ext = nullptr,
                 void *range_table = nullptr) {
   NVT_CHECK_ARG(state && wsp, "null state/workspace");
+  if ((path & 0xFF) == NVT_PATH_SORT) {
+    if constexpr (sizeof(K) == 4) {
+      NVT_CHECK_ARG(weights == nullptr, "the sort path takes int32 keys without weights");
+      NVT_CHECK_ARG(hot_image_ext != nullptr, "the sort path needs the column's histogram block");
+      NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(keys) & 15) == 0, "keys must be 16-byte aligned");
+      NVT_CHECK_ARG(n == 0 || (keys && out_keys && out_cnt), "null keys/out");
+      if (clear_state) NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
+      if (n == 0) return NVT_OK;
+      return sort_count_i32((const int32_t *)keys, valid, n, wsp, (unsigned *)hot_image_ext,
+                            (int32_t *)out_keys, out_cnt, out_cap, state, s);
+    } else {
+      set_error("dense_count: the sort path takes int32 keys");
+      return NVT_EINVAL;
+    }
+  }
   if ((path & 0xFF) == NVT_PATH_RANGE) {
     if constexpr (sizeof(K) == 4) {
       NVT_CHECK_ARG(weights == nullptr, "the range path takes int32 keys without weights");
@@ -2214,6 +2229,11 @@ int nvt_range_table_bytes(int nb_log2, uint64_t *bytes) {
 }
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");
+  if ((path & 0xFF) == NVT_PATH_SORT) {
+    NVT_CHECK_ARG(key_bytes == 4 && !weighted, "the sort path takes int32 keys without weights");
+    *bytes = sort_count_ws_bytes(n) + 64;
+    return NVT_OK;
+  }
   if ((path & 0xFF) == NVT_PATH_RANGE) {
     const int nb_log2 = (path >> 8) & 0xFF;
     NVT_CHECK_ARG(key_bytes == 4 && !weighted && nb_log2 >= 6 && nb_log2 <= 10,
@@ -2309,8 +2329,10 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
       rc = dense_count<int32_t>((const int32_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,
                                 (int32_t *)c.out_keys, c.out_counts, c.out_capacity, c.state, cs,
                                 !contiguous,
-                                ((c.path & NVT_PATH_HOT) || (c.path & 0xFF) == NVT_PATH_RANGE) ? c.hot_image
-                                                                                            : nullptr,
+                                ((c.path & NVT_PATH_HOT) || (c.path & 0xFF) == NVT_PATH_RANGE ||
+                                 (c.path & 0xFF) == NVT_PATH_SORT)
+                                    ? c.hot_image
+                                    : nullptr,
                                 c.range_table);
     else if (c.key_bytes == 8)
       rc = dense_count<int64_t>((const int64_t *)c.keys, c.valid, c.weights, c.n, c.path, c.ws,

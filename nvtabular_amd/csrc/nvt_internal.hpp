@@ -40,6 +40,13 @@ int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int n
                     int32_t *aux, int32_t *out_keys, int64_t *out_cnt, uint64_t out_cap,
                     void *range_table, uint64_t *state, hipStream_t s);
 
+// nvt_sort_count.hip: path NVT_PATH_SORT of nvt_dense_count_* (radix sort + run lengths; hist =
+// the column's uint32[256] class histogram block)
+uint64_t sort_count_ws_bytes(uint64_t n);
+int sort_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, void *ws, unsigned *hist,
+                   int32_t *out_keys, int64_t *out_cnt, uint64_t out_cap, uint64_t *state,
+                   hipStream_t s);
+
 // nvt_sort.hip: vocabulary order of a KEY-SORTED (key, count) list (range path) in one stable
 // counting pass on min(count, 255) + encode table filled in the same pass
 uint64_t vocab_order_tmp_bytes(uint64_t n, uint64_t n_big);

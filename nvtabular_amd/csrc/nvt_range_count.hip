@@ -76,6 +76,7 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
   __shared__ unsigned fill[1 << kRpMaxNbLog2], flushed[1 << kRpMaxNbLog2];
   __shared__ unsigned long long s_nulls, s_sent;
   __shared__ unsigned s_ovf;
+  __shared__ unsigned scratch[kWave];  // one word per lane: target of the adds of non-hits
   const unsigned NB = 1u << nb_log2, CAP = (unsigned)kRpBinWords >> nb_log2;
   const unsigned g = blockIdx.x, lane = lane_id();
   for (int i = threadIdx.x; i < kHotBucketsR; i += kRpBS)
@@ -192,16 +193,20 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
       vbs[u] = nvb[u];
     }
     issue(v0 + (uint64_t)kRpBS * U + threadIdx.x);
+    // Branch-free classification of the round's keys (the per-key if / else ladder compiled to
+    // as many exec-mask instructions as there was arithmetic: ~190 instructions per key).  Every
+    // key reads its hot bucket; hits add 1 to their counter, every other lane adds 0 to a scratch
+    // word of its own; `pend` collects the valid, non-sentinel misses.
     unsigned pend = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned vb = vbs[u];
-      if (!(vb & 0x100u)) continue;
+      const bool present = (vb & 0x100u) != 0;
       const uint64_t v = v0 + (uint64_t)u * kRpBS + threadIdx.x;
-      const unsigned ok = (vb & 0x200u) ? vb & 0xFu : ((vb >> 12) >> ((v * 4) & 7)) & 0xFu;
-      const unsigned in = (vb & 0x200u) ? (vb >> 4) & 0xFu : 0xFu;
+      const unsigned okf = ((vb >> 12) >> ((v * 4) & 7)) & 0xFu;
+      const unsigned ok = present ? ((vb & 0x200u) ? vb & 0xFu : okf) : 0u;
+      const unsigned in = present ? ((vb & 0x200u) ? (vb >> 4) & 0xFu : 0xFu) : 0u;
       nulls += __popc(in & ~ok);
-      // the hot buckets of the four keys are requested before any of them is used
       int2 hb[4];
       uint32_t sa[4];
 #pragma unroll
@@ -212,19 +217,15 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int q = 4 * u + j;
-        if (!((ok >> j) & 1)) continue;
         const int32_t key = kv[q];
-        if (key == kEmpty) {
-          ++sent;
-          continue;
-        }
-        int slot = -1;
-        slot = hb[j].x == key ? (int)(2 * sa[j]) : slot;
-        slot = hb[j].y == key ? (int)(2 * sa[j] + 1) : slot;
-        if (slot >= 0)
-          atomicAdd(&tc[slot], 1u);
-        else
-          pend |= 1u << q;
+        const bool okj = (ok >> j) & 1;
+        const bool is_sent = okj & (key == kEmpty);
+        const bool hx = hb[j].x == key, hy = hb[j].y == key;
+        const bool hit = okj & !is_sent & (hx | hy);
+        const unsigned slot = 2u * sa[j] + (hy ? 1u : 0u);
+        atomicAdd(hit ? &tc[slot] : &scratch[lane], hit ? 1u : 0u);
+        sent += is_sent ? 1u : 0u;
+        pend |= ((okj & !is_sent & !hit) ? 1u : 0u) << q;
       }
     }
     // append the cold keys; a key whose bin is full waits for the flush and tries again

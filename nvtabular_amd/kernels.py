@@ -355,6 +355,11 @@ RANGE_KEYS_PER_BUCKET = 5000
 PATH_RANGE_MAX_DISTINCT = int(os.environ.get("NVT_RANGE_MAX", 6_500_000))
 USE_RANGE = os.environ.get("NVT_RANGE", "1") != "0"
 
+# path 10 (sort path, NVT_PATH_SORT): int32 keys without weights beyond the range path -- radix sort
+# of the rows + run lengths, key-sorted output (Criteo-1TB's 38-40 M-unique columns)
+PATH_SORT = 10
+USE_SORT = os.environ.get("NVT_SORT_PATH", "1") != "0"
+
 _ws_cache = {}
 _RT_BYTES = {}   # range_bits -> nvt_range_table_bytes
 _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
@@ -365,7 +370,7 @@ _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 COUNT_STREAMS = max(1, min(3, int(os.environ.get("NVT_COUNT_STREAMS", "3"))))
 PATH_HOT, HOT_IMAGE_WORDS = 16, 8192   # include/nvt_hip.h NVT_PATH_HOT, NVT_HOT_IMAGE_WORDS
 HOT_FILTER = os.environ.get("NVT_HOT_FILTER", "1") != "0"
-_PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 9: 2.0, 1: 2.5, 2: 3.2, 3: 3.5}
+_PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 9: 2.0, 1: 2.5, 2: 3.2, 3: 3.5, 10: 6.0}
 
 
 def _workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
@@ -389,6 +394,8 @@ def _path_for(hint: int, small_tables: bool = False, allow_range: bool = True) -
         return 7  # (with the hot-key filter path 1 is faster there: 241 against 307 us)
     if USE_RANGE and HOT_FILTER and allow_range and not small_tables and hint <= PATH_RANGE_MAX_DISTINCT:
         return PATH_RANGE
+    if USE_SORT and not small_tables and hint > PATH_RANGE_MAX_DISTINCT:
+        return PATH_SORT
     if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
         return 1
     if hint <= PATH_P2_MAX_DISTINCT:
@@ -472,7 +479,11 @@ class DenseCountJob:
         desc.state = self.state.data_ptr()
         desc.hot_image = None
         desc.range_table = None
-        if path == PATH_RANGE:
+        if path == PATH_SORT:
+            # uint32[256] block that receives the histogram of min(count, 255)
+            self.hot_image = torch.empty(256, dtype=torch.int32, device=self.dev)
+            desc.hot_image = self.hot_image.data_ptr()
+        elif path == PATH_RANGE:
             # aux block: hot image + range parameters (sample kernel) + class histogram
             self.hot_image = torch.empty(RANGE_AUX_WORDS, dtype=torch.int32, device=self.dev)
             desc.hot_image = self.hot_image.data_ptr()
@@ -498,6 +509,8 @@ class DenseCountJob:
         ovf = st[_lib.ST_OVERFLOW]
         if ovf & 1:
             order = PATH_ORDER
+            if self.path == PATH_SORT:  # (no LDS tables to overflow)
+                raise _lib.NvtHipError("dense count: the sort path reported a table overflow")
             if self.path == PATH_RANGE and self.range_bits() < 10:
                 # more distinct keys than the hint promised (cold start): all 1024 buckets first
                 self.min_range_bits = 10
@@ -518,19 +531,30 @@ class DenseCountJob:
             self.path = order[nxt]
             if self.path == 7 and self._launch_path_of(1) & PATH_HOT:
                 self.path = 1  # the filtered path 1 beats two key classes (see _path_for)
-            if self.path == 1 and self.hint > PATH_P1_MAX_DISTINCT:
+            if self.path == 1 and self.range_failed and USE_SORT and self.kb == 4 and self.weights is None:
+                # the range path gave up at 1024 buckets: more keys than it holds, or keys that
+                # are not spread over their range -- the sort path copes with both in one go
+                # (the next fit picks its path from the distinct count found here)
+                self.path = PATH_SORT
+            elif self.path == 1 and self.hint > PATH_P1_MAX_DISTINCT:
                 self.path = 2 if self.hint <= PATH_P2_MAX_DISTINCT else 3
             self.cap_guess = max(self.cap_guess, _PATH_MAX[self.path])
             return False
         if ovf & 2:
             if self.cap_guess > self.n:
                 raise _lib.NvtHipError("dense count: output list overflowed at full capacity")
-            need = st[_lib.ST_NEED] if self.path == PATH_RANGE else 0
+            need = st[_lib.ST_NEED] if self.path in (PATH_RANGE, PATH_SORT) else 0
             # (the range path reports the exact size; the hash paths only that it was too small)
             self.cap_guess = need + 64 if need > self.cap_guess else max(4 * self.cap_guess, 1 << 20)
             return False
         m = st[_lib.ST_OCCUPIED]
         max_count = st[_lib.ST_MAXCOUNT]
+        if self.path == PATH_SORT:
+            self.result = (self.out_k[:m], self.out_c[:m], st[_lib.ST_NULLS],
+                           dict(path=self.path, distinct=m, max_count=max_count,
+                                rows=st[_lib.ST_ROWS], sorted_by_key=True, cls_hist=self.hot_image,
+                                n_big=st[_lib.ST_BIG], range_failed=self.range_failed))
+            return True
         if self.path == PATH_RANGE:
             # key-ordered list (the sentinel key, smallest int32, already leads it) + what the
             # one-pass vocabulary ordering needs: histogram of min(count, 255), entries >= 255
@@ -569,7 +593,7 @@ class DenseCountJob:
 SAMPLE_ROWS = 1 << 18               # cold start: distinct keys of this many leading rows ...
 SAMPLE_MIN_ROWS = 8 * SAMPLE_ROWS   # ... when the column is at least this long
 # distinct keys each path is sized for (output-capacity guess when a path is entered by escalation)
-_PATH_MAX = {6: 1024, 0: 98304, 7: 196608, 9: PATH_RANGE_MAX_DISTINCT, 1: PATH_P1_MAX_DISTINCT,
+_PATH_MAX = {6: 1024, 0: 98304, 7: 196608, 9: PATH_RANGE_MAX_DISTINCT, 10: 1 << 30, 1: PATH_P1_MAX_DISTINCT,
              2: PATH_P2_MAX_DISTINCT, 3: PATH_P3_MAX_DISTINCT}
 
 

@@ -72,7 +72,7 @@ def test_range_path_falls_back_when_keys_are_not_spread():
     ids[::1000] = 2**31 - 7
     keys = torch.from_numpy(ids).cuda()
     k, c, nn, info = _count_forced(keys, None, K.PATH_RANGE, 900_000)
-    assert info["path"] != K.PATH_RANGE
+    assert info["path"] != K.PATH_RANGE and info["range_failed"]
     got = pd.Series(c.cpu().numpy(), index=k.cpu().numpy()).sort_index()
     exp = pd.Series(np.ones(n, dtype=np.int64)).groupby(ids).sum()
     np.testing.assert_array_equal(got.index.to_numpy(), exp.index.to_numpy())
@@ -125,3 +125,61 @@ def test_workflow_on_the_range_path_vs_oracle(tmp_path, n, card):
     wf.fit(nvt.Dataset(frame))
     again = wf.transform(frame)["c"].data.cpu().numpy()
     np.testing.assert_array_equal(again, exp)
+
+
+@pytest.mark.parametrize("n,card", [(1003, 400), (300_000, 10**9), (2_500_000, 3_000_000)])
+@pytest.mark.parametrize("nulls", [False, True])
+def test_sort_path_counts_exact_and_key_ordered(n, card, nulls):
+    """NVT_PATH_SORT (csrc/nvt_sort_count.hip): radix sort of the rows + run lengths -- exact
+    counts in key order whatever the key distribution, class histogram for the ordering pass."""
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.device import pack_bitmap
+
+    rng = np.random.default_rng(n)
+    ids = rng.integers(-card, card, n).astype(np.int64).clip(-2**31, 2**31 - 1).astype(np.int32)
+    ids[3] = np.iinfo(np.int32).min
+    ids[5] = np.iinfo(np.int32).max
+    ids[100:400] = 77                      # one key with a count >= 255
+    mask = rng.random(n) < 0.2 if nulls else np.zeros(n, dtype=bool)
+    keys = torch.from_numpy(ids).cuda()
+    valid = torch.from_numpy(pack_bitmap(~mask)).cuda() if nulls else None
+    k, c, nn, info = _count_forced(keys, valid, K.PATH_SORT, 1000)  # (too small a hint: relaunch)
+    assert info["path"] == K.PATH_SORT and info["sorted_by_key"]
+    exp = pd.Series(np.ones(n, dtype=np.int64)[~mask]).groupby(ids[~mask]).sum()
+    np.testing.assert_array_equal(k.cpu().numpy(), exp.index.to_numpy())
+    np.testing.assert_array_equal(c.cpu().numpy(), exp.to_numpy())
+    assert nn == int(mask.sum()) and info["max_count"] == int(exp.max())
+    hist = info["cls_hist"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    np.testing.assert_array_equal(hist, np.bincount(np.minimum(exp.to_numpy(), 255), minlength=256))
+    assert info["n_big"] == int((exp.to_numpy() >= 255).sum())
+
+
+def test_workflow_on_the_sort_path_vs_oracle(tmp_path):
+    """A column beyond the range path (forced with a small NVT_RANGE_MAX): sort path -> one-pass
+    ordering -> hashed encode table; labels and unique.*.parquet equal the oracle's."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K, ops
+    from nvtabular_amd.device import DeviceColumn, DeviceFrame
+
+    rng = np.random.default_rng(8)
+    n = 3_000_000
+    ids = rng.integers(0, 4_000_000, n).astype(np.int32)
+    old = K.PATH_RANGE_MAX_DISTINCT
+    K.PATH_RANGE_MAX_DISTINCT = 100_000
+    try:
+        frame = DeviceFrame({"c": DeviceColumn(torch.from_numpy(ids).cuda())})
+        op = ops.Categorify(out_path=str(tmp_path / "g"))
+        wf = nvt.Workflow(["c"] >> op)
+        wf.fit(nvt.Dataset(frame))
+        got = wf.transform(frame)["c"].data.cpu().numpy()
+        assert op._last_paths["c#0"] == K.PATH_SORT
+    finally:
+        K.PATH_RANGE_MAX_DISTINCT = old
+    df = pd.DataFrame({"c": ids})
+    paths = O.categorify_fit([df], ["c"], str(tmp_path / "c"), tie_break="stable")
+    exp = O.categorify_transform(df, ["c"], paths)["c"].to_numpy()
+    np.testing.assert_array_equal(got, exp)
+    a = pd.read_parquet(tmp_path / "g" / "categories" / "unique.c.parquet")
+    b = pd.read_parquet(paths["c"])
+    np.testing.assert_array_equal(a["c"].to_numpy().astype(np.int64), b["c"].to_numpy().astype(np.int64))
+    np.testing.assert_array_equal(a["c_size"].to_numpy(), b["c_size"].to_numpy())

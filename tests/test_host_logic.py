@@ -52,14 +52,19 @@ def test_path_selection_thresholds():
     assert K._path_for(K.PATH_S_MAX_DISTINCT + 1) == (9 if rng_on else 1 if K.HOT_FILTER else 7)
     assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_DISTINCT) + 1) == (9 if rng_on else 1)
     assert K._path_for(K.PATH_P1_MAX_DISTINCT + 1) == (9 if rng_on else 2)
-    assert K._path_for(K.PATH_RANGE_MAX_DISTINCT + 1) == 2
-    assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1) == 3
+    # beyond the range path: the sort path (int32 keys without weights), hash partitions otherwise
+    assert K._path_for(K.PATH_RANGE_MAX_DISTINCT + 1) == (K.PATH_SORT if K.USE_SORT else 2)
+    assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1) == (K.PATH_SORT if K.USE_SORT else 3)
+    assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1, small_tables=True) == 3
     j = K.DenseCountJob.__new__(K.DenseCountJob)
     j.min_range_bits = 8
     for hint, bits in ((12_000, 8), (1_200_000, 8), (1_300_000, 9), (2_600_000, 10), (6_400_000, 10)):
         j.hint = hint
         assert j.range_bits() == bits, (hint, j.range_bits())
-    assert K._path_for(K.PATH_P3_MAX_DISTINCT + 1) == -1   # global-table fallback
+    # (int32 keys without weights never reach the global-table fallback: the sort path has no
+    # capacity limit below 2^30 rows)
+    assert K._path_for(K.PATH_P3_MAX_DISTINCT + 1) == (K.PATH_SORT if K.USE_SORT else -1)
+    assert K._path_for(K.PATH_P3_MAX_DISTINCT + 1, small_tables=True) == -1   # global-table fallback
     # int64 keys / weighted merges use the smaller tables
     assert K._path_for(K.PATH_S_MAX_WEIGHTED + 1, small_tables=True) == 7
     assert K._path_for(int(K.PATH_S2_FACTOR * K.PATH_S_MAX_WEIGHTED) + 1, small_tables=True) == 1
