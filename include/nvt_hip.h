@@ -431,7 +431,16 @@ typedef struct nvt_vocab_col {
    * column's aux block (nvt_count_col.hot_image) that holds the map parameters. */
   const int32_t *range_aux;
   int32_t range_nb_log2;
+  /* flat_slots_log2 > 0 (with a key-sorted source, int32 keys): `table` is BUILT here as a flat
+   * range table of 2^flat_slots_log2 slots (+ n + 64 tail slots: capacity = the sum) straight
+   * from the sorted keys by a prefix maximum -- no random inserts; range_aux = a device
+   * int32[NVT_FLAT_AUX_WORDS] block that RECEIVES the map parameters (pass it to nvt_encode_col)
+   * and, in word NVT_FLAT_AUX_MAXDISP, the longest displacement of an entry from its home slot
+   * (large: the keys cluster in their range, build an ordinary table with nvt_encode_build_*) */
+  int32_t flat_slots_log2;
 } nvt_vocab_col;
+#define NVT_FLAT_AUX_WORDS (NVT_RANGE_AUX_LO + 16)
+#define NVT_FLAT_AUX_MAXDISP (NVT_RANGE_AUX_LO + 8)
 int nvt_vocab_order_tmp_bytes(uint64_t n, uint64_t n_big, uint64_t *bytes);
 /* hist[c] = entries with min(counts[i], 255) == c, for a key-sorted list that did not come from
  * the range path (multi-GPU: gathered owner shards); hist[255] = n_big */

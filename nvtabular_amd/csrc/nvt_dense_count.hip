@@ -989,6 +989,7 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
     image[NVT_RANGE_AUX_LO + 2] = (int32_t)(uint32_t)mul;
     image[NVT_RANGE_AUX_LO + 3] = (int32_t)(uint32_t)(mul >> 32);
     image[NVT_RANGE_AUX_LO + 4] = sh;
+    image[NVT_RANGE_AUX_LO + 5] = 0;  // bucket-region table layout (nvt_range.hpp)
     s_map[0] = lo;
     s_map[1] = span;
     s_map[2] = mul;

@@ -101,7 +101,7 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
                                        c.n_big, c.max_count, (int32_t *)c.keys, c.counts,
                                        c.sort_tmp, c.first_label, c.table, c.capacity,
                                        c.sentinel_label, c.range_aux, c.range_nb_log2, s,
-                                       batch_tail ? &deferred : nullptr);
+                                       batch_tail ? &deferred : nullptr, c.flat_slots_log2);
       if (rc) return rc;
       if (deferred) {
         tails.push_back({(int32_t *)c.keys, c.counts, c.n_big, c.first_label, c.table, c.capacity,

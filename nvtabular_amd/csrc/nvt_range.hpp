@@ -27,6 +27,8 @@ struct RangeMap {
   uint32_t ulo, span;
   uint64_t mul;
   int sh;
+  int flat;  // 1: the table is ONE run of F slots (+ tail), slot = f (vocabulary tables built from a
+             //    key-sorted list: flat_build_kernel); 0: bucket regions dumped by the counting pass
   __device__ __forceinline__ uint32_t fine(int32_t key) const {
     const uint32_t u = ukey(key);
     uint32_t d = u > ulo ? u - ulo : 0u;
@@ -39,7 +41,7 @@ struct RangeMap {
   // runs forward without wrapping; the counting pass guarantees an empty slot ends every chain)
   __device__ __forceinline__ uint64_t table_slot(int32_t key) const {
     const uint32_t f = fine(key);
-    return (uint64_t)(f >> 14) * kRpRegion + (f & (kRpSlots - 1));
+    return flat ? (uint64_t)f : (uint64_t)(f >> 14) * kRpRegion + (f & (kRpSlots - 1));
   }
 };
 
@@ -49,6 +51,7 @@ __device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {
   m.span = (uint32_t)aux[NVT_RANGE_AUX_LO + 1];
   m.mul = (uint64_t)(uint32_t)aux[NVT_RANGE_AUX_LO + 2] | ((uint64_t)(uint32_t)aux[NVT_RANGE_AUX_LO + 3] << 32);
   m.sh = aux[NVT_RANGE_AUX_LO + 4];
+  m.flat = aux[NVT_RANGE_AUX_LO + 5];
   return m;
 }
 

@@ -1129,11 +1129,140 @@ __global__ __launch_bounds__(kBlock) void class_hist_kernel(const int64_t *__res
   if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
+// ---- flat range table from a KEY-SORTED list: no atomics, no random inserts ---------------------
+// A vocabulary table with linear probing and a MONOTONE slot function can be laid out directly
+// from the sorted keys: home slots h_i = f(K_i) are non-decreasing in i, so the position of entry
+// i is p_i = max(h_i, p_{i-1} + 1) = i + max_{j <= i}(h_j - j) -- a prefix MAXIMUM over the list
+// (decoupled look-back over the tiles), after which every entry is written once, positions
+// increasing.  Against 36 M random 8-byte CAS inserts (the sort path's vocabularies, or the
+// union a multi-GPU merge gathers): one streaming pass.  Lookups probe forward from f(key) to
+// the key or an empty slot, exactly like the dumped tables of the range path (RangeMap.flat).
+// The largest displacement p_i - h_i goes to aux[NVT_FLAT_AUX_MAXDISP]: keys that cluster in
+// their range make long runs, the caller then builds an ordinary hashed table instead.
+__global__ void flat_params_kernel(const int32_t *__restrict__ keys, uint64_t n, int slots_log2,
+                                   int32_t *aux) {
+  // span of the (sorted) keys, the sentinel key (smallest int32, not in the table) left out
+  const uint64_t first = (n > 1 && keys[0] == INT32_MIN) ? 1 : 0;
+  const uint64_t lo = ukey(keys[first]), hi = ukey(keys[n - 1]);
+  const uint64_t span = hi - lo, F = 1ull << slots_log2;
+  uint64_t mul;
+  int sh;
+  if (span + 1 >= F) {
+    mul = (F << 32) / (span + 1);
+    sh = 32;
+  } else {
+    mul = F / (span + 1);
+    sh = 0;
+  }
+  aux[NVT_RANGE_AUX_LO] = (int32_t)(uint32_t)lo;
+  aux[NVT_RANGE_AUX_LO + 1] = (int32_t)(uint32_t)span;
+  aux[NVT_RANGE_AUX_LO + 2] = (int32_t)(uint32_t)mul;
+  aux[NVT_RANGE_AUX_LO + 3] = (int32_t)(uint32_t)(mul >> 32);
+  aux[NVT_RANGE_AUX_LO + 4] = sh;
+  aux[NVT_RANGE_AUX_LO + 5] = 1;  // flat layout
+  aux[NVT_FLAT_AUX_MAXDISP] = 0;
+}
+
+constexpr unsigned long long kFbAgg = 1ull << 62, kFbPrefix = 2ull << 62, kFbMask = (1ull << 62) - 1ull;
+constexpr long long kFbBias = 1ll << 40;  // h - i is > -2^30: biased to an unsigned value
+
+__global__ __launch_bounds__(kS2BS) void flat_build_kernel(
+    const int32_t *__restrict__ keys, const int32_t *__restrict__ label_of, uint64_t n,
+    int32_t *aux, unsigned long long *status, unsigned *ticket, unsigned long long *table,
+    uint64_t table_slots) {
+  constexpr int NW = kS2BS / kWave;
+  __shared__ unsigned long long wmax[NW];
+  __shared__ unsigned long long s_carry;
+  __shared__ unsigned s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const unsigned tile = s_tile, w = threadIdx.x / kWave, l = lane_id();
+  const RangeMap map = load_map(aux);
+  // element (wave w, row r, lane l): waves own contiguous 1024-entry runs (s2_elem)
+  int32_t k[kS2Rows];
+  unsigned long long d[kS2Rows];  // biased h - i, 0 = no entry
+  unsigned long long run = 0;     // running maximum over this wave's rows so far
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    const uint64_t i = s2_elem(tile, w, r, l);
+    k[r] = i < n ? keys[i] : INT32_MIN;
+    d[r] = 0;
+    if (i < n && k[r] != INT32_MIN) d[r] = (unsigned long long)((long long)map.fine(k[r]) - (long long)i + kFbBias);
+  }
+  // inclusive prefix maximum inside the wave's run: lanes of a row, then the rows in order
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    unsigned long long v = d[r];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long o = __shfl_up(v, off, 64);
+      if (l >= (unsigned)off) v = o > v ? o : v;
+    }
+    v = run > v ? run : v;
+    d[r] = v;
+    run = __shfl(v, 63, 64);
+  }
+  if (l == 63) wmax[w] = run;
+  __syncthreads();
+  unsigned long long wprev = 0, tmax = 0;
+  for (int q = 0; q < NW; ++q) {
+    if (q < (int)w) wprev = wmax[q] > wprev ? wmax[q] : wprev;
+    tmax = wmax[q] > tmax ? wmax[q] : tmax;
+  }
+  if (threadIdx.x == 0) {
+    unsigned long long *my = status + tile;
+    __hip_atomic_store(my, (tile == 0 ? kFbPrefix : kFbAgg) | tmax, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long carry = 0;
+    if (tile > 0) {
+      unsigned tb = tile - 1;
+      while (true) {
+        const unsigned long long v = __hip_atomic_load(status + tb, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned f = (unsigned)(v >> 62);
+        if (f == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        const unsigned long long val = v & kFbMask;
+        carry = val > carry ? val : carry;
+        if (f == 2) break;
+        --tb;
+      }
+      const unsigned long long incl = carry > tmax ? carry : tmax;
+      __hip_atomic_store(my, kFbPrefix | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_carry = carry;
+  }
+  __syncthreads();
+  const unsigned long long before = s_carry > wprev ? s_carry : wprev;
+  unsigned maxdisp = 0;
+#pragma unroll
+  for (int r = 0; r < kS2Rows; ++r) {
+    const uint64_t i = s2_elem(tile, w, r, l);
+    if (i >= n || k[r] == INT32_MIN) continue;
+    const unsigned long long m = d[r] > before ? d[r] : before;
+    const uint64_t p = (uint64_t)((long long)i + ((long long)m - kFbBias));
+    const uint64_t h = map.fine(k[r]);
+    const unsigned disp = (unsigned)(p - h < 0xFFFFFFFFull ? p - h : 0xFFFFFFFFull);
+    maxdisp = disp > maxdisp ? disp : maxdisp;
+    if (p < table_slots)
+      table[p] = ((unsigned long long)(uint32_t)label_of[i] << 32) | (uint32_t)k[r];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = __shfl_down(maxdisp, off, 64);
+    maxdisp = o > maxdisp ? o : maxdisp;
+  }
+  if (l == 0 && maxdisp > 0) atomicMax(reinterpret_cast<unsigned *>(aux + NVT_FLAT_AUX_MAXDISP), maxdisp);
+}
+
 uint64_t vocab_order_tmp_bytes(uint64_t n, uint64_t n_big) {
   const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
   uint64_t sort_bytes = 0;
   if (n_big > 1) (void)nvt_vocab_sort_tmp_bytes(4, n_big, &sort_bytes);
-  return pad16(ntiles * 256 * 4 + 64) + sort_bytes + pad16(n * 4) + 64;  // + label_of[n]
+  // status words of the class scatter | sort scratch | label_of[n] | status words of the flat build
+  return pad16(ntiles * 256 * 4 + 64) + pad16(sort_bytes) + pad16(n * 4) + pad16(ntiles * 8 + 64) + 64;
 }
 
 int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, uint64_t n,
@@ -1141,7 +1270,7 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
                             int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label,
                             void *table, uint64_t capacity, int64_t *sentinel_label,
                             const int32_t *range_aux, int range_nb_log2, hipStream_t s,
-                            bool *tail_deferred) {
+                            bool *tail_deferred, int flat_slots_log2) {
   if (tail_deferred) *tail_deferred = false;
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(n < (1ull << 30), "at most 2^30-1 vocabulary entries");
@@ -1153,10 +1282,19 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
   if (n_big > 1) (void)nvt_vocab_sort_tmp_bytes(4, n_big, &sort_bytes);
   char *sort_tmp = reinterpret_cast<char *>(tmp) + pad16(ntiles * 256 * 4 + 64);
   int32_t *label_of = reinterpret_cast<int32_t *>(sort_tmp + pad16(sort_bytes));
+  unsigned long long *fb_status =
+      reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(label_of) + pad16(n * 4));
   // range table (range_aux set): `table` holds {key, position} slots already (dumped by the
-  // counting pass) and only needs its positions replaced by labels -- no clear, no inserts
+  // counting pass) and only needs its positions replaced by labels -- no clear, no inserts.
+  // flat (flat_slots_log2 > 0, range_aux = the block that RECEIVES the map): the table is laid
+  // out from the sorted keys by a prefix maximum, see flat_build_kernel.
+  const bool flat = table != nullptr && range_aux != nullptr && flat_slots_log2 > 0;
   const bool ranged = table != nullptr && range_aux != nullptr;
-  if (table && !ranged) {
+  if (flat) {
+    NVT_CHECK_ARG(capacity >= (1ull << flat_slots_log2) + n + 64, "flat table: slots + n + 64");
+    int rc = encode_clear_any(4, table, capacity, sentinel_label, s);
+    if (rc) return rc;
+  } else if (table && !ranged) {
     int rc = encode_clear_any(4, table, capacity, sentinel_label, s);
     if (rc) return rc;
   } else if (ranged) {
@@ -1170,7 +1308,16 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
         ranged ? nullptr : (unsigned long long *)table, capacity - 1, first_label, sentinel_label,
         ranged ? label_of : nullptr);
     NVT_CHECK_LAUNCH();
-    if (ranged) {
+    if (flat) {
+      int32_t *aux = const_cast<int32_t *>(range_aux);
+      flat_params_kernel<<<1, 1, 0, s>>>(src_keys, n, flat_slots_log2, aux);
+      NVT_CHECK_LAUNCH();
+      NVT_CHECK_HIP(hipMemsetAsync(fb_status, 0, ntiles * 8 + 64, s));
+      flat_build_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(
+          src_keys, label_of, n, aux, fb_status, reinterpret_cast<unsigned *>(fb_status + ntiles),
+          (unsigned long long *)table, capacity);
+      NVT_CHECK_LAUNCH();
+    } else if (ranged) {
       const uint64_t nslots = ((uint64_t)1 << range_nb_log2) * kRpRegion + kRpGuard;
       range_patch_kernel<<<stream_grid(nslots / 2, kBlock, 8), kBlock, 0, s>>>(
           (unsigned long long *)table, nslots, label_of);

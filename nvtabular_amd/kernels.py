@@ -359,6 +359,7 @@ USE_RANGE = os.environ.get("NVT_RANGE", "1") != "0"
 # of the rows + run lengths, key-sorted output (Criteo-1TB's 38-40 M-unique columns)
 PATH_SORT = 10
 USE_SORT = os.environ.get("NVT_SORT_PATH", "1") != "0"
+USE_FLAT_TABLE = os.environ.get("NVT_FLAT_TABLE", "1") != "0"
 
 _ws_cache = {}
 _RT_BYTES = {}   # range_bits -> nvt_range_table_bytes
@@ -818,8 +819,11 @@ _SORT_BYTES = {}  # (key_bytes, n) -> nvt_vocab_sort_tmp_bytes
 class EncodeTable:
     """key -> label probe table built from an ordered vocabulary."""
 
+    FLAT_AUX_WORDS, FLAT_AUX_MAXDISP = 8192 + 16, 8192 + 8   # include/nvt_hip.h NVT_FLAT_AUX_*
+    FLAT_MAX_DISPLACEMENT = 4096   # longer probe runs than this: the keys cluster, use a hashed table
+
     def __init__(self, vocab_keys: torch.Tensor, first_label: int, unique: bool = False,
-                 defer_build: bool = False, range_table=None):
+                 defer_build: bool = False, range_table=None, flat: bool = False):
         """range_table = (table, aux, bits): the table was dumped by the range path of the
         counting stage and is addressed by the monotone map stored in ``aux``; it is completed
         (positions -> labels) by nvt_vocab_finalize_many -- no table is allocated or built here."""
@@ -849,10 +853,20 @@ class EncodeTable:
         self.pending = False   # True until the current stream has been made to wait for it
         if unique and 0 < self.n_vocab <= resident:
             return
+        self.flat_bits = 0
         if range_table is not None:
             assert defer_build and unique and self.key_bytes == 4
             self.table, self.range_aux, self.range_bits = range_table
             self.capacity = 0
+            self.sentinel_label = torch.empty(1, dtype=torch.int64, device=dev)
+            return
+        if flat and USE_FLAT_TABLE and defer_build and unique and self.key_bytes == 4:
+            # flat range table laid out from the key-sorted source by nvt_vocab_finalize_many
+            # (prefix maximum, no random inserts): 2^k >= 2 n slots + n + 64 tail slots
+            self.flat_bits = max(6, (2 * self.n_vocab - 1).bit_length())
+            self.capacity = (1 << self.flat_bits) + self.n_vocab + 64
+            self.table = torch.empty(self.capacity * 8, dtype=torch.uint8, device=dev)
+            self.range_aux = torch.empty(self.FLAT_AUX_WORDS, dtype=torch.int32, device=dev)
             self.sentinel_label = torch.empty(1, dtype=torch.int64, device=dev)
             return
         key = (self.key_bytes, self.capacity)
@@ -884,7 +898,7 @@ class EncodeTable:
             return self._fill_vocab_desc_sorted(d, counts, max_count, src)
         d.src_keys = d.src_counts = d.cls_hist = d.range_aux = None
         d.n_big = 0
-        d.range_nb_log2 = 0
+        d.range_nb_log2 = d.flat_slots_log2 = 0
         # the counts are ordered in place on the same internal stream as the keys: they must
         # outlive the hand-off event exactly like keys / table / sort_tmp (a rank that writes
         # no artifacts used to drop its only reference right after the launch)
@@ -940,6 +954,7 @@ class EncodeTable:
         d.n_big = int(n_big)
         d.range_aux = ptr(self.range_aux)
         d.range_nb_log2 = int(self.range_bits)
+        d.flat_slots_log2 = int(self.flat_bits)
         key = ("order", n, int(n_big))
         nbytes = _SORT_BYTES.get(key)
         if nbytes is None:
@@ -959,6 +974,12 @@ class EncodeTable:
             self.pending = True
         else:
             d.ready_event = None
+
+    def flat_ok(self) -> bool:
+        """Flat range tables only: True when no entry sits further than FLAT_MAX_DISPLACEMENT slots
+        from its home slot.  Synchronises (the finalisation of this vocabulary has to be done)."""
+        self.wait_ready()
+        return int(self.range_aux[self.FLAT_AUX_MAXDISP].item()) & 0xFFFFFFFF <= self.FLAT_MAX_DISPLACEMENT
 
     def wait_ready(self):
         """Order the CURRENT stream behind this vocabulary's sort / table build (no host

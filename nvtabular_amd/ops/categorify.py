@@ -435,11 +435,20 @@ class Categorify(StatOperator):
                 keys, counts = torch.empty_like(keys), torch.empty_like(counts)
                 if info.get("range_table") is not None:
                     rtab = (info["range_table"], info["range_aux"], info["range_bits"])
-            tab = K.EncodeTable(keys, start, unique=True, defer_build=True, range_table=rtab)
+            # a key-sorted source without a dumped table (sort path, multi-GPU merge): the table
+            # is laid out from the sorted keys in one pass (flat range table)
+            tab = K.EncodeTable(keys, start, unique=True, defer_build=True, range_table=rtab,
+                                flat=src is not None and rtab is None)
             tab.fill_vocab_desc(d, counts, max_count, src=src)
             built.append((g, keys, counts, tab, start))
         K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
                 "nvt_vocab_finalize_many")
+        for i, (g, keys, counts, tab, start) in enumerate(built):
+            if tab.flat_bits and not tab.flat_ok():
+                # keys that cluster in their range make long probe runs in a monotone table: an
+                # ordinary hashed table instead (built from the ordered vocabulary, now final)
+                tab = K.EncodeTable(keys, start, unique=True)
+                built[i] = (g, keys, counts, tab, start)
         for g, keys, counts, tab, start in built:
             if not tab.pending:
                 tab.sort_tmp = None  # scratch of work already ordered on this stream

@@ -183,3 +183,39 @@ def test_workflow_on_the_sort_path_vs_oracle(tmp_path):
     b = pd.read_parquet(paths["c"])
     np.testing.assert_array_equal(a["c"].to_numpy().astype(np.int64), b["c"].to_numpy().astype(np.int64))
     np.testing.assert_array_equal(a["c_size"].to_numpy(), b["c_size"].to_numpy())
+
+
+def test_flat_table_falls_back_to_a_hashed_table_for_clustered_keys(tmp_path):
+    """Two dense clusters of keys 2^30 apart: in a monotone table every cluster is one long probe
+    run (flat_build_kernel reports the displacement); Categorify then builds a hashed table.  Labels
+    stay exact either way; the spread-out case keeps the flat table."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K, ops
+    from nvtabular_amd.device import DeviceColumn, DeviceFrame
+
+    rng = np.random.default_rng(9)
+    n = 2_400_000  # (>= 2 M rows: the cold fit estimates the distinct count from a prefix)
+    old = K.PATH_RANGE_MAX_DISTINCT
+    K.PATH_RANGE_MAX_DISTINCT = 50_000
+    try:
+        for clustered in (True, False):
+            if clustered:
+                ids = rng.integers(0, 300_000, n).astype(np.int64)
+                ids[n // 2:] += 2**30
+            else:
+                ids = rng.integers(0, 2**31 - 1, n).astype(np.int64)
+            ids = ids.astype(np.int32)
+            frame = DeviceFrame({"c": DeviceColumn(torch.from_numpy(ids).cuda())})
+            op = ops.Categorify(out_path=str(tmp_path / f"g{int(clustered)}"))
+            wf = nvt.Workflow(["c"] >> op)
+            wf.fit(nvt.Dataset(frame))
+            got = wf.transform(frame)["c"].data.cpu().numpy()
+            assert op._last_paths["c#0"] == K.PATH_SORT
+            tab = op._encoders["c"].table
+            assert (tab.flat_bits == 0) == clustered, (clustered, tab.flat_bits)
+            df = pd.DataFrame({"c": ids})
+            paths = O.categorify_fit([df], ["c"], str(tmp_path / f"c{int(clustered)}"), tie_break="stable")
+            exp = O.categorify_transform(df, ["c"], paths)["c"].to_numpy()
+            np.testing.assert_array_equal(got, exp)
+    finally:
+        K.PATH_RANGE_MAX_DISTINCT = old
