@@ -846,6 +846,7 @@ class EncodeTable:
         resident = ENCODE_RESIDENT_I32 if self.key_bytes == 4 else ENCODE_RESIDENT_I64
         self.table = self.sentinel_label = None
         self.range_aux, self.range_bits = None, 0
+        self.flat_bits = 0
         self.sort_tmp = None
         self._counts = None    # the counts tensor while an internal stream still orders it
         self._src = None       # key-sorted source list of the one-pass ordering, same lifetime
@@ -853,7 +854,6 @@ class EncodeTable:
         self.pending = False   # True until the current stream has been made to wait for it
         if unique and 0 < self.n_vocab <= resident:
             return
-        self.flat_bits = 0
         if range_table is not None:
             assert defer_build and unique and self.key_bytes == 4
             self.table, self.range_aux, self.range_bits = range_table
