@@ -179,8 +179,8 @@ def test_cfg5_multihot_lists_categorify_hashbucket(tmp_path):
 def test_cfg3_high_cardinality_column_stays_on_partitioned_path():
     """BASELINE.json configs[2]'s worst columns (Criteo-1TB C1/C10/C20/C22: ~4e7 uniques):
     64 M rows of uniform draws from 4.8e7 ids -> ~3.5e7 distinct keys in one partition.  The
-    groupby-size must come from the partitioned LDS path (path 3), not the global-atomic
-    fallback, and equal torch.unique exactly; the encode round-trips."""
+    groupby-size must come from the sort path (int32 keys) or the partitioned LDS path 3, never
+    the global-atomic fallback, and equal torch.unique exactly; the encode round-trips."""
     import torch
 
     from nvtabular_amd import kernels as K
@@ -190,10 +190,17 @@ def test_cfg3_high_cardinality_column_stays_on_partitioned_path():
     g = torch.Generator(device=dev).manual_seed(7)
     keys = (torch.randint(0, card, (n,), device=dev, generator=g, dtype=torch.int64) * 2654435761 % (2**31)
             ).to(torch.int32)
-    k, c, nulls, info = K.dense_count(keys, None, hint=40_000_000)
-    assert info["path"] == 3, info
     uk, uc = torch.unique(keys, return_counts=True)
+    # int32 keys without weights: the sort path (key-sorted output, no re-sort needed) ...
+    k, c, nulls, info = K.dense_count(keys, None, hint=40_000_000)
+    assert info["path"] == K.PATH_SORT and info["sorted_by_key"], info["path"]
     assert info["distinct"] == uk.numel() > 32_000_000
+    assert torch.equal(k, uk) and torch.equal(c, uc)
+    # ... and the hash-partitioned path 3 (what int64 keys / weighted merges of this size take)
+    job = K.DenseCountJob(keys, None, None, hint=40_000_000)
+    job.path = 3
+    k, c, nulls, info = K.dense_count_many([job])[0]
+    assert info["path"] == 3, info["path"]
     order = torch.argsort(k)
     assert torch.equal(k[order], uk) and torch.equal(c[order], uc)
     del order, uk, uc
