@@ -2312,6 +2312,7 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
     if (rc) return rc;
   }
   bool waited[kSideStreams] = {false, false, false};
+  int rc_all = NVT_OK;
   if (fork && sampled) NVT_CHECK_HIP(hipEventRecord(pool->aux, main_s));
   for (int i = 0; i < ncols; ++i) {
     const nvt_count_col &c = cols[i];
@@ -2341,16 +2342,19 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
                                 !contiguous);
     else {
       set_error("nvt_dense_count_many: key_bytes must be 4 or 8 (column %d)", i);
-      return NVT_EINVAL;
+      rc = NVT_EINVAL;
     }
-    if (rc) return rc;
+    if (rc) {
+      rc_all = rc;  // the columns launched so far keep running on the internal streams: they
+      break;        // are joined below all the same, so the caller may free / reuse its buffers
+    }
   }
   if (fork)
     for (size_t k = 0; k < wss.size(); ++k) {
       NVT_CHECK_HIP(hipEventRecord(pool->join[k], pool->s[k]));
       NVT_CHECK_HIP(hipStreamWaitEvent(main_s, pool->join[k], 0));
     }
-  return NVT_OK;
+  return rc_all;
 }
 int nvt_dense_count_i32(const int32_t *keys, const uint8_t *valid, const int64_t *weights,
                         uint64_t n, int path, void *ws, int32_t *out_keys, int64_t *out_counts,

@@ -803,6 +803,7 @@ int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
     NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
     for (int k = 0; k < lanes; ++k) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[k], pool->fork, 0));
   }
+  int rc_all = NVT_OK;
   for (int i = 0; i < ncols; ++i) {
     const nvt_encode_col &c = cols[i];
     hipStream_t cs = fork ? pool->s[i % lanes] : main_s;
@@ -820,16 +821,19 @@ int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
                                   c.first_label, cs);
     else {
       set_error("nvt_encode_many: key_bytes must be 4 or 8 (column %d)", i);
-      return NVT_EINVAL;
+      rc = NVT_EINVAL;
     }
-    if (rc) return rc;
+    if (rc) {
+      rc_all = rc;  // (the internal streams are joined below all the same)
+      break;
+    }
   }
   if (fork)
     for (int k = 0; k < lanes; ++k) {
       NVT_CHECK_HIP(hipEventRecord(pool->join[k], pool->s[k]));
       NVT_CHECK_HIP(hipStreamWaitEvent(main_s, pool->join[k], 0));
     }
-  return NVT_OK;
+  return rc_all;
 }
 int nvt_hash_bucket_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, uint32_t num_buckets,
                         int32_t *out, const uint64_t *xor_in, uint64_t *xor_out, void *stream) {

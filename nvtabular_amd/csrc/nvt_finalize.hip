@@ -28,9 +28,27 @@ constexpr int kSide = kSideStreams;
 
 using namespace nvt;
 
+static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_s, SidePool *&pool,
+                         bool &forked);
+
 extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, void *stream) {
   NVT_CHECK_ARG(ncols == 0 || cols, "null descriptors");
-  hipStream_t main_s = (hipStream_t)stream;
+  SidePool *pool = nullptr;
+  bool forked = false;
+  const int rc = finalize_impl(cols, ncols, (hipStream_t)stream, pool, forked);
+  if (rc != NVT_OK && forked && pool != nullptr) {
+    // an error after the fork: whatever was launched keeps running on the internal streams; join
+    // them into the caller's stream so that it may free / reuse the buffers it handed over
+    for (int i = 0; i < kSide; ++i) {
+      (void)hipEventRecord(pool->join[i], pool->s[i]);
+      (void)hipStreamWaitEvent((hipStream_t)stream, pool->join[i], 0);
+    }
+  }
+  return rc;
+}
+
+static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_s, SidePool *&pool,
+                         bool &forked) {
   std::vector<int> small, big;
   for (int i = 0; i < ncols; ++i) {
     const nvt_vocab_col &c = cols[i];
@@ -47,10 +65,10 @@ extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, voi
   std::sort(big.begin(), big.end(), [&](int a, int b) { return cols[a].n > cols[b].n; });
   // large vocabularies: forked onto the internal streams (only when there is something to overlap)
   const bool fork = big.size() + (small.empty() ? 0 : 1) > 1 && !getenv("NVT_FINALIZE_SERIAL");
-  SidePool *pool = nullptr;
   if (fork) {
     int rc = side_pool(0, &pool);
     if (rc) return rc;
+    forked = true;
     NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
     for (int i = 0; i < kSide; ++i) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[i], pool->fork, 0));
   }
