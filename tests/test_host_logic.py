@@ -108,3 +108,37 @@ def test_graph_json_dtype_and_tag_records():
         Tags.CONTINUOUS, Tags.CATEGORICAL]
     assert G._paths_from_json(G._paths_to_json({("a", "b"): "/x/art/categories/u.parquet"}, "/x/art"),
                               "/y") == {("a", "b"): "/y/categories/u.parquet"}
+
+
+def test_one_pass_class_order_equals_count_desc_key_asc():
+    """The rule behind nvt_sort.hip's cls_scatter_kernel, emulated in numpy: for a KEY-SORTED
+    (key, count) list, "count descending, key ascending" (categorify.py:1300,1316 with the stable
+    tie rule) == class 255 (count >= 255) sorted on its own, followed by classes 254 .. 1, each in
+    the key order the list already has.  (The GPU tests compare the kernel with the oracle; this
+    pins the algebra the kernel relies on.)"""
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    keys = np.unique(rng.integers(-2**31, 2**31 - 1, 50_000).astype(np.int64))  # sorted, distinct
+    counts = np.minimum(rng.zipf(1.3, keys.size), 10**6).astype(np.int64)
+    want = np.lexsort((keys, -counts))                       # count desc, key asc
+    cls = np.minimum(counts, 255)
+    digit = 255 - cls                                        # class 255 first
+    order = np.argsort(digit, kind="stable")                 # ONE stable counting pass
+    n_big = int((cls == 255).sum())
+    head = order[:n_big]
+    head = head[np.lexsort((keys[head], -counts[head]))]     # the small sort of class 255
+    got = np.concatenate([head, order[n_big:]])
+    np.testing.assert_array_equal(got, want)
+    # and the flat range table: positions of the sorted keys under a monotone slot function with
+    # linear probing are a prefix maximum, p_i = i + max_{j <= i}(h_j - j)
+    slots = 1 << 17
+    span = int(keys[-1] - keys[0])
+    h = ((keys - keys[0]).astype(np.float64) * (slots / (span + 1))).astype(np.int64)
+    p = np.arange(keys.size) + np.maximum.accumulate(h - np.arange(keys.size))
+    ref = np.empty(keys.size, dtype=np.int64)
+    last = -1
+    for i, hi in enumerate(h.tolist()):                      # sequential linear probing
+        last = max(hi, last + 1)
+        ref[i] = last
+    np.testing.assert_array_equal(p, ref)
