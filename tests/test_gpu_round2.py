@@ -207,13 +207,18 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows",
-                          "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                          "400000", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000",
+                          "--no-extra"],
                          capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["collective_backend"] == "gloo"
     assert rec["value"] > 0 and rec["scaling"] == "weak"
+    # an N > 1 line is a complete line: roofline by family, the CPU baseline (rank 0, its own
+    # shard) and the parity leg (a single-rank fit inside dist.local_only())
+    assert rec["roofline"]["per_family"]["count"]["ms_per_step"] > 0
+    assert rec["cpu_baseline"]["value"] > 0 and rec["parity"]["parity_ok"] is True
 
 
 def test_fully_staged_encode_with_unseen_keys_and_nulls(tmp_path):
