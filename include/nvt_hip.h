@@ -324,14 +324,91 @@ int nvt_seg_aggregate(const uint64_t *words, uint64_t n, uint64_t ngroups, const
 int nvt_gather_f64(const double *src, const int64_t *group, uint64_t n, double miss, void *out,
                    int out_dtype, void *stream);
 /* TargetEncoding (target_encoding.py:341-363): with g = group_all[i], f = group_fold[i]
- *   out[i] = g < 0 ? y_mean
- *          : (sum_all[g] - (f>=0 ? sum_fold[f] : 0) + p*y_mean) /
- *            (cnt_all[g] - (f>=0 ? cnt_fold[f] : 0) + p)          -> float32/float64
- * group_fold == NULL means kfold <= 1. */
+ *   out[i] = (g < 0 || f < 0) ? y_mean     (the reference's unmatched left merges)
+ *          : (sum_all[g] - sum_fold[f] + p*y_mean) / (cnt_all[g] - cnt_fold[f] + p)
+ * -> float32/float64.  group_fold == NULL means kfold <= 1: no fold terms, only g decides. */
 int nvt_te_apply(const int64_t *group_all, const int64_t *group_fold, const double *sum_all,
                  const int64_t *cnt_all, const double *sum_fold, const int64_t *cnt_fold,
                  uint64_t n, double p_smooth, double y_mean, void *out, int out_dtype,
                  void *stream);
+
+/* the same with the DENSE fold statistics of nvt_sgb_reduce: f = g * kfold + fold[i], a pair
+ * with cnt_fold[f] == 0 has no rows (unmatched merge: y_mean). */
+int nvt_te_apply_folds(const int64_t *group_all, const uint8_t *fold, int kfold,
+                       const double *sum_all, const int64_t *cnt_all, const double *sum_fold,
+                       const int64_t *cnt_fold, uint64_t n, double p_smooth, double y_mean,
+                       void *out, int out_dtype, void *stream);
+
+/* ---- ONE int32 key column without nulls: groupby-aggregate by sorting ------------------
+ * (categorify.py:955-1137 _top_level_groupby .. _bottom_level_groupby for JoinGroupby /
+ * TargetEncoding, join_groupby.py:150-173, target_encoding.py:254-299.)  The rows are radix-
+ * sorted by (key, fold), the groups come out DENSE and ordered by key:
+ *   out_keys / out_keys32 [cap]            the group keys, ascending
+ *   out_size  uint64[cap * kfold]          rows of (group g, fold f) at g * kfold + f
+ *   out_sum / out_sumsq / out_min / out_max  double[nvals][cap * kfold] (NaN / null values
+ *                                          skipped; min / max of an empty entry stay +-inf;
+ *                                          the last three per flags NVT_GB_SUMSQ / _MINMAX)
+ *   tot_size uint64[cap], tot_sum double[nvals][cap]   (kfold > 1 only) sums over the folds
+ *   te_records double[nvals][cap][2 * (kfold + 1)] or NULL (kfold > 1 only): per group
+ *                                          {sum, count, (sum_f, count_f) for every fold}, the
+ *                                          layout nvt_flat_lookup_te reads with one probe
+ * nvt_sgb_sort: words (key image << 32 | fold << row_bits | row) sorted on bits [row_bits, 64);
+ * fold: uint8[n] ids < kfold, NULL with kfold == 1; n <= 2^(32 - bits(kfold - 1)), n < 2^30.
+ * *sorted_out = device pointer INSIDE ws (nvt_sgb_sort_ws_bytes(n) bytes; keep ws alive),
+ * *row_bits_out = 32 - bits(kfold - 1).  The sorted words serve every aggregate on the same key
+ * column of the same rows (JoinGroupby after TargetEncoding ignores the fold bits: kfold = 1).
+ * nvt_sgb_regroup: run heads of the sorted words -> group ids (out_keys / out_keys32 [cap]) and
+ * the words rewritten as ((g * kfold + fold) << 32 | row) into regrouped[n] (not aliasing
+ * sorted); cap * kfold < 2^32 - 1.  state[NVT_ST_OCCUPIED] = groups found; more than cap:
+ * only the first cap groups are kept (their rows carry slot 0xFFFFFFFF) and
+ * state[NVT_ST_NEED] = the capacity a second call needs.  ws: nvt_sgb_regroup_ws_bytes(n).
+ * nvt_sgb_reduce: the statistics of the regrouped words (the arrays above; they are
+ * initialised here).  kfold = words_kfold: per-(group, fold) entries + totals (+ te_records);
+ * kfold = 1 with words_kfold > 1: per-group entries from words regrouped for ANOTHER
+ * aggregate's folds (JoinGroupby after TargetEncoding on the same column: one sort, one
+ * regroup).  state: the block nvt_sgb_regroup filled (device, read by the kernels only).
+ * No host synchronisation anywhere. */
+int nvt_sgb_sort_ws_bytes(uint64_t n, uint64_t *bytes);
+int nvt_sgb_sort(const int32_t *keys, const uint8_t *fold, int kfold, uint64_t n, void *ws,
+                 uint64_t **sorted_out, int *row_bits_out, void *stream);
+int nvt_sgb_regroup_ws_bytes(uint64_t n, uint64_t *bytes);
+int nvt_sgb_regroup(const uint64_t *sorted, int row_bits, int kfold, uint64_t n, uint64_t cap,
+                    int64_t *out_keys, int32_t *out_keys32, uint64_t *regrouped, uint64_t *state,
+                    void *ws, void *stream);
+int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const void *const *vals,
+                   const int *vdtypes, const uint8_t *const *val_valid, int nvals, int flags,
+                   uint64_t n, uint64_t cap, uint64_t *out_size, double *out_sum, double *out_sumsq,
+                   double *out_min, double *out_max, uint64_t *tot_size, double *tot_sum,
+                   double *te_records, const uint64_t *state, void *stream);
+/* key -> position in an ascending int32 key list (the group ids of nvt_sgb_regroup) through
+ * a flat range table laid out from the list in one pass (no inserts): replaces
+ * nvt_gb_index_build + nvt_gb_lookup for such groups (join_groupby.py:198-203,
+ * target_encoding.py:350-371).  aux: int32[NVT_FLAT_AUX_WORDS]; table: capacity 8-byte slots,
+ * capacity >= 2^slots_log2 + n + 64; tmp: nvt_flat_index_tmp_bytes(n).
+ * aux[NVT_FLAT_AUX_MAXDISP] = longest displacement (keys clustered in their range make long
+ * probe runs: the caller may prefer a hashed index).  nvt_flat_lookup: out[i] = position of
+ * keys[i] (int32 / int64 column, optional validity bitmap) or -1. */
+int nvt_flat_index_tmp_bytes(uint64_t n, uint64_t *bytes);
+int nvt_flat_index_build(const int32_t *keys, uint64_t n, int slots_log2, int32_t *aux, void *table,
+                         uint64_t capacity, void *tmp, void *stream);
+int nvt_flat_lookup(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
+                    const void *table, uint64_t capacity, int64_t *out, void *stream);
+/* JoinGroupby.transform in one pass (join_groupby.py:198-217): outs[c][i] = records[g][c] with
+ * g = the group of keys[i], miss[c] when the key has no group; records double[groups][ncols]
+ * (ncols <= 16), out_dtypes f32 / f64 / i32 / i64 (value-converting stores).  *unseen (device
+ * word, may be NULL) is OR-ed with 1 when any row had no group -- the reference's
+ * astype(int32) of a count column raises then (join_groupby.py:214). */
+int nvt_flat_lookup_gather(const void *keys, int dtype, const uint8_t *valid, uint64_t n,
+                           const int32_t *aux, const void *table, uint64_t capacity,
+                           const double *records, int ncols, void *const *outs, const int *out_dtypes,
+                           const double *miss, uint64_t *unseen, void *stream);
+/* TargetEncoding.transform in one pass (target_encoding.py:341-371): probe + nvt_te_apply(_folds)
+ * on records double[groups][2 * (kfold + 1)] = {sum, count, (sum_f, count_f) ...} (te_records
+ * of nvt_sgb_reduce); fold == NULL (kfold 1): records double[groups][2] = {sum, count}. */
+int nvt_flat_lookup_te(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
+                       const void *table, uint64_t capacity, const uint8_t *fold, int kfold,
+                       const double *records, double p_smooth, double y_mean, void *out,
+                       int out_dtype, void *stream);
 
 /* ---- batched entry points: ONE call per operator per partition -----------------------
  * The reference hands a whole dataframe to the backend per operator call

@@ -473,6 +473,32 @@ __global__ __launch_bounds__(kBlock) void te_kernel(
   }
 }
 
+// the same with DENSE fold statistics (nvt_sgb_reduce): entry g * kfold + fold[i] of
+// sum_fold / cnt_fold belongs to (group g, fold of row i); a pair without rows has count 0 and
+// is the reference's unmatched [fold, key] merge: y_mean
+template <typename OUT>
+__global__ __launch_bounds__(kBlock) void te_dense_kernel(
+    const int64_t *__restrict__ group_all, const uint8_t *__restrict__ fold, unsigned kfold,
+    const double *__restrict__ sum_all, const int64_t *__restrict__ cnt_all,
+    const double *__restrict__ sum_fold, const int64_t *__restrict__ cnt_fold, uint64_t n,
+    double p, double y_mean, OUT *__restrict__ out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t g = group_all[i];
+    double v = y_mean;
+    if (g >= 0) {
+      const uint64_t f = (uint64_t)g * kfold + fold[i];
+      const int64_t cf = cnt_fold[f];
+      if (cf > 0) {
+        const double s = sum_all[g] - sum_fold[f];
+        const double c = (double)(cnt_all[g] - cf);
+        v = (s + p * y_mean) / (c + p);
+      }
+    }
+    out[i] = (OUT)v;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void widen_kernel(const T *__restrict__ src, uint64_t n,
                                                        int64_t *__restrict__ out) {
@@ -869,6 +895,30 @@ int nvt_te_apply(const int64_t *group_all, const int64_t *group_fold, const doub
                                               cnt_fold, n, p_smooth, y_mean, (double *)out);
   else {
     set_error("nvt_te_apply: out dtype must be f32/f64");
+    return NVT_EINVAL;
+  }
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_te_apply_folds(const int64_t *group_all, const uint8_t *fold, int kfold,
+                       const double *sum_all, const int64_t *cnt_all, const double *sum_fold,
+                       const int64_t *cnt_fold, uint64_t n, double p_smooth, double y_mean,
+                       void *out, int out_dtype, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(group_all && fold && sum_all && cnt_all && sum_fold && cnt_fold && out, "null pointer");
+  NVT_CHECK_ARG(kfold >= 2 && kfold <= 256, "kfold must be 2..256");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("te_apply", 0, s);
+  unsigned grid = stream_grid(n, kBlock * 4);
+  if (out_dtype == NVT_F32)
+    te_dense_kernel<float><<<grid, kBlock, 0, s>>>(group_all, fold, (unsigned)kfold, sum_all, cnt_all,
+                                                   sum_fold, cnt_fold, n, p_smooth, y_mean, (float *)out);
+  else if (out_dtype == NVT_F64)
+    te_dense_kernel<double><<<grid, kBlock, 0, s>>>(group_all, fold, (unsigned)kfold, sum_all, cnt_all,
+                                                    sum_fold, cnt_fold, n, p_smooth, y_mean, (double *)out);
+  else {
+    set_error("nvt_te_apply_folds: out dtype must be f32/f64");
     return NVT_EINVAL;
   }
   NVT_CHECK_LAUNCH();

@@ -286,8 +286,16 @@ struct SegAcc {
   double cnt, sum, sq, mn, mx;
 };
 
+// EXCL: every slot's rows are ONE run of the words and its accumulators still hold their initial
+// values (nvt_sgb_reduce): a run that begins and ends inside a wave's 64 words belongs to that
+// lane alone and is written with plain stores -- only the runs that touch the row's first or
+// last word (they may continue in the neighbouring rows) need atomics.  With ~4 rows per group
+// that is 14 of 16 runs.  slot_div: the words' slots are g * slot_div + fold and this
+// aggregate wants g (words regrouped for another aggregate's folds).
+template <bool EXCL>
 __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArgs a, uint64_t n,
-                                                              const uint64_t *__restrict__ words) {
+                                                              const uint64_t *__restrict__ words,
+                                                              uint32_t slot_div) {
   const double inf = std::numeric_limits<double>::infinity();
   const unsigned lane = lane_id();
   const uint64_t nwaves = (uint64_t)gridDim.x * (kBlock / kWave);
@@ -298,13 +306,13 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
     const uint64_t i = base + lane;
     const bool act = i < n;
     const uint64_t w = act ? words[i] : ~0ull;
-    const uint32_t slot = (uint32_t)(w >> 32);
+    const uint32_t raw = (uint32_t)(w >> 32);
+    const uint32_t slot = (slot_div > 1 && raw != 0xFFFFFFFFu) ? raw / slot_div : raw;
     const uint32_t row = (uint32_t)w;
-    const bool live = act && slot < t.cap;
-    const uint32_t prev = __shfl_up(slot, 1, 64);
-    const bool head = lane == 0 || prev != slot;
+    const bool live = act && raw != 0xFFFFFFFFu && slot < t.cap;
     const uint32_t next = __shfl_down(slot, 1, 64);
     const bool tail = lane == 63 || next != slot;
+    bool excl = false;
     // size / count (rows whose FIRST key component is non-null, categorify.py:995-999)
     {
       double sz = live ? 1.0 : 0.0;
@@ -318,9 +326,16 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
           ct += oct;
         }
       }
+      // the run's first word sits at lane + 1 - sz: inside the row when that is > 0
+      excl = EXCL && lane < 63 && (double)(lane + 1) > sz;
       if (live && tail) {
-        atomicAdd(&t.size[slot], (unsigned long long)sz);
-        if (t.count && ct > 0) atomicAdd(&t.count[slot], (unsigned long long)ct);
+        if (excl) {
+          t.size[slot] = (unsigned long long)sz;
+          if (t.count && ct > 0) t.count[slot] = (unsigned long long)ct;
+        } else {
+          atomicAdd(&t.size[slot], (unsigned long long)sz);
+          if (t.count && ct > 0) atomicAdd(&t.count[slot], (unsigned long long)ct);
+        }
       }
     }
     for (int j = 0; j < t.nvals; ++j) {
@@ -347,16 +362,25 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
       }
       if (live && tail && any > 0) {
         const uint64_t o = (uint64_t)j * t.cap + slot;
-        atomicAdd(&t.sum[o], sum);
-        if (t.vcount) atomicAdd(&t.vcount[o], (unsigned long long)any);
-        if (t.sumsq) atomicAdd(&t.sumsq[o], sq);
-        if (t.vmin) {
-          atomic_min_f64(&t.vmin[o], mn);
-          atomic_max_f64(&t.vmax[o], mx);
+        if (excl) {
+          t.sum[o] = sum;
+          if (t.vcount) t.vcount[o] = (unsigned long long)any;
+          if (t.sumsq) t.sumsq[o] = sq;
+          if (t.vmin) {
+            t.vmin[o] = mn;
+            t.vmax[o] = mx;
+          }
+        } else {
+          atomicAdd(&t.sum[o], sum);
+          if (t.vcount) atomicAdd(&t.vcount[o], (unsigned long long)any);
+          if (t.sumsq) atomicAdd(&t.sumsq[o], sq);
+          if (t.vmin) {
+            atomic_min_f64(&t.vmin[o], mn);
+            atomic_max_f64(&t.vmax[o], mx);
+          }
         }
       }
     }
-    (void)head;
   }
 }
 
@@ -554,6 +578,186 @@ __global__ __launch_bounds__(kBlock) void gb_lookup_kernel(GbView t, GbRowArgs a
     unsigned g = 0xFFFFFFFFu;
     if (slot >= 0) g = t.head[slot].index;
     out[i] = g == 0xFFFFFFFFu ? -1 : (int64_t)g;
+  }
+}
+
+// ---- one int32 key column: groupby by SORTING (JoinGroupby / TargetEncoding fit) --------------
+// The hash update above costs a random 16-byte probe per row (gb_assign 1.28 ms for 20 M rows),
+// a sort of (slot, row) words, and a compaction of the sparse table afterwards.  With ONE key
+// column of at most 32 bits none of the three is needed: the rows are sorted by the key itself,
+//   sgb_pack_kernel      words = (key image << 32 | fold << rb | row)
+//   sort_words_bits      onesweep LSD radix on bits [rb, 64): every key's rows are one run, the
+//                        folds of a key (TargetEncoding's kfold) consecutive sub-runs
+//   sgb_rle_kernel       run heads -> group index g (decoupled look-back over the tiles): the
+//                        groups come out DENSE and ordered by key, the words are rewritten as
+//                        ((g * kfold + fold) << 32 | row)
+//   gb_segreduce_kernel  the same wave-level segmented reduction as above, into dense arrays
+//                        indexed g * kfold + fold (monotone in the sorted order: atomics of
+//                        neighbouring waves fall into neighbouring sectors)
+//   sgb_fold_total_kernel  per-key totals as the sum over the key's folds (TargetEncoding needs
+//                        both tables, categorify.py:1344-1540 run twice in the reference)
+// and the key -> group index for the transform side is a flat range table laid out from the
+// sorted keys (flat_build_kernel, nvt_sort.hip) instead of a second hash table.
+constexpr int kSgbRows = 8;
+constexpr int kSgbTile = kBlock * kSgbRows;
+constexpr unsigned long long kSgbAgg = 1ull << 62, kSgbPrefix = 2ull << 62,
+                             kSgbMask = (1ull << 62) - 1ull;
+
+__global__ __launch_bounds__(kBlock) void sgb_pack_kernel(const int32_t *__restrict__ keys,
+                                                          const uint8_t *__restrict__ fold,
+                                                          uint64_t n, int rb,
+                                                          uint64_t *__restrict__ words) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const uint64_t img = (uint32_t)keys[i] ^ 0x80000000u;  // order-preserving image
+    const uint64_t f = fold ? (uint64_t)fold[i] : 0ull;
+    words[i] = (img << 32) | (f << rb) | i;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sgb_rle_kernel(
+    const uint64_t *__restrict__ in, uint64_t n, int rb, unsigned kfold, uint64_t cap,
+    unsigned long long *status, unsigned *ticket, int64_t *__restrict__ out_keys,
+    int32_t *__restrict__ out_keys32, uint64_t *__restrict__ out_words, uint64_t *state) {
+  constexpr int NW = kBlock / kWave;
+  __shared__ unsigned wtot[NW];
+  __shared__ unsigned long long s_base;
+  __shared__ unsigned s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const unsigned tile = s_tile, w = threadIdx.x / kWave, l = lane_id();
+  const uint64_t wave0 = (uint64_t)tile * kSgbTile + (uint64_t)w * (kSgbRows * kWave);
+  uint64_t W[kSgbRows];
+  unsigned long long hb[kSgbRows];  // ballot of the run heads of every 64-word row
+  // key image in front of this wave's run (one address: a broadcast load)
+  uint32_t prev_hi = (wave0 > 0 && wave0 < n) ? (uint32_t)(in[wave0 - 1] >> 32) : 0u;
+  unsigned wheads = 0;
+#pragma unroll
+  for (int r = 0; r < kSgbRows; ++r) {
+    const uint64_t i = wave0 + (uint64_t)r * kWave + l;
+    const bool act = i < n;
+    W[r] = act ? in[i] : ~0ull;
+    const uint32_t hi = (uint32_t)(W[r] >> 32);
+    uint32_t up = __shfl_up(hi, 1, 64);
+    if (l == 0) up = prev_hi;
+    const bool head = act && (i == 0 || hi != up);
+    hb[r] = __ballot(head);
+    prev_hi = __shfl(hi, 63, 64);
+    wheads += (unsigned)__popcll(hb[r]);
+  }
+  if (l == 0) wtot[w] = wheads;
+  __syncthreads();
+  unsigned wbase = 0, ttot = 0;
+  for (int q = 0; q < NW; ++q) {
+    if (q < (int)w) wbase += wtot[q];
+    ttot += wtot[q];
+  }
+  if (threadIdx.x == 0) {
+    unsigned long long *my = status + tile;
+    __hip_atomic_store(my, (tile == 0 ? kSgbPrefix : kSgbAgg) | (unsigned long long)ttot,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long carry = 0;
+    if (tile > 0) {
+      unsigned tb = tile - 1;
+      while (true) {
+        const unsigned long long v =
+            __hip_atomic_load(status + tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned f = (unsigned)(v >> 62);
+        if (f == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        carry += v & kSgbMask;
+        if (f == 2) break;
+        --tb;
+      }
+      __hip_atomic_store(my, kSgbPrefix | (carry + ttot), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_base = carry;
+    if ((uint64_t)(tile + 1) * kSgbTile >= n) {  // the tile that holds the last row
+      const unsigned long long g = carry + ttot;
+      state[NVT_ST_OCCUPIED] = g;
+      state[NVT_ST_ROWS] = n;
+      if (g > cap) state[NVT_ST_NEED] = g;
+    }
+  }
+  __syncthreads();
+  uint64_t g0 = s_base + wbase;  // run heads in front of this wave's rows
+  const uint64_t rowmask = rb >= 32 ? 0xFFFFFFFFull : ((1ull << rb) - 1ull);
+#pragma unroll
+  for (int r = 0; r < kSgbRows; ++r) {
+    const uint64_t i = wave0 + (uint64_t)r * kWave + l;
+    const unsigned incl = (unsigned)__popcll(hb[r] & ((2ull << l) - 1ull));
+    if (i < n) {
+      const uint64_t g = g0 + incl - 1;  // >= 0: row 0 is a head
+      const uint32_t hi = (uint32_t)(W[r] >> 32);
+      const bool fits = g < cap;
+      if (((hb[r] >> l) & 1ull) && fits) {
+        const int32_t key = (int32_t)(hi ^ 0x80000000u);
+        out_keys[g] = (int64_t)key;
+        out_keys32[g] = key;
+      }
+      const uint64_t low = W[r] & 0xFFFFFFFFull;
+      const uint64_t fold = (rb >= 32 || kfold == 1) ? 0ull : (low >> rb);
+      const uint64_t slot = fits ? g * kfold + fold : 0xFFFFFFFFull;
+      out_words[i] = (slot << 32) | (low & rowmask);
+    }
+    g0 += (unsigned)__popcll(hb[r]);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sgb_fill_kernel(double *__restrict__ p, uint64_t n,
+                                                          double v) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// per-key totals over the folds (+ the one-probe records of the transform).  A workgroup takes
+// kBlock consecutive groups: their kfold-entry runs of fsize / fsum are contiguous and are read
+// coalesced, the records (2 * (kfold + 1) doubles per group) are assembled in LDS and leave as
+// one contiguous block (a thread per group wrote 12 scattered 8-byte words: 462 us for 5 M groups).
+constexpr int kSgbMaxFoldLds = 16;
+__global__ __launch_bounds__(kBlock) void sgb_fold_total_kernel(
+    const uint64_t *__restrict__ state, unsigned kfold, uint64_t cap, int nvals,
+    const unsigned long long *__restrict__ fsize, const double *__restrict__ fsum,
+    unsigned long long *__restrict__ tsize, double *__restrict__ tsum,
+    double *__restrict__ records) {
+  __shared__ double lrec[kBlock * 2 * (kSgbMaxFoldLds + 1)];
+  uint64_t ng = state[NVT_ST_OCCUPIED];
+  ng = ng < cap ? ng : cap;
+  const unsigned rs = 2 * (kfold + 1);
+  const uint64_t nblocks = (ng + kBlock - 1) / kBlock;
+  for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const uint64_t g0 = b * kBlock;
+    const unsigned cnt = (unsigned)((ng - g0) < (uint64_t)kBlock ? (ng - g0) : (uint64_t)kBlock);
+    for (int j = 0; j < (nvals > 0 ? nvals : 1); ++j) {
+      // stage {sum_f, count_f} of the block's groups: element e = (group, fold) in memory order
+      for (unsigned e = threadIdx.x; e < cnt * kfold; e += kBlock) {
+        const unsigned g = e / kfold, f = e - g * kfold;
+        lrec[g * rs + 3 + 2 * f] = (double)fsize[g0 * kfold + e];
+        if (nvals) lrec[g * rs + 2 + 2 * f] = fsum[(uint64_t)j * cap * kfold + g0 * kfold + e];
+      }
+      __syncthreads();
+      if (threadIdx.x < cnt) {
+        const unsigned g = threadIdx.x;
+        double d = 0.0, c = 0.0;
+        for (unsigned f = 0; f < kfold; ++f) {
+          if (nvals) d += lrec[g * rs + 2 + 2 * f];
+          c += lrec[g * rs + 3 + 2 * f];
+        }
+        lrec[g * rs] = d;
+        lrec[g * rs + 1] = c;
+        if (j == 0) tsize[g0 + g] = (unsigned long long)c;  // counts < 2^53: exact
+        if (nvals) tsum[(uint64_t)j * cap + g0 + g] = d;
+      }
+      __syncthreads();
+      if (records && nvals) {
+        double *dst = records + ((uint64_t)j * cap + g0) * rs;
+        for (unsigned e = threadIdx.x; e < cnt * rs; e += kBlock) dst[e] = lrec[e];
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -762,7 +966,7 @@ int nvt_gb_update(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *co
   uint64_t *sorted = nullptr;
   int rc = sort_words_bits(words, n, 32, 32 + cap_bits, sort_tmp, &sorted, s);
   if (rc) return rc;
-  gb_segreduce_kernel<<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(view_of(t), a, n, sorted);
+  gb_segreduce_kernel<false><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(view_of(t), a, n, sorted, 1u);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
@@ -900,8 +1104,129 @@ int nvt_seg_aggregate(const uint64_t *words, uint64_t n, uint64_t ngroups, const
   NVT_CHECK_ARG(nvals == 0 || out_sum, "null out_sum");
   hipStream_t s = (hipStream_t)stream;
   NVT_PROF("groupby_aggregate", 0, s);
-  gb_segreduce_kernel<<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, words);
+  gb_segreduce_kernel<false><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, words, 1u);
   NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+static uint64_t sgb_pad(uint64_t x) { return (x + 255) & ~255ull; }
+
+int nvt_sgb_sort_ws_bytes(uint64_t n, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes, "null out");
+  *bytes = sgb_pad(n * 8) + sgb_pad(sort_words_tmp_bytes(n)) + 512;
+  return NVT_OK;
+}
+
+int nvt_sgb_sort(const int32_t *keys, const uint8_t *fold, int kfold, uint64_t n, void *ws,
+                 uint64_t **sorted_out, int *row_bits_out, void *stream) {
+  NVT_CHECK_ARG(keys && ws && sorted_out && row_bits_out, "null pointer");
+  NVT_CHECK_ARG(kfold >= 1 && kfold <= 256, "kfold must be 1..256");
+  NVT_CHECK_ARG((kfold > 1) == (fold != nullptr), "fold ids come with kfold > 1");
+  int fb = 0;
+  while ((1 << fb) < kfold) ++fb;
+  const int rb = 32 - fb;
+  NVT_CHECK_ARG(n >= 1 && n < (1ull << 30) && n <= (1ull << rb), "row index does not fit next to the fold");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_sort", n * 4ull, s);
+  uint64_t *words = reinterpret_cast<uint64_t *>(ws);
+  void *sort_tmp = reinterpret_cast<char *>(ws) + sgb_pad(n * 8);
+  sgb_pack_kernel<<<stream_grid(n, kBlock * 4), kBlock, 0, s>>>(keys, fold, n, rb, words);
+  NVT_CHECK_LAUNCH();
+  uint64_t *sorted = nullptr;
+  int rc = sort_words_bits(words, n, rb, 64, sort_tmp, &sorted, s);
+  if (rc) return rc;
+  *sorted_out = sorted;
+  *row_bits_out = rb;
+  return NVT_OK;
+}
+
+int nvt_sgb_regroup_ws_bytes(uint64_t n, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes, "null out");
+  const uint64_t ntiles = (n + kSgbTile - 1) / kSgbTile;
+  *bytes = sgb_pad(ntiles * 8 + 64) + 256;
+  return NVT_OK;
+}
+
+int nvt_sgb_regroup(const uint64_t *sorted, int row_bits, int kfold, uint64_t n, uint64_t cap,
+                    int64_t *out_keys, int32_t *out_keys32, uint64_t *regrouped, uint64_t *state,
+                    void *ws, void *stream) {
+  NVT_CHECK_ARG(sorted && out_keys && out_keys32 && regrouped && state && ws, "null pointer");
+  NVT_CHECK_ARG(regrouped != sorted, "regrouped must not alias the sorted words");
+  NVT_CHECK_ARG(kfold >= 1 && kfold <= 256, "kfold must be 1..256");
+  NVT_CHECK_ARG(row_bits >= 24 && row_bits <= 32, "row_bits must be 24..32");
+  NVT_CHECK_ARG(kfold == 1 || (1 << (32 - row_bits)) >= kfold, "the sorted words carry fewer fold bits");
+  NVT_CHECK_ARG(n >= 1 && n < (1ull << 30), "1 .. 2^30-1 rows");
+  NVT_CHECK_ARG(cap >= 1 && cap * (uint64_t)kfold < 0xFFFFFFFFull, "capacity * kfold must be < 2^32 - 1");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_sorted", n * 4ull, s);
+  const uint64_t ntiles = (n + kSgbTile - 1) / kSgbTile;
+  unsigned long long *status = reinterpret_cast<unsigned long long *>(ws);
+  unsigned *ticket = reinterpret_cast<unsigned *>(status + ntiles);
+  NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 8 + 64, s));
+  NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
+  sgb_rle_kernel<<<(unsigned)ntiles, kBlock, 0, s>>>(sorted, n, row_bits, (unsigned)kfold, cap, status,
+                                                     ticket, out_keys, out_keys32, regrouped, state);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const void *const *vals,
+                   const int *vdtypes, const uint8_t *const *val_valid, int nvals, int flags,
+                   uint64_t n, uint64_t cap, uint64_t *out_size, double *out_sum, double *out_sumsq,
+                   double *out_min, double *out_max, uint64_t *tot_size, double *tot_sum,
+                   double *te_records, const uint64_t *state, void *stream) {
+  NVT_CHECK_ARG(regrouped && out_size && state, "null pointer");
+  NVT_CHECK_ARG(nvals >= 0 && nvals <= kMaxVals, "nvals must be 0..8");
+  NVT_CHECK_ARG(nvals == 0 || (vals && vdtypes && out_sum), "null vals / out_sum");
+  NVT_CHECK_ARG(words_kfold >= 1 && words_kfold <= 256, "words_kfold must be 1..256");
+  NVT_CHECK_ARG(kfold == words_kfold || kfold == 1, "kfold must be 1 or the words' kfold");
+  NVT_CHECK_ARG(kfold == 1 || kfold <= kSgbMaxFoldLds, "at most 16 folds");
+  NVT_CHECK_ARG(kfold == 1 || (tot_size && (nvals == 0 || tot_sum)), "null totals");
+  NVT_CHECK_ARG(te_records == nullptr || (kfold > 1 && nvals > 0), "records come with folds and values");
+  NVT_CHECK_ARG(((flags & NVT_GB_SUMSQ) != 0) == (out_sumsq != nullptr) || nvals == 0, "sumsq flag / array");
+  NVT_CHECK_ARG(((flags & NVT_GB_MINMAX) != 0) == (out_min != nullptr && out_max != nullptr) || nvals == 0,
+                "min/max flag / arrays");
+  NVT_CHECK_ARG(n >= 1 && n < (1ull << 30), "1 .. 2^30-1 rows");
+  NVT_CHECK_ARG(cap >= 1 && cap * (uint64_t)kfold < 0xFFFFFFFFull, "capacity * kfold must be < 2^32 - 1");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_sorted", n * 4ull, s);
+  const uint64_t slots = cap * (uint64_t)kfold;
+  NVT_CHECK_HIP(hipMemsetAsync(out_size, 0, slots * 8, s));
+  if (nvals) NVT_CHECK_HIP(hipMemsetAsync(out_sum, 0, slots * 8 * nvals, s));
+  if (nvals && out_sumsq) NVT_CHECK_HIP(hipMemsetAsync(out_sumsq, 0, slots * 8 * nvals, s));
+  if (nvals && out_min) {
+    const double inf = std::numeric_limits<double>::infinity();
+    sgb_fill_kernel<<<stream_grid(slots * nvals, kBlock * 4), kBlock, 0, s>>>(out_min, slots * nvals, inf);
+    sgb_fill_kernel<<<stream_grid(slots * nvals, kBlock * 4), kBlock, 0, s>>>(out_max, slots * nvals, -inf);
+    NVT_CHECK_LAUNCH();
+  }
+  GbView t;
+  memset(&t, 0, sizeof(t));
+  t.nkeys = 1;
+  t.nvals = nvals;
+  t.cap = slots;
+  t.size = reinterpret_cast<unsigned long long *>(out_size);
+  t.sum = out_sum;
+  t.sumsq = nvals ? out_sumsq : nullptr;
+  t.vmin = nvals ? out_min : nullptr;
+  t.vmax = nvals ? out_max : nullptr;
+  GbRowArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int j = 0; j < nvals; ++j) {
+    NVT_CHECK_ARG(vals[j], "null value column");
+    a.vals[j] = vals[j];
+    a.vdtype[j] = vdtypes[j];
+    a.val_valid[j] = val_valid ? val_valid[j] : nullptr;
+  }
+  const uint32_t div = kfold == words_kfold ? 1u : (uint32_t)words_kfold;
+  gb_segreduce_kernel<true><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, regrouped, div);
+  NVT_CHECK_LAUNCH();
+  if (kfold > 1) {
+    sgb_fold_total_kernel<<<stream_grid(cap, kBlock, 8), kBlock, 0, s>>>(
+        state, (unsigned)kfold, cap, nvals, reinterpret_cast<const unsigned long long *>(out_size),
+        out_sum, reinterpret_cast<unsigned long long *>(tot_size), tot_sum, te_records);
+    NVT_CHECK_LAUNCH();
+  }
   return NVT_OK;
 }
 

@@ -632,12 +632,18 @@ __global__ __launch_bounds__(kS2BS) void os_hist_words_kernel(const uint64_t *__
 #pragma unroll
     for (int p = 0; p < kOsMaxPass; ++p) {
       if (p < npass) {
-        // sorted-by-group inputs are heavily skewed (one hot group = one digit value):
-        // aggregate equal digits per wave before touching the LDS histogram
+        // sorted-by-group inputs are heavily skewed (one hot group = one digit value): a wave
+        // whose 64 digits are all equal adds once; otherwise plain LDS atomics (a full
+        // match-any aggregation per digit cost more than the conflicts it saved: 324 us for
+        // 20 M words)
         const unsigned d = (unsigned)(c >> (8 * p)) & 0xFF;
-        const unsigned long long peers = match_digit(d, act);
-        if (act && (peers & ((1ull << l) - 1ull)) == 0)
-          atomicAdd(&h[p * 256 + d], (unsigned)__popcll(peers));
+        const unsigned long long am = __ballot(act);
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+        if (am == ~0ull && __ballot(d == d0) == ~0ull) {
+          if (l == 0) atomicAdd(&h[p * 256 + d0], 64u);
+        } else if (act) {
+          atomicAdd(&h[p * 256 + d], 1u);
+        }
       }
     }
   }
@@ -1160,6 +1166,7 @@ __global__ void flat_params_kernel(const int32_t *__restrict__ keys, uint64_t n,
   aux[NVT_RANGE_AUX_LO + 3] = (int32_t)(uint32_t)(mul >> 32);
   aux[NVT_RANGE_AUX_LO + 4] = sh;
   aux[NVT_RANGE_AUX_LO + 5] = 1;  // flat layout
+  aux[NVT_RANGE_AUX_LO + 6] = keys[0] == INT32_MIN ? 1 : 0;  // position 0 holds the smallest int32 (not in the table)
   aux[NVT_FLAT_AUX_MAXDISP] = 0;
 }
 
@@ -1247,7 +1254,7 @@ __global__ __launch_bounds__(kS2BS) void flat_build_kernel(
     const unsigned disp = (unsigned)(p - h < 0xFFFFFFFFull ? p - h : 0xFFFFFFFFull);
     maxdisp = disp > maxdisp ? disp : maxdisp;
     if (p < table_slots)
-      table[p] = ((unsigned long long)(uint32_t)label_of[i] << 32) | (uint32_t)k[r];
+      table[p] = ((unsigned long long)(uint32_t)(label_of ? label_of[i] : (int32_t)i) << 32) | (uint32_t)k[r];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1255,6 +1262,156 @@ __global__ __launch_bounds__(kS2BS) void flat_build_kernel(
     maxdisp = o > maxdisp ? o : maxdisp;
   }
   if (l == 0 && maxdisp > 0) atomicMax(reinterpret_cast<unsigned *>(aux + NVT_FLAT_AUX_MAXDISP), maxdisp);
+}
+
+// key -> position in the sorted list through a flat range table whose labels are the positions
+// (groupby group ids, join_groupby.py:198-203 / target_encoding.py:350-371: the reference's left
+// merge on the key column).  Probing runs forward from the key's home slot; the entries along a
+// run are in key order, so a larger key ends an unsuccessful probe as an empty slot does.
+struct FlatIndexView {
+  RangeMap map;
+  bool has_min;
+  const unsigned long long *table;
+  uint64_t slots;
+};
+
+__device__ __forceinline__ FlatIndexView flat_view(const int32_t *__restrict__ aux,
+                                                   const unsigned long long *table, uint64_t slots) {
+  FlatIndexView v;
+  v.map = load_map(aux);
+  v.has_min = aux[NVT_RANGE_AUX_LO + 6] != 0;
+  v.table = table;
+  v.slots = slots;
+  return v;
+}
+
+template <typename K>
+__device__ __forceinline__ int64_t flat_probe(const FlatIndexView &v, const K *__restrict__ keys,
+                                              const uint8_t *__restrict__ valid, uint64_t i) {
+  const int64_t kv = (int64_t)keys[i];
+  if (!bit_valid(valid, i) || kv < (int64_t)INT32_MIN || kv > (int64_t)INT32_MAX) return -1;
+  const int32_t k = (int32_t)kv;
+  if (k == INT32_MIN) return v.has_min ? 0 : -1;
+  const uint32_t uk = ukey(k);
+  for (uint64_t sl = v.map.fine(k); sl < v.slots; ++sl) {
+    const unsigned long long e = v.table[sl];
+    const int32_t ek = (int32_t)(uint32_t)e;
+    if (ek == k) return (int64_t)(uint32_t)(e >> 32);
+    if (ek == INT32_MIN || ukey(ek) > uk) break;
+  }
+  return -1;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kBlock) void flat_lookup_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const int32_t *__restrict__ aux, const unsigned long long *__restrict__ table, uint64_t slots,
+    int64_t *__restrict__ out) {
+  const FlatIndexView v = flat_view(aux, table, slots);
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    out[i] = flat_probe(v, keys, valid, i);
+}
+
+// JoinGroupby.transform in one pass (join_groupby.py:198-217): probe, then the group's record
+// of `ncols` float64 statistics (one 32-byte sector for count / sum / mean / std) instead of a
+// group-id column in HBM and one random gather per statistic.
+constexpr int kGatherMaxCols = 16;
+struct GatherOuts {
+  void *out[kGatherMaxCols];
+  int dtype[kGatherMaxCols];
+  double miss[kGatherMaxCols];
+};
+
+template <typename OUT>
+__device__ __forceinline__ void gather_store(void *out, uint64_t i, double x) {
+  reinterpret_cast<OUT *>(out)[i] = (OUT)x;
+}
+
+template <typename K, int NC>
+__global__ __launch_bounds__(kBlock) void flat_lookup_gather_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const int32_t *__restrict__ aux, const unsigned long long *__restrict__ table, uint64_t slots,
+    const double *__restrict__ records, GatherOuts o, unsigned long long *unseen) {
+  const FlatIndexView v = flat_view(aux, table, slots);
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  bool any_unseen = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t g = flat_probe(v, keys, valid, i);
+    any_unseen |= g < 0;
+    double x[NC];
+    const double *rec = records + (uint64_t)(g < 0 ? 0 : g) * NC;
+    if constexpr (NC % 2 == 0) {  // records are 16-byte aligned: two statistics per load
+#pragma unroll
+      for (int c = 0; c < NC; c += 2) {
+        const double2 p = *reinterpret_cast<const double2 *>(rec + c);
+        x[c] = p.x;
+        x[c + 1] = p.y;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) x[c] = rec[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {  // compile-time c: descriptors stay in scalar registers
+      const double y = g < 0 ? o.miss[c] : x[c];
+      switch (o.dtype[c]) {
+        case NVT_F32: gather_store<float>(o.out[c], i, y); break;
+        case NVT_F64: gather_store<double>(o.out[c], i, y); break;
+        case NVT_I32: gather_store<int32_t>(o.out[c], i, y); break;
+        default: gather_store<int64_t>(o.out[c], i, y); break;
+      }
+    }
+  }
+  if (unseen && __ballot(any_unseen) != 0ull && lane_id() == 0) atomicOr(unseen, 1ull);
+}
+
+template <typename K>
+static int launch_gather(int ncols, unsigned grid, hipStream_t s, const K *keys, const uint8_t *valid,
+                         uint64_t n, const int32_t *aux, const unsigned long long *tab,
+                         uint64_t capacity, const double *records, const GatherOuts &o,
+                         unsigned long long *flag) {
+#define NVT_G(NC)                                                                                 \
+  case NC:                                                                                        \
+    flat_lookup_gather_kernel<K, NC><<<grid, kBlock, 0, s>>>(keys, valid, n, aux, tab, capacity, \
+                                                             records, o, flag);                  \
+    break;
+  switch (ncols) {
+    NVT_G(1) NVT_G(2) NVT_G(3) NVT_G(4) NVT_G(5) NVT_G(6) NVT_G(7) NVT_G(8)
+    NVT_G(9) NVT_G(10) NVT_G(11) NVT_G(12) NVT_G(13) NVT_G(14) NVT_G(15) NVT_G(16)
+    default: return NVT_EINVAL;
+  }
+#undef NVT_G
+  return NVT_OK;
+}
+
+// TargetEncoding.transform in one pass (target_encoding.py:341-371): probe, then the group's
+// record {sum, count, (sum_f, count_f) for every fold} -- 16 * (kfold + 1) contiguous bytes.
+// A (group, fold) pair without rows is the reference's unmatched [fold, key] merge: y_mean.
+template <typename K, typename OUT>
+__global__ __launch_bounds__(kBlock) void flat_lookup_te_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const int32_t *__restrict__ aux, const unsigned long long *__restrict__ table, uint64_t slots,
+    const uint8_t *__restrict__ fold, unsigned kfold, const double *__restrict__ records, double p,
+    double y_mean, OUT *__restrict__ out) {
+  const FlatIndexView v = flat_view(aux, table, slots);
+  const unsigned stride_rec = 2 * (kfold + 1);
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t g = flat_probe(v, keys, valid, i);
+    double r = y_mean;
+    if (g >= 0) {
+      const double *rec = records + (uint64_t)g * stride_rec;
+      const double2 tot = *reinterpret_cast<const double2 *>(rec);
+      if (fold) {
+        const double2 f = *reinterpret_cast<const double2 *>(rec + 2 + 2 * (unsigned)fold[i]);
+        if (f.y > 0.0) r = (tot.x - f.x + p * y_mean) / (tot.y - f.y + p);
+      } else {
+        r = (tot.x + p * y_mean) / (tot.y + p);
+      }
+    }
+    out[i] = (OUT)r;
+  }
 }
 
 uint64_t vocab_order_tmp_bytes(uint64_t n, uint64_t n_big) {
@@ -1418,6 +1575,126 @@ int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, int64_t max_c
                        void *stream) {
   NVT_CHECK_ARG(n <= 1 || (keys && counts && tmp), "null pointer");
   return vocab_sort_any(8, keys, counts, n, max_count, tmp, (hipStream_t)stream);
+}
+
+int nvt_flat_index_tmp_bytes(uint64_t n, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes, "null out");
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  *bytes = pad16(ntiles * 8 + 64) + 64;
+  return NVT_OK;
+}
+
+int nvt_flat_index_build(const int32_t *keys, uint64_t n, int slots_log2, int32_t *aux, void *table,
+                         uint64_t capacity, void *tmp, void *stream) {
+  NVT_CHECK_ARG(keys && aux && table && tmp, "null pointer");
+  NVT_CHECK_ARG(n >= 1 && n < (1ull << 30), "1 .. 2^30-1 keys");
+  NVT_CHECK_ARG(slots_log2 >= 6 && slots_log2 <= 31, "slots_log2 must be 6..31");
+  NVT_CHECK_ARG(capacity >= (1ull << slots_log2) + n + 64, "flat table: slots + n + 64");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_index", 0, s);
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  unsigned long long *status = reinterpret_cast<unsigned long long *>(tmp);
+  // the sentinel label of an encode table has no meaning here: it lands in the status block and
+  // is wiped with it
+  int rc = encode_clear_any(4, table, capacity, reinterpret_cast<int64_t *>(status), s);
+  if (rc) return rc;
+  NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 8 + 64, s));
+  flat_params_kernel<<<1, 1, 0, s>>>(keys, n, slots_log2, aux);
+  NVT_CHECK_LAUNCH();
+  flat_build_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(
+      keys, nullptr, n, aux, status, reinterpret_cast<unsigned *>(status + ntiles),
+      (unsigned long long *)table, capacity);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_flat_lookup(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
+                    const void *table, uint64_t capacity, int64_t *out, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(keys && aux && table && out, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_lookup", n * (dtype == NVT_I64 ? 8ull : 4ull), s);
+  const unsigned grid = stream_grid(n, kBlock * 2);
+  const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(table);
+  switch (dtype) {
+    case NVT_I32:
+      flat_lookup_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)keys, valid, n, aux, tab, capacity, out);
+      break;
+    case NVT_I64:
+      flat_lookup_kernel<int64_t><<<grid, kBlock, 0, s>>>((const int64_t *)keys, valid, n, aux, tab, capacity, out);
+      break;
+    default:
+      set_error("nvt_flat_lookup: key dtype must be int32 / int64 (got %d)", dtype);
+      return NVT_EINVAL;
+  }
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+
+int nvt_flat_lookup_gather(const void *keys, int dtype, const uint8_t *valid, uint64_t n,
+                           const int32_t *aux, const void *table, uint64_t capacity,
+                           const double *records, int ncols, void *const *outs, const int *out_dtypes,
+                           const double *miss, uint64_t *unseen, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(keys && aux && table && records && outs && out_dtypes && miss, "null pointer");
+  NVT_CHECK_ARG(ncols >= 1 && ncols <= kGatherMaxCols, "1..16 statistics per call");
+  GatherOuts o;
+  memset(&o, 0, sizeof(o));
+  for (int c = 0; c < ncols; ++c) {
+    NVT_CHECK_ARG(outs[c], "null output column");
+    NVT_CHECK_ARG(out_dtypes[c] == NVT_F32 || out_dtypes[c] == NVT_F64 || out_dtypes[c] == NVT_I32 ||
+                      out_dtypes[c] == NVT_I64, "output dtype must be f32 / f64 / i32 / i64");
+    o.out[c] = outs[c];
+    o.dtype[c] = out_dtypes[c];
+    o.miss[c] = miss[c];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_lookup", n * (dtype == NVT_I64 ? 8ull : 4ull), s);
+  const unsigned grid = stream_grid(n, kBlock * 2);
+  const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(table);
+  unsigned long long *flag = reinterpret_cast<unsigned long long *>(unseen);
+  int rc;
+  if (dtype == NVT_I32)
+    rc = launch_gather<int32_t>(ncols, grid, s, (const int32_t *)keys, valid, n, aux, tab, capacity,
+                                records, o, flag);
+  else if (dtype == NVT_I64)
+    rc = launch_gather<int64_t>(ncols, grid, s, (const int64_t *)keys, valid, n, aux, tab, capacity,
+                                records, o, flag);
+  else {
+    set_error("nvt_flat_lookup_gather: key dtype must be int32 / int64 (got %d)", dtype);
+    return NVT_EINVAL;
+  }
+  if (rc) return rc;
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_flat_lookup_te(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
+                       const void *table, uint64_t capacity, const uint8_t *fold, int kfold,
+                       const double *records, double p_smooth, double y_mean, void *out,
+                       int out_dtype, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(keys && aux && table && records && out, "null pointer");
+  NVT_CHECK_ARG(kfold >= 1 && kfold <= 256 && ((kfold > 1) == (fold != nullptr)), "fold ids come with kfold > 1");
+  NVT_CHECK_ARG(dtype == NVT_I32 || dtype == NVT_I64, "key dtype must be int32 / int64");
+  NVT_CHECK_ARG(out_dtype == NVT_F32 || out_dtype == NVT_F64, "out dtype must be f32 / f64");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("te_apply", n * (dtype == NVT_I64 ? 8ull : 4ull), s);
+  const unsigned grid = stream_grid(n, kBlock * 2);
+  const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(table);
+  const unsigned kf = fold ? (unsigned)kfold : 0u;  // record stride 2 * (kf + 1)
+#define NVT_TE_LAUNCH(K, OUT)                                                                   \
+  flat_lookup_te_kernel<K, OUT><<<grid, kBlock, 0, s>>>((const K *)keys, valid, n, aux, tab,    \
+                                                        capacity, fold, kf, records, p_smooth, \
+                                                        y_mean, (OUT *)out)
+  if (dtype == NVT_I32 && out_dtype == NVT_F32) NVT_TE_LAUNCH(int32_t, float);
+  else if (dtype == NVT_I32) NVT_TE_LAUNCH(int32_t, double);
+  else if (out_dtype == NVT_F32) NVT_TE_LAUNCH(int64_t, float);
+  else NVT_TE_LAUNCH(int64_t, double);
+#undef NVT_TE_LAUNCH
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
 }
 
 }  // extern "C"

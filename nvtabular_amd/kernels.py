@@ -1435,6 +1435,254 @@ class GroupbyTable:
         return out
 
 
+# ---- one int32 key column: groupby-aggregate by sorting + flat index -------------------------
+SORTED_GROUPBY = os.environ.get("NVT_SORTED_GROUPBY", "1") != "0"
+SORTED_GROUPBY_MIN_ROWS = 1 << 15   # below: launch latency, the hash update is as good
+SORTED_GROUPBY_MAX_KFOLD = 16
+
+
+# sorted words shared between the aggregates of ONE pass over one partition (Workflow.fit opens
+# and closes it around the partition's fit_partition calls; None = no sharing)
+_PASS_MEMO = None
+
+
+class pass_memo:
+    """``with K.pass_memo():`` -- results that depend only on a partition's columns (the sorted
+    (key, row) words of the sort-path groupby) are shared between the operators fitted inside."""
+
+    def __enter__(self):
+        global _PASS_MEMO
+        self.prev, _PASS_MEMO = _PASS_MEMO, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _PASS_MEMO
+        _PASS_MEMO = self.prev
+        return False
+
+
+def sorted_groupby_eligible(keys: torch.Tensor, key_valid, n: int, kfold: int = 1) -> bool:
+    """One int32 key column without a validity bitmap, enough rows, row index + fold in 32 bits."""
+    if not SORTED_GROUPBY or keys.dtype != torch.int32 or key_valid is not None:
+        return False
+    fb = (kfold - 1).bit_length()
+    return (SORTED_GROUPBY_MIN_ROWS <= n < (1 << 30) and n <= (1 << (32 - fb))
+            and 1 <= kfold <= SORTED_GROUPBY_MAX_KFOLD)
+
+
+def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int, vals, val_valid,
+                   sumsq=False, minmax=False, cap_hint: int = 0, te_records=False):
+    """nvt_sgb_sort + nvt_sgb_regroup + nvt_sgb_reduce: groups of ONE int32 key column, dense
+    and ordered by key.  Returns the dict GroupbyTable.compact() returns (keys as int64, all-zero
+    null mask, count == size: no null keys on this path) plus ``keys32``, ``sorted``, ``shared``
+    and -- with folds (TargetEncoding) -- ``fold`` = dict(kfold, size[g * kfold],
+    sum[j][g * kfold], records); size / sum are then the totals over the folds.
+    Inside ``pass_memo`` the sorted words and the group ids of a key column are computed once for
+    all aggregates on it (the second one is a single reduction, without a read-back)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    dev = keys.device
+    n = int(keys.numel())
+    keys = keys.contiguous()
+    vals = [aligned(v.view(torch.uint8) if v.dtype == torch.bool else v) for v in vals]
+    nvals = len(vals)
+    flags = (_lib.NVT_GB_SUMSQ if sumsq else 0) | (_lib.NVT_GB_MINMAX if minmax else 0)
+    memo_key = ("sgb", keys.data_ptr(), n, keys._version)
+    hit = _PASS_MEMO.get(memo_key) if _PASS_MEMO is not None else None
+    if hit is None or not (kfold == 1 or (hit["kfold"] == kfold and hit["fold"] == ptr(fold))):
+        need = C.c_uint64()
+        check(lib.nvt_sgb_sort_ws_bytes(n, C.byref(need)), "nvt_sgb_sort_ws_bytes")
+        sort_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        sp, rbc = C.c_void_p(), C.c_int()
+        check(lib.nvt_sgb_sort(keys.data_ptr(), ptr(fold), kfold, n, sort_ws.data_ptr(), C.byref(sp),
+                               C.byref(rbc), stream_ptr()), "nvt_sgb_sort")
+        hit = dict(sorted=sp.value, rb=rbc.value, kfold=kfold, fold=ptr(fold), ws=sort_ws,
+                   keys=keys, fold_t=fold, groups=None)
+        if _PASS_MEMO is not None:
+            _PASS_MEMO[memo_key] = hit
+    grp = hit["groups"]
+    if grp is None:
+        # group ids: words regrouped with the kfold of the SORT (an aggregate without folds
+        # divides the slots), one read-back of the group count
+        wk = hit["kfold"]
+        need = C.c_uint64()
+        check(lib.nvt_sgb_regroup_ws_bytes(n, C.byref(need)), "nvt_sgb_regroup_ws_bytes")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        words = torch.empty(n, dtype=torch.int64, device=dev)
+        state = torch.empty(_lib.STATE_WORDS, dtype=torch.int64, device=dev)
+        cap = min(n, cap_hint + cap_hint // 4 + 1024) if cap_hint > 0 else n
+        cap = min(cap, (0xFFFFFFFE // wk) - 1)
+        while True:
+            k64 = torch.empty(cap, dtype=torch.int64, device=dev)
+            k32 = torch.empty(cap, dtype=torch.int32, device=dev)
+            check(lib.nvt_sgb_regroup(hit["sorted"], hit["rb"], wk, n, cap, k64.data_ptr(),
+                                      k32.data_ptr(), words.data_ptr(), state.data_ptr(),
+                                      ws.data_ptr(), stream_ptr()), "nvt_sgb_regroup")
+            st = read_back(state).tolist()
+            g = int(st[_lib.ST_OCCUPIED])
+            if not st[_lib.ST_NEED]:
+                break
+            STATS["count_relaunches"] += 1
+            if g * wk >= 0xFFFFFFFE:
+                raise _lib.NvtHipError("sorted_groupby: groups * kfold does not fit 32 bits")
+            cap = g
+        grp = hit["groups"] = dict(words=words, kfold=wk, k64=k64[:g], k32=k32[:g], g=g, state=state)
+    g, wk = grp["g"], grp["kfold"]
+    cap = max(g, 1)
+    slots = cap * kfold
+    size = torch.empty(slots, dtype=torch.int64, device=dev)
+    mk = lambda on, m=slots: (  # noqa: E731
+        torch.empty((nvals, m), dtype=torch.float64, device=dev) if on and nvals else None)
+    fsum, fsq, fmin, fmax = mk(True), mk(sumsq), mk(minmax), mk(minmax)
+    tsize = torch.empty(cap, dtype=torch.int64, device=dev) if kfold > 1 else None
+    tsum = mk(kfold > 1, cap)
+    rec = (torch.empty((nvals, cap, 2 * (kfold + 1)), dtype=torch.float64, device=dev)
+           if te_records and kfold > 1 and nvals else None)
+    vp = _lib.ptr_array([v.data_ptr() for v in vals])
+    vv = _lib.ptr_array([ptr(v) for v in val_valid])
+    vd = (C.c_int * max(1, nvals))(*[dtype_code(v.dtype) for v in vals])
+    check(lib.nvt_sgb_reduce(
+        grp["words"].data_ptr(), wk, kfold, vp, vd, vv, nvals, flags, n, cap, size.data_ptr(),
+        ptr(fsum), ptr(fsq), ptr(fmin), ptr(fmax), ptr(tsize), ptr(tsum), ptr(rec),
+        grp["state"].data_ptr(), stream_ptr()), "nvt_sgb_reduce")
+    nan = float("nan")
+
+    def rows(mat, m):
+        return [mat[j, :m] for j in range(nvals)] if mat is not None else []
+
+    def no_inf(cols):
+        return [torch.where(torch.isinf(c), torch.full_like(c, nan), c) for c in cols]
+
+    out = dict(keys=[grp["k64"]], keys32=grp["k32"],
+               null_mask=torch.zeros(g, dtype=torch.uint8, device=dev),
+               sumsq=rows(fsq, g), min=no_inf(rows(fmin, g)), max=no_inf(rows(fmax, g)), n=g,
+               sorted=True, shared=grp)
+    if kfold > 1:
+        out["size"], out["sum"] = tsize[:g], rows(tsum, g)
+        out["fold"] = dict(kfold=kfold, size=size[:g * kfold], sum=rows(fsum, g * kfold),
+                           records=[rec[j, :g] for j in range(nvals)] if rec is not None else None)
+    else:
+        out["size"], out["sum"] = size[:g], rows(fsum, g)
+    out["count"] = out["size"]
+    return out
+
+
+def flat_index_for(comp) -> "FlatIndex":
+    """The FlatIndex of a sorted_groupby result; aggregates that share their group ids (one key
+    column, one pass) share the index too."""
+    shared = comp.get("shared")
+    if shared is not None and shared.get("index") is not None:
+        return shared["index"]
+    index = FlatIndex(comp["keys32"])
+    if shared is not None:
+        shared["index"] = index
+    return index
+
+
+class FlatIndex:
+    """key -> position in an ascending int32 key list (group ids of sorted_groupby): a flat
+    range table laid out from the list in one pass (nvt_flat_index_build).  Same ``lookup``
+    as GroupbyTable (the transform side of JoinGroupby / TargetEncoding)."""
+
+    FLAT_AUX_WORDS, FLAT_AUX_MAXDISP = 8192 + 16, 8192 + 8   # include/nvt_hip.h NVT_FLAT_AUX_*
+    MAX_DISPLACEMENT = 4096
+
+    def __init__(self, keys32: torch.Tensor):
+        _lib.require_gpu()
+        lib = _lib.load()
+        self.keys32 = keys32.contiguous()
+        self.n = n = int(keys32.numel())
+        dev = keys32.device
+        self.slots_log2 = max(6, (2 * n - 1).bit_length())
+        self.capacity = (1 << self.slots_log2) + n + 64
+        self.table = torch.empty(self.capacity, dtype=torch.int64, device=dev)
+        self.aux = torch.zeros(self.FLAT_AUX_WORDS, dtype=torch.int32, device=dev)
+        need = C.c_uint64()
+        check(lib.nvt_flat_index_tmp_bytes(n, C.byref(need)), "nvt_flat_index_tmp_bytes")
+        tmp = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        check(lib.nvt_flat_index_build(self.keys32.data_ptr(), n, self.slots_log2, self.aux.data_ptr(),
+                                       self.table.data_ptr(), self.capacity, tmp.data_ptr(),
+                                       stream_ptr()), "nvt_flat_index_build")
+        self._ok = None
+
+    def ok(self) -> bool:
+        """False when the keys cluster in their range (an entry further than MAX_DISPLACEMENT
+        slots from its home slot): the caller builds a hashed index instead.  One read-back."""
+        if self._ok is None:
+            word = self.aux[self.FLAT_AUX_MAXDISP:self.FLAT_AUX_MAXDISP + 2].view(torch.int64)
+            d = int(read_back(word)[0]) & 0xFFFFFFFF
+            self._ok = d <= self.MAX_DISPLACEMENT
+        return self._ok
+
+    def lookup(self, keys, key_valid) -> torch.Tensor:
+        k = keys[0]
+        if k.dtype not in (torch.int32, torch.int64):
+            k = widen_i64(k)
+        k = k.contiguous()
+        n = k.numel()
+        out = torch.empty(n, dtype=torch.int64, device=k.device)
+        check(_lib.load().nvt_flat_lookup(k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n,
+                                          self.aux.data_ptr(), self.table.data_ptr(), self.capacity,
+                                          out.data_ptr(), stream_ptr()), "nvt_flat_lookup")
+        return out
+
+
+    def _key(self, keys):
+        k = keys[0]
+        if k.dtype not in (torch.int32, torch.int64):
+            k = widen_i64(k)
+        return k.contiguous()
+
+    def gather(self, keys, key_valid, records: torch.Tensor, out_dtypes, miss):
+        """JoinGroupby.transform in one launch: (outs, unseen) with outs[c][i] =
+        records[group of keys[i], c] (miss[c] for a key without group) and ``unseen`` a device
+        word that is non-zero when any row had no group."""
+        k = self._key(keys)
+        n, ncols = k.numel(), int(records.shape[1])
+        assert records.dtype == torch.float64 and records.is_contiguous() and ncols == len(out_dtypes)
+        outs = [torch.empty(n, dtype=dt, device=k.device) for dt in out_dtypes]
+        unseen = torch.zeros(1, dtype=torch.int64, device=k.device)
+        check(_lib.load().nvt_flat_lookup_gather(
+            k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
+            self.table.data_ptr(), self.capacity, records.data_ptr(), ncols,
+            _lib.ptr_array([o.data_ptr() for o in outs]),
+            (C.c_int * ncols)(*[dtype_code(dt) for dt in out_dtypes]),
+            (C.c_double * ncols)(*[float(m) for m in miss]), unseen.data_ptr(), stream_ptr()),
+            "nvt_flat_lookup_gather")
+        return outs, unseen
+
+    def te(self, keys, key_valid, fold, kfold, records: torch.Tensor, p_smooth, y_mean, out_dtype):
+        """TargetEncoding.transform in one launch (records: [groups, 2 * (kfold + 1)], or
+        [groups, 2] without folds)."""
+        k = self._key(keys)
+        n = k.numel()
+        assert records.dtype == torch.float64 and records.is_contiguous()
+        assert int(records.shape[1]) == (2 * (kfold + 1) if fold is not None else 2)
+        out = torch.empty(n, dtype=out_dtype, device=k.device)
+        check(_lib.load().nvt_flat_lookup_te(
+            k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
+            self.table.data_ptr(), self.capacity, ptr(fold.contiguous() if fold is not None else None),
+            int(kfold) if fold is not None else 1, records.data_ptr(), float(p_smooth), float(y_mean),
+            out.data_ptr(), dtype_code(out_dtype), stream_ptr()), "nvt_flat_lookup_te")
+        return out
+
+
+def te_apply_folds(group_all, fold, kfold, sum_all, cnt_all, sum_fold, cnt_fold, p_smooth, y_mean,
+                   out_dtype=torch.float32):
+    _lib.require_gpu()
+    n = group_all.numel()
+    out = torch.empty(n, dtype=out_dtype, device=group_all.device)
+    check(
+        _lib.load().nvt_te_apply_folds(
+            group_all.data_ptr(), fold.contiguous().data_ptr(), int(kfold), sum_all.data_ptr(),
+            cnt_all.data_ptr(), sum_fold.data_ptr(), cnt_fold.data_ptr(), n, float(p_smooth),
+            float(y_mean), out.data_ptr(), dtype_code(out_dtype), stream_ptr(),
+        ),
+        "nvt_te_apply_folds",
+    )
+    return out
+
+
 def _order_ws(n: int, device) -> torch.Tensor:
     need = C.c_uint64()
     check(_lib.load().nvt_order_rows_ws_bytes(n, C.byref(need)), "nvt_order_rows_ws_bytes")

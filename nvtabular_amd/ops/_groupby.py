@@ -19,12 +19,23 @@ from ..device import DeviceFrame, key_view
 
 class GroupAgg:
     def __init__(self, name: str, key_cols: List[str], val_cols: List[str], sumsq=False,
-                 minmax=False, hint: int = 0):
+                 minmax=False, hint: int = 0, fold=None, fold_name: str = "", fold_hint: int = 0):
         self.name = name
         self.key_cols = list(key_cols)
         self.val_cols = list(val_cols)
         self.sumsq, self.minmax = sumsq, minmax
         self.table = None
+        # one int32 key column: the groups of the first partition come from the sort path
+        # (K.sorted_groupby), dense and ordered by key; a second partition demotes them to a
+        # hash table and the fit continues as before
+        self.sorted_comp = None
+        # fold = (fold column, kfold): TargetEncoding's second aggregate on [fold] + key_cols
+        # rides on this one -- dense per-(group, fold) statistics on the sort path, a classic
+        # GroupAgg (fold_agg) otherwise
+        self.fold = fold
+        self.fold_name = fold_name
+        self.fold_hint = int(fold_hint)
+        self.fold_agg = None
         # expected groups per partition: carried from the operator's previous fit (hints dict);
         # unknown -> assume half the rows are distinct (high-cardinality keys are what these
         # operators are used on, and an undersized table costs a full extra pass per retry)
@@ -53,9 +64,43 @@ class GroupAgg:
             self.val_dtypes.setdefault(c, col.data.dtype)
         return keys, kvalid, vals, vvalid
 
+    def _fold_classic(self) -> "GroupAgg":
+        if self.fold_agg is None:
+            self.fold_agg = GroupAgg(self.fold_name, [self.fold[0]] + self.key_cols, self.val_cols,
+                                     hint=self.fold_hint)
+        return self.fold_agg
+
+    def _demote(self):
+        """A second partition arrives: the sorted groups of the first become hash tables."""
+        comp, self.sorted_comp = self.sorted_comp, None
+        self.table = _table_from_comp(comp, 1, len(self.val_cols), self.sumsq, self.minmax)
+        if "fold" in comp:
+            self._fold_classic().table = _table_from_comp(fold_sparse(comp), 2, len(self.val_cols),
+                                                          False, False)
+
     def update(self, frame: DeviceFrame):
+        from .. import dist
+
         keys, kvalid, vals, vvalid = self._inputs(frame)
         n = int(keys[0].numel())
+        kfold = self.fold[1] if self.fold else 1
+        fold_t = None
+        if self.fold:
+            fcol = frame[self.fold[0]]
+            fold_t = fcol.data if fcol.data.dtype == torch.uint8 and fcol.valid is None else None
+        if (self.table is None and self.sorted_comp is None and len(keys) == 1
+                and (self.fold_agg is None or self.fold_agg.table is None)
+                and (not self.fold or (fold_t is not None and dist.world_size() == 1))
+                and K.sorted_groupby_eligible(keys[0], kvalid[0], n, kfold)):
+            comp = K.sorted_groupby(keys[0], fold_t, kfold, vals, vvalid, sumsq=self.sumsq,
+                                    minmax=self.minmax, cap_hint=self.hint, te_records=True)
+            self.hint = max(self.hint, comp["n"])
+            self.sorted_comp = comp
+            return
+        if self.sorted_comp is not None:
+            self._demote()
+        if self.fold:
+            self._fold_classic().update(frame)
         hint = self.hint if self.hint > 0 else max(1 << 12, n // 2)
         # load <= 2/3 on the hinted group count (16-byte slot headers: four per sector, so the
         # longer probe runs of a fuller table mostly stay inside one sector, and a 128 MB head
@@ -80,6 +125,16 @@ class GroupAgg:
         """Compacted groups (after the cross-rank merge), ordered by key for determinism."""
         from .. import dist
 
+        if self.sorted_comp is not None:
+            comp = self.sorted_comp
+            if dist.world_size() > 1:  # (never with folds: update() keeps those off this path)
+                comp = dist.merge_groups(comp, 1, len(self.val_cols), sumsq=self.sumsq,
+                                         minmax=self.minmax)
+            else:
+                index = K.flat_index_for(comp)
+                if index.ok():  # else: _Stats builds a hashed index from the keys
+                    comp["index_table"] = index
+            return comp
         if self.table is None:
             self.table = K.GroupbyTable(len(self.key_cols), len(self.val_cols), 64,
                                         sumsq=self.sumsq, minmax=self.minmax)
@@ -90,6 +145,28 @@ class GroupAgg:
             for c in list(self.strings):
                 self.strings[c] = dist.merge_string_luts(self.strings[c])
         return comp
+
+
+def _table_from_comp(comp, nkeys, nvals, sumsq, minmax) -> "K.GroupbyTable":
+    tab = K.GroupbyTable(nkeys, nvals, max(64, 2 * int(comp["n"]) + 1), sumsq=sumsq, minmax=minmax)
+    tab.merge([k.contiguous() for k in comp["keys"]], comp["null_mask"], comp["size"].contiguous(),
+              comp["count"].contiguous(), [c.contiguous() for c in comp["sum"]],
+              [c.contiguous() for c in comp["sumsq"]], [c.contiguous() for c in comp["min"]],
+              [c.contiguous() for c in comp["max"]])
+    return tab
+
+
+def fold_sparse(comp):
+    """Dense per-(group, fold) statistics of the sort path -> the compacted [fold, key] groups
+    the reference's second groupby produces (only pairs that have rows)."""
+    f = comp["fold"]
+    kfold = f["kfold"]
+    idx = torch.nonzero(f["size"] > 0).squeeze(1)
+    size = f["size"][idx]
+    return dict(keys=[idx % kfold, comp["keys"][0][idx // kfold]],
+                null_mask=torch.zeros(idx.numel(), dtype=torch.uint8, device=idx.device),
+                size=size, count=size, sum=[c[idx] for c in f["sum"]], sumsq=[], min=[], max=[],
+                n=int(idx.numel()))
 
 
 def stats_frame(agg: GroupAgg, comp, stats, name_sep="_", count_name=None) -> pd.DataFrame:

@@ -33,6 +33,24 @@ class _Stats:
             self.index = K.GroupbyTable(len(key_cols), 0, max(64, 2 * self.n + 1))
             self.index.index_build([k.contiguous() for k in keys], null_mask)
         self.columns = columns  # name -> float64/int64 tensor [groups]
+        self._records = None
+        self._te_records = {}
+
+    def records(self) -> torch.Tensor:
+        """[groups, len(columns)] float64, one row per group in column order: the layout
+        K.FlatIndex.gather reads with one probe per row."""
+        if self._records is None:
+            self._records = torch.stack([c.to(torch.float64) for c in self.columns.values()],
+                                        dim=1).contiguous()
+        return self._records
+
+    def te_records(self, target) -> torch.Tensor:
+        """[groups, 2] {sum, count} of one target (TargetEncoding without folds)."""
+        if target not in self._te_records:
+            self._te_records[target] = torch.stack(
+                [self.columns[f"sum:{target}"].to(torch.float64),
+                 self.columns["count"].to(torch.float64)], dim=1).contiguous()
+        return self._te_records[target]
 
 
 class JoinGroupby(StatOperator):
@@ -167,6 +185,32 @@ class JoinGroupby(StatOperator):
                 k, v = key_view(frame[c].materialize())
                 keys.append(k)
                 valids.append(v)
+            plan = []  # (column, output dtype, value of a row without group)
+            for cname in st.columns:
+                out_dt, miss = torch.float64, float("nan")
+                if cname in st.f32_columns:
+                    out_dt = torch.float32
+                for agg, npdt in AGG_DTYPES.items():
+                    if cname.endswith(f"{self.name_sep}{agg}"):
+                        out_dt = torch.int32 if npdt == np.int32 else torch.float32
+                plan.append((cname, out_dt, 0.0 if out_dt == torch.int32 else miss))
+            if isinstance(st.index, K.FlatIndex) and 1 <= len(plan) <= 16:
+                # sort-path groups: probe + every statistic of the group's record in ONE launch
+                outs, unseen = st.index.gather(keys, valids, st.records(), [p[1] for p in plan],
+                                               [p[2] for p in plan])
+                any_unseen = None  # read back once, and only when an integer column needs it
+                for (cname, out_dt, _), o in zip(plan, outs):
+                    if cname in new:
+                        continue
+                    if out_dt == torch.int32 and any_unseen is None:
+                        any_unseen = bool(int(K.read_back(unseen)[0]))
+                    if out_dt == torch.int32 and any_unseen:
+                        raise ValueError(
+                            f"Cannot convert non-finite values (NA or inf) to integer: column "
+                            f"{cname} has unseen categories"
+                        )
+                    new[cname] = DeviceColumn(o)
+                continue
             grp = st.index.lookup(keys, valids)
             for cname, src in st.columns.items():
                 if cname in new:

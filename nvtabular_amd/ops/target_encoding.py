@@ -13,7 +13,7 @@ from ..node import Node
 from ..schema import Tags
 from ..selector import ColumnSelector
 from .base import StatOperator
-from ._groupby import GroupAgg, stats_frame
+from ._groupby import GroupAgg, fold_sparse, stats_frame
 from .categorify import _make_name
 from .join_groupby import _Stats, _stats_from_frame
 from .normalize import moments_begin, moments_end, moments_partition
@@ -57,6 +57,17 @@ def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
         f = _add_fold(n, kfold, fold_seed).astype(np.uint8)
         cached = _FOLD_CACHE[key] = torch.from_numpy(f).to(device)
     return DeviceColumn(cached[:n])
+
+
+class _FoldDense:
+    """Per-(group, fold) statistics of the sort path: entry g * kfold + fold of ``count`` /
+    ``sums[target]`` (K.sorted_groupby); the transform needs no second lookup."""
+
+    def __init__(self, kfold, count, sums, records=None):
+        self.kfold, self.count, self.sums = int(kfold), count.contiguous(), sums
+        # target -> [groups, 2 * (kfold + 1)] {sum, count, (sum_f, count_f) ...}: the one-probe
+        # layout of K.FlatIndex.te
+        self.records = records
 
 
 class TargetEncoding(StatOperator):
@@ -103,11 +114,16 @@ class TargetEncoding(StatOperator):
             state["moments"] = moments_begin(targets)
         for cols in self._groups(col_selector):
             name = _make_name(*cols, sep=self.name_sep)
-            state["aggs"][name] = GroupAgg(name, cols, targets, hint=self._hints.get(name, 0))
             if self.kfold > 1:
+                # the [fold, key] aggregate rides on the key aggregate (one sort serves both
+                # when the key is one int32 column; two hash tables otherwise)
                 fcols = [self.fold_name] + cols
                 fname = _make_name(*fcols, sep=self.name_sep)
-                state["aggs"][fname] = GroupAgg(fname, fcols, targets, hint=self._hints.get(fname, 0))
+                state["aggs"][name] = GroupAgg(name, cols, targets, hint=self._hints.get(name, 0),
+                                               fold=(self.fold_name, self.kfold), fold_name=fname,
+                                               fold_hint=self._hints.get(fname, 0))
+            else:
+                state["aggs"][name] = GroupAgg(name, cols, targets, hint=self._hints.get(name, 0))
         return state
 
     def fit_partition(self, state, col_selector, df):
@@ -125,25 +141,52 @@ class TargetEncoding(StatOperator):
         base = os.path.join(self.out_path, "categories")
         os.makedirs(base, exist_ok=True)
         paths = {}
-        for name, agg in state["aggs"].items():
-            comp = agg.finalize()
+
+        def register(name, agg, comp):
             self._hints[name] = max(64, int(comp["n"]))
             d = os.path.join(base, f"cat_stats.{name}.parquet")
             self._pending[name] = (agg, comp, d)
-            if not self.defer_artifacts:
-                self.flush_artifacts()
             paths[name] = d
             cols = {"count": comp["count"]}
             for j, t in enumerate(agg.val_cols):
                 cols[f"sum:{t}"] = comp["sum"][j]
             self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols,
                                               index_table=comp.get("index_table"))
+
+        for name, agg in state["aggs"].items():
+            comp = agg.finalize()
+            register(name, agg, comp)
+            if agg.fold is None:
+                continue
+            fname = agg.fold_name
+            if "fold" not in comp:  # two hash tables
+                fa = agg._fold_classic()
+                register(fname, fa, fa.finalize())
+                continue
+            # sort path: dense per-(group, fold) statistics; the [fold, key] groups of the
+            # artifact are derived from them when the file is written
+            f = comp["fold"]
+            view = GroupAgg(fname, [self.fold_name] + agg.key_cols, agg.val_cols)
+            view.key_dtypes = {self.fold_name: torch.uint8, **agg.key_dtypes}
+            view.val_dtypes = dict(agg.val_dtypes)
+            self._hints[fname] = max(64, int(comp["n"]) * min(self.kfold, 2))
+            d = os.path.join(base, f"cat_stats.{fname}.parquet")
+            self._pending[fname] = (view, (lambda c=comp: fold_sparse(c)), d)
+            paths[fname] = d
+            self._device_stats[fname] = _FoldDense(
+                self.kfold, f["size"], {t: f["sum"][j] for j, t in enumerate(agg.val_cols)},
+                records=({t: f["records"][j] for j, t in enumerate(agg.val_cols)}
+                         if f.get("records") is not None else None))
+        if not self.defer_artifacts:
+            self.flush_artifacts()
         moments = moments_end(state["moments"]) if state["moments"] is not None else None
         return paths, moments
 
     def flush_artifacts(self):
         """Write any deferred cat_stats.<group>.parquet directories."""
         for agg, comp, d in self._pending.values():
+            if callable(comp):
+                comp = comp()
             os.makedirs(d, exist_ok=True)
             stats_frame(agg, comp, ["count", "sum"], self.name_sep).to_parquet(
                 os.path.join(d, "part.0.parquet"), index=False)
@@ -206,14 +249,37 @@ class TargetEncoding(StatOperator):
                     valids.append(v)
                 return st.index.lookup(keys, valids)
 
-            g_all = lookup(st_all, cat_group)
             g_fold, st_fold = None, None
             if fit_folds:
                 fcols = [self.fold_name] + cat_group
                 st_fold = self._stats_for(_make_name(*fcols, sep=self.name_sep), fcols)
+            # one int32 key column fitted on the sort path: probe + formula in ONE launch per
+            # target (no group-id columns in HBM)
+            fused = isinstance(st_all.index, K.FlatIndex) and (
+                (not fit_folds) or (isinstance(st_fold, _FoldDense) and st_fold.records is not None))
+            if fused:
+                k, v = key_view(work[cat_group[0]].materialize())
+                for i, t in enumerate(targets):
+                    ym = y_mean[t] if isinstance(y_mean, dict) else y_mean
+                    if fit_folds:
+                        rec, fold_t = st_fold.records[t], work[self.fold_name].data
+                    else:
+                        rec, fold_t = st_all.te_records(t), None
+                    new[out_col[i]] = DeviceColumn(st_all.index.te(
+                        [k], [v], fold_t, self.kfold, rec, self.p_smooth, ym, out_dt))
+                continue
+            g_all = lookup(st_all, cat_group)
+            if fit_folds and not isinstance(st_fold, _FoldDense):
                 g_fold = lookup(st_fold, fcols)
             for i, t in enumerate(targets):
                 ym = y_mean[t] if isinstance(y_mean, dict) else y_mean
+                if isinstance(st_fold, _FoldDense):
+                    new[out_col[i]] = DeviceColumn(K.te_apply_folds(
+                        g_all, work[self.fold_name].data, st_fold.kfold,
+                        st_all.columns[f"sum:{t}"].to(torch.float64).contiguous(),
+                        st_all.columns["count"].to(torch.int64).contiguous(),
+                        st_fold.sums[t], st_fold.count, self.p_smooth, ym, out_dt))
+                    continue
                 out = K.te_apply(
                     g_all, g_fold,
                     st_all.columns[f"sum:{t}"].to(torch.float64).contiguous(),

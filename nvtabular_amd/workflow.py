@@ -21,7 +21,7 @@ import pandas as pd
 
 from . import dist
 from .device import DeviceFrame, as_device_frame
-from .kernels import annotate
+from .kernels import annotate, pass_memo
 from .io import Dataset
 from .node import Node, iter_nodes
 from .ops.base import StatOperator
@@ -191,10 +191,11 @@ class Workflow:
             states = {id(n): n.op.fit_begin(n.input_columns) for n in phase}
             for part in dataset.to_iter(columns=roots, shard=shard):
                 cache: Dict[int, DeviceFrame] = {}
-                for n in phase:
-                    inp = self._node_input(n, part, cache)
-                    with annotate(n.op.range_name("fit")):
-                        n.op.fit_partition(states[id(n)], n.input_columns, inp)
+                with pass_memo():  # one pass over this partition: shared intermediates
+                    for n in phase:
+                        inp = self._node_input(n, part, cache)
+                        with annotate(n.op.range_name("fit")):
+                            n.op.fit_partition(states[id(n)], n.input_columns, inp)
             # operators whose fit_end only reads a few scalars back (Normalize) go first: their
             # read-back is the step's one host synchronisation, and Categorify's fit_end (which
             # finds its counts already complete) then enqueues the vocabulary sorts and table

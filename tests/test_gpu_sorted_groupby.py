@@ -1,0 +1,264 @@
+"""Sort path of the single-key groupby (nvt_sgb_sort + nvt_sgb_regroup + nvt_sgb_reduce, the
+flat index and the fused transforms nvt_flat_lookup_gather / nvt_flat_lookup_te):
+JoinGroupby / TargetEncoding fit and transform on ONE int32 key column.  Checked against
+pandas groupby at the kernel level and against the oracle's restatement of the reference
+(categorify.py:955-1137, join_groupby.py:175-217, target_encoding.py:254-384) end to end."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _skewed_keys(rng, n, card, lo=-(2**31), hi=2**31 - 1):
+    ids = rng.integers(lo, hi, card, dtype=np.int64).astype(np.int32)
+    pick = (rng.random(n) ** 3 * card).astype(np.int64)
+    return ids[pick]
+
+
+@pytest.mark.parametrize("kfold", [1, 5, 16])
+def test_sgb_aggregate_vs_pandas(kfold):
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.device import pack_bitmap_device
+
+    rng = np.random.default_rng(5 + kfold)
+    n, card = 200_003, 30_000
+    key = _skewed_keys(rng, n, card)
+    key[:3] = [np.iinfo(np.int32).min, np.iinfo(np.int32).max, 0]
+    x = rng.normal(size=n)
+    x[rng.random(n) < 0.05] = np.nan
+    y = rng.random(n).astype(np.float32)
+    yvalid = rng.random(n) < 0.9
+    fold = rng.integers(0, kfold, n).astype(np.uint8) if kfold > 1 else None
+    dev = "cuda"
+    tk = torch.from_numpy(key).to(dev)
+    vals = [torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)]
+    vvalid = [None, pack_bitmap_device(torch.from_numpy(yvalid).to(dev))]
+    tf = torch.from_numpy(fold).to(dev) if fold is not None else None
+    minmax = kfold == 1
+    for hint in (0, 100):  # 100: too small -> the exact-size relaunch
+        comp = K.sorted_groupby(tk, tf, kfold, vals, vvalid, sumsq=minmax, minmax=minmax, cap_hint=hint)
+        df = pd.DataFrame({"k": key, "x": x, "y": np.where(yvalid, y.astype(np.float64), np.nan)})
+        gb = df.groupby("k", sort=True)
+        exp_keys = np.array(sorted(set(key.tolist())), dtype=np.int64)
+        assert comp["n"] == exp_keys.size
+        np.testing.assert_array_equal(comp["keys"][0].cpu().numpy(), exp_keys)
+        np.testing.assert_array_equal(comp["keys32"].cpu().numpy(), exp_keys.astype(np.int32))
+        np.testing.assert_array_equal(comp["size"].cpu().numpy(), gb.size().to_numpy())
+        for j, c in enumerate(["x", "y"]):
+            np.testing.assert_allclose(comp["sum"][j].cpu().numpy(), gb[c].sum().to_numpy(),
+                                       rtol=1e-11, atol=1e-11)
+        if minmax:
+            for j, c in enumerate(["x", "y"]):
+                np.testing.assert_allclose(comp["sumsq"][j].cpu().numpy(),
+                                           (df[c] ** 2).groupby(df["k"]).sum().to_numpy(), rtol=1e-11, atol=1e-11)
+                np.testing.assert_array_equal(comp["min"][j].cpu().numpy(), gb[c].min().to_numpy())
+                np.testing.assert_array_equal(comp["max"][j].cpu().numpy(), gb[c].max().to_numpy())
+        if kfold > 1:
+            f = comp["fold"]
+            df["f"] = fold
+            pos = np.searchsorted(exp_keys, key.astype(np.int64)) * kfold + fold
+            size = np.bincount(pos, minlength=exp_keys.size * kfold)
+            np.testing.assert_array_equal(f["size"].cpu().numpy(), size)
+            for j, c in enumerate(["x", "y"]):
+                v = df[c].to_numpy()
+                s = np.bincount(pos[~np.isnan(v)], weights=v[~np.isnan(v)], minlength=size.size)
+                np.testing.assert_allclose(f["sum"][j].cpu().numpy(), s, rtol=1e-11, atol=1e-11)
+
+
+def test_flat_index_lookup_and_clustered_fallback():
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.device import pack_bitmap_device
+
+    rng = np.random.default_rng(2)
+    keys = np.unique(rng.integers(-(2**31), 2**31 - 1, 300_000, dtype=np.int64).astype(np.int32))
+    keys[0] = np.iinfo(np.int32).min  # (still ascending: the smallest int32)
+    dev = "cuda"
+    idx = K.FlatIndex(torch.from_numpy(keys).to(dev))
+    assert idx.ok()
+    probe = np.concatenate([keys[::3], rng.integers(-(2**31), 2**31 - 1, 100_000, dtype=np.int64).astype(np.int32)])
+    pos = np.searchsorted(keys, probe)
+    pos_c = np.minimum(pos, keys.size - 1)
+    exp = np.where(keys[pos_c] == probe, pos_c, -1)
+    got = idx.lookup([torch.from_numpy(probe).to(dev)], [None]).cpu().numpy()
+    np.testing.assert_array_equal(got, exp)
+    # int64 column (values outside int32 are unseen), validity bitmap (null key -> -1)
+    p64 = probe.astype(np.int64)
+    p64[:10] += 2**40
+    valid = rng.random(p64.size) < 0.8
+    got = idx.lookup([torch.from_numpy(p64).to(dev)],
+                     [pack_bitmap_device(torch.from_numpy(valid).to(dev))]).cpu().numpy()
+    exp64 = exp.copy()
+    exp64[:10] = -1
+    exp64[~valid] = -1
+    np.testing.assert_array_equal(got, exp64)
+    # without the smallest int32 in the list it is unseen
+    idx2 = K.FlatIndex(torch.from_numpy(keys[1:].copy()).to(dev))
+    q = torch.tensor([np.iinfo(np.int32).min, int(keys[1]), int(keys[-1])], dtype=torch.int32, device=dev)
+    assert idx2.lookup([q], [None]).tolist() == [-1, 0, keys.size - 2]
+    # dense ids + one far outlier: every key has the same home slot -> not ok (hashed index instead)
+    clustered = np.concatenate([np.arange(100_000, dtype=np.int32), np.array([2**31 - 5], dtype=np.int32)])
+    assert not K.FlatIndex(torch.from_numpy(clustered).to(dev)).ok()
+
+
+def _frames(n, card, seed, nulls=False):
+    rng = np.random.default_rng(seed)
+    df = pd.DataFrame({
+        "k": _skewed_keys(rng, n, card, 0, 2**31 - 1),
+        "x": rng.normal(size=n),
+        "y": (rng.random(n) < 0.3).astype("float32"),
+    })
+    df.loc[rng.random(n) < 0.05, "x"] = np.nan
+    return df
+
+
+@pytest.mark.parametrize("nparts", [1, 2])
+def test_joingroupby_sorted_path_vs_oracle(tmp_path, nparts):
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+
+    df = _frames(120_000, 9_000, 21)
+    parts = [df] if nparts == 1 else [df.iloc[:70_000].reset_index(drop=True),
+                                      df.iloc[70_000:].reset_index(drop=True)]
+    stats = ["count", "sum", "mean", "std", "var", "min", "max"]
+    jg = ops.JoinGroupby(out_path=str(tmp_path / "g"), stats=stats, cont_cols=["x", "y"])
+    wf = nvt.Workflow(["k"] >> jg).fit(nvt.Dataset(parts))
+    index = jg._device_stats["k"].index
+    # one partition: sorted groups + flat index; two: the first partition's groups were demoted
+    assert isinstance(index, K.FlatIndex) == (nparts == 1)
+    got = wf.transform(nvt.Dataset(parts)).to_ddf().compute()
+    cats = O.join_groupby_fit([p.copy() for p in parts], ["k"], ["x", "y"], stats, str(tmp_path / "c"))
+    exp = O.join_groupby_transform(df.copy(), ["k"], cats)
+    assert sorted(got.columns) == sorted(exp.columns)
+    for c in exp.columns:
+        if c.endswith("_count"):
+            np.testing.assert_array_equal(got[c].to_numpy(), exp[c].to_numpy())
+        else:
+            np.testing.assert_allclose(got[c].to_numpy().astype("float64"),
+                                       exp[c].to_numpy().astype("float64"), rtol=2e-5, atol=1e-6, err_msg=c)
+    # the artifact lists the same groups with the same statistics
+    a = pd.read_parquet(jg.categories["k"]).sort_values("k").reset_index(drop=True)
+    b = pd.read_parquet(cats["k"]).sort_values("k").reset_index(drop=True)
+    assert list(a["k"]) == list(b["k"]) and a["k"].dtype == b["k"].dtype
+    np.testing.assert_array_equal(a["k_count"].to_numpy(), b["k_count"].to_numpy())
+    np.testing.assert_allclose(a["k_x_sum"].to_numpy(), b["k_x_sum"].to_numpy(), rtol=1e-9, atol=1e-9)
+    # unseen keys and nulls at transform time
+    new = pd.DataFrame({"k": pd.array([int(df["k"][0]), 2**31 - 2, None], dtype="Int32").astype("float64"),
+                        "x": [0.0, 0.0, 0.0], "y": np.zeros(3, dtype="float32")})
+    jg2 = ops.JoinGroupby(out_path=str(tmp_path / "g2"), stats=["sum"], cont_cols=["x"])
+    wf2 = nvt.Workflow(["k"] >> jg2).fit(nvt.Dataset(parts))
+    o2 = wf2.transform(nvt.Dataset(new)).to_ddf().compute()
+    assert np.isfinite(o2["k_x_sum"][0]) and np.isnan(o2["k_x_sum"][1]) and np.isnan(o2["k_x_sum"][2])
+
+
+@pytest.mark.parametrize("kfold,fold_seed", [(1, None), (5, 42), (3, None)])
+@pytest.mark.parametrize("nparts", [1, 2])
+def test_target_encoding_sorted_path_vs_oracle(tmp_path, kfold, fold_seed, nparts):
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+    from nvtabular_amd.ops.target_encoding import _FoldDense
+
+    df = _frames(100_000, 7_000, 33)
+    parts = [df] if nparts == 1 else [df.iloc[:60_000].reset_index(drop=True),
+                                      df.iloc[60_000:].reset_index(drop=True)]
+    te = ops.TargetEncoding(["y", "x"], out_path=str(tmp_path / "g"), kfold=kfold, fold_seed=fold_seed,
+                            p_smooth=20)
+    wf = nvt.Workflow(["k"] >> te).fit(nvt.Dataset(parts))
+    if kfold > 1:
+        assert isinstance(te._device_stats["__fold___k"], _FoldDense) == (nparts == 1)
+    got = wf.transform(nvt.Dataset(parts)).to_ddf().compute()
+    oparts = [p.copy() for p in parts]
+    stats, means = O.target_encoding_fit(oparts, ["k"], ["y", "x"], str(tmp_path / "c"), kfold=kfold,
+                                         fold_seed=fold_seed)
+    exp = pd.concat([
+        O.target_encoding_transform(p[["k", "y", "x"]].copy(), ["k"], ["y", "x"], stats, means,
+                                    kfold=kfold, fold_seed=fold_seed, p_smooth=20)
+        for p in parts], ignore_index=True)
+    assert list(got.columns) == list(exp.columns)
+    for c in exp.columns:
+        assert got[c].dtype == np.float32
+        np.testing.assert_allclose(got[c].to_numpy(), exp[c].to_numpy(), rtol=1e-5, atol=1e-6, err_msg=c)
+    if kfold > 1:  # the [fold, key] artifact: same groups, counts and sums as the reference's
+        a = pd.read_parquet(te.stats["__fold___k"]).sort_values(["__fold__", "k"]).reset_index(drop=True)
+        b = pd.read_parquet(stats["__fold___k"]).sort_values(["__fold__", "k"]).reset_index(drop=True)
+        assert list(a.columns) == list(b.columns)
+        for c in b.columns:
+            np.testing.assert_allclose(a[c].to_numpy().astype("float64"), b[c].to_numpy().astype("float64"),
+                                       rtol=1e-9, atol=1e-9, err_msg=c)
+    # a frame the fit never saw: unseen keys and unseen (fold, key) pairs fall back to the mean
+    other = _frames(50_000, 20_000, 77)
+    got2 = wf.transform(nvt.Dataset(other)).to_ddf().compute()
+    exp2 = O.target_encoding_transform(other[["k", "y", "x"]].copy(), ["k"], ["y", "x"], stats, means,
+                                       kfold=kfold, fold_seed=fold_seed, p_smooth=20)
+    for c in exp2.columns:
+        np.testing.assert_allclose(got2[c].to_numpy(), exp2[c].to_numpy(), rtol=1e-5, atol=1e-6, err_msg=c)
+
+
+def test_sorted_path_save_load_roundtrip(tmp_path):
+    """Workflow.save -> load rebuilds the lookup from the parquet artifacts (hashed index, sparse
+    fold table): same output as the dense statistics of the fit."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    df = _frames(80_000, 5_000, 4)
+    te = ["k"] >> ops.TargetEncoding("y", out_path=str(tmp_path / "te"), kfold=5, p_smooth=20)
+    jg = ["k"] >> ops.JoinGroupby(out_path=str(tmp_path / "jg"), stats=["count", "mean"], cont_cols=["x"])
+    wf = nvt.Workflow(te + jg).fit(nvt.Dataset(df))
+    a = wf.transform(nvt.Dataset(df)).to_ddf().compute()
+    wf.save(str(tmp_path / "wf"))
+    b = nvt.Workflow.load(str(tmp_path / "wf")).transform(nvt.Dataset(df)).to_ddf().compute()
+    assert list(a.columns) == list(b.columns)
+    for c in a.columns:
+        np.testing.assert_allclose(a[c].to_numpy().astype("float64"), b[c].to_numpy().astype("float64"),
+                                   rtol=1e-6, atol=1e-7, err_msg=c)
+
+
+@pytest.mark.parametrize("order", ["te_jg", "jg_te"])
+def test_aggregates_of_one_pass_share_sort_and_groups(tmp_path, order):
+    """TargetEncoding and JoinGroupby on the same column in one workflow: the second aggregate
+    reuses the sorted words (and, after TargetEncoding, the group ids regrouped with its folds).
+    Same results as each operator fitted alone (the oracle)."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+
+    df = _frames(90_000, 6_000, 55)
+    stats = ["count", "sum", "mean", "std"]
+    te = ["k"] >> ops.TargetEncoding("y", out_path=str(tmp_path / "te"), kfold=5, fold_seed=42, p_smooth=20)
+    jg = ["k"] >> ops.JoinGroupby(out_path=str(tmp_path / "jg"), stats=stats, cont_cols=["x"])
+    sorts = []
+    real = K._lib.load().nvt_sgb_sort
+
+    wf = nvt.Workflow(te + jg if order == "te_jg" else jg + te)
+    calls = {"sort": 0}
+    orig = K.sorted_groupby
+
+    def counting(*a, **kw):
+        before = K._PASS_MEMO is not None and len(K._PASS_MEMO)
+        out = orig(*a, **kw)
+        calls["sort"] += int(K._PASS_MEMO is not None and len(K._PASS_MEMO) > before)
+        return out
+
+    K.sorted_groupby = counting
+    try:
+        import nvtabular_amd.ops._groupby as G
+        wf.fit(nvt.Dataset(df))
+    finally:
+        K.sorted_groupby = orig
+    got = wf.transform(nvt.Dataset(df)).to_ddf().compute()
+    cats = O.join_groupby_fit([df.copy()], ["k"], ["x"], stats, str(tmp_path / "c"))
+    exp_j = O.join_groupby_transform(df.copy(), ["k"], cats)
+    st, means = O.target_encoding_fit([df.copy()], ["k"], ["y"], str(tmp_path / "c2"), kfold=5, fold_seed=42)
+    exp_t = O.target_encoding_transform(df[["k", "y"]].copy(), ["k"], ["y"], st, means, kfold=5,
+                                        fold_seed=42, p_smooth=20)
+    for exp in (exp_j, exp_t):
+        for c in exp.columns:
+            if c in ("k", "x", "y"):
+                continue
+            np.testing.assert_allclose(got[c].to_numpy().astype("float64"), exp[c].to_numpy().astype("float64"),
+                                       rtol=2e-5, atol=1e-6, err_msg=c)
+    assert (got["k_count"].to_numpy() == exp_j["k_count"].to_numpy()).all()
