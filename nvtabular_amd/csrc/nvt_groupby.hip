@@ -300,9 +300,14 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
   const unsigned lane = lane_id();
   const uint64_t nwaves = (uint64_t)gridDim.x * (kBlock / kWave);
   const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
-  // waves walk the sorted words in 64-element steps (fixed trip count: every lane of a wave
-  // takes part in the shuffles)
-  for (uint64_t base = wave0 * kWave; base < n; base += nwaves * kWave) {
+  // every wave walks ONE contiguous chunk of the sorted words in 64-element steps (fixed trip
+  // count: every lane takes part in the shuffles).  The slots of a chunk are a contiguous range
+  // when the words are ordered by slot: the accumulators a wave writes are its own region, far
+  // from the other waves' (a grid-stride walk put the whole GPU's stores into the same ~1 MB
+  // window of the dense arrays at any time: 596 us instead of 443 for 20 M rows)
+  const uint64_t per_wave = ((n + nwaves - 1) / nwaves + kWave - 1) / kWave * kWave;
+  const uint64_t chunk_end = (wave0 + 1) * per_wave < n ? (wave0 + 1) * per_wave : n;
+  for (uint64_t base = wave0 * per_wave; base < chunk_end; base += kWave) {
     const uint64_t i = base + lane;
     const bool act = i < n;
     const uint64_t w = act ? words[i] : ~0ull;

@@ -625,24 +625,34 @@ __global__ __launch_bounds__(kS2BS) void os_hist_words_kernel(const uint64_t *__
   const unsigned l = lane_id();
   const uint64_t stride = (uint64_t)gridDim.x * kS2BS;
   const uint64_t iters = (n + stride - 1) / stride;
-  for (uint64_t it = 0; it < iters; ++it) {
-    const uint64_t i = it * stride + (uint64_t)blockIdx.x * kS2BS + threadIdx.x;
-    const bool act = i < n;
-    const uint64_t c = act ? w[i] >> bit_lo : 0ull;
+  constexpr int U = 4;  // loads in flight per thread (256 workgroups stream the whole array)
+  for (uint64_t it = 0; it < iters; it += U) {
+    uint64_t cw[U];
+    bool av[U];
 #pragma unroll
-    for (int p = 0; p < kOsMaxPass; ++p) {
-      if (p < npass) {
-        // sorted-by-group inputs are heavily skewed (one hot group = one digit value): a wave
-        // whose 64 digits are all equal adds once; otherwise plain LDS atomics (a full
-        // match-any aggregation per digit cost more than the conflicts it saved: 324 us for
-        // 20 M words)
-        const unsigned d = (unsigned)(c >> (8 * p)) & 0xFF;
-        const unsigned long long am = __ballot(act);
-        const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-        if (am == ~0ull && __ballot(d == d0) == ~0ull) {
-          if (l == 0) atomicAdd(&h[p * 256 + d0], 64u);
-        } else if (act) {
-          atomicAdd(&h[p * 256 + d], 1u);
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = (it + u) * stride + (uint64_t)blockIdx.x * kS2BS + threadIdx.x;
+      av[u] = (it + u) < iters && i < n;
+      cw[u] = av[u] ? w[i] >> bit_lo : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool act = av[u];
+      const uint64_t c = cw[u];
+#pragma unroll
+      for (int p = 0; p < kOsMaxPass; ++p) {
+        if (p < npass) {
+          // sorted-by-group inputs are heavily skewed (one hot group = one digit value): a wave
+          // whose 64 digits are all equal adds once; otherwise plain LDS atomics (a full
+          // match-any aggregation per digit cost more than the conflicts it saved)
+          const unsigned d = (unsigned)(c >> (8 * p)) & 0xFF;
+          const unsigned long long am = __ballot(act);
+          const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+          if (am == ~0ull && __ballot(d == d0) == ~0ull) {
+            if (l == 0) atomicAdd(&h[p * 256 + d0], 64u);
+          } else if (act) {
+            atomicAdd(&h[p * 256 + d], 1u);
+          }
         }
       }
     }
