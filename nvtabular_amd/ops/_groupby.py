@@ -90,7 +90,7 @@ class GroupAgg:
             fold_t = fcol.data if fcol.data.dtype == torch.uint8 and fcol.valid is None else None
         if (self.table is None and self.sorted_comp is None and len(keys) == 1
                 and (self.fold_agg is None or self.fold_agg.table is None)
-                and (not self.fold or (fold_t is not None and dist.world_size() == 1))
+                and (not self.fold or fold_t is not None)
                 and K.sorted_groupby_eligible(keys[0], kvalid[0], n, kfold)):
             comp = K.sorted_groupby(keys[0], fold_t, kfold, vals, vvalid, sumsq=self.sumsq,
                                     minmax=self.minmax, cap_hint=self.hint, te_records=True)
@@ -127,10 +127,15 @@ class GroupAgg:
 
         if self.sorted_comp is not None:
             comp = self.sorted_comp
-            if dist.world_size() > 1:  # (never with folds: update() keeps those off this path)
-                comp = dist.merge_groups(comp, 1, len(self.val_cols), sumsq=self.sumsq,
-                                         minmax=self.minmax)
-            else:
+            if dist.world_size() > 1:
+                if "fold" in comp:
+                    # the ranks merge compacted groups: the dense per-(group, fold) statistics
+                    # become the [fold, key] groups of the second aggregate, merged on their own
+                    self._fold_classic().sorted_comp = fold_sparse(comp)
+                    comp = {k: v for k, v in comp.items() if k != "fold"}
+                comp = dist.merge_groups(comp, len(self.key_cols), len(self.val_cols),
+                                         sumsq=self.sumsq, minmax=self.minmax)
+            elif len(self.key_cols) == 1 and "keys32" in comp:
                 index = K.flat_index_for(comp)
                 if index.ok():  # else: _Stats builds a hashed index from the keys
                     comp["index_table"] = index

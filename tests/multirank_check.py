@@ -30,6 +30,17 @@ tmp = tempfile.mkdtemp()
 wf = nvt.Workflow((["a", "b"] >> ops.Categorify(out_path=os.path.join(tmp, f"r{rank}")))
                   + (["x"] >> ops.FillMissing() >> ops.Normalize()))
 got = wf.fit_transform(nvt.Dataset(mine)).to_ddf().compute()
+
+
+def stat_graph(path):
+    # one int32 key column, 200 k rows per rank: every rank fits on the sort path, the ranks merge
+    # compacted groups (the dense fold statistics as [fold, key] groups)
+    te = ["a"] >> ops.TargetEncoding("x", kfold=5, fold_seed=42, p_smooth=20, out_path=os.path.join(path, "te"))
+    jg = ["a"] >> ops.JoinGroupby(cont_cols=["x"], stats=["count", "sum", "mean"], out_path=os.path.join(path, "jg"))
+    return nvt.Workflow(te + jg)
+
+
+got_s = stat_graph(os.path.join(tmp, f"s{rank}")).fit_transform(nvt.Dataset(mine)).to_ddf().compute()
 td.barrier()
 # single-process reference on the union (world_size() is 1 inside this block)
 td.destroy_process_group()
@@ -42,5 +53,17 @@ exp = exp_all.iloc[lo: lo + len(mine)].reset_index(drop=True)
 for c in ("a", "b"):
     np.testing.assert_array_equal(got[c].to_numpy(), exp[c].to_numpy(), err_msg=c)
 np.testing.assert_allclose(got["x"].to_numpy(), exp["x"].to_numpy(), rtol=1e-9, atol=1e-12)
+# TargetEncoding / JoinGroupby: the reference on the union keeps the ranks' frames as its
+# partitions (fold ids are drawn per partition, target_encoding.py:427-439)
+ref_s = stat_graph(os.path.join(tmp, f"refs{rank}"))
+exp_s = ref_s.fit_transform(nvt.Dataset([make(r) for r in range(world)])).to_ddf().compute()
+exp_s = exp_s.iloc[lo: lo + len(mine)].reset_index(drop=True)
+assert list(got_s.columns) == list(exp_s.columns)
+for c in got_s.columns:
+    if c.endswith("_count"):
+        np.testing.assert_array_equal(got_s[c].to_numpy(), exp_s[c].to_numpy(), err_msg=c)
+    else:
+        np.testing.assert_allclose(got_s[c].to_numpy().astype("float64"), exp_s[c].to_numpy().astype("float64"),
+                                   rtol=1e-6, atol=1e-7, err_msg=c)
 print(f"rank {rank}: multi-rank fit == single-process fit of the union "
       f"({len(mine)} of {len(full)} rows, vocab a = {int(exp_all['a'].max()) - 2})", flush=True)
