@@ -352,6 +352,11 @@ int nvt_te_apply_folds(const int64_t *group_all, const uint8_t *fold, int kfold,
  *   te_records double[nvals][cap][2 * (kfold + 1)] or NULL (kfold > 1 only): per group
  *                                          {sum, count, (sum_f, count_f) for every fold}, the
  *                                          layout nvt_flat_lookup_te reads with one probe
+ * Keys: an int32 column (key_bias = INT32_MIN) or an int64 column whose keys span less than
+ * 2^32 (key_bias = the smallest key; nvt_key_minmax writes {min, max} to device memory); the
+ * 32-bit key image is key - key_bias.  out_keys hold the keys themselves, out_keys32 =
+ * key - key_bias - 2^31 (what the flat index stores: pass key_offset = key_bias + 2^31 to the
+ * nvt_flat_lookup* functions; 0 for int32 columns).
  * nvt_sgb_sort: words (key image << 32 | fold << row_bits | row) sorted on bits [row_bits, 64);
  * fold: uint8[n] ids < kfold, NULL with kfold == 1; n <= 2^(32 - bits(kfold - 1)), n < 2^30.
  * *sorted_out = device pointer INSIDE ws (nvt_sgb_sort_ws_bytes(n) bytes; keep ws alive),
@@ -369,12 +374,13 @@ int nvt_te_apply_folds(const int64_t *group_all, const uint8_t *fold, int kfold,
  * regroup).  state: the block nvt_sgb_regroup filled (device, read by the kernels only).
  * No host synchronisation anywhere. */
 int nvt_sgb_sort_ws_bytes(uint64_t n, uint64_t *bytes);
-int nvt_sgb_sort(const int32_t *keys, const uint8_t *fold, int kfold, uint64_t n, void *ws,
-                 uint64_t **sorted_out, int *row_bits_out, void *stream);
+int nvt_key_minmax(const void *keys, int key_dtype, uint64_t n, int64_t *out2, void *stream);
+int nvt_sgb_sort(const void *keys, int key_dtype, int64_t key_bias, const uint8_t *fold, int kfold,
+                 uint64_t n, void *ws, uint64_t **sorted_out, int *row_bits_out, void *stream);
 int nvt_sgb_regroup_ws_bytes(uint64_t n, uint64_t *bytes);
-int nvt_sgb_regroup(const uint64_t *sorted, int row_bits, int kfold, uint64_t n, uint64_t cap,
-                    int64_t *out_keys, int32_t *out_keys32, uint64_t *regrouped, uint64_t *state,
-                    void *ws, void *stream);
+int nvt_sgb_regroup(const uint64_t *sorted, int row_bits, int kfold, int64_t key_bias, uint64_t n,
+                    uint64_t cap, int64_t *out_keys, int32_t *out_keys32, uint64_t *regrouped,
+                    uint64_t *state, void *ws, void *stream);
 int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const void *const *vals,
                    const int *vdtypes, const uint8_t *const *val_valid, int nvals, int flags,
                    uint64_t n, uint64_t cap, uint64_t *out_size, double *out_sum, double *out_sumsq,
@@ -387,12 +393,13 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
  * capacity >= 2^slots_log2 + n + 64; tmp: nvt_flat_index_tmp_bytes(n).
  * aux[NVT_FLAT_AUX_MAXDISP] = longest displacement (keys clustered in their range make long
  * probe runs: the caller may prefer a hashed index).  nvt_flat_lookup: out[i] = position of
- * keys[i] (int32 / int64 column, optional validity bitmap) or -1. */
+ * keys[i] - key_offset (int32 / int64 column, optional validity bitmap) or -1. */
 int nvt_flat_index_tmp_bytes(uint64_t n, uint64_t *bytes);
 int nvt_flat_index_build(const int32_t *keys, uint64_t n, int slots_log2, int32_t *aux, void *table,
                          uint64_t capacity, void *tmp, void *stream);
 int nvt_flat_lookup(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
-                    const void *table, uint64_t capacity, int64_t *out, void *stream);
+                    const void *table, uint64_t capacity, int64_t key_offset, int64_t *out,
+                    void *stream);
 /* JoinGroupby.transform in one pass (join_groupby.py:198-217): outs[c][i] = records[g][c] with
  * g = the group of keys[i], miss[c] when the key has no group; records double[groups][ncols]
  * (ncols <= 16), out_dtypes f32 / f64 / i32 / i64 (value-converting stores).  *unseen (device
@@ -400,14 +407,14 @@ int nvt_flat_lookup(const void *keys, int dtype, const uint8_t *valid, uint64_t 
  * astype(int32) of a count column raises then (join_groupby.py:214). */
 int nvt_flat_lookup_gather(const void *keys, int dtype, const uint8_t *valid, uint64_t n,
                            const int32_t *aux, const void *table, uint64_t capacity,
-                           const double *records, int ncols, void *const *outs, const int *out_dtypes,
-                           const double *miss, uint64_t *unseen, void *stream);
+                           int64_t key_offset, const double *records, int ncols, void *const *outs,
+                           const int *out_dtypes, const double *miss, uint64_t *unseen, void *stream);
 /* TargetEncoding.transform in one pass (target_encoding.py:341-371): probe + nvt_te_apply(_folds)
  * on records double[groups][2 * (kfold + 1)] = {sum, count, (sum_f, count_f) ...} (te_records
  * of nvt_sgb_reduce); fold == NULL (kfold 1): records double[groups][2] = {sum, count}. */
 int nvt_flat_lookup_te(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
-                       const void *table, uint64_t capacity, const uint8_t *fold, int kfold,
-                       const double *records, double p_smooth, double y_mean, void *out,
+                       const void *table, uint64_t capacity, int64_t key_offset, const uint8_t *fold,
+                       int kfold, const double *records, double p_smooth, double y_mean, void *out,
                        int out_dtype, void *stream);
 
 /* ---- batched entry points: ONE call per operator per partition -----------------------

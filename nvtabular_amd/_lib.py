@@ -95,18 +95,19 @@ SIGNATURES = {
     "nvt_te_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _dbl, _dbl, _vp, _i32, _vp],
     "nvt_te_apply_folds": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _u64, _dbl, _dbl, _vp, _i32, _vp],
     "nvt_sgb_sort_ws_bytes": [_u64, C.POINTER(_u64)],
-    "nvt_sgb_sort": [_vp, _vp, _i32, _u64, _vp, C.POINTER(_vp), C.POINTER(C.c_int), _vp],
+    "nvt_key_minmax": [_vp, _i32, _u64, _vp, _vp],
+    "nvt_sgb_sort": [_vp, _i32, _i64, _vp, _i32, _u64, _vp, C.POINTER(_vp), C.POINTER(C.c_int), _vp],
     "nvt_sgb_regroup_ws_bytes": [_u64, C.POINTER(_u64)],
-    "nvt_sgb_regroup": [_vp, _i32, _i32, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nvt_sgb_regroup": [_vp, _i32, _i32, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp],
     "nvt_sgb_reduce": [_vp, _i32, _i32, _pp, C.POINTER(C.c_int), _pp, _i32, _i32, _u64, _u64,
                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "nvt_flat_lookup_gather": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _vp, _i32, _pp,
+    "nvt_flat_lookup_gather": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _i32, _pp,
                                C.POINTER(C.c_int), C.POINTER(_dbl), _vp, _vp],
-    "nvt_flat_lookup_te": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _vp, _i32, _vp, _dbl, _dbl, _vp,
+    "nvt_flat_lookup_te": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _i32, _vp, _dbl, _dbl, _vp,
                            _i32, _vp],
     "nvt_flat_index_tmp_bytes": [_u64, C.POINTER(_u64)],
     "nvt_flat_index_build": [_vp, _u64, _i32, _vp, _vp, _u64, _vp, _vp],
-    "nvt_flat_lookup": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _vp, _vp],
+    "nvt_flat_lookup": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_widen_i64": [_vp, _i32, _u64, _vp, _vp],
     "nvt_popcount": [_vp, _u64, _vp, _vp],
 }

@@ -608,22 +608,50 @@ constexpr int kSgbTile = kBlock * kSgbRows;
 constexpr unsigned long long kSgbAgg = 1ull << 62, kSgbPrefix = 2ull << 62,
                              kSgbMask = (1ull << 62) - 1ull;
 
-__global__ __launch_bounds__(kBlock) void sgb_pack_kernel(const int32_t *__restrict__ keys,
+template <typename K>
+__global__ __launch_bounds__(kBlock) void sgb_pack_kernel(const K *__restrict__ keys, int64_t bias,
                                                           const uint8_t *__restrict__ fold,
                                                           uint64_t n, int rb,
                                                           uint64_t *__restrict__ words) {
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const uint64_t img = (uint32_t)keys[i] ^ 0x80000000u;  // order-preserving image
+    // order-preserving 32-bit image: key - bias with bias = the smallest key (int32 columns:
+    // INT32_MIN, i.e. the sign bit flipped); the caller guarantees max - bias < 2^32
+    const uint64_t img = (uint32_t)((uint64_t)(int64_t)keys[i] - (uint64_t)bias);
     const uint64_t f = fold ? (uint64_t)fold[i] : 0ull;
     words[i] = (img << 32) | (f << rb) | i;
+  }
+}
+
+// smallest / largest key of a column (int64 columns take the sort path when their keys span
+// less than 2^32): out2 = {min, max}, initialised by the caller to {INT64_MAX, INT64_MIN}
+template <typename K>
+__global__ __launch_bounds__(kBlock) void key_minmax_kernel(const K *__restrict__ keys, uint64_t n,
+                                                            long long *out2) {
+  long long mn = INT64_MAX, mx = INT64_MIN;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const long long k = (long long)keys[i];
+    mn = k < mn ? k : mn;
+    mx = k > mx ? k : mx;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long a = __shfl_down(mn, off, 64), b = __shfl_down(mx, off, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if (lane_id() == 0) {
+    atomicMin(&out2[0], mn);
+    atomicMax(&out2[1], mx);
   }
 }
 
 __global__ __launch_bounds__(kBlock) void sgb_rle_kernel(
     const uint64_t *__restrict__ in, uint64_t n, int rb, unsigned kfold, uint64_t cap,
     unsigned long long *status, unsigned *ticket, int64_t *__restrict__ out_keys,
-    int32_t *__restrict__ out_keys32, uint64_t *__restrict__ out_words, uint64_t *state) {
+    int32_t *__restrict__ out_keys32, uint64_t *__restrict__ out_words, uint64_t *state,
+    int64_t bias) {
   constexpr int NW = kBlock / kWave;
   __shared__ unsigned wtot[NW];
   __shared__ unsigned long long s_base;
@@ -699,9 +727,8 @@ __global__ __launch_bounds__(kBlock) void sgb_rle_kernel(
       const uint32_t hi = (uint32_t)(W[r] >> 32);
       const bool fits = g < cap;
       if (((hb[r] >> l) & 1ull) && fits) {
-        const int32_t key = (int32_t)(hi ^ 0x80000000u);
-        out_keys[g] = (int64_t)key;
-        out_keys32[g] = key;
+        out_keys[g] = (int64_t)((uint64_t)hi + (uint64_t)bias);  // the key itself
+        out_keys32[g] = (int32_t)(hi ^ 0x80000000u);              // key - bias - 2^31: the flat index's key
       }
       const uint64_t low = W[r] & 0xFFFFFFFFull;
       const uint64_t fold = (rb >= 32 || kfold == 1) ? 0ull : (low >> rb);
@@ -1122,9 +1149,27 @@ int nvt_sgb_sort_ws_bytes(uint64_t n, uint64_t *bytes) {
   return NVT_OK;
 }
 
-int nvt_sgb_sort(const int32_t *keys, const uint8_t *fold, int kfold, uint64_t n, void *ws,
-                 uint64_t **sorted_out, int *row_bits_out, void *stream) {
+int nvt_key_minmax(const void *keys, int key_dtype, uint64_t n, int64_t *out2, void *stream) {
+  NVT_CHECK_ARG(keys && out2, "null pointer");
+  NVT_CHECK_ARG(key_dtype == NVT_I32 || key_dtype == NVT_I64, "key dtype must be int32 / int64");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t init[2] = {INT64_MAX, INT64_MIN};
+  NVT_CHECK_HIP(hipMemcpyAsync(out2, init, sizeof(init), hipMemcpyHostToDevice, s));
+  if (n == 0) return NVT_OK;
+  NVT_PROF("groupby_sort", n * (key_dtype == NVT_I64 ? 8ull : 4ull), s);
+  const unsigned grid = stream_grid(n, kBlock * 8);
+  if (key_dtype == NVT_I32)
+    key_minmax_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)keys, n, (long long *)out2);
+  else
+    key_minmax_kernel<int64_t><<<grid, kBlock, 0, s>>>((const int64_t *)keys, n, (long long *)out2);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_sgb_sort(const void *keys, int key_dtype, int64_t key_bias, const uint8_t *fold, int kfold,
+                 uint64_t n, void *ws, uint64_t **sorted_out, int *row_bits_out, void *stream) {
   NVT_CHECK_ARG(keys && ws && sorted_out && row_bits_out, "null pointer");
+  NVT_CHECK_ARG(key_dtype == NVT_I32 || key_dtype == NVT_I64, "key dtype must be int32 / int64");
   NVT_CHECK_ARG(kfold >= 1 && kfold <= 256, "kfold must be 1..256");
   NVT_CHECK_ARG((kfold > 1) == (fold != nullptr), "fold ids come with kfold > 1");
   int fb = 0;
@@ -1132,10 +1177,14 @@ int nvt_sgb_sort(const int32_t *keys, const uint8_t *fold, int kfold, uint64_t n
   const int rb = 32 - fb;
   NVT_CHECK_ARG(n >= 1 && n < (1ull << 30) && n <= (1ull << rb), "row index does not fit next to the fold");
   hipStream_t s = (hipStream_t)stream;
-  NVT_PROF("groupby_sort", n * 4ull, s);
+  NVT_PROF("groupby_sort", n * (key_dtype == NVT_I64 ? 8ull : 4ull), s);
   uint64_t *words = reinterpret_cast<uint64_t *>(ws);
   void *sort_tmp = reinterpret_cast<char *>(ws) + sgb_pad(n * 8);
-  sgb_pack_kernel<<<stream_grid(n, kBlock * 4), kBlock, 0, s>>>(keys, fold, n, rb, words);
+  const unsigned grid = stream_grid(n, kBlock * 4);
+  if (key_dtype == NVT_I32)
+    sgb_pack_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)keys, key_bias, fold, n, rb, words);
+  else
+    sgb_pack_kernel<int64_t><<<grid, kBlock, 0, s>>>((const int64_t *)keys, key_bias, fold, n, rb, words);
   NVT_CHECK_LAUNCH();
   uint64_t *sorted = nullptr;
   int rc = sort_words_bits(words, n, rb, 64, sort_tmp, &sorted, s);
@@ -1152,9 +1201,9 @@ int nvt_sgb_regroup_ws_bytes(uint64_t n, uint64_t *bytes) {
   return NVT_OK;
 }
 
-int nvt_sgb_regroup(const uint64_t *sorted, int row_bits, int kfold, uint64_t n, uint64_t cap,
-                    int64_t *out_keys, int32_t *out_keys32, uint64_t *regrouped, uint64_t *state,
-                    void *ws, void *stream) {
+int nvt_sgb_regroup(const uint64_t *sorted, int row_bits, int kfold, int64_t key_bias, uint64_t n,
+                    uint64_t cap, int64_t *out_keys, int32_t *out_keys32, uint64_t *regrouped,
+                    uint64_t *state, void *ws, void *stream) {
   NVT_CHECK_ARG(sorted && out_keys && out_keys32 && regrouped && state && ws, "null pointer");
   NVT_CHECK_ARG(regrouped != sorted, "regrouped must not alias the sorted words");
   NVT_CHECK_ARG(kfold >= 1 && kfold <= 256, "kfold must be 1..256");
@@ -1170,7 +1219,8 @@ int nvt_sgb_regroup(const uint64_t *sorted, int row_bits, int kfold, uint64_t n,
   NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 8 + 64, s));
   NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
   sgb_rle_kernel<<<(unsigned)ntiles, kBlock, 0, s>>>(sorted, n, row_bits, (unsigned)kfold, cap, status,
-                                                     ticket, out_keys, out_keys32, regrouped, state);
+                                                     ticket, out_keys, out_keys32, regrouped, state,
+                                                     key_bias);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

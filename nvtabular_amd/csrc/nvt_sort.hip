@@ -1280,15 +1280,18 @@ __global__ __launch_bounds__(kS2BS) void flat_build_kernel(
 // run are in key order, so a larger key ends an unsuccessful probe as an empty slot does.
 struct FlatIndexView {
   RangeMap map;
+  int64_t offset;  // table key = column key - offset (0 for int32 columns)
   bool has_min;
   const unsigned long long *table;
   uint64_t slots;
 };
 
 __device__ __forceinline__ FlatIndexView flat_view(const int32_t *__restrict__ aux,
-                                                   const unsigned long long *table, uint64_t slots) {
+                                                   const unsigned long long *table, uint64_t slots,
+                                                   int64_t offset) {
   FlatIndexView v;
   v.map = load_map(aux);
+  v.offset = offset;
   v.has_min = aux[NVT_RANGE_AUX_LO + 6] != 0;
   v.table = table;
   v.slots = slots;
@@ -1298,7 +1301,8 @@ __device__ __forceinline__ FlatIndexView flat_view(const int32_t *__restrict__ a
 template <typename K>
 __device__ __forceinline__ int64_t flat_probe(const FlatIndexView &v, const K *__restrict__ keys,
                                               const uint8_t *__restrict__ valid, uint64_t i) {
-  const int64_t kv = (int64_t)keys[i];
+  int64_t kv;
+  if (__builtin_sub_overflow((int64_t)keys[i], v.offset, &kv)) return -1;
   if (!bit_valid(valid, i) || kv < (int64_t)INT32_MIN || kv > (int64_t)INT32_MAX) return -1;
   const int32_t k = (int32_t)kv;
   if (k == INT32_MIN) return v.has_min ? 0 : -1;
@@ -1316,8 +1320,8 @@ template <typename K>
 __global__ __launch_bounds__(kBlock) void flat_lookup_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const int32_t *__restrict__ aux, const unsigned long long *__restrict__ table, uint64_t slots,
-    int64_t *__restrict__ out) {
-  const FlatIndexView v = flat_view(aux, table, slots);
+    int64_t offset, int64_t *__restrict__ out) {
+  const FlatIndexView v = flat_view(aux, table, slots, offset);
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
     out[i] = flat_probe(v, keys, valid, i);
@@ -1342,8 +1346,8 @@ template <typename K, int NC>
 __global__ __launch_bounds__(kBlock) void flat_lookup_gather_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const int32_t *__restrict__ aux, const unsigned long long *__restrict__ table, uint64_t slots,
-    const double *__restrict__ records, GatherOuts o, unsigned long long *unseen) {
-  const FlatIndexView v = flat_view(aux, table, slots);
+    int64_t offset, const double *__restrict__ records, GatherOuts o, unsigned long long *unseen) {
+  const FlatIndexView v = flat_view(aux, table, slots, offset);
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   bool any_unseen = false;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -1379,12 +1383,12 @@ __global__ __launch_bounds__(kBlock) void flat_lookup_gather_kernel(
 template <typename K>
 static int launch_gather(int ncols, unsigned grid, hipStream_t s, const K *keys, const uint8_t *valid,
                          uint64_t n, const int32_t *aux, const unsigned long long *tab,
-                         uint64_t capacity, const double *records, const GatherOuts &o,
-                         unsigned long long *flag) {
+                         uint64_t capacity, int64_t offset, const double *records,
+                         const GatherOuts &o, unsigned long long *flag) {
 #define NVT_G(NC)                                                                                 \
   case NC:                                                                                        \
     flat_lookup_gather_kernel<K, NC><<<grid, kBlock, 0, s>>>(keys, valid, n, aux, tab, capacity, \
-                                                             records, o, flag);                  \
+                                                             offset, records, o, flag);          \
     break;
   switch (ncols) {
     NVT_G(1) NVT_G(2) NVT_G(3) NVT_G(4) NVT_G(5) NVT_G(6) NVT_G(7) NVT_G(8)
@@ -1402,9 +1406,9 @@ template <typename K, typename OUT>
 __global__ __launch_bounds__(kBlock) void flat_lookup_te_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const int32_t *__restrict__ aux, const unsigned long long *__restrict__ table, uint64_t slots,
-    const uint8_t *__restrict__ fold, unsigned kfold, const double *__restrict__ records, double p,
-    double y_mean, OUT *__restrict__ out) {
-  const FlatIndexView v = flat_view(aux, table, slots);
+    int64_t offset, const uint8_t *__restrict__ fold, unsigned kfold,
+    const double *__restrict__ records, double p, double y_mean, OUT *__restrict__ out) {
+  const FlatIndexView v = flat_view(aux, table, slots, offset);
   const unsigned stride_rec = 2 * (kfold + 1);
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -1619,7 +1623,8 @@ int nvt_flat_index_build(const int32_t *keys, uint64_t n, int slots_log2, int32_
 }
 
 int nvt_flat_lookup(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
-                    const void *table, uint64_t capacity, int64_t *out, void *stream) {
+                    const void *table, uint64_t capacity, int64_t key_offset, int64_t *out,
+                    void *stream) {
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(keys && aux && table && out, "null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -1628,10 +1633,12 @@ int nvt_flat_lookup(const void *keys, int dtype, const uint8_t *valid, uint64_t 
   const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(table);
   switch (dtype) {
     case NVT_I32:
-      flat_lookup_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)keys, valid, n, aux, tab, capacity, out);
+      flat_lookup_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)keys, valid, n, aux, tab, capacity,
+                                                          key_offset, out);
       break;
     case NVT_I64:
-      flat_lookup_kernel<int64_t><<<grid, kBlock, 0, s>>>((const int64_t *)keys, valid, n, aux, tab, capacity, out);
+      flat_lookup_kernel<int64_t><<<grid, kBlock, 0, s>>>((const int64_t *)keys, valid, n, aux, tab, capacity,
+                                                          key_offset, out);
       break;
     default:
       set_error("nvt_flat_lookup: key dtype must be int32 / int64 (got %d)", dtype);
@@ -1644,8 +1651,8 @@ int nvt_flat_lookup(const void *keys, int dtype, const uint8_t *valid, uint64_t 
 
 int nvt_flat_lookup_gather(const void *keys, int dtype, const uint8_t *valid, uint64_t n,
                            const int32_t *aux, const void *table, uint64_t capacity,
-                           const double *records, int ncols, void *const *outs, const int *out_dtypes,
-                           const double *miss, uint64_t *unseen, void *stream) {
+                           int64_t key_offset, const double *records, int ncols, void *const *outs,
+                           const int *out_dtypes, const double *miss, uint64_t *unseen, void *stream) {
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(keys && aux && table && records && outs && out_dtypes && miss, "null pointer");
   NVT_CHECK_ARG(ncols >= 1 && ncols <= kGatherMaxCols, "1..16 statistics per call");
@@ -1667,10 +1674,10 @@ int nvt_flat_lookup_gather(const void *keys, int dtype, const uint8_t *valid, ui
   int rc;
   if (dtype == NVT_I32)
     rc = launch_gather<int32_t>(ncols, grid, s, (const int32_t *)keys, valid, n, aux, tab, capacity,
-                                records, o, flag);
+                                key_offset, records, o, flag);
   else if (dtype == NVT_I64)
     rc = launch_gather<int64_t>(ncols, grid, s, (const int64_t *)keys, valid, n, aux, tab, capacity,
-                                records, o, flag);
+                                key_offset, records, o, flag);
   else {
     set_error("nvt_flat_lookup_gather: key dtype must be int32 / int64 (got %d)", dtype);
     return NVT_EINVAL;
@@ -1681,8 +1688,8 @@ int nvt_flat_lookup_gather(const void *keys, int dtype, const uint8_t *valid, ui
 }
 
 int nvt_flat_lookup_te(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
-                       const void *table, uint64_t capacity, const uint8_t *fold, int kfold,
-                       const double *records, double p_smooth, double y_mean, void *out,
+                       const void *table, uint64_t capacity, int64_t key_offset, const uint8_t *fold,
+                       int kfold, const double *records, double p_smooth, double y_mean, void *out,
                        int out_dtype, void *stream) {
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(keys && aux && table && records && out, "null pointer");
@@ -1696,8 +1703,8 @@ int nvt_flat_lookup_te(const void *keys, int dtype, const uint8_t *valid, uint64
   const unsigned kf = fold ? (unsigned)kfold : 0u;  // record stride 2 * (kf + 1)
 #define NVT_TE_LAUNCH(K, OUT)                                                                   \
   flat_lookup_te_kernel<K, OUT><<<grid, kBlock, 0, s>>>((const K *)keys, valid, n, aux, tab,    \
-                                                        capacity, fold, kf, records, p_smooth, \
-                                                        y_mean, (OUT *)out)
+                                                        capacity, key_offset, fold, kf, records, \
+                                                        p_smooth, y_mean, (OUT *)out)
   if (dtype == NVT_I32 && out_dtype == NVT_F32) NVT_TE_LAUNCH(int32_t, float);
   else if (dtype == NVT_I32) NVT_TE_LAUNCH(int32_t, double);
   else if (out_dtype == NVT_F32) NVT_TE_LAUNCH(int64_t, float);

@@ -1462,8 +1462,10 @@ class pass_memo:
 
 
 def sorted_groupby_eligible(keys: torch.Tensor, key_valid, n: int, kfold: int = 1) -> bool:
-    """One int32 key column without a validity bitmap, enough rows, row index + fold in 32 bits."""
-    if not SORTED_GROUPBY or keys.dtype != torch.int32 or key_valid is not None:
+    """One int32 / int64 key column without a validity bitmap, enough rows, row index + fold in
+    32 bits.  (int64 columns additionally need keys spanning less than 2^32: sorted_groupby
+    finds out and returns None otherwise.)"""
+    if not SORTED_GROUPBY or keys.dtype not in (torch.int32, torch.int64) or key_valid is not None:
         return False
     fb = (kfold - 1).bit_length()
     return (SORTED_GROUPBY_MIN_ROWS <= n < (1 << 30) and n <= (1 << (32 - fb))
@@ -1478,26 +1480,46 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
     and -- with folds (TargetEncoding) -- ``fold`` = dict(kfold, size[g * kfold],
     sum[j][g * kfold], records); size / sum are then the totals over the folds.
     Inside ``pass_memo`` the sorted words and the group ids of a key column are computed once for
-    all aggregates on it (the second one is a single reduction, without a read-back)."""
+    all aggregates on it (the second one is a single reduction, without a read-back).
+    int64 key columns: one more read-back ({min, max} of the column); None when the keys span
+    2^32 or more (the caller falls back to the hash tables).  ``key_offset`` is what the flat
+    index subtracts from a column value (0 for int32 columns)."""
     _lib.require_gpu()
     lib = _lib.load()
     dev = keys.device
     n = int(keys.numel())
     keys = keys.contiguous()
+    kdt = dtype_code(keys.dtype)
     vals = [aligned(v.view(torch.uint8) if v.dtype == torch.bool else v) for v in vals]
     nvals = len(vals)
     flags = (_lib.NVT_GB_SUMSQ if sumsq else 0) | (_lib.NVT_GB_MINMAX if minmax else 0)
     memo_key = ("sgb", keys.data_ptr(), n, keys._version)
     hit = _PASS_MEMO.get(memo_key) if _PASS_MEMO is not None else None
+    if hit is not None and hit["bias"] is None:
+        return None  # (int64 keys too far apart: found out by an earlier aggregate of this pass)
     if hit is None or not (kfold == 1 or (hit["kfold"] == kfold and hit["fold"] == ptr(fold))):
+        if hit is not None:
+            bias = hit["bias"]
+        elif keys.dtype == torch.int32:
+            bias = -(1 << 31)
+        else:
+            mm = torch.empty(2, dtype=torch.int64, device=dev)
+            check(lib.nvt_key_minmax(keys.data_ptr(), kdt, n, mm.data_ptr(), stream_ptr()),
+                  "nvt_key_minmax")
+            lo, hi = (int(v) for v in read_back(mm).tolist())
+            bias = lo if hi - lo < (1 << 32) else None
+            if bias is None:
+                if _PASS_MEMO is not None:
+                    _PASS_MEMO[memo_key] = dict(bias=None, kfold=0, fold=None, groups=None)
+                return None
         need = C.c_uint64()
         check(lib.nvt_sgb_sort_ws_bytes(n, C.byref(need)), "nvt_sgb_sort_ws_bytes")
         sort_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         sp, rbc = C.c_void_p(), C.c_int()
-        check(lib.nvt_sgb_sort(keys.data_ptr(), ptr(fold), kfold, n, sort_ws.data_ptr(), C.byref(sp),
-                               C.byref(rbc), stream_ptr()), "nvt_sgb_sort")
+        check(lib.nvt_sgb_sort(keys.data_ptr(), kdt, bias, ptr(fold), kfold, n, sort_ws.data_ptr(),
+                               C.byref(sp), C.byref(rbc), stream_ptr()), "nvt_sgb_sort")
         hit = dict(sorted=sp.value, rb=rbc.value, kfold=kfold, fold=ptr(fold), ws=sort_ws,
-                   keys=keys, fold_t=fold, groups=None)
+                   keys=keys, fold_t=fold, groups=None, bias=bias)
         if _PASS_MEMO is not None:
             _PASS_MEMO[memo_key] = hit
     grp = hit["groups"]
@@ -1515,7 +1537,7 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
         while True:
             k64 = torch.empty(cap, dtype=torch.int64, device=dev)
             k32 = torch.empty(cap, dtype=torch.int32, device=dev)
-            check(lib.nvt_sgb_regroup(hit["sorted"], hit["rb"], wk, n, cap, k64.data_ptr(),
+            check(lib.nvt_sgb_regroup(hit["sorted"], hit["rb"], wk, hit["bias"], n, cap, k64.data_ptr(),
                                       k32.data_ptr(), words.data_ptr(), state.data_ptr(),
                                       ws.data_ptr(), stream_ptr()), "nvt_sgb_regroup")
             st = read_back(state).tolist()
@@ -1526,7 +1548,9 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
             if g * wk >= 0xFFFFFFFE:
                 raise _lib.NvtHipError("sorted_groupby: groups * kfold does not fit 32 bits")
             cap = g
-        grp = hit["groups"] = dict(words=words, kfold=wk, k64=k64[:g], k32=k32[:g], g=g, state=state)
+        # ("shared": what outlives the pass -- the lookup index of these groups, built once)
+        grp = hit["groups"] = dict(words=words, kfold=wk, k64=k64[:g], k32=k32[:g], g=g, state=state,
+                                   shared={})
     g, wk = grp["g"], grp["kfold"]
     cap = max(g, 1)
     slots = cap * kfold
@@ -1556,7 +1580,7 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
     out = dict(keys=[grp["k64"]], keys32=grp["k32"],
                null_mask=torch.zeros(g, dtype=torch.uint8, device=dev),
                sumsq=rows(fsq, g), min=no_inf(rows(fmin, g)), max=no_inf(rows(fmax, g)), n=g,
-               sorted=True, shared=grp)
+               sorted=True, shared=grp["shared"], key_offset=hit["bias"] + (1 << 31))
     if kfold > 1:
         out["size"], out["sum"] = tsize[:g], rows(tsum, g)
         out["fold"] = dict(kfold=kfold, size=size[:g * kfold], sum=rows(fsum, g * kfold),
@@ -1573,7 +1597,7 @@ def flat_index_for(comp) -> "FlatIndex":
     shared = comp.get("shared")
     if shared is not None and shared.get("index") is not None:
         return shared["index"]
-    index = FlatIndex(comp["keys32"])
+    index = FlatIndex(comp["keys32"], comp.get("key_offset", 0))
     if shared is not None:
         shared["index"] = index
     return index
@@ -1587,9 +1611,11 @@ class FlatIndex:
     FLAT_AUX_WORDS, FLAT_AUX_MAXDISP = 8192 + 16, 8192 + 8   # include/nvt_hip.h NVT_FLAT_AUX_*
     MAX_DISPLACEMENT = 4096
 
-    def __init__(self, keys32: torch.Tensor):
+    def __init__(self, keys32: torch.Tensor, key_offset: int = 0):
         _lib.require_gpu()
         lib = _lib.load()
+        # the list holds column value - key_offset (int64 columns whose keys span < 2^32)
+        self.key_offset = int(key_offset)
         self.keys32 = keys32.contiguous()
         self.n = n = int(keys32.numel())
         dev = keys32.device
@@ -1623,7 +1649,8 @@ class FlatIndex:
         out = torch.empty(n, dtype=torch.int64, device=k.device)
         check(_lib.load().nvt_flat_lookup(k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n,
                                           self.aux.data_ptr(), self.table.data_ptr(), self.capacity,
-                                          out.data_ptr(), stream_ptr()), "nvt_flat_lookup")
+                                          self.key_offset, out.data_ptr(), stream_ptr()),
+              "nvt_flat_lookup")
         return out
 
 
@@ -1644,7 +1671,7 @@ class FlatIndex:
         unseen = torch.zeros(1, dtype=torch.int64, device=k.device)
         check(_lib.load().nvt_flat_lookup_gather(
             k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
-            self.table.data_ptr(), self.capacity, records.data_ptr(), ncols,
+            self.table.data_ptr(), self.capacity, self.key_offset, records.data_ptr(), ncols,
             _lib.ptr_array([o.data_ptr() for o in outs]),
             (C.c_int * ncols)(*[dtype_code(dt) for dt in out_dtypes]),
             (C.c_double * ncols)(*[float(m) for m in miss]), unseen.data_ptr(), stream_ptr()),
@@ -1661,7 +1688,8 @@ class FlatIndex:
         out = torch.empty(n, dtype=out_dtype, device=k.device)
         check(_lib.load().nvt_flat_lookup_te(
             k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
-            self.table.data_ptr(), self.capacity, ptr(fold.contiguous() if fold is not None else None),
+            self.table.data_ptr(), self.capacity, self.key_offset,
+            ptr(fold.contiguous() if fold is not None else None),
             int(kfold) if fold is not None else 1, records.data_ptr(), float(p_smooth), float(y_mean),
             out.data_ptr(), dtype_code(out_dtype), stream_ptr()), "nvt_flat_lookup_te")
         return out

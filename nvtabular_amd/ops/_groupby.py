@@ -94,9 +94,10 @@ class GroupAgg:
                 and K.sorted_groupby_eligible(keys[0], kvalid[0], n, kfold)):
             comp = K.sorted_groupby(keys[0], fold_t, kfold, vals, vvalid, sumsq=self.sumsq,
                                     minmax=self.minmax, cap_hint=self.hint, te_records=True)
-            self.hint = max(self.hint, comp["n"])
-            self.sorted_comp = comp
-            return
+            if comp is not None:  # (None: int64 keys spanning 2^32 or more)
+                self.hint = max(self.hint, comp["n"])
+                self.sorted_comp = comp
+                return
         if self.sorted_comp is not None:
             self._demote()
         if self.fold:

@@ -104,10 +104,13 @@ def test_flat_index_lookup_and_clustered_fallback():
     assert not K.FlatIndex(torch.from_numpy(clustered).to(dev)).ok()
 
 
-def _frames(n, card, seed, nulls=False):
+def _frames(n, card, seed, key="int32"):
     rng = np.random.default_rng(seed)
+    k = _skewed_keys(rng, n, card, 0, 2**31 - 1)
+    if key == "int64":  # an int64 column whose keys span less than 2^32, far from zero
+        k = k.astype(np.int64) * 2 - 7_000_000_000_000
     df = pd.DataFrame({
-        "k": _skewed_keys(rng, n, card, 0, 2**31 - 1),
+        "k": k,
         "x": rng.normal(size=n),
         "y": (rng.random(n) < 0.3).astype("float32"),
     })
@@ -115,13 +118,14 @@ def _frames(n, card, seed, nulls=False):
     return df
 
 
+@pytest.mark.parametrize("key", ["int32", "int64"])
 @pytest.mark.parametrize("nparts", [1, 2])
-def test_joingroupby_sorted_path_vs_oracle(tmp_path, nparts):
+def test_joingroupby_sorted_path_vs_oracle(tmp_path, nparts, key):
     import nvtabular_amd as nvt
     from nvtabular_amd import kernels as K
     from nvtabular_amd import ops
 
-    df = _frames(120_000, 9_000, 21)
+    df = _frames(120_000, 9_000, 21, key)
     parts = [df] if nparts == 1 else [df.iloc[:70_000].reset_index(drop=True),
                                       df.iloc[70_000:].reset_index(drop=True)]
     stats = ["count", "sum", "mean", "std", "var", "min", "max"]
@@ -147,7 +151,7 @@ def test_joingroupby_sorted_path_vs_oracle(tmp_path, nparts):
     np.testing.assert_array_equal(a["k_count"].to_numpy(), b["k_count"].to_numpy())
     np.testing.assert_allclose(a["k_x_sum"].to_numpy(), b["k_x_sum"].to_numpy(), rtol=1e-9, atol=1e-9)
     # unseen keys and nulls at transform time
-    new = pd.DataFrame({"k": pd.array([int(df["k"][0]), 2**31 - 2, None], dtype="Int32").astype("float64"),
+    new = pd.DataFrame({"k": pd.array([int(df["k"][0]), 2**31 - 2, None], dtype="Int64").astype("float64"),
                         "x": [0.0, 0.0, 0.0], "y": np.zeros(3, dtype="float32")})
     jg2 = ops.JoinGroupby(out_path=str(tmp_path / "g2"), stats=["sum"], cont_cols=["x"])
     wf2 = nvt.Workflow(["k"] >> jg2).fit(nvt.Dataset(parts))
@@ -155,14 +159,15 @@ def test_joingroupby_sorted_path_vs_oracle(tmp_path, nparts):
     assert np.isfinite(o2["k_x_sum"][0]) and np.isnan(o2["k_x_sum"][1]) and np.isnan(o2["k_x_sum"][2])
 
 
+@pytest.mark.parametrize("key", ["int32", "int64"])
 @pytest.mark.parametrize("kfold,fold_seed", [(1, None), (5, 42), (3, None)])
 @pytest.mark.parametrize("nparts", [1, 2])
-def test_target_encoding_sorted_path_vs_oracle(tmp_path, kfold, fold_seed, nparts):
+def test_target_encoding_sorted_path_vs_oracle(tmp_path, kfold, fold_seed, nparts, key):
     import nvtabular_amd as nvt
     from nvtabular_amd import ops
     from nvtabular_amd.ops.target_encoding import _FoldDense
 
-    df = _frames(100_000, 7_000, 33)
+    df = _frames(100_000, 7_000, 33, key)
     parts = [df] if nparts == 1 else [df.iloc[:60_000].reset_index(drop=True),
                                       df.iloc[60_000:].reset_index(drop=True)]
     te = ops.TargetEncoding(["y", "x"], out_path=str(tmp_path / "g"), kfold=kfold, fold_seed=fold_seed,
@@ -190,7 +195,7 @@ def test_target_encoding_sorted_path_vs_oracle(tmp_path, kfold, fold_seed, npart
             np.testing.assert_allclose(a[c].to_numpy().astype("float64"), b[c].to_numpy().astype("float64"),
                                        rtol=1e-9, atol=1e-9, err_msg=c)
     # a frame the fit never saw: unseen keys and unseen (fold, key) pairs fall back to the mean
-    other = _frames(50_000, 20_000, 77)
+    other = _frames(50_000, 20_000, 77, key)
     got2 = wf.transform(nvt.Dataset(other)).to_ddf().compute()
     exp2 = O.target_encoding_transform(other[["k", "y", "x"]].copy(), ["k"], ["y", "x"], stats, means,
                                        kfold=kfold, fold_seed=fold_seed, p_smooth=20)
@@ -262,3 +267,20 @@ def test_aggregates_of_one_pass_share_sort_and_groups(tmp_path, order):
             np.testing.assert_allclose(got[c].to_numpy().astype("float64"), exp[c].to_numpy().astype("float64"),
                                        rtol=2e-5, atol=1e-6, err_msg=c)
     assert (got["k_count"].to_numpy() == exp_j["k_count"].to_numpy()).all()
+
+
+def test_int64_keys_spanning_more_than_32_bits_keep_the_hash_tables(tmp_path):
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+
+    df = _frames(60_000, 3_000, 8)
+    df["k"] = df["k"].astype(np.int64) * 1_000_003  # spans ~2^51
+    jg = ops.JoinGroupby(out_path=str(tmp_path / "g"), stats=["count", "sum"], cont_cols=["x"])
+    wf = nvt.Workflow(["k"] >> jg).fit(nvt.Dataset(df))
+    assert isinstance(jg._device_stats["k"].index, K.GroupbyTable)
+    got = wf.transform(nvt.Dataset(df)).to_ddf().compute()
+    cats = O.join_groupby_fit([df.copy()], ["k"], ["x"], ["count", "sum"], str(tmp_path / "c"))
+    exp = O.join_groupby_transform(df.copy(), ["k"], cats)
+    np.testing.assert_array_equal(got["k_count"].to_numpy(), exp["k_count"].to_numpy())
+    np.testing.assert_allclose(got["k_x_sum"].to_numpy(), exp["k_x_sum"].to_numpy(), rtol=1e-9, atol=1e-9)
