@@ -390,12 +390,13 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
  * a flat range table laid out from the list in one pass (no inserts): replaces
  * nvt_gb_index_build + nvt_gb_lookup for such groups (join_groupby.py:198-203,
  * target_encoding.py:350-371).  aux: int32[NVT_FLAT_AUX_WORDS]; table: capacity 8-byte slots,
- * capacity >= 2^slots_log2 + n + 64; tmp: nvt_flat_index_tmp_bytes(n).
+ * capacity >= slots + n + 64 (slots: home slots, any count from 64 to 2^32 - 1); tmp:
+ * nvt_flat_index_tmp_bytes(n).
  * aux[NVT_FLAT_AUX_MAXDISP] = longest displacement (keys clustered in their range make long
  * probe runs: the caller may prefer a hashed index).  nvt_flat_lookup: out[i] = position of
  * keys[i] - key_offset (int32 / int64 column, optional validity bitmap) or -1. */
 int nvt_flat_index_tmp_bytes(uint64_t n, uint64_t *bytes);
-int nvt_flat_index_build(const int32_t *keys, uint64_t n, int slots_log2, int32_t *aux, void *table,
+int nvt_flat_index_build(const int32_t *keys, uint64_t n, uint64_t slots, int32_t *aux, void *table,
                          uint64_t capacity, void *tmp, void *stream);
 int nvt_flat_lookup(const void *keys, int dtype, const uint8_t *valid, uint64_t n, const int32_t *aux,
                     const void *table, uint64_t capacity, int64_t key_offset, int64_t *out,

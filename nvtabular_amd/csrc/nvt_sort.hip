@@ -1155,12 +1155,12 @@ __global__ __launch_bounds__(kBlock) void class_hist_kernel(const int64_t *__res
 // the key or an empty slot, exactly like the dumped tables of the range path (RangeMap.flat).
 // The largest displacement p_i - h_i goes to aux[NVT_FLAT_AUX_MAXDISP]: keys that cluster in
 // their range make long runs, the caller then builds an ordinary hashed table instead.
-__global__ void flat_params_kernel(const int32_t *__restrict__ keys, uint64_t n, int slots_log2,
+__global__ void flat_params_kernel(const int32_t *__restrict__ keys, uint64_t n, uint64_t slots,
                                    int32_t *aux) {
   // span of the (sorted) keys, the sentinel key (smallest int32, not in the table) left out
   const uint64_t first = (n > 1 && keys[0] == INT32_MIN) ? 1 : 0;
   const uint64_t lo = ukey(keys[first]), hi = ukey(keys[n - 1]);
-  const uint64_t span = hi - lo, F = 1ull << slots_log2;
+  const uint64_t span = hi - lo, F = slots;  // any slot count < 2^32 (no power of two needed)
   uint64_t mul;
   int sh;
   if (span + 1 >= F) {
@@ -1481,7 +1481,7 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
     NVT_CHECK_LAUNCH();
     if (flat) {
       int32_t *aux = const_cast<int32_t *>(range_aux);
-      flat_params_kernel<<<1, 1, 0, s>>>(src_keys, n, flat_slots_log2, aux);
+      flat_params_kernel<<<1, 1, 0, s>>>(src_keys, n, 1ull << flat_slots_log2, aux);
       NVT_CHECK_LAUNCH();
       NVT_CHECK_HIP(hipMemsetAsync(fb_status, 0, ntiles * 8 + 64, s));
       flat_build_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(
@@ -1598,12 +1598,12 @@ int nvt_flat_index_tmp_bytes(uint64_t n, uint64_t *bytes) {
   return NVT_OK;
 }
 
-int nvt_flat_index_build(const int32_t *keys, uint64_t n, int slots_log2, int32_t *aux, void *table,
+int nvt_flat_index_build(const int32_t *keys, uint64_t n, uint64_t slots, int32_t *aux, void *table,
                          uint64_t capacity, void *tmp, void *stream) {
   NVT_CHECK_ARG(keys && aux && table && tmp, "null pointer");
   NVT_CHECK_ARG(n >= 1 && n < (1ull << 30), "1 .. 2^30-1 keys");
-  NVT_CHECK_ARG(slots_log2 >= 6 && slots_log2 <= 31, "slots_log2 must be 6..31");
-  NVT_CHECK_ARG(capacity >= (1ull << slots_log2) + n + 64, "flat table: slots + n + 64");
+  NVT_CHECK_ARG(slots >= 64 && slots < (1ull << 32), "slots must be 64 .. 2^32-1");
+  NVT_CHECK_ARG(capacity >= slots + n + 64, "flat table: slots + n + 64");
   hipStream_t s = (hipStream_t)stream;
   NVT_PROF("groupby_index", 0, s);
   const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
@@ -1613,7 +1613,7 @@ int nvt_flat_index_build(const int32_t *keys, uint64_t n, int slots_log2, int32_
   int rc = encode_clear_any(4, table, capacity, reinterpret_cast<int64_t *>(status), s);
   if (rc) return rc;
   NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 8 + 64, s));
-  flat_params_kernel<<<1, 1, 0, s>>>(keys, n, slots_log2, aux);
+  flat_params_kernel<<<1, 1, 0, s>>>(keys, n, slots, aux);
   NVT_CHECK_LAUNCH();
   flat_build_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(
       keys, nullptr, n, aux, status, reinterpret_cast<unsigned *>(status + ntiles),

@@ -1439,6 +1439,7 @@ class GroupbyTable:
 SORTED_GROUPBY = os.environ.get("NVT_SORTED_GROUPBY", "1") != "0"
 SORTED_GROUPBY_MIN_ROWS = 1 << 15   # below: launch latency, the hash update is as good
 SORTED_GROUPBY_MAX_KFOLD = 16
+FLAT_INDEX_LOAD = float(os.environ.get("NVT_FLAT_INDEX_LOAD", "0.5"))
 
 
 # sorted words shared between the aggregates of ONE pass over one partition (Workflow.fit opens
@@ -1619,14 +1620,16 @@ class FlatIndex:
         self.keys32 = keys32.contiguous()
         self.n = n = int(keys32.numel())
         dev = keys32.device
-        self.slots_log2 = max(6, (2 * n - 1).bit_length())
-        self.capacity = (1 << self.slots_log2) + n + 64
+        # home slots: FLAT_INDEX_LOAD of them hold a key (no power of two needed; the smaller
+        # the table the more of it the caches keep)
+        self.slots = max(64, int(n / FLAT_INDEX_LOAD) + 1)
+        self.capacity = self.slots + n + 64
         self.table = torch.empty(self.capacity, dtype=torch.int64, device=dev)
         self.aux = torch.zeros(self.FLAT_AUX_WORDS, dtype=torch.int32, device=dev)
         need = C.c_uint64()
         check(lib.nvt_flat_index_tmp_bytes(n, C.byref(need)), "nvt_flat_index_tmp_bytes")
         tmp = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        check(lib.nvt_flat_index_build(self.keys32.data_ptr(), n, self.slots_log2, self.aux.data_ptr(),
+        check(lib.nvt_flat_index_build(self.keys32.data_ptr(), n, self.slots, self.aux.data_ptr(),
                                        self.table.data_ptr(), self.capacity, tmp.data_ptr(),
                                        stream_ptr()), "nvt_flat_index_build")
         self._ok = None
