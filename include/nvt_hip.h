@@ -516,13 +516,14 @@ typedef struct nvt_vocab_col {
    * column's aux block (nvt_count_col.hot_image) that holds the map parameters. */
   const int32_t *range_aux;
   int32_t range_nb_log2;
-  /* flat_slots_log2 > 0 (with a key-sorted source, int32 keys): `table` is BUILT here as a flat
-   * range table of 2^flat_slots_log2 slots (+ n + 64 tail slots: capacity = the sum) straight
+  /* flat_slots > 0 (with a key-sorted source, int32 keys): `table` is BUILT here as a flat
+   * range table of flat_slots home slots (any count from 64 to 2^32 - 1; + n + 64 tail slots:
+   * capacity = the sum) straight
    * from the sorted keys by a prefix maximum -- no random inserts; range_aux = a device
    * int32[NVT_FLAT_AUX_WORDS] block that RECEIVES the map parameters (pass it to nvt_encode_col)
    * and, in word NVT_FLAT_AUX_MAXDISP, the longest displacement of an entry from its home slot
    * (large: the keys cluster in their range, build an ordinary table with nvt_encode_build_*) */
-  int32_t flat_slots_log2;
+  uint64_t flat_slots;
 } nvt_vocab_col;
 #define NVT_FLAT_AUX_WORDS (NVT_RANGE_AUX_LO + 16)
 #define NVT_FLAT_AUX_MAXDISP (NVT_RANGE_AUX_LO + 8)

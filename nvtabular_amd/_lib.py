@@ -138,7 +138,7 @@ class VocabCol(C.Structure):
                 ("first_label", _i64), ("table", _vp), ("capacity", _u64),
                 ("sentinel_label", _vp), ("ready_event", _vp), ("src_keys", _vp),
                 ("src_counts", _vp), ("cls_hist", _vp), ("n_big", _u64), ("range_aux", _vp),
-                ("range_nb_log2", C.c_int32), ("flat_slots_log2", C.c_int32)]
+                ("range_nb_log2", C.c_int32), ("flat_slots", C.c_uint64)]
 
 
 class EncodeCol(C.Structure):

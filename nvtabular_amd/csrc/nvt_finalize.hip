@@ -119,7 +119,7 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
                                        c.n_big, c.max_count, (int32_t *)c.keys, c.counts,
                                        c.sort_tmp, c.first_label, c.table, c.capacity,
                                        c.sentinel_label, c.range_aux, c.range_nb_log2, s,
-                                       batch_tail ? &deferred : nullptr, c.flat_slots_log2);
+                                       batch_tail ? &deferred : nullptr, c.flat_slots);
       if (rc) return rc;
       if (deferred) {
         tails.push_back({(int32_t *)c.keys, c.counts, c.n_big, c.first_label, c.table, c.capacity,

@@ -55,7 +55,7 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
                             int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label,
                             void *table, uint64_t capacity, int64_t *sentinel_label,
                             const int32_t *range_aux, int range_nb_log2, hipStream_t s,
-                            bool *tail_deferred = nullptr, int flat_slots_log2 = 0);
+                            bool *tail_deferred = nullptr, uint64_t flat_slots = 0);
 // the deferred part: sort of the n_big leading entries (class 255) + their labels
 struct OrderTail {
   int32_t *keys;

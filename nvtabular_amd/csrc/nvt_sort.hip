@@ -1441,7 +1441,7 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
                             int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label,
                             void *table, uint64_t capacity, int64_t *sentinel_label,
                             const int32_t *range_aux, int range_nb_log2, hipStream_t s,
-                            bool *tail_deferred, int flat_slots_log2) {
+                            bool *tail_deferred, uint64_t flat_slots) {
   if (tail_deferred) *tail_deferred = false;
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(n < (1ull << 30), "at most 2^30-1 vocabulary entries");
@@ -1457,12 +1457,13 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
       reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(label_of) + pad16(n * 4));
   // range table (range_aux set): `table` holds {key, position} slots already (dumped by the
   // counting pass) and only needs its positions replaced by labels -- no clear, no inserts.
-  // flat (flat_slots_log2 > 0, range_aux = the block that RECEIVES the map): the table is laid
+  // flat (flat_slots > 0, range_aux = the block that RECEIVES the map): the table is laid
   // out from the sorted keys by a prefix maximum, see flat_build_kernel.
-  const bool flat = table != nullptr && range_aux != nullptr && flat_slots_log2 > 0;
+  const bool flat = table != nullptr && range_aux != nullptr && flat_slots > 0;
   const bool ranged = table != nullptr && range_aux != nullptr;
   if (flat) {
-    NVT_CHECK_ARG(capacity >= (1ull << flat_slots_log2) + n + 64, "flat table: slots + n + 64");
+    NVT_CHECK_ARG(flat_slots >= 64 && flat_slots < (1ull << 32), "flat table: 64 .. 2^32-1 slots");
+    NVT_CHECK_ARG(capacity >= flat_slots + n + 64, "flat table: slots + n + 64");
     int rc = encode_clear_any(4, table, capacity, sentinel_label, s);
     if (rc) return rc;
   } else if (table && !ranged) {
@@ -1481,7 +1482,7 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
     NVT_CHECK_LAUNCH();
     if (flat) {
       int32_t *aux = const_cast<int32_t *>(range_aux);
-      flat_params_kernel<<<1, 1, 0, s>>>(src_keys, n, 1ull << flat_slots_log2, aux);
+      flat_params_kernel<<<1, 1, 0, s>>>(src_keys, n, flat_slots, aux);
       NVT_CHECK_LAUNCH();
       NVT_CHECK_HIP(hipMemsetAsync(fb_status, 0, ntiles * 8 + 64, s));
       flat_build_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(

@@ -846,7 +846,7 @@ class EncodeTable:
         resident = ENCODE_RESIDENT_I32 if self.key_bytes == 4 else ENCODE_RESIDENT_I64
         self.table = self.sentinel_label = None
         self.range_aux, self.range_bits = None, 0
-        self.flat_bits = 0
+        self.flat_slots = 0
         self.sort_tmp = None
         self._counts = None    # the counts tensor while an internal stream still orders it
         self._src = None       # key-sorted source list of the one-pass ordering, same lifetime
@@ -863,8 +863,10 @@ class EncodeTable:
         if flat and USE_FLAT_TABLE and defer_build and unique and self.key_bytes == 4:
             # flat range table laid out from the key-sorted source by nvt_vocab_finalize_many
             # (prefix maximum, no random inserts): 2^k >= 2 n slots + n + 64 tail slots
-            self.flat_bits = max(6, (2 * self.n_vocab - 1).bit_length())
-            self.capacity = (1 << self.flat_bits) + self.n_vocab + 64
+            # home slots at load FLAT_INDEX_LOAD (no power of two: 36 M keys took 2^27 slots = 1 GiB
+            # to clear and fill, now 576 MB)
+            self.flat_slots = max(64, int(self.n_vocab / FLAT_INDEX_LOAD) + 1)
+            self.capacity = self.flat_slots + self.n_vocab + 64
             self.table = torch.empty(self.capacity * 8, dtype=torch.uint8, device=dev)
             self.range_aux = torch.empty(self.FLAT_AUX_WORDS, dtype=torch.int32, device=dev)
             self.sentinel_label = torch.empty(1, dtype=torch.int64, device=dev)
@@ -898,7 +900,8 @@ class EncodeTable:
             return self._fill_vocab_desc_sorted(d, counts, max_count, src)
         d.src_keys = d.src_counts = d.cls_hist = d.range_aux = None
         d.n_big = 0
-        d.range_nb_log2 = d.flat_slots_log2 = 0
+        d.range_nb_log2 = 0
+        d.flat_slots = 0
         # the counts are ordered in place on the same internal stream as the keys: they must
         # outlive the hand-off event exactly like keys / table / sort_tmp (a rank that writes
         # no artifacts used to drop its only reference right after the launch)
@@ -954,7 +957,7 @@ class EncodeTable:
         d.n_big = int(n_big)
         d.range_aux = ptr(self.range_aux)
         d.range_nb_log2 = int(self.range_bits)
-        d.flat_slots_log2 = int(self.flat_bits)
+        d.flat_slots = int(self.flat_slots)
         key = ("order", n, int(n_big))
         nbytes = _SORT_BYTES.get(key)
         if nbytes is None:

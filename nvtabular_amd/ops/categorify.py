@@ -444,7 +444,7 @@ class Categorify(StatOperator):
         K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
                 "nvt_vocab_finalize_many")
         for i, (g, keys, counts, tab, start) in enumerate(built):
-            if tab.flat_bits and not tab.flat_ok():
+            if tab.flat_slots and not tab.flat_ok():
                 # keys that cluster in their range make long probe runs in a monotone table: an
                 # ordinary hashed table instead (built from the ordered vocabulary, now final)
                 tab = K.EncodeTable(keys, start, unique=True)

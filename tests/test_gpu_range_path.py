@@ -212,7 +212,7 @@ def test_flat_table_falls_back_to_a_hashed_table_for_clustered_keys(tmp_path):
             got = wf.transform(frame)["c"].data.cpu().numpy()
             assert op._last_paths["c#0"] == K.PATH_SORT
             tab = op._encoders["c"].table
-            assert (tab.flat_bits == 0) == clustered, (clustered, tab.flat_bits)
+            assert (tab.flat_slots == 0) == clustered, (clustered, tab.flat_slots)
             df = pd.DataFrame({"c": ids})
             paths = O.categorify_fit([df], ["c"], str(tmp_path / f"c{int(clustered)}"), tie_break="stable")
             exp = O.categorify_transform(df, ["c"], paths)["c"].to_numpy()
