@@ -284,3 +284,53 @@ def test_int64_keys_spanning_more_than_32_bits_keep_the_hash_tables(tmp_path):
     exp = O.join_groupby_transform(df.copy(), ["k"], cats)
     np.testing.assert_array_equal(got["k_count"].to_numpy(), exp["k_count"].to_numpy())
     np.testing.assert_allclose(got["k_x_sum"].to_numpy(), exp["k_x_sum"].to_numpy(), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [32768, 32769, 34816, 100_001])
+@pytest.mark.parametrize("shape", ["one_group", "all_distinct", "two_hot", "runs"])
+def test_sgb_edge_shapes(n, shape):
+    """Tile / wave boundaries of the run-length pass and the segmented reduction: sizes around
+    the 2048-word tile, a single group, all keys distinct, two giant groups, sorted input."""
+    from nvtabular_amd import kernels as K
+
+    rng = np.random.default_rng(n)
+    if shape == "one_group":
+        key = np.full(n, -5, dtype=np.int32)
+    elif shape == "all_distinct":
+        key = rng.permutation(n).astype(np.int32) - n // 2
+    elif shape == "two_hot":
+        key = np.where(rng.random(n) < 0.5, np.int32(7), np.int32(2**31 - 1)).astype(np.int32)
+    else:
+        key = np.sort(rng.integers(0, n // 3, n)).astype(np.int32)
+    kfold = 3
+    fold = rng.integers(0, kfold, n).astype(np.uint8)
+    y = rng.normal(size=n)
+    tk, tf, ty = (torch.from_numpy(a).cuda() for a in (key, fold, y))
+    for kf, f in ((1, None), (kfold, tf)):
+        comp = K.sorted_groupby(tk, f, kf, [ty], [None], sumsq=kf == 1, minmax=kf == 1, te_records=True)
+        uk, inv = np.unique(key, return_inverse=True)
+        np.testing.assert_array_equal(comp["keys"][0].cpu().numpy(), uk.astype(np.int64))
+        np.testing.assert_array_equal(comp["size"].cpu().numpy(), np.bincount(inv, minlength=uk.size))
+        np.testing.assert_allclose(comp["sum"][0].cpu().numpy(), np.bincount(inv, weights=y, minlength=uk.size),
+                                   rtol=1e-10, atol=1e-9)
+        if kf == 1:
+            mn = np.full(uk.size, np.inf)
+            np.minimum.at(mn, inv, y)
+            np.testing.assert_array_equal(comp["min"][0].cpu().numpy(), mn)
+        else:
+            pos = inv * kfold + fold
+            np.testing.assert_array_equal(comp["fold"]["size"].cpu().numpy(),
+                                          np.bincount(pos, minlength=uk.size * kfold))
+            np.testing.assert_allclose(comp["fold"]["sum"][0].cpu().numpy(),
+                                       np.bincount(pos, weights=y, minlength=uk.size * kfold), rtol=1e-10, atol=1e-9)
+            rec = comp["fold"]["records"][0].cpu().numpy()
+            np.testing.assert_allclose(rec[:, 0], comp["sum"][0].cpu().numpy(), rtol=0, atol=0)
+            np.testing.assert_array_equal(rec[:, 1], comp["size"].cpu().numpy().astype(np.float64))
+            np.testing.assert_array_equal(rec[:, 3::2].reshape(-1), comp["fold"]["size"].cpu().numpy().astype(np.float64))
+        idx = K.flat_index_for(comp)
+        probe = torch.from_numpy(np.concatenate([key[:1000], key[:1000] + 1])).cuda()
+        got = idx.lookup([probe], [None]).cpu().numpy()
+        pk = probe.cpu().numpy()
+        p = np.minimum(np.searchsorted(uk, pk), uk.size - 1)
+        if idx.ok():
+            np.testing.assert_array_equal(got, np.where(uk[p] == pk, p, -1))
