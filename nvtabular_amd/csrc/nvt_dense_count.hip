@@ -977,7 +977,7 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
     const uint64_t span = hi - lo, F = 1ull << (nb_log2 + 14);
     uint64_t mul;
     int sh;
-    if (span + 1 >= F) {
+    if (span + 1 > F) {  // (strictly: mul < 2^32, RangeMap multiplies 32 x 32 bits)
       mul = (F << 32) / (span + 1);
       sh = 32;
     } else {

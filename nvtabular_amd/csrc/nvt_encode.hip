@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label,
     const int32_t *__restrict__ range_aux = nullptr) {
   constexpr bool global_needed = GLOBAL;
-  RangeMap rmap = {0u, 0u, 0ull, 0, 0};
+  RangeMap rmap = {0u, 0u, 0u, 0, 0};
   if constexpr (RANGE) rmap = load_map(range_aux);
   auto first_slot = [&](K key) -> uint64_t {
     if constexpr (RANGE) return rmap.table_slot((int32_t)key);

@@ -21,19 +21,22 @@ __device__ __forceinline__ uint32_t ukey(int32_t k) { return (uint32_t)k ^ 0x800
 // key -> "fine slot" f in [0, NB * 16384): bucket = f >> 14, home slot = f & 16383.
 // f = (min(max(u - ulo, 0), span) * mul) >> sh with (mul, sh) chosen by the sample kernel so
 // that the padded span of the sampled keys covers ALL buckets evenly (a power-of-two bucket
-// width left up to half of them empty): span + 1 >= F = NB * 16384: mul = F * 2^32 / (span + 1),
+// width left up to half of them empty): span + 1 > F = NB * 16384: mul = F * 2^32 / (span + 1),
 // sh = 32; smaller spans (dense ids): mul = F / (span + 1), sh = 0 -- keys spread with gaps.
+// mul < 2^32 in both forms, so the map is ONE 32 x 32-bit multiply per key (high half or low
+// half of the product; the 64-bit form cost two v_mad_u64_u32 and a 64-bit shift per key in the
+// partition, count and encode kernels).
 struct RangeMap {
   uint32_t ulo, span;
-  uint64_t mul;
-  int sh;
+  uint32_t mul;
+  int sh;  // 32 or 0
   int flat;  // 1: the table is ONE run of F slots (+ tail), slot = f (vocabulary tables built from a
              //    key-sorted list: flat_build_kernel); 0: bucket regions dumped by the counting pass
   __device__ __forceinline__ uint32_t fine(int32_t key) const {
     const uint32_t u = ukey(key);
     uint32_t d = u > ulo ? u - ulo : 0u;
     d = d < span ? d : span;
-    return (uint32_t)(((uint64_t)d * mul) >> sh);
+    return sh ? __umulhi(d, mul) : d * mul;
   }
   __device__ __forceinline__ uint32_t bucket(int32_t key) const { return fine(key) >> 14; }
   __device__ __forceinline__ uint32_t slot(int32_t key) const { return fine(key) & (kRpSlots - 1); }
@@ -49,7 +52,7 @@ __device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {
   RangeMap m;
   m.ulo = (uint32_t)aux[NVT_RANGE_AUX_LO];
   m.span = (uint32_t)aux[NVT_RANGE_AUX_LO + 1];
-  m.mul = (uint64_t)(uint32_t)aux[NVT_RANGE_AUX_LO + 2] | ((uint64_t)(uint32_t)aux[NVT_RANGE_AUX_LO + 3] << 32);
+  m.mul = (uint32_t)aux[NVT_RANGE_AUX_LO + 2];  // (word + 3: the high half, always 0)
   m.sh = aux[NVT_RANGE_AUX_LO + 4];
   m.flat = aux[NVT_RANGE_AUX_LO + 5];
   return m;

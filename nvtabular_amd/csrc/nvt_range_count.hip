@@ -96,15 +96,20 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
 
   // flush every bin that holds >= kRpLine keys (or, with `all`, whatever it holds): one
   // 16-lane group per bin, four bins per wave instruction; bin t is owned by thread t
+  // ... spread over ALL 16 waves: wave w owns bins [w * NB / 16, (w + 1) * NB / 16), lane l the
+  // bookkeeping of the l-th of them.  (With thread t owning bin t, 256 buckets kept 4 waves busy
+  // and 12 waiting at the barrier for up to 16 rounds of the loop below.)
+  const unsigned BPW = NB / (kRpBS / kWave);  // 16 / 32 / 64 bins per wave
   auto flush_bins = [&](bool all) {
-    if (threadIdx.x < NB) {  // whole waves: NB is a multiple of 64
-      const unsigned t = threadIdx.x;
-      unsigned f = fill[t];
+    {
+      const bool owner = lane < BPW;
+      const unsigned wave_base = (threadIdx.x / kWave) * BPW;
+      const unsigned t = wave_base + (owner ? lane : 0u);
+      unsigned f = owner ? fill[t] : 0u;
       f = f < CAP ? f : CAP;
       const unsigned nfl = all ? f : (f / kRpLine) * kRpLine;  // keys leaving the bin
       unsigned long long todo = __ballot(nfl > 0);
       const unsigned sub = lane >> 4, l16 = lane & 15;
-      const unsigned wave_base = t - lane;
       while (todo) {
         int sel = -1;
 #pragma unroll
@@ -136,8 +141,10 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
           if (l16 < rem) bins[bin * CAP + l16] = keep;
         }
       }
-      fill[t] = f - nfl;
-      flushed[t] += nfl;
+      if (owner) {
+        fill[t] = f - nfl;
+        flushed[t] += nfl;
+      }
     }
   };
 

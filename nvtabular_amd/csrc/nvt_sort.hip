@@ -1163,7 +1163,7 @@ __global__ void flat_params_kernel(const int32_t *__restrict__ keys, uint64_t n,
   const uint64_t span = hi - lo, F = slots;  // any slot count < 2^32 (no power of two needed)
   uint64_t mul;
   int sh;
-  if (span + 1 >= F) {
+  if (span + 1 > F) {  // (strictly: mul < 2^32, RangeMap multiplies 32 x 32 bits)
     mul = (F << 32) / (span + 1);
     sh = 32;
   } else {
