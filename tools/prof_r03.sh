@@ -10,7 +10,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ou
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o cfg4 -- python $GRAFT_REPO_ROOT/tools/cfg4_probe.py > $out/cfg4.log 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(find $out -name "stats_kernel_stats.csv" | head -1); cp $f $out/r03_kernel_stats.csv
-f=$(find $out -name "cfg4_kernel_stats.csv" | head -1); cp $f $out/r03_cfg4_kernel_stats.csv
+f=$(find $out -name "cfg4_kernel_stats.csv" | head -1); cp $f $out/r03_cfg4_sorted_kernel_stats.csv
 fc=$(find $out -name "fetch_counter_collection.csv" | head -1); wc=$(find $out -name "write_counter_collection.csv" | head -1)
 mkdir -p $out/pmc; cp $fc $out/pmc/fetch_counter_collection.csv; cp $wc $out/pmc/write_counter_collection.csv
 python tools/pmc_summarize_r03.py $out/pmc $out/r03_pmc_traffic.json > $out/pmc_summary.txt 2>&1
