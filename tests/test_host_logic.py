@@ -142,3 +142,35 @@ def test_one_pass_class_order_equals_count_desc_key_asc():
         last = max(hi, last + 1)
         ref[i] = last
     np.testing.assert_array_equal(p, ref)
+
+
+def test_fold_sparse_and_sorted_groupby_eligibility():
+    """Host logic of the groupby sort path: dense per-(group, fold) statistics -> the compacted
+    [fold, key] groups of the reference's second aggregate (only pairs that have rows), and
+    which inputs may take the sort path at all."""
+    import torch
+
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.ops._groupby import fold_sparse
+
+    kfold = 3
+    keys = torch.tensor([-7, 2, 40], dtype=torch.int64)
+    fsize = torch.tensor([1, 0, 2, 0, 0, 5, 3, 3, 0], dtype=torch.int64)  # [g * kfold + f]
+    fsum = torch.arange(9, dtype=torch.float64) * 1.5
+    comp = dict(keys=[keys], n=3, fold=dict(kfold=kfold, size=fsize, sum=[fsum]))
+    sp = fold_sparse(comp)
+    assert sp["n"] == 5
+    assert sp["keys"][0].tolist() == [0, 2, 2, 0, 1]          # fold ids
+    assert sp["keys"][1].tolist() == [-7, -7, 2, 40, 40]      # keys
+    assert sp["size"].tolist() == [1, 2, 5, 3, 3] and sp["count"].tolist() == sp["size"].tolist()
+    assert sp["sum"][0].tolist() == [0.0, 3.0, 7.5, 9.0, 10.5]
+    assert sp["null_mask"].tolist() == [0] * 5 and sp["sumsq"] == [] and sp["min"] == []
+    n = K.SORTED_GROUPBY_MIN_ROWS
+    k32, k64 = torch.zeros(4, dtype=torch.int32), torch.zeros(4, dtype=torch.int64)
+    assert K.sorted_groupby_eligible(k32, None, n) and K.sorted_groupby_eligible(k64, None, n, 5)
+    assert not K.sorted_groupby_eligible(k32, None, n - 1)                 # launch latency
+    assert not K.sorted_groupby_eligible(k32, torch.zeros(1, dtype=torch.uint8), n)  # null keys
+    assert not K.sorted_groupby_eligible(torch.zeros(4, dtype=torch.uint8), None, n)
+    assert not K.sorted_groupby_eligible(k32, None, n, K.SORTED_GROUPBY_MAX_KFOLD + 1)
+    assert not K.sorted_groupby_eligible(k32, None, (1 << 29) + 1, 5)      # row index + 3 fold bits > 32
+    assert K.sorted_groupby_eligible(k32, None, (1 << 29), 5)
