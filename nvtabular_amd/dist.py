@@ -306,6 +306,20 @@ def _range_owner(k64: torch.Tensor, lo: int, hi: int, G: int) -> torch.Tensor:
     return ((k64 - lo) // width).clamp_(0, G - 1)
 
 
+PACK_COUNT_ROWS = True  # (tests switch it off to drive the two-word format with int32 keys)
+STATS = {"packed_exchanges": 0, "plain_exchanges": 0}  # diagnostics
+
+
+def _pack_kc(k64: torch.Tensor, c64: torch.Tensor) -> torch.Tensor:
+    """(int32-ranged key, count < 2^31) -> one int64 word: count in the high half."""
+    return (c64 << 32) | (k64 & 0xFFFFFFFF)
+
+
+def _unpack_kc(words: torch.Tensor, key_dtype):
+    keys = ((words << 32) >> 32).to(key_dtype)  # arithmetic shifts: the low half, sign-extended
+    return keys.contiguous(), (words >> 32).contiguous()
+
+
 def _sort_by_key_default(keys, counts):
     if keys.is_cuda:
         from . import kernels as K
@@ -338,7 +352,8 @@ def merge_counts_many(tables):
         owner(key) = key range r of G equal ranges per column (monotone in the key)
         rows sorted by (owner, column)            -> [G x ncol] send-count matrix
         all-to-all of the count matrix            (1)
-        all-to-all(v) of the (key, count) rows    (1, int64 pairs)
+        all-to-all(v) of the (key, count) rows    (1; one int64 word per row for int32 keys
+                                                   and counts < 2^31, else int64 pairs)
         owner-side merge per column (weighted dense count), then ordered BY KEY
         all-gather of the [ncol] merged lengths   (1)
         all-gather(v) of the merged rows          (1)
@@ -363,16 +378,25 @@ def merge_counts_many(tables):
     k64s = [k.to(torch.int64) for k, _, _ in tables]
     # ---- global key range per column ---------------------------------------------------
     big = torch.iinfo(torch.int64).max
-    rng = torch.empty(ncol, 2, dtype=torch.int64, device=dev)  # (-min, max): one MAX reduce
-    for j, k in enumerate(k64s):
+    # (-min, max, rows counted on this rank): one MAX reduce
+    rng = torch.empty(ncol, 3, dtype=torch.int64, device=dev)
+    for j, (k, (_, c, _)) in enumerate(zip(k64s, tables)):
         if lens[j]:
             rng[j, 0] = -(k.min().clamp(min=-big))
             rng[j, 1] = k.max()
+            rng[j, 2] = c.sum()
         else:
             rng[j, 0] = -big
             rng[j, 1] = -big
+            rng[j, 2] = 0
     _all_reduce(rng, td.ReduceOp.MAX)
     rng_h = rng.cpu().tolist()
+    # int32 keys and no merged count that can reach 2^31 (G times the largest per-rank total
+    # bounds it): a (key, count) row travels as ONE int64 word instead of two -- half the bytes
+    # of the all-to-all and of the all-gather, the part of a fit that grows with the ranks
+    packed = (all(dt == torch.int32 for dt in dtypes)
+              and G * max(r[2] for r in rng_h) < (1 << 31) and PACK_COUNT_ROWS)
+    STATS["packed_exchanges" if packed else "plain_exchanges"] += 1
     # ---- rows grouped by (owner, column) --------------------------------------------
     own_parts, dest_parts = [], []
     for j, k in enumerate(k64s):
@@ -385,7 +409,10 @@ def merge_counts_many(tables):
         dest_parts.append(own * ncol + j)
     owner_all = torch.cat(own_parts)
     dest = torch.cat(dest_parts)
-    rows = torch.stack([torch.cat(k64s), torch.cat([c.to(torch.int64) for _, c, _ in tables])], dim=1)
+    if packed:
+        rows = _pack_kc(torch.cat(k64s), torch.cat([c.to(torch.int64) for _, c, _ in tables]))
+    else:
+        rows = torch.stack([torch.cat(k64s), torch.cat([c.to(torch.int64) for _, c, _ in tables])], dim=1)
     if dest.is_cuda:
         # stable radix sort of (destination << 32 | row) words on the destination bits
         from . import kernels as K
@@ -411,7 +438,10 @@ def merge_counts_many(tables):
     for j in range(ncol):
         pieces = [recv[off[src * ncol + j] : off[src * ncol + j + 1]] for src in range(G)]
         part = torch.cat(pieces) if G > 1 else pieces[0]
-        parts.append((part[:, 0].contiguous().to(dtypes[j]), part[:, 1].contiguous()))
+        if packed:
+            parts.append(_unpack_kc(part, dtypes[j]))
+        else:
+            parts.append((part[:, 0].contiguous().to(dtypes[j]), part[:, 1].contiguous()))
     live = [j for j in range(ncol) if parts[j][0].numel()]
     if _merge_counts_many_fn is not None:
         results = dict(zip(live, _merge_counts_many_fn([parts[j] for j in live])))
@@ -421,9 +451,10 @@ def merge_counts_many(tables):
     for j in range(ncol):
         if j in results:
             mk, mc = _sort_by_key_fn(*results[j])
-            merged.append(torch.stack([mk.to(torch.int64), mc.to(torch.int64)], dim=1))
+            merged.append(_pack_kc(mk.to(torch.int64), mc.to(torch.int64)) if packed
+                          else torch.stack([mk.to(torch.int64), mc.to(torch.int64)], dim=1))
         else:
-            merged.append(torch.empty((0, 2), dtype=torch.int64, device=dev))
+            merged.append(torch.empty((0,) if packed else (0, 2), dtype=torch.int64, device=dev))
     # ---- replicate: every rank gets every owner's share, rank (= key range) order -------------
     mlen = torch.tensor([m.shape[0] for m in merged], dtype=torch.int64, device=dev)
     all_len = torch.stack(_all_gather_same(mlen)).cpu()  # [G, ncol]
@@ -439,7 +470,10 @@ def merge_counts_many(tables):
     out = []
     for j in range(ncol):
         seg = torch.cat([everything[goff[r * ncol + j] : goff[r * ncol + j + 1]] for r in range(G)])
-        keys, counts = seg[:, 0].contiguous().to(dtypes[j]), seg[:, 1].contiguous()
+        if packed:
+            keys, counts = _unpack_kc(seg, dtypes[j])
+        else:
+            keys, counts = seg[:, 0].contiguous().to(dtypes[j]), seg[:, 1].contiguous()
         info = None
         if keys.numel():
             hist = _class_hist_fn(counts)

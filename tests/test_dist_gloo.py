@@ -72,6 +72,26 @@ def _worker(rank, world, port, q):
         np.testing.assert_array_equal(info["cls_hist"].numpy(),
                                       np.bincount(np.minimum(cc.numpy(), 255), minlength=256))
         assert info["n_big"] == int((cc.numpy() >= 255).sum())
+    # every column int32 (negative keys, INT32_MIN / MAX, a column empty on rank 1): the rows
+    # travel as ONE int64 word (count << 32 | key); same result as the two-word format
+    kneg = np.unique(np.concatenate([rng.integers(-2**31, 2**31 - 1, 500),
+                                     [-2**31, 2**31 - 1, -1, 0]])).astype("int32")
+    cneg = rng.integers(1, 400, kneg.size).astype("int64")
+    tabs32 = [(torch.from_numpy(l32.index.to_numpy()), torch.from_numpy(l32.to_numpy()), [1]),
+              (torch.from_numpy(kneg), torch.from_numpy(cneg), [2, rank]),
+              (torch.arange(5 if rank == 0 else 0, dtype=torch.int32),
+               torch.full((5 if rank == 0 else 0,), 9, dtype=torch.int64), [])]
+    before = dict(dist.STATS)
+    packed = dist.merge_counts_many(tabs32)
+    assert dist.STATS["packed_exchanges"] == before["packed_exchanges"] + 1
+    dist.PACK_COUNT_ROWS = False
+    plain = dist.merge_counts_many(tabs32)
+    dist.PACK_COUNT_ROWS = True
+    for (pk, pc, ps, pi), (uk, uc, us, ui) in zip(packed, plain):
+        assert pk.dtype == torch.int32 and torch.equal(pk, uk) and torch.equal(pc, uc) and ps == us
+        assert (np.diff(pk.numpy().astype(np.int64)) > 0).all()
+    assert packed[1][0][0].item() == -2**31 and packed[1][0][-1].item() == 2**31 - 1
+    assert int(packed[1][1].sum()) >= int(cneg.sum())
     m0 = pd.Series(many[0][1].numpy(), index=many[0][0].numpy()).sort_index()
     assert sorted(many[2][0].tolist()) == list(range(7)) and many[2][1].tolist() == [1] * 7
     q.put(("many", rank, m0.index.to_numpy(), m0.to_numpy(), many[1][0].numpy(), many[1][1].numpy(),
