@@ -386,6 +386,17 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
                    uint64_t n, uint64_t cap, uint64_t *out_size, double *out_sum, double *out_sumsq,
                    double *out_min, double *out_max, uint64_t *tot_size, double *tot_sum,
                    double *te_records, const uint64_t *state, void *stream);
+/* Owner-side merge of the (key, count) rows of the multi-GPU exchange by sorting
+ * (categorify.py:1054-1070 _mid_level_groupby, done on the owner rank): rows = n words
+ * (count << 32 | int32 key), 0 <= count < 2^31, in nseg segments [seg_off[s], seg_off[s + 1])
+ * (device uint64[nseg + 1]; source-major, column-minor: segment s holds column s % ncol).
+ * Output: the (column, key) groups ordered by column, then key: out_keys int32[n], out_col
+ * int64[n], out_sum double[n] (summed counts: exact below 2^53); state[NVT_ST_OCCUPIED] =
+ * groups.  n < 2^26, ncol <= 64.  ws: nvt_count_merge_sorted_ws_bytes(n).  No host sync. */
+int nvt_count_merge_sorted_ws_bytes(uint64_t n, uint64_t *bytes);
+int nvt_count_merge_sorted(const int64_t *rows, uint64_t n, const uint64_t *seg_off, int nseg,
+                           int ncol, int32_t *out_keys, int64_t *out_col, double *out_sum,
+                           uint64_t *state, void *ws, void *stream);
 /* key -> position in an ascending int32 key list (the group ids of nvt_sgb_regroup) through
  * a flat range table laid out from the list in one pass (no inserts): replaces
  * nvt_gb_index_build + nvt_gb_lookup for such groups (join_groupby.py:198-203,

@@ -105,6 +105,8 @@ SIGNATURES = {
                                C.POINTER(C.c_int), C.POINTER(_dbl), _vp, _vp],
     "nvt_flat_lookup_te": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _i32, _vp, _dbl, _dbl, _vp,
                            _i32, _vp],
+    "nvt_count_merge_sorted_ws_bytes": [_u64, C.POINTER(_u64)],
+    "nvt_count_merge_sorted": [_vp, _u64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nvt_flat_index_tmp_bytes": [_u64, C.POINTER(_u64)],
     "nvt_flat_index_build": [_vp, _u64, _u64, _vp, _vp, _u64, _vp, _vp],
     "nvt_flat_lookup": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _vp],

@@ -335,10 +335,10 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
       excl = EXCL && lane < 63 && (double)(lane + 1) > sz;
       if (live && tail) {
         if (excl) {
-          t.size[slot] = (unsigned long long)sz;
+          if (t.size) t.size[slot] = (unsigned long long)sz;
           if (t.count && ct > 0) t.count[slot] = (unsigned long long)ct;
         } else {
-          atomicAdd(&t.size[slot], (unsigned long long)sz);
+          if (t.size) atomicAdd(&t.size[slot], (unsigned long long)sz);
           if (t.count && ct > 0) atomicAdd(&t.count[slot], (unsigned long long)ct);
         }
       }
@@ -647,6 +647,10 @@ __global__ __launch_bounds__(kBlock) void key_minmax_kernel(const K *__restrict_
   }
 }
 
+// MERGE (owner-side merge of (key, count) rows, nvt_count_merge_sorted): the words are
+// (column << (rb + 32) | key image << rb | row), a group is a (column, key) pair; out_keys
+// receives the group's COLUMN, out_keys32 its key, the rewritten words carry slot = group.
+template <bool MERGE>
 __global__ __launch_bounds__(kBlock) void sgb_rle_kernel(
     const uint64_t *__restrict__ in, uint64_t n, int rb, unsigned kfold, uint64_t cap,
     unsigned long long *status, unsigned *ticket, int64_t *__restrict__ out_keys,
@@ -662,16 +666,18 @@ __global__ __launch_bounds__(kBlock) void sgb_rle_kernel(
   const uint64_t wave0 = (uint64_t)tile * kSgbTile + (uint64_t)w * (kSgbRows * kWave);
   uint64_t W[kSgbRows];
   unsigned long long hb[kSgbRows];  // ballot of the run heads of every 64-word row
-  // key image in front of this wave's run (one address: a broadcast load)
-  uint32_t prev_hi = (wave0 > 0 && wave0 < n) ? (uint32_t)(in[wave0 - 1] >> 32) : 0u;
+  // group field (key image; MERGE: column + key image) in front of this wave's run (one
+  // address: a broadcast load)
+  const int fsh = MERGE ? rb : 32;
+  uint64_t prev_hi = (wave0 > 0 && wave0 < n) ? in[wave0 - 1] >> fsh : 0ull;
   unsigned wheads = 0;
 #pragma unroll
   for (int r = 0; r < kSgbRows; ++r) {
     const uint64_t i = wave0 + (uint64_t)r * kWave + l;
     const bool act = i < n;
     W[r] = act ? in[i] : ~0ull;
-    const uint32_t hi = (uint32_t)(W[r] >> 32);
-    uint32_t up = __shfl_up(hi, 1, 64);
+    const uint64_t hi = W[r] >> fsh;
+    uint64_t up = __shfl_up(hi, 1, 64);
     if (l == 0) up = prev_hi;
     const bool head = act && (i == 0 || hi != up);
     hb[r] = __ballot(head);
@@ -724,16 +730,24 @@ __global__ __launch_bounds__(kBlock) void sgb_rle_kernel(
     const unsigned incl = (unsigned)__popcll(hb[r] & ((2ull << l) - 1ull));
     if (i < n) {
       const uint64_t g = g0 + incl - 1;  // >= 0: row 0 is a head
-      const uint32_t hi = (uint32_t)(W[r] >> 32);
       const bool fits = g < cap;
-      if (((hb[r] >> l) & 1ull) && fits) {
-        out_keys[g] = (int64_t)((uint64_t)hi + (uint64_t)bias);  // the key itself
-        out_keys32[g] = (int32_t)(hi ^ 0x80000000u);              // key - bias - 2^31: the flat index's key
+      if constexpr (MERGE) {
+        if (((hb[r] >> l) & 1ull) && fits) {
+          out_keys[g] = (int64_t)(W[r] >> (rb + 32));                             // column
+          out_keys32[g] = (int32_t)((uint32_t)(W[r] >> rb) ^ 0x80000000u);        // key
+        }
+        out_words[i] = ((fits ? g : 0xFFFFFFFFull) << 32) | (W[r] & rowmask);
+      } else {
+        const uint32_t hi = (uint32_t)(W[r] >> 32);
+        if (((hb[r] >> l) & 1ull) && fits) {
+          out_keys[g] = (int64_t)((uint64_t)hi + (uint64_t)bias);  // the key itself
+          out_keys32[g] = (int32_t)(hi ^ 0x80000000u);              // key - bias - 2^31: the flat index's key
+        }
+        const uint64_t low = W[r] & 0xFFFFFFFFull;
+        const uint64_t fold = (rb >= 32 || kfold == 1) ? 0ull : (low >> rb);
+        const uint64_t slot = fits ? g * kfold + fold : 0xFFFFFFFFull;
+        out_words[i] = (slot << 32) | (low & rowmask);
       }
-      const uint64_t low = W[r] & 0xFFFFFFFFull;
-      const uint64_t fold = (rb >= 32 || kfold == 1) ? 0ull : (low >> rb);
-      const uint64_t slot = fits ? g * kfold + fold : 0xFFFFFFFFull;
-      out_words[i] = (slot << 32) | (low & rowmask);
     }
     g0 += (unsigned)__popcll(hb[r]);
   }
@@ -790,6 +804,34 @@ __global__ __launch_bounds__(kBlock) void sgb_fold_total_kernel(
       }
       __syncthreads();
     }
+  }
+}
+
+// owner-side merge of the (key, count) rows a rank receives in the multi-GPU exchange
+// (categorify.py:1054-1070 _mid_level_groupby on the owner): rows = (count << 32 | key) words in
+// `nseg` segments (source-major, column-minor: segment s belongs to column s % ncol).  The rows
+// are tagged with their column and sorted by (column, key): equal keys of a column become one
+// run whose counts are summed by the segmented reduction -- the merged lists come out ordered
+// by key (what the vocabulary ordering wants) without a hash table and without a second sort.
+constexpr int kMergeRowBits = 26;  // rows per call < 2^26; 32 key bits; 6 column bits
+__global__ __launch_bounds__(kBlock) void merge_pack_kernel(const int64_t *__restrict__ rows,
+                                                            uint64_t n,
+                                                            const uint64_t *__restrict__ seg_off,
+                                                            int nseg, int ncol,
+                                                            uint64_t *__restrict__ words,
+                                                            int32_t *__restrict__ cnt32) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int lo = 0, hi = nseg;  // the segment with seg_off[s] <= i < seg_off[s + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seg_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint64_t col = (uint64_t)(lo % ncol);
+    const uint64_t w = (uint64_t)rows[i];
+    const uint64_t img = (uint32_t)w ^ 0x80000000u;
+    words[i] = (col << (kMergeRowBits + 32)) | (img << kMergeRowBits) | i;
+    cnt32[i] = (int32_t)(w >> 32);
   }
 }
 
@@ -1218,9 +1260,9 @@ int nvt_sgb_regroup(const uint64_t *sorted, int row_bits, int kfold, int64_t key
   unsigned *ticket = reinterpret_cast<unsigned *>(status + ntiles);
   NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 8 + 64, s));
   NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
-  sgb_rle_kernel<<<(unsigned)ntiles, kBlock, 0, s>>>(sorted, n, row_bits, (unsigned)kfold, cap, status,
-                                                     ticket, out_keys, out_keys32, regrouped, state,
-                                                     key_bias);
+  sgb_rle_kernel<false><<<(unsigned)ntiles, kBlock, 0, s>>>(sorted, n, row_bits, (unsigned)kfold, cap,
+                                                            status, ticket, out_keys, out_keys32,
+                                                            regrouped, state, key_bias);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
@@ -1282,6 +1324,65 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
         out_sum, reinterpret_cast<unsigned long long *>(tot_size), tot_sum, te_records);
     NVT_CHECK_LAUNCH();
   }
+  return NVT_OK;
+}
+
+int nvt_count_merge_sorted_ws_bytes(uint64_t n, uint64_t *bytes) {
+  NVT_CHECK_ARG(bytes, "null out");
+  const uint64_t ntiles = (n + kSgbTile - 1) / kSgbTile;
+  *bytes = sgb_pad(n * 8) + sgb_pad(sort_words_tmp_bytes(n)) + sgb_pad(n * 4) + sgb_pad(n * 8) +
+           sgb_pad(ntiles * 8 + 64) + 512;
+  return NVT_OK;
+}
+
+int nvt_count_merge_sorted(const int64_t *rows, uint64_t n, const uint64_t *seg_off, int nseg,
+                           int ncol, int32_t *out_keys, int64_t *out_col, double *out_sum,
+                           uint64_t *state, void *ws, void *stream) {
+  NVT_CHECK_ARG(rows && seg_off && out_keys && out_col && out_sum && state && ws, "null pointer");
+  NVT_CHECK_ARG(n >= 1 && n < (1ull << kMergeRowBits), "1 .. 2^26-1 rows per call");
+  NVT_CHECK_ARG(nseg >= 1 && ncol >= 1 && ncol <= (1 << (64 - 32 - kMergeRowBits)) && nseg % ncol == 0,
+                "1..64 columns, whole groups of segments");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("count_merge_sorted", n * 8ull, s);
+  const uint64_t ntiles = (n + kSgbTile - 1) / kSgbTile;
+  char *p = reinterpret_cast<char *>(ws);
+  uint64_t *words = reinterpret_cast<uint64_t *>(p);
+  p += sgb_pad(n * 8);
+  void *sort_tmp = p;
+  p += sgb_pad(sort_words_tmp_bytes(n));
+  int32_t *cnt32 = reinterpret_cast<int32_t *>(p);
+  p += sgb_pad(n * 4);
+  uint64_t *regrouped = reinterpret_cast<uint64_t *>(p);
+  p += sgb_pad(n * 8);
+  unsigned long long *status = reinterpret_cast<unsigned long long *>(p);
+  unsigned *ticket = reinterpret_cast<unsigned *>(status + ntiles);
+  NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 8 + 64, s));
+  NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
+  NVT_CHECK_HIP(hipMemsetAsync(out_sum, 0, n * 8, s));
+  merge_pack_kernel<<<stream_grid(n, kBlock * 4), kBlock, 0, s>>>(rows, n, seg_off, nseg, ncol, words,
+                                                                  cnt32);
+  NVT_CHECK_LAUNCH();
+  int cb = 1;
+  while ((1 << cb) < ncol) ++cb;
+  uint64_t *sorted = nullptr;
+  int rc = sort_words_bits(words, n, kMergeRowBits, kMergeRowBits + 32 + cb, sort_tmp, &sorted, s);
+  if (rc) return rc;
+  sgb_rle_kernel<true><<<(unsigned)ntiles, kBlock, 0, s>>>(sorted, n, kMergeRowBits, 1u, n, status,
+                                                           ticket, out_col, out_keys, regrouped, state,
+                                                           0);
+  NVT_CHECK_LAUNCH();
+  GbView t;
+  memset(&t, 0, sizeof(t));
+  t.nkeys = 1;
+  t.nvals = 1;
+  t.cap = n;
+  t.sum = out_sum;
+  GbRowArgs a;
+  memset(&a, 0, sizeof(a));
+  a.vals[0] = cnt32;
+  a.vdtype[0] = NVT_I32;
+  gb_segreduce_kernel<true><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, regrouped, 1u);
+  NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
 

@@ -307,7 +307,8 @@ def _range_owner(k64: torch.Tensor, lo: int, hi: int, G: int) -> torch.Tensor:
 
 
 PACK_COUNT_ROWS = True  # (tests switch it off to drive the two-word format with int32 keys)
-STATS = {"packed_exchanges": 0, "plain_exchanges": 0}  # diagnostics
+STATS = {"packed_exchanges": 0, "plain_exchanges": 0, "sorted_merges": 0}  # diagnostics
+MERGE_BY_SORTING = True
 
 
 def _pack_kc(k64: torch.Tensor, c64: torch.Tensor) -> torch.Tensor:
@@ -434,22 +435,35 @@ def merge_counts_many(tables):
     off = torch.zeros(G * ncol + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
     off = off.tolist()
-    parts = []
-    for j in range(ncol):
-        pieces = [recv[off[src * ncol + j] : off[src * ncol + j + 1]] for src in range(G)]
-        part = torch.cat(pieces) if G > 1 else pieces[0]
-        if packed:
-            parts.append(_unpack_kc(part, dtypes[j]))
+    sorted_merge, results = None, {}
+    if packed and recv.is_cuda and _merge_counts_many_fn is _hip_merge_counts_many and MERGE_BY_SORTING:
+        from . import kernels as K
+
+        if 0 < recv.numel() <= K.MERGE_SORTED_MAX_ROWS and ncol <= K.MERGE_SORTED_MAX_COLS:
+            # ONE sort of all received rows by (column, key) + a segmented sum: the merged lists
+            # come out ordered by key (no hash tables, no per-column sort afterwards)
+            sorted_merge = K.merge_counts_sorted(recv, off, ncol)
+            STATS["sorted_merges"] += 1
+    if sorted_merge is None:
+        parts = []
+        for j in range(ncol):
+            pieces = [recv[off[src * ncol + j] : off[src * ncol + j + 1]] for src in range(G)]
+            part = torch.cat(pieces) if G > 1 else pieces[0]
+            if packed:
+                parts.append(_unpack_kc(part, dtypes[j]))
+            else:
+                parts.append((part[:, 0].contiguous().to(dtypes[j]), part[:, 1].contiguous()))
+        live = [j for j in range(ncol) if parts[j][0].numel()]
+        if _merge_counts_many_fn is not None:
+            results = dict(zip(live, _merge_counts_many_fn([parts[j] for j in live])))
         else:
-            parts.append((part[:, 0].contiguous().to(dtypes[j]), part[:, 1].contiguous()))
-    live = [j for j in range(ncol) if parts[j][0].numel()]
-    if _merge_counts_many_fn is not None:
-        results = dict(zip(live, _merge_counts_many_fn([parts[j] for j in live])))
-    else:
-        results = {j: _merge_counts_fn(*parts[j]) for j in live}
+            results = {j: _merge_counts_fn(*parts[j]) for j in live}
     merged = []
     for j in range(ncol):
-        if j in results:
+        if sorted_merge is not None:
+            mk, mc = sorted_merge[j]
+            merged.append(_pack_kc(mk.to(torch.int64), mc))
+        elif j in results:
             mk, mc = _sort_by_key_fn(*results[j])
             merged.append(_pack_kc(mk.to(torch.int64), mc.to(torch.int64)) if packed
                           else torch.stack([mk.to(torch.int64), mc.to(torch.int64)], dim=1))

@@ -1607,6 +1607,45 @@ def flat_index_for(comp) -> "FlatIndex":
     return index
 
 
+MERGE_SORTED_MAX_ROWS = (1 << 26) - 1   # include/nvt_hip.h nvt_count_merge_sorted
+MERGE_SORTED_MAX_COLS = 64
+
+
+def merge_counts_sorted(rows: torch.Tensor, seg_off: List[int], ncol: int):
+    """nvt_count_merge_sorted: owner-side merge of received (count << 32 | int32 key) rows lying in
+    len(seg_off) - 1 segments (source-major, column-minor).  Returns [(keys int32, counts
+    int64)] per column, every list ordered by key.  One read-back (groups per column)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    dev = rows.device
+    n = int(rows.numel())
+    empty = lambda: (torch.empty(0, dtype=torch.int32, device=dev),  # noqa: E731
+                     torch.empty(0, dtype=torch.int64, device=dev))
+    if n == 0:
+        return [empty() for _ in range(ncol)]
+    rows = rows.contiguous()
+    off = torch.tensor(seg_off, dtype=torch.int64, device=dev)
+    need = C.c_uint64()
+    check(lib.nvt_count_merge_sorted_ws_bytes(n, C.byref(need)), "nvt_count_merge_sorted_ws_bytes")
+    ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    keys = torch.empty(n, dtype=torch.int32, device=dev)
+    col = torch.empty(n, dtype=torch.int64, device=dev)
+    sums = torch.empty(n, dtype=torch.float64, device=dev)
+    state = torch.empty(_lib.STATE_WORDS, dtype=torch.int64, device=dev)
+    check(lib.nvt_count_merge_sorted(rows.data_ptr(), n, off.data_ptr(), len(seg_off) - 1, ncol,
+                                     keys.data_ptr(), col.data_ptr(), sums.data_ptr(),
+                                     state.data_ptr(), ws.data_ptr(), stream_ptr()),
+          "nvt_count_merge_sorted")
+    g = int(read_back(state)[_lib.ST_OCCUPIED])
+    per_col = read_back(torch.bincount(col[:g], minlength=ncol).to(torch.int64)).tolist()
+    out, lo = [], 0
+    for j in range(ncol):
+        hi = lo + int(per_col[j])
+        out.append((keys[lo:hi], sums[lo:hi].to(torch.int64)) if hi > lo else empty())
+        lo = hi
+    return out
+
+
 class FlatIndex:
     """key -> position in an ascending int32 key list (group ids of sorted_groupby): a flat
     range table laid out from the list in one pass (nvt_flat_index_build).  Same ``lookup``

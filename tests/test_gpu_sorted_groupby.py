@@ -334,3 +334,44 @@ def test_sgb_edge_shapes(n, shape):
         p = np.minimum(np.searchsorted(uk, pk), uk.size - 1)
         if idx.ok():
             np.testing.assert_array_equal(got, np.where(uk[p] == pk, p, -1))
+
+
+def test_merge_counts_sorted_vs_numpy():
+    """nvt_count_merge_sorted: (count << 32 | key) rows in source-major, column-minor segments ->
+    per column the key-ordered union with summed counts (the owner-side merge of the multi-GPU
+    exchange, categorify.py:1054-1070)."""
+    from nvtabular_amd import kernels as K
+
+    rng = np.random.default_rng(11)
+    G, ncol = 3, 5
+    segs, off = [], [0]
+    per_col = {j: [] for j in range(ncol)}
+    for src in range(G):
+        for j in range(ncol):
+            m = 0 if (src == 1 and j == 2) else int(rng.integers(1, 40_000))
+            if j == 4:
+                k = np.unique(rng.integers(-2**31, 2**31 - 1, m, dtype=np.int64)).astype(np.int32)
+                if src == 0:
+                    k = np.unique(np.concatenate([k, np.array([-2**31, 2**31 - 1], dtype=np.int32)]))
+            else:
+                k = np.unique(rng.integers(-500 * (j + 1), 30_000, m)).astype(np.int32)
+            c = rng.integers(1, 2**20 if j == 3 else 50, k.size).astype(np.int64)
+            if j == 3 and k.size:
+                c[0] = 2**31 - 1  # the largest count a packed row can carry
+            segs.append((c << 32) | (k.astype(np.int64) & 0xFFFFFFFF))
+            per_col[j].append((k, c))
+            off.append(off[-1] + k.size)
+    rows = torch.from_numpy(np.concatenate(segs)).cuda()
+    got = K.merge_counts_sorted(rows, off, ncol)
+    assert len(got) == ncol
+    for j in range(ncol):
+        k = np.concatenate([p[0] for p in per_col[j]])
+        c = np.concatenate([p[1] for p in per_col[j]])
+        uk, inv = np.unique(k, return_inverse=True)
+        exp = np.zeros(uk.size, dtype=np.int64)
+        np.add.at(exp, inv, c)
+        gk, gc = got[j]
+        assert gk.dtype == torch.int32 and gc.dtype == torch.int64
+        np.testing.assert_array_equal(gk.cpu().numpy(), uk)
+        np.testing.assert_array_equal(gc.cpu().numpy(), exp)
+    assert K.merge_counts_sorted(rows[:0], [0] * (G * ncol + 1), ncol)[0][0].numel() == 0
