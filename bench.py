@@ -859,6 +859,11 @@ def main():
             torch.cuda.empty_cache()
         result["extra_configs"] = extras
     if rank == 0:
+        from nvtabular_amd import dist as _d
+
+        if _d.TIMING:  # NVT_DIST_TIMING=1 (diagnostic, device-synchronised sections of the merge)
+            result["dist_timing_ms_total"] = {k: round(1e3 * v, 2) for k, v in _d.TIMING.items()}
+            result["dist_stats"] = dict(_d.STATS)
         print(json.dumps(result))
     if world > 1:
         import torch.distributed as td

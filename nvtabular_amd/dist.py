@@ -306,6 +306,28 @@ def _range_owner(k64: torch.Tensor, lo: int, hi: int, G: int) -> torch.Tensor:
     return ((k64 - lo) // width).clamp_(0, G - 1)
 
 
+TIMING = None  # NVT_DIST_TIMING=1: dict section -> seconds (device-synchronised: diagnostic only)
+if __import__("os").environ.get("NVT_DIST_TIMING"):
+    TIMING = {}
+
+
+_last_mark = [0.0]
+
+
+def _mark(name=None):
+    """Diagnostic timing (NVT_DIST_TIMING=1): seconds since the previous mark go to TIMING[name]."""
+    if TIMING is None:
+        return
+    import time
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    now = time.perf_counter()
+    if name is not None:
+        TIMING[name] = TIMING.get(name, 0.0) + now - _last_mark[0]
+    _last_mark[0] = now
+
+
 PACK_COUNT_ROWS = True  # (tests switch it off to drive the two-word format with int32 keys)
 STATS = {"packed_exchanges": 0, "plain_exchanges": 0, "sorted_merges": 0}  # diagnostics
 MERGE_BY_SORTING = True
@@ -373,6 +395,7 @@ def merge_counts_many(tables):
     if G == 1:
         return [(k, c, list(sc), None) for k, c, sc in tables]
     ncol = len(tables)
+    _mark()
     dev = tables[0][0].device
     dtypes = [k.dtype for k, _, _ in tables]
     lens = [int(k.numel()) for k, _, _ in tables]
@@ -392,6 +415,7 @@ def merge_counts_many(tables):
             rng[j, 2] = 0
     _all_reduce(rng, td.ReduceOp.MAX)
     rng_h = rng.cpu().tolist()
+    _mark("ranges")
     # int32 keys and no merged count that can reach 2^31 (G times the largest per-rank total
     # bounds it): a (key, count) row travels as ONE int64 word instead of two -- half the bytes
     # of the all-to-all and of the all-gather, the part of a fit that grows with the ranks
@@ -423,6 +447,7 @@ def merge_counts_many(tables):
     else:  # host stand-in of the CPU tests
         order = torch.argsort(dest, stable=True)
     send_mat = torch.bincount(dest, minlength=G * ncol).to(torch.int64).view(G, ncol)
+    _mark("group_rows")
     # ---- count matrix: row g of mine goes to rank g ------------------------------------
     if _backend() == "nccl":
         recv_mat = torch.empty_like(send_mat)
@@ -431,6 +456,7 @@ def merge_counts_many(tables):
         recv_mat = torch.stack([m[rank()] for m in _all_gather_same(send_mat.contiguous())])
     send_h, recv_h = send_mat.cpu(), recv_mat.cpu()
     recv = _all_to_all_v(rows[order].contiguous(), send_h.sum(1).tolist(), recv_h.sum(1).tolist())
+    _mark("all_to_all")
     # ---- owner-side merge, column by column, then key order -----------------------------
     off = torch.zeros(G * ncol + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
@@ -469,10 +495,12 @@ def merge_counts_many(tables):
                           else torch.stack([mk.to(torch.int64), mc.to(torch.int64)], dim=1))
         else:
             merged.append(torch.empty((0,) if packed else (0, 2), dtype=torch.int64, device=dev))
+    _mark("owner_merge")
     # ---- replicate: every rank gets every owner's share, rank (= key range) order -------------
     mlen = torch.tensor([m.shape[0] for m in merged], dtype=torch.int64, device=dev)
     all_len = torch.stack(_all_gather_same(mlen)).cpu()  # [G, ncol]
     everything = _all_gather_v(torch.cat(merged), sizes=all_len.sum(1).tolist())
+    _mark("all_gather")
     goff = torch.zeros(G * ncol + 1, dtype=torch.int64)
     goff[1:] = torch.cumsum(all_len.reshape(-1), 0)
     goff = goff.tolist()
@@ -499,6 +527,7 @@ def merge_counts_many(tables):
         nb = torch.stack([i["cls_hist"][255] for i in infos]).to(torch.int64).cpu().tolist()
         for i, v in zip(infos, nb):
             i["n_big"] = int(v) & 0xFFFFFFFF
+    _mark("unpack_hist")
     return out
 
 

@@ -1,0 +1,54 @@
+"""Cost of the torch plumbing of dist.merge_counts_many on an exclusive GPU: 31 M (key, count)
+entries in 26 columns (the bench's per-rank lists), G = 8."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nvtabular_amd import kernels as K
+
+dev = torch.device("cuda", 0)
+G, ncol = 8, 26
+lens = [6_200_000, 39_000, 17_000, 7_400, 20_000, 3, 7_100, 1_500, 63, 6_100_000, 1_570_000, 368_000, 10,
+        2_200, 11_900, 155, 4, 976, 14, 3_000_000, 5_700_000, 5_000_000, 560_000, 12_900, 108, 36]
+g = torch.Generator(device=dev).manual_seed(1)
+cols = [(torch.randint(-2**31, 2**31 - 1, (n,), device=dev, dtype=torch.int64, generator=g).to(torch.int32).sort().values,
+         torch.randint(1, 100, (n,), device=dev, dtype=torch.int64, generator=g)) for n in lens]
+tot = sum(lens)
+
+
+def T(name, fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    print(f"{name:34s} {1e3 * (time.perf_counter() - t0) / reps:8.3f} ms", flush=True)
+    return out
+
+
+k64s = T("to(int64) x26", lambda: [k.to(torch.int64) for k, _ in cols])
+T("min/max/sum x26 -> rng", lambda: [(k.min(), k.max(), c.sum()) for (k, c) in cols])
+owns = T("range_owner x26", lambda: [((k - int(-2**31)) // (2**32 // G)).clamp_(0, G - 1) for k in k64s])
+dest = T("dest = own*ncol+j, cat", lambda: torch.cat([o * ncol + j for j, o in enumerate(owns)]))
+rows = T("pack rows (cat, shift, or)", lambda: (torch.cat([c for _, c in cols]) << 32) | (torch.cat(k64s) & 0xFFFFFFFF))
+words = T("K.order_rows", lambda: K.order_rows(int(dest.numel()), dev, gid=dest, ngroups=G * ncol))
+order = words & 0xFFFFFFFF
+T("rows[order]", lambda: rows[order].contiguous())
+T("bincount(dest, 208)", lambda: torch.bincount(dest, minlength=G * ncol))
+sd = dest[order]
+T("searchsorted alternative", lambda: torch.searchsorted(sd, torch.arange(G * ncol + 1, device=dev)))
+off = [0]
+per = tot // (G * ncol)
+for s in range(G * ncol):
+    off.append(off[-1] + per)
+recv = rows[: off[-1]]
+T("merge_counts_sorted", lambda: K.merge_counts_sorted(recv, off, ncol))
+merged = K.merge_counts_sorted(recv, off, ncol)
+T("pack merged x26 + cat", lambda: torch.cat([(mc << 32) | (mk.to(torch.int64) & 0xFFFFFFFF) for mk, mc in merged]))
+every = torch.cat([rows] * 2)[: 60_000_000]
+seg = every.numel() // (G * ncol)
+T("per-column cat of G slices + unpack", lambda: [
+    (lambda s_: (((s_ << 32) >> 32).to(torch.int32), s_ >> 32))(torch.cat([every[(r * ncol + j) * seg:(r * ncol + j + 1) * seg] for r in range(G)]))
+    for j in range(ncol)])
+cnts = [every[j * seg * G:(j + 1) * seg * G] >> 32 for j in range(ncol)]
+T("class_hist x26", lambda: [K.class_hist(c) for c in cnts])
