@@ -253,3 +253,38 @@ def test_bench_generator_5m_rows_vs_oracle(tmp_path):
         g = out[c].data.cpu().numpy()
         e = ref[c].to_numpy()
         assert float(np.max(np.abs(g - e) / np.maximum(np.abs(e), 1.0))) <= 1e-6, c
+
+
+@pytest.mark.timeout(300)
+def test_merge_counts_sorted_at_exchange_size():
+    """The owner-side merge at the size an 8-rank Criteo fit hands it (~31 M received rows in
+    8 x 26 segments; here 40 M): per column the keys come out strictly ascending, the counts sum
+    to what was received, and a column present in one segment only is returned unchanged."""
+    from nvtabular_amd import kernels as K
+
+    dev = torch.device("cuda", 0)
+    G, ncol, n = 8, 26, 40_000_000
+    g = torch.Generator(device=dev).manual_seed(3)
+    per = n // (G * ncol)
+    off = [s * per for s in range(G * ncol + 1)]
+    n = off[-1]
+    # column j draws its keys from a range of (j + 1) * 100 k ids: heavy overlap between sources
+    col_of_row = (torch.arange(n, device=dev) // per) % ncol
+    span = (col_of_row + 1) * 100_000
+    keys = (torch.rand(n, device=dev, generator=g, dtype=torch.float64) * span).to(torch.int64) - 50_000
+    cnt = torch.randint(1, 1000, (n,), device=dev, dtype=torch.int64, generator=g)
+    rows = (cnt << 32) | (keys & 0xFFFFFFFF)
+    out = K.merge_counts_sorted(rows, off, ncol)
+    assert len(out) == ncol
+    for j, (mk, mc) in enumerate(out):
+        sel = col_of_row == j
+        assert bool((mk[1:] > mk[:-1]).all()), j
+        assert int(mc.sum().item()) == int(cnt[sel].sum().item()), j
+        assert mk.numel() == int(torch.unique(keys[sel]).numel()), j
+    # exactness on one column against a scatter-add
+    j = 5
+    sel = col_of_row == j
+    kj = keys[sel] + 50_000
+    ref = torch.zeros(int(kj.max().item()) + 1, dtype=torch.int64, device=dev).index_add_(0, kj, cnt[sel])
+    mk, mc = out[j]
+    assert torch.equal(ref[(mk.to(torch.int64) + 50_000)], mc)
