@@ -377,7 +377,8 @@ def merge_counts_many(tables):
         all-to-all of the count matrix            (1)
         all-to-all(v) of the (key, count) rows    (1; one int64 word per row for int32 keys
                                                    and counts < 2^31, else int64 pairs)
-        owner-side merge per column (weighted dense count), then ordered BY KEY
+        owner-side merge: ONE sort of the received rows by (column, key) + segmented sum
+        (nvt_count_merge_sorted; else weighted dense count per column, then ordered BY KEY)
         all-gather of the [ncol] merged lengths   (1)
         all-gather(v) of the merged rows          (1)
         all-reduce of the scalars                 (1)
