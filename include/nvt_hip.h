@@ -397,6 +397,31 @@ int nvt_count_merge_sorted_ws_bytes(uint64_t n, uint64_t *bytes);
 int nvt_count_merge_sorted(const int64_t *rows, uint64_t n, const uint64_t *seg_off, int nseg,
                            int ncol, int32_t *out_keys, int64_t *out_col, double *out_sum,
                            uint64_t *state, void *ws, void *stream);
+/* ---- multi-GPU vocabulary exchange: the device work around the collectives (the
+ * reference's tree reduce of per-partition frames, categorify.py:1423-1529).  One launch per step
+ * for ALL columns of a fit (<= 64 columns of int32 keys + int64 counts, ranks x columns <= 4096):
+ *   nvt_exchange_ranges   rng int64[ncol][3] = {-min key, max key, sum of counts}; a column
+ *                         without entries: {-INT64_MAX, -INT64_MAX, 0} (one MAX all-reduce follows)
+ *   nvt_exchange_hist     send_mat uint64[G][ncol] = rows of column j owned by rank g, with
+ *                         owner(key) = min((key - lo[j]) / width[j], G - 1) (key ranges)
+ *   nvt_exchange_scatter  rows_out = (count << 32 | key) words grouped by (owner, column);
+ *                         cursors uint64[G][ncol] (device) = the start of every group, advanced by
+ *                         the call; the order inside a group is unspecified (counts < 2^31)
+ *   nvt_exchange_unpack   n gathered words in nseg segments [seg_off[s], seg_off[s + 1]) ->
+ *                         keys_out / counts_out at dst_off[s] + (position in the segment)
+ * lo / width: HOST arrays; seg_off / dst_off: device arrays.  No host synchronisation. */
+typedef struct nvt_xcol {
+  const int32_t *keys;
+  const int64_t *counts;
+  uint64_t n;
+} nvt_xcol;
+int nvt_exchange_ranges(const nvt_xcol *cols, int ncol, int64_t *rng, void *stream);
+int nvt_exchange_hist(const nvt_xcol *cols, int ncol, const int64_t *lo, const uint64_t *width, int G,
+                      uint64_t *send_mat, void *stream);
+int nvt_exchange_scatter(const nvt_xcol *cols, int ncol, const int64_t *lo, const uint64_t *width, int G,
+                         uint64_t *cursors, int64_t *rows_out, void *stream);
+int nvt_exchange_unpack(const int64_t *words, uint64_t n, const uint64_t *seg_off, const uint64_t *dst_off,
+                        int nseg, int32_t *keys_out, int64_t *counts_out, void *stream);
 /* key -> position in an ascending int32 key list (the group ids of nvt_sgb_regroup) through
  * a flat range table laid out from the list in one pass (no inserts): replaces
  * nvt_gb_index_build + nvt_gb_lookup for such groups (join_groupby.py:198-203,

@@ -105,6 +105,10 @@ SIGNATURES = {
                                C.POINTER(C.c_int), C.POINTER(_dbl), _vp, _vp],
     "nvt_flat_lookup_te": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _i32, _vp, _dbl, _dbl, _vp,
                            _i32, _vp],
+    "nvt_exchange_ranges": [_vp, _i32, _vp, _vp],
+    "nvt_exchange_hist": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp],
+    "nvt_exchange_scatter": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp, _vp],
+    "nvt_exchange_unpack": [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp],
     "nvt_count_merge_sorted_ws_bytes": [_u64, C.POINTER(_u64)],
     "nvt_count_merge_sorted": [_vp, _u64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "nvt_flat_index_tmp_bytes": [_u64, C.POINTER(_u64)],
@@ -113,6 +117,10 @@ SIGNATURES = {
     "nvt_widen_i64": [_vp, _i32, _u64, _vp, _vp],
     "nvt_popcount": [_vp, _u64, _vp, _vp],
 }
+
+
+class XCol(C.Structure):
+    _fields_ = [("keys", _vp), ("counts", _vp), ("n", _u64)]
 
 
 class MomentsCol(C.Structure):

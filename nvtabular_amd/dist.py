@@ -331,6 +331,7 @@ def _mark(name=None):
 PACK_COUNT_ROWS = True  # (tests switch it off to drive the two-word format with int32 keys)
 STATS = {"packed_exchanges": 0, "plain_exchanges": 0, "sorted_merges": 0}  # diagnostics
 MERGE_BY_SORTING = True
+HIP_EXCHANGE = True  # batched nvt_exchange_* launches around the collectives (int32 keys on the GPU)
 
 
 def _pack_kc(k64: torch.Tensor, c64: torch.Tensor) -> torch.Tensor:
@@ -400,20 +401,33 @@ def merge_counts_many(tables):
     dev = tables[0][0].device
     dtypes = [k.dtype for k, _, _ in tables]
     lens = [int(k.numel()) for k, _, _ in tables]
-    k64s = [k.to(torch.int64) for k, _, _ in tables]
     # ---- global key range per column ---------------------------------------------------
     big = torch.iinfo(torch.int64).max
+    # device path: all columns int32 on the GPU -- every step around the collectives is ONE
+    # batched launch (nvt_exchange_*, kernels.ExchangeBatch) instead of ~8 torch kernels per column
+    xb = None
+    if (dev.type == "cuda" and HIP_EXCHANGE and _merge_counts_many_fn is _hip_merge_counts_many
+            and all(dt == torch.int32 for dt in dtypes)):
+        from . import kernels as K
+
+        if ncol <= K.EXCHANGE_MAX_COLS and G * ncol <= K.EXCHANGE_MAX_CELLS:
+            xb = K.ExchangeBatch([(k, c.to(torch.int64)) for k, c, _ in tables])
     # (-min, max, rows counted on this rank): one MAX reduce
-    rng = torch.empty(ncol, 3, dtype=torch.int64, device=dev)
-    for j, (k, (_, c, _)) in enumerate(zip(k64s, tables)):
-        if lens[j]:
-            rng[j, 0] = -(k.min().clamp(min=-big))
-            rng[j, 1] = k.max()
-            rng[j, 2] = c.sum()
-        else:
-            rng[j, 0] = -big
-            rng[j, 1] = -big
-            rng[j, 2] = 0
+    if xb is not None:
+        rng = xb.ranges()
+        k64s = None
+    else:
+        k64s = [k.to(torch.int64) for k, _, _ in tables]
+        rng = torch.empty(ncol, 3, dtype=torch.int64, device=dev)
+        for j, (k, (_, c, _)) in enumerate(zip(k64s, tables)):
+            if lens[j]:
+                rng[j, 0] = -(k.min().clamp(min=-big))
+                rng[j, 1] = k.max()
+                rng[j, 2] = c.sum()
+            else:
+                rng[j, 0] = -big
+                rng[j, 1] = -big
+                rng[j, 2] = 0
     _all_reduce(rng, td.ReduceOp.MAX)
     rng_h = rng.cpu().tolist()
     _mark("ranges")
@@ -423,6 +437,61 @@ def merge_counts_many(tables):
     packed = (all(dt == torch.int32 for dt in dtypes)
               and G * max(r[2] for r in rng_h) < (1 << 31) and PACK_COUNT_ROWS)
     STATS["packed_exchanges" if packed else "plain_exchanges"] += 1
+    if xb is not None and not packed:  # (counts too large for one word: the general path)
+        xb = None
+        k64s = [k.to(torch.int64) for k, _, _ in tables]
+    if xb is not None:
+        send_mat, recv_mat, send_h, recv_h, recv = _exchange_rows_hip(xb, rng_h, G, ncol)
+    else:
+        send_mat, recv_mat, send_h, recv_h, recv = _exchange_rows_torch(
+            tables, k64s, lens, rng_h, G, ncol, dev, packed)
+    _mark("all_to_all")
+    # ---- owner-side merge, column by column, then key order -----------------------------
+    off = torch.zeros(G * ncol + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
+    off = off.tolist()
+    sorted_merge, results, packed_all = None, {}, None
+    if packed and recv.is_cuda and _merge_counts_many_fn is _hip_merge_counts_many and MERGE_BY_SORTING:
+        from . import kernels as K
+
+        if 0 < recv.numel() <= K.MERGE_SORTED_MAX_ROWS and ncol <= K.MERGE_SORTED_MAX_COLS:
+            # ONE sort of all received rows by (column, key) + a segmented sum: the merged lists
+            # come out ordered by key (no hash tables, no per-column sort afterwards)
+            sorted_merge, packed_all, packed_len = K.merge_counts_sorted(recv, off, ncol, want_packed=True)
+            STATS["sorted_merges"] += 1
+    return _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted_merge,
+                                packed_all, packed_len if sorted_merge is not None else None,
+                                xb is not None)
+
+
+def _exchange_rows_hip(xb, rng_h, G, ncol):
+    """Send side on the device path: count matrix, send buffer grouped by (owner, column), the
+    all-to-all(v).  (The order of the rows inside a group is unspecified: the owner sorts.)"""
+    big = torch.iinfo(torch.int64).max
+    los, widths = [], []
+    for j in range(ncol):
+        lo, hi = -rng_h[j][0], rng_h[j][1]
+        if hi == -big:  # no entry on any rank
+            lo, hi = 0, 0
+        los.append(lo)
+        widths.append(max(1, -(-(hi - lo + 1) // G)))
+    send_mat = xb.hist(los, widths, G)
+    _mark("group_rows")
+    if _backend() == "nccl":
+        recv_mat = torch.empty_like(send_mat)
+        td.all_to_all_single(recv_mat, send_mat.contiguous())
+    else:
+        recv_mat = torch.stack([m[rank()] for m in _all_gather_same(send_mat.contiguous())])
+    send_h, recv_h = send_mat.cpu(), recv_mat.cpu()
+    starts = torch.zeros(G * ncol, dtype=torch.int64)
+    starts[1:] = torch.cumsum(send_h.reshape(-1), 0)[:-1]
+    rows = xb.scatter(los, widths, G, starts.to(send_mat.device))
+    recv = _all_to_all_v(rows, send_h.sum(1).tolist(), recv_h.sum(1).tolist())
+    return send_mat, recv_mat, send_h, recv_h, recv
+
+
+def _exchange_rows_torch(tables, k64s, lens, rng_h, G, ncol, dev, packed):
+    """Send side, general path (any key dtype, host tensors of the gloo tests)."""
     # ---- rows grouped by (owner, column) --------------------------------------------
     own_parts, dest_parts = [], []
     for j, k in enumerate(k64s):
@@ -457,20 +526,14 @@ def merge_counts_many(tables):
         recv_mat = torch.stack([m[rank()] for m in _all_gather_same(send_mat.contiguous())])
     send_h, recv_h = send_mat.cpu(), recv_mat.cpu()
     recv = _all_to_all_v(rows[order].contiguous(), send_h.sum(1).tolist(), recv_h.sum(1).tolist())
-    _mark("all_to_all")
-    # ---- owner-side merge, column by column, then key order -----------------------------
-    off = torch.zeros(G * ncol + 1, dtype=torch.int64)
-    off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
-    off = off.tolist()
-    sorted_merge, results = None, {}
-    if packed and recv.is_cuda and _merge_counts_many_fn is _hip_merge_counts_many and MERGE_BY_SORTING:
-        from . import kernels as K
+    return send_mat, recv_mat, send_h, recv_h, recv
 
-        if 0 < recv.numel() <= K.MERGE_SORTED_MAX_ROWS and ncol <= K.MERGE_SORTED_MAX_COLS:
-            # ONE sort of all received rows by (column, key) + a segmented sum: the merged lists
-            # come out ordered by key (no hash tables, no per-column sort afterwards)
-            sorted_merge = K.merge_counts_sorted(recv, off, ncol)
-            STATS["sorted_merges"] += 1
+
+def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted_merge, packed_all,
+                         packed_len, device_path):
+    """Owner-side merge (when the sorted merge did not already do it), all-gather of the merged
+    shards, the per-column lists every rank ends with."""
+    results = {}
     if sorted_merge is None:
         parts = []
         for j in range(ncol):
@@ -488,8 +551,7 @@ def merge_counts_many(tables):
     merged = []
     for j in range(ncol):
         if sorted_merge is not None:
-            mk, mc = sorted_merge[j]
-            merged.append(_pack_kc(mk.to(torch.int64), mc))
+            break  # (packed_all below: the merged rows of all columns, packed once)
         elif j in results:
             mk, mc = _sort_by_key_fn(*results[j])
             merged.append(_pack_kc(mk.to(torch.int64), mc.to(torch.int64)) if packed
@@ -498,9 +560,13 @@ def merge_counts_many(tables):
             merged.append(torch.empty((0,) if packed else (0, 2), dtype=torch.int64, device=dev))
     _mark("owner_merge")
     # ---- replicate: every rank gets every owner's share, rank (= key range) order -------------
-    mlen = torch.tensor([m.shape[0] for m in merged], dtype=torch.int64, device=dev)
+    if sorted_merge is not None:
+        mine, mlen = packed_all, torch.tensor(packed_len, dtype=torch.int64, device=dev)
+    else:
+        mine = torch.cat(merged)
+        mlen = torch.tensor([m.shape[0] for m in merged], dtype=torch.int64, device=dev)
     all_len = torch.stack(_all_gather_same(mlen)).cpu()  # [G, ncol]
-    everything = _all_gather_v(torch.cat(merged), sizes=all_len.sum(1).tolist())
+    everything = _all_gather_v(mine, sizes=all_len.sum(1).tolist())
     _mark("all_gather")
     goff = torch.zeros(G * ncol + 1, dtype=torch.int64)
     goff[1:] = torch.cumsum(all_len.reshape(-1), 0)
@@ -511,12 +577,34 @@ def merge_counts_many(tables):
     _all_reduce(scal)
     scal = scal.cpu().tolist()
     out = []
+    unpacked = None
+    if device_path and packed and everything.is_cuda and everything.numel():
+        # column-major in ONE launch: segment (r, j) lands behind the shares of the ranks < r of
+        # column j, so every column is one contiguous key-ordered list
+        from . import kernels as K
+
+        col_tot = [int(t) for t in all_len.sum(0).tolist()]
+        col_start = [0]  # every column starts on a 16-byte boundary of both arrays
+        for t in col_tot:
+            col_start.append(col_start[-1] + (t + 3) // 4 * 4)
+        dst = [0] * (G * ncol)
+        for j in range(ncol):
+            at = col_start[j]
+            for r in range(G):
+                dst[r * ncol + j] = at
+                at += int(all_len[r, j])
+        keys_all, cnts_all = K.exchange_unpack(everything, goff, dst, col_start[-1])
+        unpacked = [(keys_all[col_start[j]:col_start[j] + col_tot[j]],
+                     cnts_all[col_start[j]:col_start[j] + col_tot[j]]) for j in range(ncol)]
     for j in range(ncol):
-        seg = torch.cat([everything[goff[r * ncol + j] : goff[r * ncol + j + 1]] for r in range(G)])
-        if packed:
-            keys, counts = _unpack_kc(seg, dtypes[j])
+        if unpacked is not None:
+            keys, counts = unpacked[j]
         else:
-            keys, counts = seg[:, 0].contiguous().to(dtypes[j]), seg[:, 1].contiguous()
+            seg = torch.cat([everything[goff[r * ncol + j] : goff[r * ncol + j + 1]] for r in range(G)])
+            if packed:
+                keys, counts = _unpack_kc(seg, dtypes[j])
+            else:
+                keys, counts = seg[:, 0].contiguous().to(dtypes[j]), seg[:, 1].contiguous()
         info = None
         if keys.numel():
             hist = _class_hist_fn(counts)

@@ -1607,14 +1607,81 @@ def flat_index_for(comp) -> "FlatIndex":
     return index
 
 
+EXCHANGE_MAX_COLS, EXCHANGE_MAX_CELLS = 64, 4096   # include/nvt_hip.h nvt_exchange_*
+
+
+class ExchangeBatch:
+    """The (keys int32, counts int64) lists of ALL columns of a fit as one descriptor array for
+    the nvt_exchange_* launches of dist.merge_counts_many."""
+
+    def __init__(self, tables):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.keep = [(k.contiguous(), c.contiguous()) for k, c in tables]
+        self.ncol = len(self.keep)
+        self.total = sum(int(k.numel()) for k, _ in self.keep)
+        self.dev = self.keep[0][0].device
+        self.cols = (_lib.XCol * self.ncol)()
+        for j, (k, c) in enumerate(self.keep):
+            assert k.dtype == torch.int32 and c.dtype == torch.int64
+            self.cols[j].keys, self.cols[j].counts, self.cols[j].n = ptr(k) or 0, ptr(c) or 0, int(k.numel())
+
+    def ranges(self) -> torch.Tensor:
+        """int64[ncol, 3] = (-min key, max key, sum of counts); a column without entries:
+        (-INT64_MAX, -INT64_MAX, 0)."""
+        rng = torch.empty((self.ncol, 3), dtype=torch.int64, device=self.dev)
+        check(self.lib.nvt_exchange_ranges(self.cols, self.ncol, rng.data_ptr(), stream_ptr()),
+              "nvt_exchange_ranges")
+        return rng
+
+    def _owner_args(self, lo, width):
+        return ((C.c_int64 * self.ncol)(*[int(v) for v in lo]),
+                (C.c_uint64 * self.ncol)(*[max(1, int(v)) for v in width]))
+
+    def hist(self, lo, width, G) -> torch.Tensor:
+        """int64[G, ncol]: rows of column j whose key range belongs to rank g."""
+        mat = torch.empty((G, self.ncol), dtype=torch.int64, device=self.dev)
+        a, b = self._owner_args(lo, width)
+        check(self.lib.nvt_exchange_hist(self.cols, self.ncol, a, b, G, mat.data_ptr(), stream_ptr()),
+              "nvt_exchange_hist")
+        return mat
+
+    def scatter(self, lo, width, G, starts: torch.Tensor) -> torch.Tensor:
+        """(count << 32 | key) words grouped by (owner, column); ``starts`` int64[G, ncol] (device)
+        = the first position of every group (consumed: advanced to the group ends)."""
+        rows = torch.empty(self.total, dtype=torch.int64, device=self.dev)
+        a, b = self._owner_args(lo, width)
+        check(self.lib.nvt_exchange_scatter(self.cols, self.ncol, a, b, G, starts.data_ptr(),
+                                            rows.data_ptr(), stream_ptr()), "nvt_exchange_scatter")
+        return rows
+
+
+def exchange_unpack(words: torch.Tensor, seg_off: List[int], dst_off: List[int], out_n: int):
+    """Gathered (count << 32 | key) words in segments -> (keys int32[out_n], counts int64[out_n]),
+    segment s copied to position dst_off[s] (column-major: every column one contiguous list)."""
+    _lib.require_gpu()
+    n = int(words.numel())
+    dev = words.device
+    keys = torch.empty(out_n, dtype=torch.int32, device=dev)
+    cnts = torch.empty(out_n, dtype=torch.int64, device=dev)
+    so = torch.tensor(seg_off, dtype=torch.int64, device=dev)
+    do = torch.tensor(dst_off, dtype=torch.int64, device=dev)
+    check(_lib.load().nvt_exchange_unpack(words.contiguous().data_ptr(), n, so.data_ptr(), do.data_ptr(),
+                                          len(seg_off) - 1, keys.data_ptr(), cnts.data_ptr(),
+                                          stream_ptr()), "nvt_exchange_unpack")
+    return keys, cnts
+
+
 MERGE_SORTED_MAX_ROWS = (1 << 26) - 1   # include/nvt_hip.h nvt_count_merge_sorted
 MERGE_SORTED_MAX_COLS = 64
 
 
-def merge_counts_sorted(rows: torch.Tensor, seg_off: List[int], ncol: int):
+def merge_counts_sorted(rows: torch.Tensor, seg_off: List[int], ncol: int, want_packed=False):
     """nvt_count_merge_sorted: owner-side merge of received (count << 32 | int32 key) rows lying in
     len(seg_off) - 1 segments (source-major, column-minor).  Returns [(keys int32, counts
-    int64)] per column, every list ordered by key.  One read-back (groups per column)."""
+    int64)] per column, every list ordered by key.  One read-back (groups per column).
+    want_packed: also the merged rows of all columns as ONE (count << 32 | key) array, column
+    after column (what the all-gather sends), and the per-column lengths."""
     _lib.require_gpu()
     lib = _lib.load()
     dev = rows.device
@@ -1622,7 +1689,8 @@ def merge_counts_sorted(rows: torch.Tensor, seg_off: List[int], ncol: int):
     empty = lambda: (torch.empty(0, dtype=torch.int32, device=dev),  # noqa: E731
                      torch.empty(0, dtype=torch.int64, device=dev))
     if n == 0:
-        return [empty() for _ in range(ncol)]
+        out = [empty() for _ in range(ncol)]
+        return (out, torch.empty(0, dtype=torch.int64, device=dev), [0] * ncol) if want_packed else out
     rows = rows.contiguous()
     off = torch.tensor(seg_off, dtype=torch.int64, device=dev)
     need = C.c_uint64()
@@ -1637,12 +1705,17 @@ def merge_counts_sorted(rows: torch.Tensor, seg_off: List[int], ncol: int):
                                      state.data_ptr(), ws.data_ptr(), stream_ptr()),
           "nvt_count_merge_sorted")
     g = int(read_back(state)[_lib.ST_OCCUPIED])
-    per_col = read_back(torch.bincount(col[:g], minlength=ncol).to(torch.int64)).tolist()
-    out, lo = [], 0
+    # groups are ordered by (column, key): the first group of column j = groups of smaller columns
+    bounds = torch.searchsorted(col[:g], torch.arange(ncol + 1, dtype=torch.int64, device=dev))
+    bounds = read_back(bounds.to(torch.int64)).tolist()
+    counts = sums[:g].to(torch.int64)
+    out = []
     for j in range(ncol):
-        hi = lo + int(per_col[j])
-        out.append((keys[lo:hi], sums[lo:hi].to(torch.int64)) if hi > lo else empty())
-        lo = hi
+        lo, hi = int(bounds[j]), int(bounds[j + 1])
+        out.append((keys[lo:hi], counts[lo:hi]) if hi > lo else empty())
+    if want_packed:
+        packed = (counts << 32) | (keys[:g].to(torch.int64) & 0xFFFFFFFF)
+        return out, packed, [int(bounds[j + 1]) - int(bounds[j]) for j in range(ncol)]
     return out
 
 

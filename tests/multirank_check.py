@@ -41,6 +41,26 @@ def stat_graph(path):
 
 
 got_s = stat_graph(os.path.join(tmp, f"s{rank}")).fit_transform(nvt.Dataset(mine)).to_ddf().compute()
+
+
+def int32_frame(r, n=300_000):
+    # every categorical int32 (what the bench feeds): the exchange takes the device path --
+    # nvt_exchange_* launches, (count << 32 | key) rows, owner merge by sorting
+    rng = np.random.default_rng(500 + r)
+    return pd.DataFrame({
+        "p": (np.minimum(rng.zipf(1.15, n), 200_000) * 2654435761 % 2**31).astype("int32"),
+        "q": rng.integers(-40, 40, n).astype("int32"),
+        "s": (rng.integers(0, 3_000_000, n) - 1_500_000).astype("int32"),
+        "t": np.full(n, 7 + r, dtype="int32")})
+
+
+from nvtabular_amd import dist as _dist
+
+before = dict(_dist.STATS)
+wf32 = nvt.Workflow(["p", "q", "s", "t"] >> ops.Categorify(out_path=os.path.join(tmp, f"i{rank}")))
+got32 = wf32.fit_transform(nvt.Dataset(int32_frame(rank))).to_ddf().compute()
+assert _dist.STATS["sorted_merges"] == before["sorted_merges"] + 1, _dist.STATS
+assert _dist.STATS["packed_exchanges"] == before["packed_exchanges"] + 1, _dist.STATS
 td.barrier()
 # single-process reference on the union (world_size() is 1 inside this block)
 td.destroy_process_group()
@@ -65,5 +85,12 @@ for c in got_s.columns:
     else:
         np.testing.assert_allclose(got_s[c].to_numpy().astype("float64"), exp_s[c].to_numpy().astype("float64"),
                                    rtol=1e-6, atol=1e-7, err_msg=c)
+full32 = pd.concat([int32_frame(r) for r in range(world)], ignore_index=True)
+ref32 = nvt.Workflow(["p", "q", "s", "t"] >> ops.Categorify(out_path=os.path.join(tmp, f"refi{rank}")))
+exp32 = ref32.fit_transform(nvt.Dataset(full32)).to_ddf().compute()
+lo32 = sum(len(int32_frame(r)) for r in range(rank))
+exp32 = exp32.iloc[lo32: lo32 + len(got32)].reset_index(drop=True)
+for c in ("p", "q", "s", "t"):
+    np.testing.assert_array_equal(got32[c].to_numpy(), exp32[c].to_numpy(), err_msg=c)
 print(f"rank {rank}: multi-rank fit == single-process fit of the union "
       f"({len(mine)} of {len(full)} rows, vocab a = {int(exp_all['a'].max()) - 2})", flush=True)

@@ -375,3 +375,62 @@ def test_merge_counts_sorted_vs_numpy():
         np.testing.assert_array_equal(gk.cpu().numpy(), uk)
         np.testing.assert_array_equal(gc.cpu().numpy(), exp)
     assert K.merge_counts_sorted(rows[:0], [0] * (G * ncol + 1), ncol)[0][0].numel() == 0
+
+
+def test_exchange_batch_kernels_vs_torch():
+    """nvt_exchange_ranges / _hist / _scatter / _unpack (the device work around the collectives of
+    dist.merge_counts_many) against the torch formulation they replace."""
+    from nvtabular_amd import dist
+    from nvtabular_amd import kernels as K
+
+    rng = np.random.default_rng(4)
+    dev = "cuda"
+    G = 8
+    sizes = [200_000, 0, 3, 77_777, 1, 4096, 4097, 50_000, 10, 123_456]
+    tabs = []
+    for j, m in enumerate(sizes):
+        k = np.unique(rng.integers(-2**31, 2**31 - 1, m, dtype=np.int64)).astype(np.int32) if j % 2 == 0 \
+            else np.unique(rng.integers(-1000 * j, 5000 * j + 5, m)).astype(np.int32)
+        if j == 0:
+            k = np.unique(np.concatenate([k, np.array([-2**31, 2**31 - 1], dtype=np.int32)]))
+        rng.shuffle(k)  # lists need not be sorted
+        c = rng.integers(1, 10_000, k.size).astype(np.int64)
+        tabs.append((torch.from_numpy(k).to(dev), torch.from_numpy(c).to(dev)))
+    ncol = len(tabs)
+    xb = K.ExchangeBatch(tabs)
+    got = xb.ranges().cpu().numpy()
+    big = np.iinfo(np.int64).max
+    for j, (k, c) in enumerate(tabs):
+        if k.numel():
+            assert got[j].tolist() == [-int(k.min()), int(k.max()), int(c.sum())], j
+        else:
+            assert got[j].tolist() == [-big, -big, 0]
+    los = [int(k.min()) if k.numel() else 0 for k, _ in tabs]
+    his = [int(k.max()) if k.numel() else 0 for k, _ in tabs]
+    widths = [max(1, -(-(h - l + 1) // G)) for l, h in zip(los, his)]
+    owners = [dist._range_owner(k.to(torch.int64), l, h, G) if k.numel() else k.to(torch.int64)
+              for (k, _), l, h in zip(tabs, los, his)]
+    exp_mat = torch.stack([torch.bincount(o, minlength=G) for o in owners], dim=1)  # [G, ncol]
+    mat = xb.hist(los, widths, G)
+    assert torch.equal(mat, exp_mat)
+    flat = exp_mat.reshape(-1).cpu()
+    starts = torch.zeros(G * ncol, dtype=torch.int64)
+    starts[1:] = torch.cumsum(flat, 0)[:-1]
+    cur = starts.to(dev)
+    rows = xb.scatter(los, widths, G, cur)
+    assert torch.equal(cur.cpu(), starts + flat)  # cursors advanced to the group ends
+    for g in range(G):
+        for j, (k, c) in enumerate(tabs):
+            a, b = int(starts[g * ncol + j]), int(starts[g * ncol + j] + flat[g * ncol + j])
+            sel = owners[j] == g
+            exp = ((c[sel] << 32) | (k[sel].to(torch.int64) & 0xFFFFFFFF)).sort().values
+            assert torch.equal(rows[a:b].sort().values, exp), (g, j)
+    # unpack: segments to arbitrary destinations
+    seg_off = [0, 5, 5, 1000, int(rows.numel())]
+    dst_off = [int(rows.numel()) - 5 + 8, 0, 8 + int(rows.numel()) - 1000, 8]
+    keys, cnts = K.exchange_unpack(rows, seg_off, dst_off, int(rows.numel()) + 16)
+    for s in range(4):
+        a, b = seg_off[s], seg_off[s + 1]
+        w = rows[a:b]
+        assert torch.equal(keys[dst_off[s]:dst_off[s] + b - a], ((w << 32) >> 32).to(torch.int32))
+        assert torch.equal(cnts[dst_off[s]:dst_off[s] + b - a], w >> 32)

@@ -52,3 +52,23 @@ T("per-column cat of G slices + unpack", lambda: [
     for j in range(ncol)])
 cnts = [every[j * seg * G:(j + 1) * seg * G] >> 32 for j in range(ncol)]
 T("class_hist x26", lambda: [K.class_hist(c) for c in cnts])
+
+print("---- device path (nvt_exchange_*) ----")
+tabs = [(k, c) for k, c in cols]
+xb = K.ExchangeBatch(tabs)
+T("ExchangeBatch.ranges", lambda: xb.ranges())
+los = [int(k.min()) if k.numel() else 0 for k, _ in cols]
+his = [int(k.max()) if k.numel() else 0 for k, _ in cols]
+widths = [max(1, -(-(h - l + 1) // G)) for l, h in zip(los, his)]
+mat = T("ExchangeBatch.hist", lambda: xb.hist(los, widths, G))
+flat = mat.reshape(-1).cpu()
+starts = torch.zeros(G * ncol, dtype=torch.int64)
+starts[1:] = torch.cumsum(flat, 0)[:-1]
+T("ExchangeBatch.scatter", lambda: xb.scatter(los, widths, G, starts.to(dev)))
+T("merge_counts_sorted(want_packed)", lambda: K.merge_counts_sorted(recv, off, ncol, want_packed=True))
+goff = [s * seg for s in range(G * ncol + 1)]
+dst = [0] * (G * ncol)
+for j in range(ncol):
+    for r in range(G):
+        dst[r * ncol + j] = (j * G + r) * seg
+T("exchange_unpack", lambda: K.exchange_unpack(every[: goff[-1]], goff, dst, goff[-1]))
