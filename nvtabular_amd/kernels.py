@@ -327,7 +327,7 @@ def count_into_new_table(
 # --------------------------------------------------------------------------
 # Categorify.fit, atomic-free: dense (key, count) lists
 # --------------------------------------------------------------------------
-PATH_S_MAX_DISTINCT = 11000         # path 0 (int32 keys, unweighted): 16384-slot LDS tables
+PATH_S_MAX_DISTINCT = int(os.environ.get("NVT_S_MAX", 11000))          # path 0 (int32 keys, unweighted): 16384-slot LDS tables
 PATH_S_MAX_WEIGHTED = 5000          # path 0 for weighted merges / int64 keys: 8192 slots
 # Path 7 = path 0 with 2 key classes per row slab (column read twice): 350 us against 420 us on
 # path 1 for 12-21 k distinct keys.
