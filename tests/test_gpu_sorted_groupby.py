@@ -434,3 +434,31 @@ def test_exchange_batch_kernels_vs_torch():
         w = rows[a:b]
         assert torch.equal(keys[dst_off[s]:dst_off[s] + b - a], ((w << 32) >> 32).to(torch.int32))
         assert torch.equal(cnts[dst_off[s]:dst_off[s] + b - a], w >> 32)
+
+
+def test_clustered_keys_fall_back_to_a_hashed_index(tmp_path):
+    """Dense ids plus one far outlier: the sort path still aggregates, but the flat index would have
+    every key in the same home slot (displacement > 4096) -> JoinGroupby / TargetEncoding look the
+    groups up through a hashed index built from the sorted keys; results unchanged."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(17)
+    n = 90_000
+    k = rng.integers(0, 40_000, n).astype(np.int32)
+    k[:5] = 2**31 - 7
+    df = pd.DataFrame({"k": k, "x": rng.normal(size=n), "y": (rng.random(n) < 0.4).astype("float32")})
+    jg = ops.JoinGroupby(out_path=str(tmp_path / "jg"), stats=["count", "mean"], cont_cols=["x"])
+    te = ops.TargetEncoding("y", out_path=str(tmp_path / "te"), kfold=4, fold_seed=1, p_smooth=10)
+    wf = nvt.Workflow((["k"] >> jg) + (["k"] >> te)).fit(nvt.Dataset(df))
+    assert isinstance(jg._device_stats["k"].index, K.GroupbyTable)
+    got = wf.transform(nvt.Dataset(df)).to_ddf().compute()
+    cats = O.join_groupby_fit([df.copy()], ["k"], ["x"], ["count", "mean"], str(tmp_path / "c"))
+    exp_j = O.join_groupby_transform(df.copy(), ["k"], cats)
+    st, means = O.target_encoding_fit([df.copy()], ["k"], ["y"], str(tmp_path / "c2"), kfold=4, fold_seed=1)
+    exp_t = O.target_encoding_transform(df[["k", "y"]].copy(), ["k"], ["y"], st, means, kfold=4, fold_seed=1,
+                                        p_smooth=10)
+    np.testing.assert_array_equal(got["k_count"].to_numpy(), exp_j["k_count"].to_numpy())
+    np.testing.assert_allclose(got["k_x_mean"].to_numpy(), exp_j["k_x_mean"].to_numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["TE_k_y"].to_numpy(), exp_t["TE_k_y"].to_numpy(), rtol=1e-5, atol=1e-6)
