@@ -91,10 +91,54 @@ def expected(inp):
     return out
 
 
+# ---- second fixture: ONE int32 key column without nulls, enough rows for the engine's sort path
+# of the single-key groupby (JoinGroupby / TargetEncoding, >= 32768 rows) --------------------------
+def make_inputs_groupby():
+    rng = np.random.default_rng(20260924)
+    n = 36_000
+    ids = rng.integers(-(2**31), 2**31 - 1, 6_000, dtype=np.int64).astype(np.int32)
+    key = ids[(rng.random(n) ** 3 * ids.size).astype(np.int64)]      # skewed frequencies
+    x = rng.normal(1.0, 4.0, size=n)
+    y = (rng.random(n) < 0.25).astype(np.float32)
+    null_x = rng.random(n) < 0.1
+    return dict(key=key, x=x, y=y, null_x=null_x)
+
+
+def oracle_frame_groupby(inp):
+    x = pd.Series(inp["x"].copy())
+    x[inp["null_x"]] = np.nan
+    return pd.DataFrame({"k": inp["key"], "x": x, "y": inp["y"]})
+
+
+def expected_groupby(inp):
+    df = oracle_frame_groupby(inp)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        stats = ["count", "sum", "mean", "std", "min", "max"]
+        cats = O.join_groupby_fit([df.copy()], ["k"], ["x"], stats, tmp + "/jg")
+        jg = O.join_groupby_transform(df.copy(), ["k"], cats)
+        for c in sorted(jg.columns):
+            if c not in ("k", "x", "y"):
+                out["jg_" + c] = jg[c].to_numpy()  # (count int32, mean / std float32, the rest float64)
+        for kfold, seed in ((5, 42), (1, None)):
+            st, means = O.target_encoding_fit([df.copy()], ["k"], ["y"], tmp + f"/te{kfold}", kfold=kfold,
+                                              fold_seed=seed)
+            te = O.target_encoding_transform(df[["k", "y"]].copy(), ["k"], ["y"], st, means, kfold=kfold,
+                                             fold_seed=seed, p_smooth=20)
+            out[f"te_k{kfold}"] = te["TE_k_y"].to_numpy().astype(np.float32)
+    return out
+
+
 def main():
     inp = make_inputs()
     exp = expected(inp)
     np.savez_compressed(os.path.join(HERE, "hotpath_v1.npz"),
+                        **{"in_" + k: v for k, v in inp.items()},
+                        **{"out_" + k: v for k, v in exp.items()})
+    print({k: (v.shape, v.dtype) for k, v in exp.items()})
+    inp = make_inputs_groupby()
+    exp = expected_groupby(inp)
+    np.savez_compressed(os.path.join(HERE, "groupby_v1.npz"),
                         **{"in_" + k: v for k, v in inp.items()},
                         **{"out_" + k: v for k, v in exp.items()})
     print({k: (v.shape, v.dtype) for k, v in exp.items()})
