@@ -548,11 +548,9 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
             results = dict(zip(live, _merge_counts_many_fn([parts[j] for j in live])))
         else:
             results = {j: _merge_counts_fn(*parts[j]) for j in live}
-    merged = []
-    for j in range(ncol):
-        if sorted_merge is not None:
-            break  # (packed_all below: the merged rows of all columns, packed once)
-        elif j in results:
+    merged = []  # (sorted merge: packed_all already holds the merged rows of all columns)
+    for j in range(ncol if sorted_merge is None else 0):
+        if j in results:
             mk, mc = _sort_by_key_fn(*results[j])
             merged.append(_pack_kc(mk.to(torch.int64), mc.to(torch.int64)) if packed
                           else torch.stack([mk.to(torch.int64), mc.to(torch.int64)], dim=1))
