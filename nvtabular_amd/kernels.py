@@ -1578,12 +1578,13 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
     def rows(mat, m):
         return [mat[j, :m] for j in range(nvals)] if mat is not None else []
 
-    def no_inf(cols):
-        return [torch.where(torch.isinf(c), torch.full_like(c, nan), c) for c in cols]
+    def untouched(cols, init):  # a group without a valid value keeps the initial +-inf: NaN, as
+        return [torch.where(c == init, torch.full_like(c, nan), c) for c in cols]  # nvt_gb_compact
 
     out = dict(keys=[grp["k64"]], keys32=grp["k32"],
                null_mask=torch.zeros(g, dtype=torch.uint8, device=dev),
-               sumsq=rows(fsq, g), min=no_inf(rows(fmin, g)), max=no_inf(rows(fmax, g)), n=g,
+               sumsq=rows(fsq, g), min=untouched(rows(fmin, g), float("inf")),
+               max=untouched(rows(fmax, g), float("-inf")), n=g,
                sorted=True, shared=grp["shared"], key_offset=hit["bias"] + (1 << 31))
     if kfold > 1:
         out["size"], out["sum"] = tsize[:g], rows(tsum, g)
