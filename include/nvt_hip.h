@@ -598,16 +598,7 @@ int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream);
  * opaque handle (a hipEvent_t without timing). */
 int nvt_event_create(void **event);
 void nvt_event_destroy(void *event);
-int nvt_event_record(void *event, void *stream);
 int nvt_stream_wait_event(void *stream, void *event);
-/* nvt_vocab_finalize_many whose internal streams start behind `after_event` (recorded by the
- * caller, nvt_event_record, at a point where the counted lists AND every buffer named in the
- * descriptors existed) instead of behind everything queued on `stream` so far: a finalisation
- * deferred to its first consumer (categorify.py:1300-1334 run lazily) then overlaps the kernels
- * the caller enqueued in between.  Work that stays on `stream` (the small vocabularies) is
- * ordered as before.  after_event == NULL: exactly nvt_vocab_finalize_many. */
-int nvt_vocab_finalize_many_after(const nvt_vocab_col *cols, int ncols, void *stream,
-                                  void *after_event);
 
 /* ---- device -> host read-back of a few words without a blocking runtime wait ----------
  * The fit needs two tiny read-backs per partition (the counting kernels' state words, the

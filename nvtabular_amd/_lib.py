@@ -168,8 +168,6 @@ SIGNATURES.update({
     "nvt_event_create": [_pp],
     "nvt_event_destroy": [_vp],
     "nvt_stream_wait_event": [_vp, _vp],
-    "nvt_event_record": [_vp, _vp],
-    "nvt_vocab_finalize_many_after": [C.POINTER(VocabCol), _i32, _vp, _vp],
     "nvt_mailbox_create": [_u64, _pp],
     "nvt_mailbox_destroy": [_vp],
     "nvt_mailbox_data": [_vp],

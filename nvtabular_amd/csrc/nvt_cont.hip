@@ -701,8 +701,7 @@ int nvt_fill_normalize_many(const nvt_fillnorm_col *cols, int ncols, void *strea
       f.filled = c.filled;
       f.has_fill = c.has_fill;
       f.do_norm = c.do_norm;
-      static const unsigned bpc = getenv("NVT_FN_BPC") ? (unsigned)atoi(getenv("NVT_FN_BPC")) : 8u;
-      const unsigned g = stream_grid(c.n / (16 / dtype_bytes(dt)) + 1, kBlock * 2, bpc);
+      const unsigned g = stream_grid(c.n / (16 / dtype_bytes(dt)) + 1, kBlock * 2, 8);
       grid = g > grid ? g : grid;
       bytes += c.n * (uint64_t)(dtype_bytes(dt) + dtype_bytes(odt));
       if (live == kBatchCols) {

@@ -29,25 +29,13 @@ constexpr int kSide = kSideStreams;
 using namespace nvt;
 
 static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_s, SidePool *&pool,
-                         bool &forked, hipEvent_t after);
-
-extern "C" int nvt_vocab_finalize_many_after(const nvt_vocab_col *cols, int ncols, void *stream,
-                                             void *after_event);
+                         bool &forked);
 
 extern "C" int nvt_vocab_finalize_many(const nvt_vocab_col *cols, int ncols, void *stream) {
-  return nvt_vocab_finalize_many_after(cols, ncols, stream, nullptr);
-}
-
-// after_event != NULL: the internal streams start behind THAT event (recorded by the caller when
-// the inputs and every buffer named in the descriptors were ready) instead of behind everything
-// queued on `stream` so far -- work the caller enqueued in between (fill + normalize of the
-// transform that triggered a deferred finalisation) runs concurrently with the ordering passes
-extern "C" int nvt_vocab_finalize_many_after(const nvt_vocab_col *cols, int ncols, void *stream,
-                                             void *after_event) {
   NVT_CHECK_ARG(ncols == 0 || cols, "null descriptors");
   SidePool *pool = nullptr;
   bool forked = false;
-  const int rc = finalize_impl(cols, ncols, (hipStream_t)stream, pool, forked, (hipEvent_t)after_event);
+  const int rc = finalize_impl(cols, ncols, (hipStream_t)stream, pool, forked);
   if (rc != NVT_OK && forked && pool != nullptr) {
     // an error after the fork: whatever was launched keeps running on the internal streams; join
     // them into the caller's stream so that it may free / reuse the buffers it handed over
@@ -60,7 +48,7 @@ extern "C" int nvt_vocab_finalize_many_after(const nvt_vocab_col *cols, int ncol
 }
 
 static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_s, SidePool *&pool,
-                         bool &forked, hipEvent_t after) {
+                         bool &forked) {
   std::vector<int> small, big;
   for (int i = 0; i < ncols; ++i) {
     const nvt_vocab_col &c = cols[i];
@@ -81,9 +69,8 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
     int rc = side_pool(0, &pool);
     if (rc) return rc;
     forked = true;
-    if (after == nullptr) NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
-    for (int i = 0; i < kSide; ++i)
-      NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[i], after ? after : pool->fork, 0));
+    NVT_CHECK_HIP(hipEventRecord(pool->fork, main_s));
+    for (int i = 0; i < kSide; ++i) NVT_CHECK_HIP(hipStreamWaitEvent(pool->s[i], pool->fork, 0));
   }
   // with a ready_event the vocabulary's stream is not joined into `stream`: the event is
   // recorded behind its last kernel and the consumer waits on it
@@ -187,11 +174,6 @@ extern "C" int nvt_event_create(void **event) {
 }
 extern "C" void nvt_event_destroy(void *event) {
   if (event) (void)hipEventDestroy((hipEvent_t)event);
-}
-extern "C" int nvt_event_record(void *event, void *stream) {
-  NVT_CHECK_ARG(event, "null event");
-  NVT_CHECK_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
-  return NVT_OK;
 }
 extern "C" int nvt_stream_wait_event(void *stream, void *event) {
   NVT_CHECK_ARG(event, "null event");

@@ -95,10 +95,6 @@ class Event:
         check(_lib.load().nvt_event_create(C.byref(h)), "nvt_event_create")
         self.handle = h
 
-    def record(self, stream: Optional[int] = None):
-        check(_lib.load().nvt_event_record(self.handle, stream_ptr() if stream is None else stream),
-              "nvt_event_record")
-
     def wait(self, stream: Optional[int] = None):
         check(_lib.load().nvt_stream_wait_event(stream_ptr() if stream is None else stream,
                                                 self.handle), "nvt_stream_wait_event")

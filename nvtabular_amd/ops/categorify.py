@@ -48,8 +48,6 @@ def _pick(opt, name, default=None):
 
 MERGE_FAN_IN = 8
 LAZY_FINALIZE = os.environ.get("NVT_LAZY_FINALIZE", "1") != "0"
-# deferred finalisation starts behind an event recorded at the end of fit (buffers allocated there)
-PRESTAGE_FINALIZE = os.environ.get("NVT_PRESTAGE_FINALIZE", "1") != "0"
 
 
 class _GroupFit:
@@ -385,10 +383,7 @@ class Categorify(StatOperator):
                 # (transform, flush_artifacts, fitted_vocabulary ...).  In fit -> transform the
                 # executor then starts the branches that do not need them (fill + normalize)
                 # first, and the ~130 launches below are issued while those kernels already run.
-                # The buffers are allocated HERE and an event marks this point of the stream: the
-                # deferred passes then start behind the event, not behind what the transform has
-                # queued meanwhile, and run concurrently with its fill + normalize.
-                self._lazy_finalize = self._finalize_prepare(fast, opts, base, mark=PRESTAGE_FINALIZE)
+                self._lazy_finalize = (fast, opts, base)
             else:
                 with K.annotate("write_uniques"):
                     self._finalize_fast(fast, opts, base)
@@ -422,15 +417,9 @@ class Categorify(StatOperator):
         lazy, self._lazy_finalize = self._lazy_finalize, None
         if lazy is not None:
             with K.annotate("write_uniques"):
-                self._finalize_launch(*lazy)
+                self._finalize_fast(*lazy)
 
     def _finalize_fast(self, groups, opts, base):
-        self._finalize_launch(*self._finalize_prepare(groups, opts, base))
-
-    def _finalize_prepare(self, groups, opts, base, mark=False):
-        """Descriptors, output buffers and encode tables of the batched finalisation (allocations
-        only).  mark: also record an event on the current stream -- everything the passes read or
-        write exists from here on, so a deferred launch may start behind this event."""
         descs = (K._lib.VocabCol * len(groups))()
         built = []
         for d, g in zip(descs, groups):
@@ -452,16 +441,8 @@ class Categorify(StatOperator):
                                 flat=src is not None and rtab is None)
             tab.fill_vocab_desc(d, counts, max_count, src=src)
             built.append((g, keys, counts, tab, start))
-        after = None
-        if mark:
-            after = K.Event()
-            after.record()
-        return descs, built, opts, base, after
-
-    def _finalize_launch(self, descs, built, opts, base, after):
-        K.check(K._lib.load().nvt_vocab_finalize_many_after(
-            descs, len(built), K.stream_ptr(), after.handle if after is not None else None),
-            "nvt_vocab_finalize_many")
+        K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
+                "nvt_vocab_finalize_many")
         for i, (g, keys, counts, tab, start) in enumerate(built):
             if tab.flat_slots and not tab.flat_ok():
                 # keys that cluster in their range make long probe runs in a monotone table: an
