@@ -197,10 +197,14 @@ def _pack64(columns: Sequence[torch.Tensor]) -> torch.Tensor:
     types widened), so that a table travels in one collective instead of one per column."""
     cols = []
     for c in columns:
-        if c.dtype == torch.float64:
-            cols.append(c.contiguous().view(torch.int64))
-        else:
+        if c.dtype.is_floating_point:
+            # any float travels as the bits of its float64 value (exact for float32 / float16;
+            # a plain .to(int64) would truncate it)
+            cols.append(c.to(torch.float64).contiguous().view(torch.int64))
+        elif c.dtype in (torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8, torch.bool):
             cols.append(c.to(torch.int64))
+        else:
+            raise TypeError(f"exchange_rows / gather_rows: unsupported column dtype {c.dtype}")
     if not cols:
         return torch.empty((0, 0), dtype=torch.int64)
     return torch.stack(cols, dim=1)
@@ -210,7 +214,7 @@ def _unpack64(mat: torch.Tensor, like: Sequence[torch.Tensor]) -> List[torch.Ten
     out = []
     for j, c in enumerate(like):
         col = mat[:, j].contiguous()
-        out.append(col.view(torch.float64) if c.dtype == torch.float64 else col.to(c.dtype))
+        out.append(col.view(torch.float64).to(c.dtype) if c.dtype.is_floating_point else col.to(c.dtype))
     return out
 
 
@@ -401,24 +405,34 @@ def merge_counts_many(tables):
     dev = tables[0][0].device
     dtypes = [k.dtype for k, _, _ in tables]
     lens = [int(k.numel()) for k, _, _ in tables]
+    # A table without entries has no key dtype of its own (Categorify.fit_end passes int64 empties
+    # for every column on a rank that received no partition).  The wire format (`packed`) and the
+    # returned key dtype must be the SAME decision on every rank, so they are derived from a
+    # "some rank holds non-int32 keys" flag that travels in the MAX all-reduce below -- never
+    # from the rank-local dtypes (a rank with empties used to build two-word rows while its
+    # peers sent one-word rows: the collectives then disagreed on byte counts).
+    wide_local = [int(n > 0 and dt != torch.int32) for dt, n in zip(dtypes, lens)]
+    if not any(wide_local):
+        tables = [(k if k.dtype == torch.int32 else k.to(torch.int32), c, sc) for k, c, sc in tables]
     # ---- global key range per column ---------------------------------------------------
     big = torch.iinfo(torch.int64).max
     # device path: all columns int32 on the GPU -- every step around the collectives is ONE
     # batched launch (nvt_exchange_*, kernels.ExchangeBatch) instead of ~8 torch kernels per column
     xb = None
     if (dev.type == "cuda" and HIP_EXCHANGE and _merge_counts_many_fn is _hip_merge_counts_many
-            and all(dt == torch.int32 for dt in dtypes)):
+            and not any(wide_local)):
         from . import kernels as K
 
         if ncol <= K.EXCHANGE_MAX_COLS and G * ncol <= K.EXCHANGE_MAX_CELLS:
             xb = K.ExchangeBatch([(k, c.to(torch.int64)) for k, c, _ in tables])
-    # (-min, max, rows counted on this rank): one MAX reduce
+    # (-min, max, rows counted on this rank, holds non-int32 keys): one MAX reduce
+    rng = torch.empty(ncol, 4, dtype=torch.int64, device=dev)
+    rng[:, 3] = torch.tensor(wide_local, dtype=torch.int64).to(dev)
     if xb is not None:
-        rng = xb.ranges()
+        rng[:, :3] = xb.ranges()
         k64s = None
     else:
         k64s = [k.to(torch.int64) for k, _, _ in tables]
-        rng = torch.empty(ncol, 3, dtype=torch.int64, device=dev)
         for j, (k, (_, c, _)) in enumerate(zip(k64s, tables)):
             if lens[j]:
                 rng[j, 0] = -(k.min().clamp(min=-big))
@@ -431,10 +445,15 @@ def merge_counts_many(tables):
     _all_reduce(rng, td.ReduceOp.MAX)
     rng_h = rng.cpu().tolist()
     _mark("ranges")
+    # the key dtype every rank returns: int64 when ANY rank holds non-int32 keys of the column,
+    # int32 when some rank holds keys and all of them are int32, the input's when nobody does
+    wide = [r[3] > 0 for r in rng_h]
+    dtypes = [torch.int64 if w else (torch.int32 if r[1] != -big else dt)
+              for w, r, dt in zip(wide, rng_h, dtypes)]
     # int32 keys and no merged count that can reach 2^31 (G times the largest per-rank total
     # bounds it): a (key, count) row travels as ONE int64 word instead of two -- half the bytes
     # of the all-to-all and of the all-gather, the part of a fit that grows with the ranks
-    packed = (all(dt == torch.int32 for dt in dtypes)
+    packed = (not any(wide)
               and G * max(r[2] for r in rng_h) < (1 << 31) and PACK_COUNT_ROWS)
     STATS["packed_exchanges" if packed else "plain_exchanges"] += 1
     if xb is not None and not packed:  # (counts too large for one word: the general path)

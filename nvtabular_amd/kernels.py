@@ -1061,6 +1061,15 @@ class EncodeTable:
         return out
 
 
+def flat_tables_ok(tabs) -> List[bool]:
+    """EncodeTable.flat_ok for several flat range tables with ONE read-back (the current stream is
+    ordered behind every table's finalisation first, no host wait per table)."""
+    for t in tabs:
+        t.wait_ready()
+    words = torch.stack([t.range_aux[EncodeTable.FLAT_AUX_MAXDISP] for t in tabs]).to(torch.int64)
+    return [(int(d) & 0xFFFFFFFF) <= EncodeTable.FLAT_MAX_DISPLACEMENT for d in read_back(words)]
+
+
 def encode_many(items, out_dtype: torch.dtype = torch.int64):
     """items: [(EncodeTable, keys, valid, null_label, oov_label, num_buckets)] -> [labels];
     every column of a Categorify.transform enqueued by ONE C call (nvt_encode_many)."""
@@ -1514,7 +1523,8 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
             bias = lo if hi - lo < (1 << 32) else None
             if bias is None:
                 if _PASS_MEMO is not None:
-                    _PASS_MEMO[memo_key] = dict(bias=None, kfold=0, fold=None, groups=None)
+                    # (keys held: the address cannot be recycled for another column in this pass)
+                    _PASS_MEMO[memo_key] = dict(bias=None, kfold=0, fold=None, groups=None, keys=keys)
                 return None
         need = C.c_uint64()
         check(lib.nvt_sgb_sort_ws_bytes(n, C.byref(need)), "nvt_sgb_sort_ws_bytes")

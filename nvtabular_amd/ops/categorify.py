@@ -443,12 +443,16 @@ class Categorify(StatOperator):
             built.append((g, keys, counts, tab, start))
         K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
                 "nvt_vocab_finalize_many")
-        for i, (g, keys, counts, tab, start) in enumerate(built):
-            if tab.flat_slots and not tab.flat_ok():
-                # keys that cluster in their range make long probe runs in a monotone table: an
-                # ordinary hashed table instead (built from the ordered vocabulary, now final)
-                tab = K.EncodeTable(keys, start, unique=True)
-                built[i] = (g, keys, counts, tab, start)
+        flats = [i for i, b in enumerate(built) if b[3].flat_slots]
+        if flats:
+            # largest displacement of every flat table: ONE read-back for all of them (it used to
+            # be a blocking read per vocabulary, serialising the host on the finalize streams)
+            for i, ok in zip(flats, K.flat_tables_ok([built[i][3] for i in flats])):
+                if not ok:
+                    # keys that cluster in their range make long probe runs in a monotone table:
+                    # an ordinary hashed table instead (built from the ordered vocabulary, now final)
+                    g, keys, counts, tab, start = built[i]
+                    built[i] = (g, keys, counts, K.EncodeTable(keys, start, unique=True), start)
         for g, keys, counts, tab, start in built:
             if not tab.pending:
                 tab.sort_tmp = None  # scratch of work already ordered on this stream
@@ -606,15 +610,18 @@ class Categorify(StatOperator):
             _write_artifacts(final)
         return unique_path
 
-    def flush_artifacts(self):
-        """Write any deferred unique.*/meta.*.parquet files (defer_artifacts=True)."""
-        # not a collective (Workflow.save may run on one rank only): the writer elected at
-        # fit_end writes, everybody drops the device copies
+    def flush_artifacts(self, force=False):
+        """Write any deferred unique.*/meta.*.parquet files (defer_artifacts=True).
+
+        Not a collective: only the writer elected at fit_end writes, everybody else just drops
+        the device copies.  ``force=True`` (Workflow.save / set_storage_path, which may run on
+        one rank only and need the files whoever that rank is) writes on any rank; the files are
+        replaced atomically (_write_artifacts), so a forced write concurrent with the elected
+        writer's is harmless -- both hold the same vocabularies."""
         self._ensure_finalized()
         for final in self._pending.values():
-            path = "/".join([final["base"], f"unique.{final['name']}.parquet"])
-            if getattr(self, "_is_writer", True) or not os.path.exists(path):
-                _write_artifacts(final)  # (a non-writer whose writer never flushed writes itself)
+            if getattr(self, "_is_writer", True) or force:
+                _write_artifacts(final)
             elif final.get("table") is not None:
                 # dropping the device copies: their buffers go back to the allocator on THIS
                 # stream, which must first be ordered behind the internal stream that sorts them
@@ -625,7 +632,7 @@ class Categorify(StatOperator):
         """categorify.py:404-415"""
         idx_count = 0
         if self.single_table:
-            self.flush_artifacts()
+            self.flush_artifacts(force=True)  # every rank re-bases the files it reads below
         for cat in categories:
             self.categories[cat] = categories[cat]
             if self.single_table:
@@ -707,7 +714,7 @@ class Categorify(StatOperator):
     def set_storage_path(self, new_path, copy=False):
         import shutil
 
-        self.flush_artifacts()
+        self.flush_artifacts(force=True)
         new = {}
         for col, old in self.categories.items():
             target = old.replace(str(self.out_path), str(new_path))
@@ -911,16 +918,20 @@ def _write_artifacts(final):
         df[f"{name}_size"] = counts.cpu().numpy()
         df.index = pd.RangeIndex(start=start, stop=start + len(df))
     os.makedirs(base, exist_ok=True)
-    if os.path.exists(unique_path):
-        os.remove(unique_path)
-    df.to_parquet(unique_path, compression=None)
+    # written beside the target and moved into place: a reader (or a second writer) never sees a
+    # missing or half-written file
+    tmp = f"{unique_path}.tmp.{os.getpid()}"
+    df.to_parquet(tmp, compression=None)
+    os.replace(tmp, unique_path)
     meta = {
         "kind": ["pad", "null", "oov", "unique"],
         "offset": [PAD_OFFSET, NULL_OFFSET, OOV_OFFSET, OOV_OFFSET + final["oov_count"]],
         "num_indices": [1, 1, final["oov_count"], unique_count],
         "num_observed": [0, final["null_size"], final["oov_size"], final["unique_size"]],
     }
-    pd.DataFrame(meta).to_parquet(meta_path)
+    tmp = f"{meta_path}.tmp.{os.getpid()}"
+    pd.DataFrame(meta).to_parquet(tmp)
+    os.replace(tmp, meta_path)
     return unique_path
 
 

@@ -92,6 +92,24 @@ def _worker(rank, world, port, q):
         assert (np.diff(pk.numpy().astype(np.int64)) > 0).all()
     assert packed[1][0][0].item() == -2**31 and packed[1][0][-1].item() == 2**31 - 1
     assert int(packed[1][1].sum()) >= int(cneg.sum())
+    # a rank that received no partition passes int64 EMPTIES for every column (Categorify.fit_end):
+    # the one-word wire format and the returned key dtype are decided collectively, not from the
+    # rank-local dtypes (the odd ranks here would otherwise send / expect two-word rows)
+    if rank % 2 == 0:
+        lone = [(torch.from_numpy(kneg), torch.from_numpy(cneg), [1, 5]),
+                (torch.from_numpy(l32.index.to_numpy()), torch.from_numpy(l32.to_numpy()), [2, 0])]
+    else:
+        lone = [(torch.empty(0, dtype=torch.int64), torch.empty(0, dtype=torch.int64), [0, 0]),
+                (torch.empty(0, dtype=torch.int64), torch.empty(0, dtype=torch.int64), [0, 0])]
+    before = dict(dist.STATS)
+    got = dist.merge_counts_many(lone)
+    assert dist.STATS["packed_exchanges"] == before["packed_exchanges"] + 1
+    assert all(t[0].dtype == torch.int32 and t[3]["sorted_by_key"] for t in got)
+    assert (np.diff(got[0][0].numpy().astype(np.int64)) > 0).all()
+    assert got[0][2] == [(world + 1) // 2, 5 * ((world + 1) // 2)]
+    lone_keys = (got[0][0].numpy().copy(), got[0][1].numpy().copy(), kneg if rank % 2 == 0 else None,
+                 cneg if rank % 2 == 0 else None)
+    q.put(("lone", rank) + lone_keys)
     m0 = pd.Series(many[0][1].numpy(), index=many[0][0].numpy()).sort_index()
     assert sorted(many[2][0].tolist()) == list(range(7)) and many[2][1].tolist() == [1] * 7
     q.put(("many", rank, m0.index.to_numpy(), m0.to_numpy(), many[1][0].numpy(), many[1][1].numpy(),
@@ -128,9 +146,17 @@ def test_merge_counts_world2_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    items = [q.get(timeout=150) for _ in range(2 * len(procs))]
+    items = [q.get(timeout=150) for _ in range(3 * len(procs))]
     many = sorted([t[1:] for t in items if t[0] == "many"], key=lambda t: t[0])
-    res = sorted([t for t in items if t[0] != "many"], key=lambda t: t[0])
+    lone = sorted([t[1:] for t in items if t[0] == "lone"], key=lambda t: t[0])
+    res = sorted([t for t in items if t[0] not in ("many", "lone")], key=lambda t: t[0])
+    # ranks without entries (int64 empties) took part in the same one-word exchange: every rank
+    # holds the union of the even ranks' lists
+    src = pd.concat([pd.Series(t[4], index=t[3]) for t in lone if t[3] is not None])
+    exp_lone = src.groupby(level=0).sum().sort_index()
+    for t in lone:
+        np.testing.assert_array_equal(t[1], exp_lone.index.to_numpy())
+        np.testing.assert_array_equal(t[2], exp_lone.to_numpy())
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
