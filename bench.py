@@ -220,6 +220,7 @@ FAMILIES = {
     # kernel family -> (scope-name prefixes, algorithmic bytes per row per column, columns)
     "count": (("dense_count_",), 4, "cat"),            # Categorify.fit: groupby-size
     "vocab_order": (("vocab_", "encode_build"), 0, "cat"),  # write_uniques + encode tables: no column bytes
+    "merge": (("merge_sorted",), 0, "cat"),            # _mid_level_groupby tree merge of partial lists
     "encode": (("encode_i32", "encode_i64"), 12, "cat"),    # Categorify.transform
     "moments": (("moments",), 4, "cont"),              # Normalize.fit
     "fill_normalize": (("fill_normalize",), 12, "cont"),
@@ -449,6 +450,151 @@ def extra_cfg3(device, tmp, rows, ncols=4, card=100_000_000, steps=3):
     return res
 
 
+def _valid_mask(col, n):
+    if col.valid is None:
+        return None
+    idx = torch.arange(n, device=col.data.device)
+    return ((col.valid[idx >> 3] >> (idx & 7).to(torch.uint8)) & 1).to(torch.bool)
+
+
+def property_checks(wf, frames, outs, cat_names, cont_names):
+    """Parity of the TIMED frames through size-independent properties (the oracle cannot run
+    45 M-row pandas groupbys in bench time; same checks as tests/test_gpu_fullsize.py, which pin
+    the labels uniquely): per categorical column the vocabulary is duplicate-free and ordered
+    (count desc, key asc), its counts sum to the non-null rows, every non-null row decodes back to
+    its key (vocab[label - 3] == key), nulls -> 1, nothing lands in the OOV slot, and
+    bincount(labels) over ALL partitions reproduces the fit's counts; per continuous column
+    mean / std equal an independent float64 torch reduction within 1e-6 relative.
+    -> {"full_frame_ok": bool, "failed": [...], "rows": total rows}."""
+    from nvtabular_amd.node import iter_nodes
+
+    cat_op = [n.op for n in iter_nodes(wf.output_node) if type(n.op).__name__ == "Categorify"][0]
+    norm_op = [n.op for n in iter_nodes(wf.output_node) if type(n.op).__name__ == "Normalize"]
+    failed = []
+    total_rows = sum(len(f) for f in frames)
+    for c in cat_names:
+        ks, counts = cat_op.fitted_vocabulary(c)
+        keys = ks[0]
+        ok = True
+        if keys.numel() > 1:
+            dc = counts[1:] - counts[:-1]
+            ok = ok and bool((dc <= 0).all()) and bool((keys[1:][dc == 0] > keys[:-1][dc == 0]).all())
+        hist = torch.zeros(keys.numel(), dtype=torch.int64, device=keys.device)
+        n_valid = 0
+        for frame, out in zip(frames, outs):
+            col, lab = frame[c], out[c].data
+            m = _valid_mask(col, len(frame))
+            lv, kv = (lab, col.data) if m is None else (lab[m], col.data[m])
+            n_valid += int(lv.numel())
+            if m is not None:
+                ok = ok and bool((lab[~m] == 1).all())
+            ok = ok and int(lv.min().item()) >= 3 and int(lv.max().item()) < 3 + keys.numel()
+            if not ok:
+                break
+            ok = ok and bool((keys[lv - 3] == kv).all())
+            hist += torch.bincount(lv - 3, minlength=keys.numel())
+            del lv, kv, m
+        ok = ok and int(counts.sum().item()) == n_valid and bool((hist == counts).all())
+        if not ok:
+            failed.append(c)
+        del hist
+    if norm_op:
+        for c in cont_names:
+            cnt, sm, sq = 0.0, 0.0, 0.0
+            xs = []
+            for frame in frames:
+                col = frame[c]
+                m = _valid_mask(col, len(frame))
+                x = col.data.to(torch.float64)
+                xs.append(x if m is None else torch.where(m, x, torch.zeros((), dtype=torch.float64, device=x.device)))
+            x = torch.cat(xs) if len(xs) > 1 else xs[0]
+            mean, std = float(x.mean().item()), float(x.std(unbiased=True).item())
+            del x, xs
+            if not (abs(norm_op[0].means[c] - mean) <= 1e-6 * abs(mean)
+                    and abs(norm_op[0].stds[c] - std) <= 1e-6 * abs(std)):
+                failed.append(c)
+    return {"full_frame_ok": not failed, "failed": failed, "rows": total_rows,
+            "checks": "vocabulary order + bijection, encode->decode round trip on every row, "
+                      "bincount(labels) == fit counts, means / stds vs float64 torch within 1e-6"}
+
+
+def extra_multipart(device, tmp, rows, nparts=8, steps=2, single_ms=None):
+    """BASELINE.json configs[2]'s SHAPE on one GPU: the cfg2 schema as `nparts` partitions of
+    `rows` rows (each its own seed: new keys keep arriving), all resident in HBM; one step =
+    Workflow.fit over all partitions (per-partition groupby-size + the fan-in-8 tree merge of
+    categorify.py:1054-1070,1423-1478 + moments) and Workflow.transform over all partitions
+    (outputs released partition by partition).  This is the only shape Criteo-1TB can run."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.node import iter_nodes
+
+    frames = [synth_criteo(rows, device, seed=31337 + 1000 * p) for p in range(nparts)]
+    cat_names = [c for c in frames[0].columns if c.startswith("C")]
+    cont_names = [c for c in frames[0].columns if c.startswith("I")]
+    wf = build_workflow(cat_names, cont_names, os.path.join(tmp, "multipart"))
+    ds = nvt.Dataset(frames)
+    t_fit = []
+
+    def step(keep=False):
+        t0 = time.perf_counter()
+        wf.fit(ds)
+        t_fit.append(time.perf_counter() - t0)
+        outs = []
+        for out in wf.transform(ds).to_iter():
+            if keep:
+                outs.append(out)
+            del out
+        return outs
+
+    step()  # cold: no hints
+    step()
+    torch.cuda.synchronize()
+    del t_fit[:]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    if os.environ.get("NVT_MP_ONLY_TIMED"):  # (tools/trace_multipart.sh: nothing behind the timed steps)
+        return {"ms_per_step": ms, "ms_per_partition": ms / nparts}
+    K.profile_begin()
+    step()
+    rep = K.profile_report()
+    op = [n.op for n in iter_nodes(wf.output_node) if type(n.op).__name__ == "Categorify"][0]
+    C, Kc = len(cat_names), len(cont_names)
+    bytes_per_row = (C * 4 + Kc * 4) + (C * 12 + Kc * 12)
+    fam = {}
+    for scope, (tot_ms, launches, _) in rep["kernels"].items():
+        f = family_of(scope)
+        fam[f] = fam.get(f, 0.0) + tot_ms
+    paths = {}
+    for k, v in op._last_paths.items():
+        paths[str(v)] = paths.get(str(v), 0) + 1
+    res = {
+        "workload": f"cfg2 schema as {nparts} partitions x {rows} rows (own seed each), resident; "
+                    "Workflow.fit over all partitions + Workflow.transform over all partitions",
+        "partitions": nparts, "rows": nparts * rows,
+        "rows_per_s": nparts * rows / (ms / 1e3), "ms_per_step": ms,
+        "ms_per_partition": ms / nparts,
+        "fit_host_ms_per_step": round(1e3 * sum(t_fit) / max(len(t_fit), 1), 2),
+        "algorithmic_GBps": nparts * rows / (ms / 1e3) * bytes_per_row / 1e9,
+        "frac_of_hbm_peak": nparts * rows / (ms / 1e3) * bytes_per_row / 1e9 / HBM_PEAK_GBS,
+        "single_partition_step_ms": single_ms,
+        "ratio_to_single_partition_step": (ms / nparts / single_ms) if single_ms else None,
+        "counting_paths": paths,
+        "vocabulary_entries": int(sum(f["unique_count"] for f in op._pending.values())),
+        # (column, NVT_OVF_* bits) of every range-path attempt that overflowed and was redone on the
+        # sort path, over all fits of this entry
+        "range_overflows": [[h, b] for h, b, _ in op._range_failures],
+        "gpu_busy_ms_per_partition": round(rep["busy_ms"] / nparts, 3),
+        "per_family_ms_per_partition": {k: round(v / nparts, 3) for k, v in sorted(fam.items())},
+        "per_kernel_ms_per_step": {k: round(v[0], 3) for k, v in rep["kernels"].items()},
+    }
+    outs = step(keep=True)
+    res["parity"] = property_checks(wf, frames, outs, cat_names, cont_names)
+    return res
+
+
 def extra_cfg5(device, tmp, rows=10_000_000, steps=3):
     """BASELINE.json configs[4]: multi-hot list<int32> column (0..8 leaves per row, Zipf over
     1 M ids) + a scalar id column: Categorify on both and HashBucket on the list column
@@ -552,6 +698,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] (TE + JoinGroupby) entry")
     ap.add_argument("--cfg4-rows", type=int, default=20_000_000)
+    ap.add_argument("--multipart", type=int, default=8, help="partitions of the cfg3_multipartition entry")
+    ap.add_argument("--only-extra", default=None, help="run only this extra_configs entry (diagnostic)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-procs", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-tmp", default=None, help=argparse.SUPPRESS)
@@ -849,7 +997,9 @@ def main():
         del frame, ds, wf
         torch.cuda.empty_cache()
         extras = {}
-        for key, fn in (("cfg4_te_joingroupby", lambda: extra_cfg4(device, tmp, args.cfg4_rows, 1_000_000)),
+        for key, fn in (("cfg3_multipartition", lambda: extra_multipart(device, tmp, n, args.multipart,
+                                                                        single_ms=ms_per_step)),
+                        ("cfg4_te_joingroupby", lambda: extra_cfg4(device, tmp, args.cfg4_rows, 1_000_000)),
                         ("cfg3_highcard_columns", lambda: extra_cfg3(device, tmp, n)),
                         ("cfg5_multihot", lambda: extra_cfg5(device, tmp))):
             try:

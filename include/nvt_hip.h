@@ -65,6 +65,10 @@ extern "C" {
 #define NVT_ST_SENTINEL 1  /* rows whose key equalled the empty sentinel     */
 #define NVT_ST_OCCUPIED 2  /* distinct keys currently in the table           */
 #define NVT_ST_OVERFLOW 3  /* != 0: table too full, result invalid -> regrow */
+/* range path, diagnostic bits beside overflow bit0: WHY the column has to be rerun */
+#define NVT_OVF_REGION 16ull  /* a (bucket, workgroup) region of the partition pass filled up  */
+#define NVT_OVF_PROBE 32ull   /* a probe chain left the bucket table (keys cluster in a range) */
+#define NVT_OVF_FULL 64ull    /* a bucket holds more than 3/4 * 16384 distinct keys            */
 #define NVT_ST_ROWS 4      /* rows consumed (nulls included)                 */
 /* words 5..7: scratch cursors of nvt_dense_count_*                                  */
 #define NVT_ST_MAXCOUNT 8  /* nvt_dense_count_*: largest count in the output list    */
@@ -397,6 +401,38 @@ int nvt_count_merge_sorted_ws_bytes(uint64_t n, uint64_t *bytes);
 int nvt_count_merge_sorted(const int64_t *rows, uint64_t n, const uint64_t *seg_off, int nseg,
                            int ncol, int32_t *out_keys, int64_t *out_col, double *out_sum,
                            uint64_t *state, void *ws, void *stream);
+/* ---- tree merge of KEY-SORTED partial results (multi-partition fit) ------------------------
+ * Replaces the concat + re-groupby of _mid_level_groupby (categorify.py:1054-1070) inside the
+ * tree of categorify.py:1423-1478 -- and the same tree under join_groupby.py:140-173 /
+ * target_encoding.py:171-214 -- for partial results that are already ORDERED BY KEY (range path,
+ * sort path, sort-path groupby): out = the union of the ascending, duplicate-free int32 key
+ * lists A and B in key order; the counts of a key that occurs in both are summed.  out_keys /
+ * out_counts hold na + nb entries, *out_n (device) receives the merged length.  counts are
+ * optional (both NULL: keys only).  src_a / src_b (optional, int32[na + nb], on every column of
+ * a call or on none): position in A / in B every output entry came from, -1 = none -- the map
+ * nvt_merge_payload combines further payload arrays with.  na + nb < 2^31.  One merge-path
+ * search launch + one tile launch for ALL columns of the call; ws:
+ * nvt_merge_sorted_ws_bytes(cols, ncols) bytes, 16-byte aligned.  No host synchronisation. */
+typedef struct nvt_merge_col {
+  const int32_t *a_keys;
+  const int64_t *a_counts;
+  uint64_t na;
+  const int32_t *b_keys;
+  const int64_t *b_counts;
+  uint64_t nb;
+  int32_t *out_keys;
+  int64_t *out_counts;
+  int32_t *src_a;
+  int32_t *src_b;
+  uint64_t *out_n;
+} nvt_merge_col;
+int nvt_merge_sorted_ws_bytes(const nvt_merge_col *cols, int ncols, uint64_t *bytes);
+int nvt_merge_sorted_many(const nvt_merge_col *cols, int ncols, void *ws, uint64_t ws_bytes,
+                          void *stream);
+/* out[i * width + j] = op(a[src_a[i] * width + j], b[src_b[i] * width + j]), a side whose index
+ * is -1 contributes nothing.  dtype NVT_I64 / NVT_F64; op 0 add, 1 min, 2 max (NaN = no value). */
+int nvt_merge_payload(const int32_t *src_a, const int32_t *src_b, uint64_t n, int width, int dtype,
+                      int op, const void *a, const void *b, void *out, void *stream);
 /* ---- multi-GPU vocabulary exchange: the device work around the collectives (the
  * reference's tree reduce of per-partition frames, categorify.py:1423-1529).  One launch per step
  * for ALL columns of a fit (<= 64 columns of int32 keys + int64 counts, ranks x columns <= 4096):

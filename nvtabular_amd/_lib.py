@@ -151,6 +151,12 @@ class VocabCol(C.Structure):
                 ("range_nb_log2", C.c_int32), ("flat_slots", C.c_uint64)]
 
 
+class MergeCol(C.Structure):
+    _fields_ = [("a_keys", _vp), ("a_counts", _vp), ("na", _u64), ("b_keys", _vp),
+                ("b_counts", _vp), ("nb", _u64), ("out_keys", _vp), ("out_counts", _vp),
+                ("src_a", _vp), ("src_b", _vp), ("out_n", _vp)]
+
+
 class EncodeCol(C.Structure):
     _fields_ = [("keys", _vp), ("valid", _vp), ("n", _u64), ("table", _vp), ("capacity", _u64),
                 ("sentinel_label", _vp), ("null_label", _i64), ("oov_label", _i64),
@@ -165,6 +171,9 @@ SIGNATURES.update({
     "nvt_dense_count_many": [C.POINTER(CountCol), _i32, _vp],
     "nvt_vocab_finalize_many": [C.POINTER(VocabCol), _i32, _vp],
     "nvt_encode_many": [C.POINTER(EncodeCol), _i32, _vp],
+    "nvt_merge_sorted_ws_bytes": [C.POINTER(MergeCol), _i32, C.POINTER(_u64)],
+    "nvt_merge_sorted_many": [C.POINTER(MergeCol), _i32, _vp, _u64, _vp],
+    "nvt_merge_payload": [_vp, _vp, _u64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "nvt_event_create": [_pp],
     "nvt_event_destroy": [_vp],
     "nvt_stream_wait_event": [_vp, _vp],

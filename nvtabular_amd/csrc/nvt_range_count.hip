@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
   if (threadIdx.x == 0) {
     if (s_nulls) atomicAdd((unsigned long long *)&state[NVT_ST_NULLS], s_nulls);
     if (s_sent) atomicAdd((unsigned long long *)&state[NVT_ST_SENTINEL], s_sent);
-    if (s_ovf) atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW], 1ull);
+    if (s_ovf) atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW], 1ull | NVT_OVF_REGION);
     if (g == 0) atomicAdd((unsigned long long *)&state[NVT_ST_ROWS], (unsigned long long)n);
   }
 }
@@ -494,7 +494,8 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
   }
   if (bad || full) {
     if (threadIdx.x == 0 && (lovf != 0 || full))
-      atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW], 1ull);
+      atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW],
+               1ull | (lovf != 0 ? NVT_OVF_PROBE : 0ull) | (full ? NVT_OVF_FULL : 0ull));
     return;
   }
   if (base + E > out_cap) return;  // reported by the last bucket

@@ -133,6 +133,10 @@ class Dataset:
     # ---- public surface -----------------------------------------------------------
     @property
     def schema(self) -> Schema:
+        if callable(self._schema):
+            # a transformed dataset: the fitted output schema (embedding sizes ...) is folded
+            # together on first use, not before the first partition's kernels are enqueued
+            self._schema = self._schema()
         if self._schema is None:
             first = next(iter(self._parts_fn()))
             self._schema = Schema.from_frame(first)

@@ -362,6 +362,7 @@ USE_SORT = os.environ.get("NVT_SORT_PATH", "1") != "0"
 USE_FLAT_TABLE = os.environ.get("NVT_FLAT_TABLE", "1") != "0"
 
 _ws_cache = {}
+_check_streams = {}   # device index -> side stream of the read-backs that must not wait for work queued later
 _RT_BYTES = {}   # range_bits -> nvt_range_table_bytes
 _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 
@@ -397,6 +398,11 @@ def _path_for(hint: int, small_tables: bool = False, allow_range: bool = True) -
         return PATH_RANGE
     if USE_SORT and not small_tables and hint > PATH_RANGE_MAX_DISTINCT:
         return PATH_SORT
+    if USE_SORT and USE_RANGE and HOT_FILTER and not small_tables and not allow_range:
+        # a column the range path gave up on (keys that cluster in their range): the sort path
+        # keeps its per-partition lists KEY-ORDERED, which is what the partition merge and the
+        # one-pass vocabulary ordering live on; the hash paths would hand back unordered lists
+        return PATH_SORT
     if hint <= (PATH_P1_MAX_SMALL if small_tables else PATH_P1_MAX_DISTINCT):
         return 1
     if hint <= PATH_P2_MAX_DISTINCT:
@@ -416,6 +422,7 @@ class DenseCountJob:
         self.range_table = None
         self.allow_range = allow_range  # False: the range path overflowed on this column before
         self.range_failed = False
+        self.range_fail_bits = 0
         self.min_range_bits = 8
         self.lib = _lib.load()
         self.keys = aligned(keys)
@@ -519,6 +526,8 @@ class DenseCountJob:
                 return False
             # (the range path assumes keys spread over their range; a hash path does not)
             nxt = order.index(1) if self.path == PATH_RANGE else order.index(self.path) + 1
+            if self.path == PATH_RANGE and not self.range_failed:
+                self.range_fail_bits = int(ovf)  # NVT_OVF_*: region / probe / full (diagnostic)
             self.range_failed = self.range_failed or self.path == PATH_RANGE
             if (self.path == 0 and USE_RANGE and HOT_FILTER and self.allow_range and self.kb == 4
                     and self.weights is None and not self.range_failed):
@@ -554,7 +563,8 @@ class DenseCountJob:
             self.result = (self.out_k[:m], self.out_c[:m], st[_lib.ST_NULLS],
                            dict(path=self.path, distinct=m, max_count=max_count,
                                 rows=st[_lib.ST_ROWS], sorted_by_key=True, cls_hist=self.hot_image,
-                                n_big=st[_lib.ST_BIG], range_failed=self.range_failed))
+                                n_big=st[_lib.ST_BIG], range_failed=self.range_failed,
+                                range_fail_bits=self.range_fail_bits))
             return True
         if self.path == PATH_RANGE:
             # key-ordered list (the sentinel key, smallest int32, already leads it) + what the
@@ -574,7 +584,7 @@ class DenseCountJob:
             m += 1
         self.result = (self.out_k[:m], self.out_c[:m], st[_lib.ST_NULLS],
                        dict(path=self.path, distinct=m, max_count=max_count, rows=st[_lib.ST_ROWS],
-                            range_failed=self.range_failed))
+                            range_failed=self.range_failed, range_fail_bits=self.range_fail_bits))
         return True
 
     def _fallback(self):
@@ -700,11 +710,24 @@ class CountBatch:
                 descs[i].ws = wps[k]
         check(_lib.load().nvt_dense_count_many(descs, len(pending), stream_ptr()),
               "nvt_dense_count_many")
+        # what results() waits for: THIS call's kernels, not whatever is queued behind them (the
+        # next partition's counting is launched before this one is read back)
+        self._done = torch.cuda.Event()
+        self._done.record()
+
+    def _read_states(self):
+        dev = self.states.device
+        side = _check_streams.get(dev.index)
+        if side is None:
+            side = _check_streams[dev.index] = torch.cuda.Stream(device=dev)
+        side.wait_event(self._done)
+        with torch.cuda.stream(side):
+            return read_back(self.states).tolist()
 
     def results(self):
         if self._results is None:
             while self.pending:
-                host = read_back(self.states).tolist()  # the single synchronisation point
+                host = self._read_states()  # the single synchronisation point
                 self.pending = [j for i, j in enumerate(self.pending) if not j.resolve(host[i])]
                 STATS["count_relaunches"] += len(self.pending)
                 self._launch()
@@ -765,6 +788,132 @@ def merge_dense(lists, hint: int = 0):
     k, c, _, info = dense_count(keys, None, counts,
                                 hint=hint or max(int(x[0].numel()) for x in lists))
     return k, c, info["max_count"]
+
+
+def merge_dense_many(groups, hints=None):
+    """merge_dense for several groups with ONE nvt_dense_count_many call (and one read-back):
+    groups[j] = the (keys, counts[, max_count]) lists of group j -> [(keys, counts, max_count)]."""
+    jobs, slots, out = [], [], [None] * len(groups)
+    for j, lists in enumerate(groups):
+        lists = [(t[0], t[1]) for t in lists if t[0].numel()]
+        if not lists:
+            continue
+        if len(lists) == 1:
+            out[j] = (lists[0][0], lists[0][1], int(groups[j][0][2]) if len(groups[j][0]) > 2 else 0)
+            continue
+        dt = torch.int64 if any(k.dtype == torch.int64 for k, _ in lists) else torch.int32
+        keys = torch.cat([k.to(dt) for k, _ in lists])
+        counts = torch.cat([c for _, c in lists])
+        hint = (hints[j] if hints else 0) or max(int(x[0].numel()) for x in lists)
+        jobs.append(DenseCountJob(keys, None, counts, hint))
+        slots.append(j)
+    if jobs:
+        for j, (k, c, _, info) in zip(slots, dense_count_many(jobs)):
+            out[j] = (k, c, info["max_count"])
+    return out
+
+
+MERGE_SORTED = os.environ.get("NVT_MERGE_SORTED", "1") != "0"
+MERGE_SORTED_MAX_TOTAL = (1 << 31) - 1   # include/nvt_hip.h nvt_merge_sorted_many: na + nb < 2^31
+
+
+def merge_sorted_pairs(pairs, want_src: bool = False):
+    """nvt_merge_sorted_many: pairs = [((keys_a, counts_a), (keys_b, counts_b))] of KEY-SORTED,
+    duplicate-free int32 lists (counts int64 or None) -> [(keys, counts)] -- the union in key
+    order, counts of equal keys summed; with want_src [(keys, counts, src_a, src_b)] where
+    src_* = the position in A / B an output entry came from (-1: none).  ONE merge-path launch +
+    ONE tile launch for all pairs, ONE read-back (the merged lengths)."""
+    if not pairs:
+        return []
+    _lib.require_gpu()
+    lib = _lib.load()
+    dev = pairs[0][0][0].device
+    descs = (_lib.MergeCol * len(pairs))()
+    out_n = torch.empty(len(pairs), dtype=torch.int64, device=dev)
+    outs, keep = [], []
+    for i, (d, ((ka, ca), (kb, cb))) in enumerate(zip(descs, pairs)):
+        assert ka.dtype == torch.int32 and kb.dtype == torch.int32
+        ka, kb = ka.contiguous(), kb.contiguous()
+        ca = ca.contiguous() if ca is not None else None
+        cb = cb.contiguous() if cb is not None else None
+        na, nb = int(ka.numel()), int(kb.numel())
+        if na + nb > MERGE_SORTED_MAX_TOTAL:
+            raise _lib.NvtHipError("merge_sorted_pairs: more than 2^31 - 1 entries in one merge")
+        ok = torch.empty(na + nb, dtype=torch.int32, device=dev)
+        oc = torch.empty(na + nb, dtype=torch.int64, device=dev) if (ca is not None or cb is not None) else None
+        # (at least one element: an empty pair must still look like "with src maps" to the library)
+        sa = torch.empty(max(na + nb, 1), dtype=torch.int32, device=dev) if want_src else None
+        sb = torch.empty(max(na + nb, 1), dtype=torch.int32, device=dev) if want_src else None
+        d.a_keys, d.a_counts, d.na = ptr(ka) if na else None, ptr(ca) if na else None, na
+        d.b_keys, d.b_counts, d.nb = ptr(kb) if nb else None, ptr(cb) if nb else None, nb
+        d.out_keys, d.out_counts = ptr(ok), ptr(oc)
+        d.src_a, d.src_b = ptr(sa), ptr(sb)
+        d.out_n = out_n[i:].data_ptr()
+        outs.append((ok, oc, sa, sb))
+        keep.append((ka, kb, ca, cb))
+    need = C.c_uint64()
+    check(lib.nvt_merge_sorted_ws_bytes(descs, len(pairs), C.byref(need)), "nvt_merge_sorted_ws_bytes")
+    ws = torch.empty(need.value + 16, dtype=torch.uint8, device=dev)
+    check(lib.nvt_merge_sorted_many(descs, len(pairs), ws.data_ptr(), need.value, stream_ptr()),
+          "nvt_merge_sorted_many")
+    ns = read_back(out_n).tolist()
+    res = []
+    for (ok, oc, sa, sb), n in zip(outs, ns):
+        n = int(n)
+        if want_src:
+            res.append((ok[:n], oc[:n] if oc is not None else None, sa[:n], sb[:n]))
+        else:
+            res.append((ok[:n], oc[:n] if oc is not None else None))
+    return res
+
+
+def merge_payload(src_a, src_b, a, b, op: str = "add", width: int = 1):
+    """nvt_merge_payload: rows of ``width`` int64 / float64 values of two merged lists combined
+    through the src maps of merge_sorted_pairs (op: add / min / max; a missing side contributes
+    nothing).  a, b: [entries * width] contiguous."""
+    n = int(src_a.numel())
+    a, b = a.contiguous(), b.contiguous()
+    assert a.dtype == b.dtype and a.dtype in (torch.int64, torch.float64)
+    out = torch.empty(n * width, dtype=a.dtype, device=src_a.device)
+    check(_lib.load().nvt_merge_payload(
+        ptr(src_a), ptr(src_b), n, int(width), dtype_code(a.dtype), {"add": 0, "min": 1, "max": 2}[op],
+        ptr(a) if a.numel() else None, ptr(b) if b.numel() else None, out.data_ptr(), stream_ptr()),
+        "nvt_merge_payload")
+    return out
+
+
+def merge_sorted_tree(col_lists):
+    """Tree merge (_mid_level_groupby, categorify.py:1054-1070, over the tree of :1423-1478) of
+    KEY-SORTED (keys int32, counts int64) lists: col_lists[j] = the lists of column j; returns
+    one (keys, counts) per column.  Every level merges disjoint pairs of ALL columns in one
+    call (nvt_merge_sorted_many) and costs one read-back; a list much larger than the others
+    (the table accumulated so far) is held back for the last level, so it is streamed once."""
+    cur = [[(k, c) for k, c in lists if int(k.numel())] for lists in col_lists]
+    while any(len(l) > 1 for l in cur):
+        pairs, plan = [], []
+        for j, lists in enumerate(cur):
+            if len(lists) < 2:
+                plan.append((j, [], lists))
+                continue
+            order = sorted(lists, key=lambda t: int(t[0].numel()))
+            held = []
+            if len(order) > 2 and int(order[-1][0].numel()) > 2 * int(order[-2][0].numel()):
+                held = [order.pop()]
+            mine = []
+            while len(order) >= 2:
+                a, b = order.pop(0), order.pop(0)
+                mine.append(len(pairs))
+                pairs.append((a, b))
+            plan.append((j, mine, order + held))
+        merged = merge_sorted_pairs(pairs)
+        cur = [[merged[i] for i in mine] + rest for j, mine, rest in plan]
+    devs = [t[0].device for lists in col_lists for t in lists]
+    dev = devs[0] if devs else torch.device("cuda", torch.cuda.current_device())
+    out = []
+    for lists in cur:
+        out.append(lists[0] if lists else (torch.empty(0, dtype=torch.int32, device=dev),
+                                           torch.empty(0, dtype=torch.int64, device=dev)))
+    return out
 
 
 def class_hist(counts: torch.Tensor) -> torch.Tensor:
@@ -1062,12 +1211,23 @@ class EncodeTable:
 
 
 def flat_tables_ok(tabs) -> List[bool]:
-    """EncodeTable.flat_ok for several flat range tables with ONE read-back (the current stream is
-    ordered behind every table's finalisation first, no host wait per table)."""
+    """EncodeTable.flat_ok for several flat range tables with ONE read-back, taken on a side
+    stream that waits for nothing but the tables' own finalisation events: work already queued on
+    the current stream (the encodes that use these very tables) is neither waited for by the host
+    nor held up on the device.  The tables must have been finalised with a ready event."""
+    dev = tabs[0].range_aux.device
+    side = _check_streams.get(dev.index)
+    if side is None:
+        side = _check_streams[dev.index] = torch.cuda.Stream(device=dev)
     for t in tabs:
-        t.wait_ready()
-    words = torch.stack([t.range_aux[EncodeTable.FLAT_AUX_MAXDISP] for t in tabs]).to(torch.int64)
-    return [(int(d) & 0xFFFFFFFF) <= EncodeTable.FLAT_MAX_DISPLACEMENT for d in read_back(words)]
+        if t.ready is not None:
+            t.ready.wait(stream=side.cuda_stream)
+        else:
+            side.wait_stream(torch.cuda.current_stream(dev))  # finalised on the caller's stream
+    with torch.cuda.stream(side):
+        words = torch.stack([t.range_aux[EncodeTable.FLAT_AUX_MAXDISP] for t in tabs]).to(torch.int64)
+        vals = read_back(words)
+    return [(int(d) & 0xFFFFFFFF) <= EncodeTable.FLAT_MAX_DISPLACEMENT for d in vals]
 
 
 def encode_many(items, out_dtype: torch.dtype = torch.int64):

@@ -48,6 +48,7 @@ def _pick(opt, name, default=None):
 
 MERGE_FAN_IN = 8
 LAZY_FINALIZE = os.environ.get("NVT_LAZY_FINALIZE", "1") != "0"
+PIPELINE_COUNTS = os.environ.get("NVT_PIPELINE_COUNTS", "1") != "0"
 
 
 class _GroupFit:
@@ -175,6 +176,9 @@ class Categorify(StatOperator):
         self._pending: Dict[str, dict] = {}
         self._last_paths: Dict[str, int] = {}  # counting path of each column's last partition
         self._no_range = set()                 # columns on which the range path overflowed
+        self._range_failures = []              # (column, NVT_OVF_* bits, distinct) of each overflow
+        self._range_oks: Dict[str, int] = {}   # partitions each column counted on the range path
+        self._flat_unchecked: List[str] = []   # flat range tables whose displacement is still unread
         self._lazy_finalize = None  # (groups, options, base) of a fit whose ordering is deferred
         self._writer_cache: Dict[str, bool] = {}
         self.vocabs = {}
@@ -229,30 +233,46 @@ class Categorify(StatOperator):
 
     def fit_partition(self, state, col_selector, frame):
         frame, _ = as_device_frame(frame)
-        # the previous partition's counts are read back only now: its kernels (and whatever
-        # other operators queued behind them) ran while the host prepared this partition
-        self._absorb_pending(state)
-        jobs, owners = [], []
+        specs = []   # (group, hkey, keys, valid) of every single-vocabulary column
+        combos = []
         for g in state.values():
             keys, valids = self._group_keys(g, frame)
             if g.combo:
-                self._fit_partition_combo(g, keys, valids)
+                combos.append((g, keys, valids))
                 continue
             # joint groups: every column of the group feeds one vocabulary (categorify.py:972-981)
             if len({k.dtype for k in keys}) > 1:
                 keys = [K.widen_i64(k) for k in keys]
             g.key_dtype = keys[0].dtype
             for ci, (k, v) in enumerate(zip(keys, valids)):
-                hkey = f"{g.name}#{ci}"
-                jobs.append(K.DenseCountJob(k, v, None, hint=self._cap_hints.get(hkey, 0),
-                                            allow_range=hkey not in self._no_range))
-                owners.append((g, hkey))
-        if jobs:
+                specs.append((g, f"{g.name}#{ci}", k, v))
+
+        def launch():
             # every column's count kernels are enqueued by ONE C call (top_level_groupby,
             # categorify.py:955); the one readback of all state words happens in
             # _absorb_pending (next partition / fit_end)
+            jobs = [K.DenseCountJob(k, v, None, hint=self._cap_hints.get(hkey, 0),
+                                    allow_range=hkey not in self._no_range)
+                    for _, hkey, k, v in specs]
             with K.annotate("top_level_groupby"):
-                self._pending_counts[id(state)] = (K.CountBatch(jobs), owners)
+                return K.CountBatch(jobs), [(g, hkey) for g, hkey, _, _ in specs]
+
+        # Once every column has a cardinality hint, this partition's counting is enqueued BEFORE
+        # the previous partition's results are read back (the read-back waits for that partition's
+        # own kernels only: CountBatch.results): the GPU goes from one partition's counting to the
+        # next without waiting for the host to digest the results in between (0.5 ms per
+        # partition on the Criteo workload).  A fresh fit reads first: it has no hints to launch on.
+        ahead = None
+        if specs and PIPELINE_COUNTS and id(state) in self._pending_counts and \
+                all(hkey in self._cap_hints for _, hkey, _, _ in specs):
+            ahead = launch()
+        # the previous partition's counts are read back only now: its kernels (and whatever
+        # other operators queued behind them) ran while the host prepared this partition
+        self._absorb_pending(state)
+        for g, keys, valids in combos:
+            self._fit_partition_combo(g, keys, valids)
+        if specs:
+            self._pending_counts[id(state)] = ahead if ahead is not None else launch()
 
     def _absorb_pending(self, state):
         item = self._pending_counts.pop(id(state), None)
@@ -264,33 +284,100 @@ class Categorify(StatOperator):
             self._cap_hints[hkey] = max(64, info["distinct"])
             self._last_paths[hkey] = info["path"]
             if info.get("range_failed"):
-                self._no_range.add(hkey)  # keys not spread over their range: hash paths from now on
-            if info.get("sorted_by_key"):
-                g.sorted = (dk, info)
+                # one overflow does not condemn a column: the hot-key sample is a heuristic (a
+                # frequent key that loses the race for its image bucket floods one region of the
+                # partition pass -- about one 45 M-row partition in a hundred on the Criteo-shaped
+                # columns).  Keys that are NOT spread over their range fail every time: banned
+                # after two overflows making up more than a fifth of the attempts.
+                self._range_failures.append((hkey, info.get("range_fail_bits", 0), info["distinct"]))
+                fails = sum(1 for h, _, _ in self._range_failures if h == hkey)
+                if fails >= 2 and 4 * fails > self._range_oks.get(hkey, 0):
+                    self._no_range.add(hkey)
+            elif info["path"] == K.PATH_RANGE:
+                self._range_oks[hkey] = self._range_oks.get(hkey, 0) + 1
+            srt = bool(info.get("sorted_by_key")) and dk.dtype == torch.int32
             g.nulls += nulls
             g.valid_rows += info["rows"] - nulls
-            per_group.setdefault(g.name, (g, []))[1].append((dk, dc, info["max_count"]))
+            per_group.setdefault(g.name, (g, []))[1].append((dk, dc, info["max_count"], srt, info))
+        due = []
         for g, lists in per_group.values():
             # tree merge with the reference's fan-in (_mid_level_groupby, split_every = 8,
-            # categorify.py:1054-1070): partial lists pile up and are re-counted (weighted
-            # dense count of their concatenation) eight at a time, not after every partition
+            # categorify.py:1054-1070): partial lists pile up and are merged eight at a time, not
+            # after every partition
             g.parts.extend(lists)
             if len(g.parts) >= MERGE_FAN_IN:
-                self._merge_parts(g)
+                due.append(g)
             elif g.table is None and len(g.parts) == 1:
-                g.table, g.parts = g.parts[0], []
+                self._adopt(g, g.parts.pop())
+        self._merge_parts_many(due)
 
-    def _merge_parts(self, g: "_GroupFit"):
-        lists = ([g.table] if g.table is not None else []) + g.parts
-        g.parts = []
-        if not lists:
+    @staticmethod
+    def _adopt(g, part):
+        """A per-partition list becomes the group's table as it is (with what its counting pass
+        left for the finalisation: key order, class histogram, dumped range table)."""
+        dk, dc, mx, srt, info = part
+        g.table = (dk, dc, mx)
+        g.sorted = (dk, info) if srt and info is not None else None
+
+    def _merge_parts_many(self, groups):
+        """_mid_level_groupby (categorify.py:1054-1070) for every group in ``groups``: the
+        accumulated table and the pending per-partition lists become one table.
+
+        KEY-SORTED int32 lists (range path, sort path -- every large column) are merged by the
+        merge-path kernel, all groups in one call per tree level, and stay key-sorted: the
+        vocabulary of a multi-partition fit is ordered by the same one-pass class scatter and
+        gets the same flat range table as a single-partition fit.  Unordered lists (the
+        LDS-resident columns: <= 11 k entries each) are concatenated and re-counted with weights,
+        all groups in one nvt_dense_count_many call."""
+        sorted_jobs, dense_jobs = [], []
+        for g in groups:
+            lists = list(g.parts)
+            if g.table is not None:
+                tab_sorted = g.sorted is not None and g.sorted[0] is g.table[0]
+                lists.insert(0, tuple(g.table) + (tab_sorted, g.sorted[1] if tab_sorted else None))
+            g.parts = []
+            lists = [t for t in lists if int(t[0].numel())]
+            if not lists:
+                continue
+            if len(lists) == 1:
+                self._adopt(g, lists[0])
+                continue
+            if (K.MERGE_SORTED and all(t[3] and t[0].dtype == torch.int32 for t in lists)
+                    and sum(int(t[0].numel()) for t in lists) <= K.MERGE_SORTED_MAX_TOTAL):
+                sorted_jobs.append((g, lists))
+            else:
+                dense_jobs.append((g, lists))
+        if sorted_jobs:
+            merged = K.merge_sorted_tree([[(t[0], t[1]) for t in lists] for _, lists in sorted_jobs])
+            for (g, lists), (k, c) in zip(sorted_jobs, merged):
+                # (the sum of the lists' maxima bounds the largest merged count)
+                g.table = (k, c, sum(int(t[2]) for t in lists))
+                # cls_hist / n_big: filled in at fit_end (_complete_sorted_info), once
+                g.sorted = (k, dict(sorted_by_key=True, cls_hist=None, n_big=None, merged_parts=True))
+        if dense_jobs:
+            outs = K.merge_dense_many([[t[:3] for t in lists] for _, lists in dense_jobs],
+                                      hints=[self._cap_hints.get(g.name, 0) for g, _ in dense_jobs])
+            for (g, _), tab in zip(dense_jobs, outs):
+                g.table = tab
+        for g in groups:
+            if g.table is not None:
+                self._cap_hints[g.name] = max(64, int(g.table[0].numel()))
+
+    def _complete_sorted_info(self, groups):
+        """Key-sorted tables that came out of the partition merge carry no class histogram yet
+        (the counting kernels produce it for single lists): one nvt_class_hist per table, ONE
+        read-back of the class-255 sizes."""
+        todo = [g for g in groups
+                if not g.combo and g.table is not None and g.sorted is not None
+                and g.sorted[0] is g.table[0] and g.sorted[1].get("cls_hist") is None
+                and int(g.table[0].numel())]
+        if not todo:
             return
-        if len(lists) == 1:
-            g.table = lists[0]
-        else:
-            g.table = K.merge_dense(lists, hint=self._cap_hints.get(g.name, 0))
-        if g.table is not None:
-            self._cap_hints[g.name] = max(64, int(g.table[0].numel()))
+        for g in todo:
+            g.sorted[1]["cls_hist"] = K.class_hist(g.table[1])
+        nb = K.read_back(torch.stack([g.sorted[1]["cls_hist"][255] for g in todo]).to(torch.int64))
+        for g, v in zip(todo, nb.tolist()):
+            g.sorted[1]["n_big"] = int(v) & 0xFFFFFFFF
 
     def _fit_partition_combo(self, g: _GroupFit, keys, valids):
         hint = self._cap_hints.get(g.name, g.hint)
@@ -328,10 +415,8 @@ class Categorify(StatOperator):
         self._is_writer = self._writer_cache[key]
         paths = {}
         groups = list(state.values())
-        for g in groups:
-            if not g.combo and g.parts:
-                with K.annotate("mid_level_groupby"):
-                    self._merge_parts(g)
+        with K.annotate("mid_level_groupby"):
+            self._merge_parts_many([g for g in groups if not g.combo and g.parts])
         if dist.world_size() > 1:
             # ONE exchange for every single-vocabulary group of this fit (dist.merge_counts_many)
             singles = [g for g in groups if not g.combo]
@@ -359,6 +444,7 @@ class Categorify(StatOperator):
                     # owners hold key ranges and gather key-sorted shards: the merged list is
                     # key-sorted, the one-pass ordering applies on every rank (int32 keys)
                     g.sorted = (k, info) if info is not None and info.get("sorted_by_key") else None
+        self._complete_sorted_info(groups)
         opts = {}
         for g in groups:
             nb = _pick(self.num_buckets, g.name) if self.num_buckets else None
@@ -443,16 +529,10 @@ class Categorify(StatOperator):
             built.append((g, keys, counts, tab, start))
         K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
                 "nvt_vocab_finalize_many")
-        flats = [i for i, b in enumerate(built) if b[3].flat_slots]
-        if flats:
-            # largest displacement of every flat table: ONE read-back for all of them (it used to
-            # be a blocking read per vocabulary, serialising the host on the finalize streams)
-            for i, ok in zip(flats, K.flat_tables_ok([built[i][3] for i in flats])):
-                if not ok:
-                    # keys that cluster in their range make long probe runs in a monotone table:
-                    # an ordinary hashed table instead (built from the ordered vocabulary, now final)
-                    g, keys, counts, tab, start = built[i]
-                    built[i] = (g, keys, counts, K.EncodeTable(keys, start, unique=True), start)
+        # flat range tables are used as they are and CHECKED LATER (_check_flat_tables, after the
+        # first encode has been queued): reading their largest displacement back here would make
+        # the host wait for the whole finalisation before anything of the transform is enqueued
+        self._flat_unchecked = [g.name for g, _, _, tab, _ in built if tab.flat_slots]
         for g, keys, counts, tab, start in built:
             if not tab.pending:
                 tab.sort_tmp = None  # scratch of work already ordered on this stream
@@ -470,6 +550,27 @@ class Categorify(StatOperator):
                 _write_artifacts(final)
             else:
                 tab.wait_ready()  # `final` (and the counts it holds) dies here: order the stream first
+
+    def _check_flat_tables(self):
+        """Keys that cluster in their range make long probe runs in a monotone (flat) table:
+        correct, but slow.  Once per fit -- after the first consumer's kernels are queued -- the
+        largest displacement of every flat table is read back (ONE read-back, on a side stream
+        behind the tables' finalisation events only) and a table beyond the limit is replaced by an
+        ordinary hashed table for everything that follows."""
+        names, self._flat_unchecked = self._flat_unchecked, []
+        todo = [(n, self._encoders[n]) for n in names
+                if n in self._encoders and getattr(self._encoders[n].table, "flat_slots", 0)]
+        if not todo:
+            return
+        for (name, enc), ok in zip(todo, K.flat_tables_ok([e.table for _, e in todo])):
+            if ok:
+                continue
+            final = self._pending.get(name)
+            keys = final["keys"][0] if final is not None else enc.table._vk
+            tab = K.EncodeTable(keys, enc.first_label_in_file, unique=True)
+            self._encoders[name] = _SingleEncoder(tab, enc.first_label_in_file)
+            if final is not None:
+                final["table"] = tab
 
     # -- vocabulary finalisation ------------------------------------------------
     def _finalize_single(self, g: _GroupFit, dist):
@@ -823,6 +924,8 @@ class Categorify(StatOperator):
                 raise RuntimeError(f"Failed to categorical encode column {names[0]}") from e
             for (name, col, _), out in zip(batch, outs):
                 new[name] = DeviceColumn(out, None, col.offsets, None, None)
+            if self._flat_unchecked:
+                self._check_flat_tables()
         return new.to_pandas() if was_pandas else new
 
     # --------------------------------------------------------------- schema --

@@ -235,7 +235,10 @@ class Workflow:
                 for part in data.to_iter(columns=roots, shard=shard):
                     yield self._run(self.output_node, part, {})
 
-            out = Dataset(gen, schema=self.output_schema, npartitions=data.npartitions)  # property: fitted
+            # (schema: lazily -- folding the fitted properties in is host work, and asking
+            # Categorify for its embedding sizes would enqueue the vocabulary ordering ahead of
+            # the kernels of the first partition that can run underneath it)
+            out = Dataset(gen, schema=lambda: self.output_schema, npartitions=data.npartitions)
             out._forwards_shard = True  # rank sharding is decided by the source dataset
             return out
         if isinstance(data, pd.DataFrame):
