@@ -32,8 +32,15 @@
 
 namespace nvt {
 
-constexpr int kMgBS = 256;
-constexpr int kMgVT = 15;  // odd: the threads' serial LDS walks start on different banks
+#ifndef NVT_MG_BS
+#define NVT_MG_BS 1024
+#endif
+#ifndef NVT_MG_VT
+#define NVT_MG_VT 5
+#endif
+constexpr int kMgBS = NVT_MG_BS;
+constexpr int kMgVT = NVT_MG_VT;  // odd: the threads' serial LDS walks start on different banks; 1024 x 5 measured
+                                  // best of {128..1024} x {3..15} (tools/var_merge.sh: short serial walks, 32 waves per CU)
 constexpr int kMgTile = kMgBS * kMgVT;
 constexpr int kMgMaxCols = 30;
 

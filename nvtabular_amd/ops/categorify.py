@@ -49,6 +49,9 @@ def _pick(opt, name, default=None):
 MERGE_FAN_IN = 8
 LAZY_FINALIZE = os.environ.get("NVT_LAZY_FINALIZE", "1") != "0"
 PIPELINE_COUNTS = os.environ.get("NVT_PIPELINE_COUNTS", "1") != "0"
+# (opt-in: measured 12.44 vs 12.15 ms per Criteo step -- the ordering kernels and the LDS-resident
+# encodes slow each other down by more than the overlap buys; profiles/r04_notes.md)
+SPLIT_FINALIZE = os.environ.get("NVT_SPLIT_FINALIZE", "0") == "1"
 
 
 class _GroupFit:
@@ -186,7 +189,11 @@ class Categorify(StatOperator):
             self.vocabs = self.process_vocabs(vocabs)
         self.categories = deepcopy(self.vocabs)
 
-    fit_end_priority = 1  # after the operators whose fit_end is a scalar read-back (workflow.py)
+    # BEFORE the operators whose fit_end is a scalar read-back (Normalize): the count states are
+    # read back behind the counting kernels only (CountBatch._read_states), so the host digests
+    # them -- a few hundred microseconds for the 26 Criteo columns -- while the moments kernel
+    # that was queued behind the counting still runs, instead of after it
+    fit_end_priority = -1
 
     def range_name(self, kind: str) -> str:
         return "Categorify_fit" if kind == "fit" else "Categorify_transform"  # categorify.py:345,477
@@ -499,11 +506,24 @@ class Categorify(StatOperator):
             return False
         return int(g.table[0].numel()) > 0
 
-    def _ensure_finalized(self):
-        lazy, self._lazy_finalize = self._lazy_finalize, None
-        if lazy is not None:
+    def _ensure_finalized(self, small_only=False):
+        """Enqueue the deferred ordering + table work of the last fit.  small_only: just the
+        vocabularies the one-launch batched sort takes (<= 16384 entries, not key-sorted) -- a
+        handful of launches; transform encodes their columns before it spends ~1 ms of host time
+        enqueueing the ~130 launches of the large vocabularies, which then run on the internal
+        streams UNDERNEATH those encodes instead of in front of them."""
+        if self._lazy_finalize is None:
+            return
+        groups, opts, base = self._lazy_finalize
+        if small_only:
+            now = [g for g in groups if _small_vocab(g)]
+            rest = [g for g in groups if not _small_vocab(g)]
+            self._lazy_finalize = (rest, opts, base) if rest else None
+        else:
+            now, self._lazy_finalize = groups, None
+        if now:
             with K.annotate("write_uniques"):
-                self._finalize_fast(*lazy)
+                self._finalize_fast(now, opts, base)
 
     def _finalize_fast(self, groups, opts, base):
         descs = (K._lib.VocabCol * len(groups))()
@@ -831,7 +851,8 @@ class Categorify(StatOperator):
 
     # ------------------------------------------------------------ transform --
     def _encoder_for(self, storage_name: str, cols: List[str], frame: DeviceFrame):
-        self._ensure_finalized()
+        if self._lazy_finalize is not None and any(g.name == storage_name for g in self._lazy_finalize[0]):
+            self._ensure_finalized()
         enc = self._encoders.get(storage_name)
         if enc is not None:
             return enc
@@ -891,16 +912,42 @@ class Categorify(StatOperator):
             assert all(x in self.freq_threshold for x in col_selector.names)
         column_mapping = self.column_mapping(col_selector)
         out_dtype = torch.int32 if np.dtype(self.output_dtype) == np.dtype("int32") else torch.int64
+        # two rounds while vocabularies of the last fit still wait for their ordering (lazy
+        # finalisation): the columns of the SMALL vocabularies are finalised and encoded first,
+        # then the large ones are enqueued (the bulk of the host's launch work) and encoded
+        names = list(column_mapping)
+        rounds = [names]
+        if self._lazy_finalize is not None and SPLIT_FINALIZE:
+            self._ensure_finalized(small_only=True)
+            if self._lazy_finalize is not None:
+                late = {g.name for g in self._lazy_finalize[0]}
+                first = [n for n in names if self._storage_of(n, column_mapping) not in late]
+                rounds = [first, [n for n in names if n not in set(first)]]
+        for todo in rounds:
+            self._encode_round(todo, column_mapping, frame, new, out_dtype)
+        # (column order of the result: as the one-round version produced it)
+        ordered = frame.copy(deep=False)
+        for name in names:
+            ordered[name] = new[name]
+        new = ordered
+        return new.to_pandas() if was_pandas else new
+
+    def _storage_of(self, name, column_mapping):
+        use_name = column_mapping.get(name, name)
+        if isinstance(use_name, (list, tuple)) and len(use_name) == 1:
+            use_name = use_name[0]
+        if use_name != name or self.encode_type == "joint":
+            return self.storage_name.get(name, name)
+        return name
+
+    def _encode_round(self, names, column_mapping, frame, new, out_dtype):
         batch = []  # single-vocabulary columns: encoded by ONE C call (nvt_encode_many)
-        for name in column_mapping:
+        for name in names:
             try:
                 use_name = column_mapping.get(name, name)
                 if isinstance(use_name, (list, tuple)) and len(use_name) == 1:
                     use_name = use_name[0]
-                if use_name != name or self.encode_type == "joint":
-                    storage_name = self.storage_name.get(name, name)
-                else:
-                    storage_name = name
+                storage_name = self._storage_of(name, column_mapping)
                 cols = list(use_name) if isinstance(use_name, (list, tuple)) else [use_name]
                 nb = _pick(self.num_buckets, storage_name) if self.num_buckets else None
                 enc = self._encoder_for(storage_name, cols, frame)
@@ -926,7 +973,6 @@ class Categorify(StatOperator):
                 new[name] = DeviceColumn(out, None, col.offsets, None, None)
             if self._flat_unchecked:
                 self._check_flat_tables()
-        return new.to_pandas() if was_pandas else new
 
     # --------------------------------------------------------------- schema --
     def column_mapping(self, col_selector):
@@ -1054,6 +1100,14 @@ def _merge_groups(acc: "K.GroupbyTable", comp) -> "K.GroupbyTable":
     if acc.state()[K._lib.ST_OVERFLOW]:
         raise K._lib.NvtHipError("groupby table overflow during merge")
     return acc
+
+
+def _small_vocab(g) -> bool:
+    """True for the vocabularies nvt_vocab_finalize_many orders in its one batched launch."""
+    if g.table is None or (g.sorted is not None and g.sorted[0] is g.table[0]):
+        return False
+    keys, _, max_count = g.table
+    return keys.dtype == torch.int32 and 2 <= int(keys.numel()) <= 16384 and 0 < int(max_count) < (1 << 32)
 
 
 class _SingleEncoder:

@@ -11,7 +11,7 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-TILE = 256 * 15   # kMgTile of nvt_merge.hip
+TILE = 1024 * 5   # kMgTile of nvt_merge.hip
 
 
 def _np_merge(ka, ca, kb, cb):

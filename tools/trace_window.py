@@ -44,3 +44,17 @@ print("gaps >= %.0f us:" % min_gap)
 for g, o, a, b in gaps:
     if g / 1e3 >= min_gap:
         print("  @%8.2f ms  %7.1f us  %s -> %s" % (o / 1e6, g / 1e3, a, b))
+
+agg = collections.defaultdict(lambda: [0, 0])
+for r in tr:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg[name(r)][0] += d
+    agg[name(r)][1] += 1
+print("kernels in the window (launches, total ms, avg us):")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:28]:
+    print("  %-46s %5d %9.3f %9.1f" % (k, v[1], v[0] / 1e6, v[0] / v[1] / 1e3))
+if "--merge" in sys.argv:
+    for r in tr:
+        if "merge_tile" in r["Kernel_Name"] or "merge_split" in r["Kernel_Name"]:
+            print("  @%8.2f ms %8.1f us  %s grid %s" % ((int(r["Start_Timestamp"]) - t0) / 1e6,
+                  (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, name(r), r.get("Grid_Size", "")))
