@@ -33,7 +33,7 @@ N_CONT = 13
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def synth_criteo(n, device, seed=20260923, n_cat=26, n_cont=N_CONT):
+def synth_criteo(n, device, seed=20260923, n_cat=26, n_cont=N_CONT, scramble=True):
     """Deterministic Criteo-shaped frame, generated on `device` (torch RNG).
 
     Categorical j: bounded power law over its Criteo cardinality (exponent cycling
@@ -52,7 +52,9 @@ def synth_criteo(n, device, seed=20260923, n_cat=26, n_cont=N_CONT):
         u = torch.rand(n, device=device, dtype=torch.float64, generator=g)
         x = ((card ** (1.0 - s) - 1.0) * u + 1.0) ** (1.0 / (1.0 - s))
         x = x.floor().clamp_(1, card).to(torch.int64)
-        ids = ((x * 2654435761 + 97 * j) % (2**31)).to(torch.int32)
+        # scramble=False: ids = the frequency rank itself (dense, frequency-ordered, pre-encoded
+        # ids -- the other common input; the range path's equal-width buckets assume hash-like ids)
+        ids = ((x * 2654435761 + 97 * j) % (2**31)).to(torch.int32) if scramble else x.to(torch.int32)
         valid = None
         nf = nulls[j % 3]
         if nf > 0:
@@ -178,7 +180,8 @@ def cpu_baseline(frame, cat_names, cont_names, sample_rows, tmp):
         "sample": f"first {sample_rows} rows of the same synthetic frame, fit+transform, pandas "
                   f"{pandas_v}, one column per task on {par['procs']} worker processes "
                   f"({os.cpu_count()} host cores visible): {par['seconds']:.1f} s; "
-                  f"single process: {dt:.1f} s = {serial:.0f} rows/s",
+                  f"single process: {dt:.1f} s = {serial:.0f} rows/s; pandas' hash groupby is "
+                  f"super-linear in the distinct keys, so the rate at the full 45 M rows would be lower",
         "single_process_rows_per_s": serial,
     }, oracle_out
 
@@ -243,7 +246,10 @@ def pmc_traffic():
     path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            d = json.load(f)
+        d["source"] = ("committed profile profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of "
+                       "this command at this size, tools/prof_r03.sh; NOT collected in this run)")
+        return d
     except Exception:
         return None
 
@@ -595,6 +601,71 @@ def extra_multipart(device, tmp, rows, nparts=8, steps=2, single_ms=None):
     return res
 
 
+def extra_dense_ids(device, tmp, rows, steps=5, single_ms=None):
+    """The headline workload with UNSCRAMBLED ids (id = frequency rank: dense, power-law over
+    [1, cardinality]): what the range path's equal-width key-range buckets cost when the keys are
+    not spread like hashes (overflow -> sort path).  Same schema, same step, parity by the
+    full-frame property checks."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd.node import iter_nodes
+
+    frame = synth_criteo(rows, device, scramble=False)
+    cat_names = [c for c in frame.columns if c.startswith("C")]
+    cont_names = [c for c in frame.columns if c.startswith("I")]
+    wf = build_workflow(cat_names, cont_names, os.path.join(tmp, "dense_ids"))
+    ds = nvt.Dataset(frame)
+
+    def step():
+        wf.fit(ds)
+        return wf.transform(frame)
+
+    ms, rep = _timed_steps(step, steps)
+    op = [n.op for n in iter_nodes(wf.output_node) if type(n.op).__name__ == "Categorify"][0]
+    paths = {}
+    for v in op._last_paths.values():
+        paths[str(v)] = paths.get(str(v), 0) + 1
+    fam = {}
+    for scope, (tot_ms, _, _) in rep["kernels"].items():
+        fam[family_of(scope)] = fam.get(family_of(scope), 0.0) + tot_ms
+    out = step()
+    res = {
+        "workload": f"cfg2 with dense frequency-ordered ids (no scrambling), {rows} rows, fit + transform",
+        "rows_per_s": rows / (ms / 1e3), "ms_per_step": ms,
+        "ratio_to_scrambled_headline": (ms / single_ms) if single_ms else None,
+        "counting_paths": paths,
+        "range_path_banned_columns": sorted(op._no_range),
+        "range_overflows": len(op._range_failures),
+        "per_family_ms": {k: round(v, 3) for k, v in sorted(fam.items())},
+        "parity": property_checks(wf, [frame], [out], cat_names, cont_names),
+    }
+    return res
+
+
+def reference_tie_break_step_ms(frame, cat_names, cont_names, tmp):
+    """One fit + transform with Categorify(tie_break="reference"): the (key, count) lists go to the
+    host and through the reference's literal two pandas sort_values calls
+    (categorify.py:1300,1316), so labels equal a reference run tie for tie.  O(#uniques) host work:
+    reported, never `value`."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    cats = cat_names >> ops.Categorify(out_path=os.path.join(tmp, "tie_ref"), defer_artifacts=True,
+                                       tie_break="reference")
+    conts = cont_names >> ops.FillMissing() >> ops.Normalize()
+    wf = nvt.Workflow(cats + conts)
+    ds = nvt.Dataset(frame)
+    wf.fit(ds)
+    out = wf.transform(frame)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wf.fit(ds)
+    out = wf.transform(frame)
+    torch.cuda.synchronize()
+    del out
+    return 1e3 * (time.perf_counter() - t0)
+
+
 def extra_cfg5(device, tmp, rows=10_000_000, steps=3):
     """BASELINE.json configs[4]: multi-hot list<int32> column (0..8 leaves per row, Zipf over
     1 M ids) + a scalar id column: Categorify on both and HashBucket on the list column
@@ -873,7 +944,16 @@ def main():
     wf_cold.fit(ds)
     out = wf_cold.transform(frame)
     barrier()
-    cold_info["fresh_workflow_warm_process_ms"] = round(1e3 * (time.perf_counter() - t3), 2)
+    fresh_ms = 1e3 * (time.perf_counter() - t3)
+    cold_info["fresh_workflow_warm_process_ms"] = round(fresh_ms, 2)
+    # full-frame parity of the TIMED frame (the state the timed steps left behind: same workflow,
+    # same frame), through the size-independent properties of tests/test_gpu_fullsize.py
+    full_frame = None
+    if world == 1:
+        try:
+            full_frame = property_checks(wf, [frame], [wf.transform(frame)], cat_names, cont_names)
+        except Exception as e:  # never break the line
+            full_frame = {"full_frame_ok": False, "error": repr(e)}
     del out, wf_cold
     if world > 1:
         import torch.distributed as td
@@ -923,6 +1003,7 @@ def main():
             "unit": "GB/s", "frac": d["frac"],
             "traffic": (d["hbm_traffic_bytes_per_step"] / launches
                         if d["hbm_traffic_bytes_per_step"] else None),
+            "traffic_source": (traffic or {}).get("source"),
             "avg_launch_us": round(1e3 * d["ms_per_step"] / launches, 2),
             "launches": int(round(launches * args.steps)),
             "algorithmic_bytes_per_launch": int(d["algorithmic_bytes_per_step"] / launches),
@@ -952,6 +1033,12 @@ def main():
         "profiled_pass_ms_per_step": round(1e3 * dt_prof / args.steps, 3),
         "cold_step_ms": round(cold_ms, 2),
         "cold_step": cold_info,
+        # what a user's FIRST fit of a workflow costs in a warm process (no cardinality hints:
+        # presample + conservative paths); `value` is the steady-state refit
+        "fresh_fit": {"ms_per_step": round(fresh_ms, 2), "rows_per_s": world * n / (fresh_ms / 1e3),
+                      "frac_of_hbm_peak": world * n / (fresh_ms / 1e3) * ((26 * 4 + N_CONT * 4) + (26 * 12 + N_CONT * 12))
+                      / 1e9 / (HBM_PEAK_GBS * world),
+                      "state": "fresh workflow (no hints), process warm"},
         "host_timeline_ms": _host_timeline(timed_marks),
         # hipMalloc calls the caching allocator had to make inside the timed region (0 = the
         # warm-up reached the steady-state footprint)
@@ -987,6 +1074,19 @@ def main():
         result["cpu_baseline"], oracle_out = cpu_baseline(frame, cat_names, cont_names, sample, tmp)
         with _dist.local_only():
             result["parity"] = parity_check(frame, cat_names, cont_names, sample, oracle_out, tmp)
+        if full_frame is not None:
+            result["parity"].update({"full_frame_ok": full_frame.get("full_frame_ok"),
+                                     "full_frame": full_frame})
+        result["parity"]["tie_break_note"] = (
+            "labels equal the reference up to permutations inside equal-count blocks "
+            "(tie_break='value': count desc, value asc; the reference's second sort_values is "
+            "pandas' unstable default); tie_break='reference' reproduces the literal order on the "
+            "host: reference_tie_break_step_ms")
+        try:
+            result["reference_tie_break_step_ms"] = round(
+                reference_tie_break_step_ms(frame, cat_names, cont_names, tmp), 1)
+        except Exception as e:
+            result["reference_tie_break_step_ms"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_extra and not args.no_cpu_baseline:
         # entries beside the headline number (never `value`); none of them may break the line
         try:
@@ -999,9 +1099,12 @@ def main():
         extras = {}
         for key, fn in (("cfg3_multipartition", lambda: extra_multipart(device, tmp, n, args.multipart,
                                                                         single_ms=ms_per_step)),
+                        ("cfg2_dense_ids", lambda: extra_dense_ids(device, tmp, n, single_ms=ms_per_step)),
                         ("cfg4_te_joingroupby", lambda: extra_cfg4(device, tmp, args.cfg4_rows, 1_000_000)),
                         ("cfg3_highcard_columns", lambda: extra_cfg3(device, tmp, n)),
                         ("cfg5_multihot", lambda: extra_cfg5(device, tmp))):
+            if args.only_extra and key not in args.only_extra.split(","):
+                continue
             try:
                 extras[key] = fn()
             except Exception as e:

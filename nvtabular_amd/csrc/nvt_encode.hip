@@ -439,6 +439,17 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
 #pragma unroll
       for (int q = 0; q < NK; ++q) {
         if (!need[q]) continue;
+        if constexpr (RANGE) {
+          if (rmap.flat) {
+            // flat table: runs are in key order -- linear for a few slots, then doubling +
+            // bisection (flat_find_from: keys that cluster in their range sit far from home)
+            const uint64_t at = flat_find_from(reinterpret_cast<const unsigned long long *>(table),
+                                               mask + 1, slot[q], (int32_t)k[q],
+                                               *reinterpret_cast<const unsigned long long *>(&e[q]));
+            if (at != ~0ull) lab[q] = (int64_t)table[at].label;
+            continue;
+          }
+        }
         while (true) {  // collisions continue here (load factor <= 0.5: short chains)
           if (e[q].key == k[q]) {
             lab[q] = (int64_t)e[q].label;
@@ -628,17 +639,19 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
     unsigned hgrid = stream_grid(n / VEC + 1, kEncBS * 2, 1);
     if constexpr (sizeof(K) == 4) {
       static const bool two = getenv("NVT_ENC_LINEAR") == nullptr;
+      // (range tables: `mask` = capacity - 1 bounds the search of a FLAT table -- capacity slots --
+      // and is unused for the dumped bucket tables, capacity 0)
       if (global_needed && (two || range_aux != nullptr)) {  // cache mode: 2-choice table filled to 7/8
         const uint64_t cap2 = (uint64_t)HotCfg<K>::slots / 8 * 7;
         n_hot = (uint32_t)(n_vocab < cap2 ? n_vocab : cap2);
         if (range_aux != nullptr) {
           if (out_bytes == 8)
             encode_hot_kernel<K, int64_t, true, true, 2, true><<<hgrid, kEncBS, 0, s>>>(
-                keys, valid, n, t, 0, sentinel_label, null_label, oov_label, num_buckets,
+                keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
                 reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label, range_aux);
           else
             encode_hot_kernel<K, int32_t, true, true, 2, true><<<hgrid, kEncBS, 0, s>>>(
-                keys, valid, n, t, 0, sentinel_label, null_label, oov_label, num_buckets,
+                keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
                 reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label, range_aux);
           NVT_CHECK_LAUNCH();
           return NVT_OK;

@@ -48,6 +48,49 @@ struct RangeMap {
   }
 };
 
+// Slot of `key` in a FLAT range table ({key, label} words laid out from a key-sorted list by
+// flat_build_kernel: every run of occupied slots is in ascending key order), or ~0 when the
+// key is not there.  The first kFlatLinear slots are probed one by one (keys that are spread
+// over their range sit within a few slots of home); beyond that the run is searched by
+// doubling steps and bisection -- O(log displacement) loads.  Keys that CLUSTER in their range
+// (dense ids with a heavy tail: a million consecutive ids in front of a sparse range) sit
+// hundreds of thousands of slots from home; a slot-by-slot walk took minutes per column there.
+// `e0` = the word already loaded from `home`.
+constexpr int kFlatLinear = 8;
+__device__ __forceinline__ uint64_t flat_find_from(const unsigned long long *__restrict__ table,
+                                                   uint64_t slots, uint64_t home, int32_t key,
+                                                   unsigned long long e0) {
+  const uint32_t uk = ukey(key);
+  auto below = [&](unsigned long long e) {  // occupied and in front of `key`
+    const int32_t ek = (int32_t)(uint32_t)e;
+    return ek != INT32_MIN && ukey(ek) < uk;
+  };
+  uint64_t sl = home;
+  unsigned long long e = e0;
+#pragma unroll 1
+  for (int step = 0; step < kFlatLinear; ++step) {
+    if ((int32_t)(uint32_t)e == key) return sl;
+    if (!below(e)) return ~0ull;
+    if (++sl >= slots) return ~0ull;
+    e = table[sl];
+  }
+  // table[sl - 1] is below the key; find hi with !below(table[hi]) by doubling, then bisect
+  uint64_t lo = sl - 1, width = kFlatLinear;
+  uint64_t hi;
+  while (true) {
+    hi = lo + width < slots - 1 ? lo + width : slots - 1;
+    if (!below(table[hi]) || hi == slots - 1) break;
+    lo = hi;
+    width <<= 1;
+  }
+  if (below(table[hi])) return ~0ull;  // (ran into the end of the table)
+  while (hi - lo > 1) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if (below(table[mid])) lo = mid; else hi = mid;
+  }
+  return (int32_t)(uint32_t)table[hi] == key ? hi : ~0ull;
+}
+
 __device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {
   RangeMap m;
   m.ulo = (uint32_t)aux[NVT_RANGE_AUX_LO];

@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(kBlock) void range_patch_kernel(unsigned long long 
 // labels of the (few) entries of class 255 after their own sort: vocab[j] -> first_label + j
 __global__ __launch_bounds__(kBlock) void range_fix_prefix_kernel(
     unsigned long long *table, const int32_t *__restrict__ aux, const int32_t *__restrict__ vocab,
-    uint64_t n_big, int64_t first_label, int64_t *sentinel_label) {
+    uint64_t n_big, int64_t first_label, int64_t *sentinel_label, uint64_t table_slots) {
   const RangeMap map = load_map(aux);
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n_big; j += stride) {
@@ -1110,6 +1110,11 @@ __global__ __launch_bounds__(kBlock) void range_fix_prefix_kernel(
       continue;
     }
     uint64_t s = map.table_slot(key);
+    if (map.flat) {  // runs in key order: bounded search (keys that cluster in their range)
+      s = flat_find_from(table, table_slots, s, key, table[s]);
+      if (s != ~0ull) table[s] = ((unsigned long long)(uint32_t)label << 32) | (uint32_t)key;
+      continue;
+    }
     while (true) {
       const unsigned long long e = table[s];
       if ((int32_t)(uint32_t)e == key) {
@@ -1306,14 +1311,10 @@ __device__ __forceinline__ int64_t flat_probe(const FlatIndexView &v, const K *_
   if (!bit_valid(valid, i) || kv < (int64_t)INT32_MIN || kv > (int64_t)INT32_MAX) return -1;
   const int32_t k = (int32_t)kv;
   if (k == INT32_MIN) return v.has_min ? 0 : -1;
-  const uint32_t uk = ukey(k);
-  for (uint64_t sl = v.map.fine(k); sl < v.slots; ++sl) {
-    const unsigned long long e = v.table[sl];
-    const int32_t ek = (int32_t)(uint32_t)e;
-    if (ek == k) return (int64_t)(uint32_t)(e >> 32);
-    if (ek == INT32_MIN || ukey(ek) > uk) break;
-  }
-  return -1;
+  const uint64_t home = v.map.fine(k);
+  if (home >= v.slots) return -1;
+  const uint64_t sl = flat_find_from(v.table, v.slots, home, k, v.table[home]);
+  return sl == ~0ull ? -1 : (int64_t)(uint32_t)(v.table[sl] >> 32);
 }
 
 template <typename K>
@@ -1510,7 +1511,8 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
     if (ranged) {
       NVT_PROF("encode_build", 0, s);
       range_fix_prefix_kernel<<<stream_grid(n_big, kBlock), kBlock, 0, s>>>(
-          (unsigned long long *)table, range_aux, out_keys, n_big, first_label, sentinel_label);
+          (unsigned long long *)table, range_aux, out_keys, n_big, first_label, sentinel_label,
+          capacity);
       NVT_CHECK_LAUNCH();
     } else {
       int rc = encode_insert_any(4, out_keys, n_big, first_label, table, capacity, sentinel_label, s);
@@ -1539,7 +1541,7 @@ int vocab_order_tail_batch(const OrderTail *t, int nt, hipStream_t s) {
     if (t[i].range_aux) {
       range_fix_prefix_kernel<<<stream_grid(t[i].n_big, kBlock), kBlock, 0, s>>>(
           (unsigned long long *)t[i].table, t[i].range_aux, t[i].keys, t[i].n_big, t[i].first_label,
-          t[i].sentinel_label);
+          t[i].sentinel_label, t[i].capacity);
       NVT_CHECK_LAUNCH();
     } else {
       rc = encode_insert_any(4, t[i].keys, t[i].n_big, t[i].first_label, t[i].table, t[i].capacity,

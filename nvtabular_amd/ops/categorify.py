@@ -182,6 +182,7 @@ class Categorify(StatOperator):
         self._range_failures = []              # (column, NVT_OVF_* bits, distinct) of each overflow
         self._range_oks: Dict[str, int] = {}   # partitions each column counted on the range path
         self._flat_unchecked: List[str] = []   # flat range tables whose displacement is still unread
+        self._no_flat = set()                  # vocabularies whose keys cluster: hashed tables
         self._lazy_finalize = None  # (groups, options, base) of a fit whose ordering is deferred
         self._writer_cache: Dict[str, bool] = {}
         self.vocabs = {}
@@ -543,8 +544,10 @@ class Categorify(StatOperator):
                     rtab = (info["range_table"], info["range_aux"], info["range_bits"])
             # a key-sorted source without a dumped table (sort path, multi-GPU merge): the table
             # is laid out from the sorted keys in one pass (flat range table)
+            # (a vocabulary whose keys cluster in their range -- found out by an earlier fit's
+            # _check_flat_tables -- gets an ordinary hashed table straight away)
             tab = K.EncodeTable(keys, start, unique=True, defer_build=True, range_table=rtab,
-                                flat=src is not None and rtab is None)
+                                flat=src is not None and rtab is None and g.name not in self._no_flat)
             tab.fill_vocab_desc(d, counts, max_count, src=src)
             built.append((g, keys, counts, tab, start))
         K.check(K._lib.load().nvt_vocab_finalize_many(descs, len(groups), K.stream_ptr()),
@@ -585,6 +588,7 @@ class Categorify(StatOperator):
         for (name, enc), ok in zip(todo, K.flat_tables_ok([e.table for _, e in todo])):
             if ok:
                 continue
+            self._no_flat.add(name)  # remembered: the next fit builds a hashed table straight away
             final = self._pending.get(name)
             keys = final["keys"][0] if final is not None else enc.table._vk
             tab = K.EncodeTable(keys, enc.first_label_in_file, unique=True)
