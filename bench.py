@@ -381,6 +381,116 @@ def extra_cfg4(device, tmp, rows, sample_rows, steps=5):
     return res
 
 
+def extra_cfg4_multipart(device, tmp, rows_per_part=1 << 28, nparts=4, card=100_000_000, steps=2,
+                         single=None):
+    """BASELINE.json configs[3] at its cardinality on ONE GPU: TargetEncoding (kfold 5, seed 42,
+    p_smooth 20) + JoinGroupby (count / sum / mean / std) over `nparts` partitions of
+    `rows_per_part` rows, 10^8-id skewed int32 key column, float32 target, all resident.  Every
+    partition's groups come from the sort path and are merged by the merge-path kernel (the fit
+    stays on the sort path across partitions); transform over all partitions.  Parity: the first
+    million rows of partition 0 against the oracle fitted on the same FOUR-partition prefix shape
+    (4 x 250 k rows)."""
+    import pandas as pd
+
+    import nvtabular_amd as nvt
+    import oracle as O
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+    from nvtabular_amd.device import DeviceColumn, DeviceFrame
+
+    p = 20.0
+    stats = ["count", "sum", "mean", "std"]
+
+    def make(seed, n):
+        g = torch.Generator(device=device).manual_seed(seed)
+        raw = (torch.rand(n, device=device, generator=g, dtype=torch.float64) ** 3 * card).to(torch.int64)
+        key = ((raw * 2654435761) % (2**31)).to(torch.int32)
+        y = torch.rand(n, device=device, generator=g, dtype=torch.float32)
+        del raw
+        return DeviceFrame({"k": DeviceColumn(key), "y": DeviceColumn(y)})
+
+    def build(path):
+        te = ["k"] >> ops.TargetEncoding("y", kfold=5, fold_seed=42, p_smooth=p, defer_artifacts=True,
+                                          out_path=os.path.join(path, "te"))
+        jg = ["k"] >> ops.JoinGroupby(cont_cols=["y"], stats=stats, defer_artifacts=True,
+                                      out_path=os.path.join(path, "jg"))
+        return nvt.Workflow(te + jg)
+
+    frames = [make(700 + i, rows_per_part) for i in range(nparts)]
+    wf = build(os.path.join(tmp, "cfg4mp"))
+    ds = nvt.Dataset(frames)
+
+    def step():
+        wf.fit(ds)
+        for out in wf.transform(ds).to_iter():
+            del out
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    K.profile_begin()
+    step()
+    rep = K.profile_report()
+    from nvtabular_amd.node import iter_nodes
+
+    jg_op = [n.op for n in iter_nodes(wf.output_node) if type(n.op).__name__ == "JoinGroupby"][0]
+    st = jg_op._device_stats["k"]
+    rows = rows_per_part * nparts
+    res = {
+        "workload": f"TargetEncoding(kfold=5, seed 42, p=20) + JoinGroupby(count,sum,mean,std), "
+                    f"{nparts} partitions x {rows_per_part} rows, {card} skewed int32 ids, float32 "
+                    "target, fit over all partitions + transform over all partitions, resident",
+        "partitions": nparts, "rows": rows, "groups": int(st.n),
+        "rows_per_s": rows / dt, "ms_per_step": 1e3 * dt, "ms_per_partition": 1e3 * dt / nparts,
+        "sorted_path_kept": isinstance(st.index, K.FlatIndex),
+        "single_partition_rows_per_s": single,
+        "ratio_to_single_partition_rows_per_s": (rows / dt / single) if single else None,
+        "gpu_busy_ms": round(rep["busy_ms"], 3),
+        "per_kernel_ms": {k: round(v[0], 3) for k, v in rep["kernels"].items()},
+    }
+    del frames, ds, wf
+    torch.cuda.empty_cache()
+    # parity: 4 x 250 k rows through the same multi-partition code path vs the oracle
+    m = 250_000
+    small = [make(900 + i, m) for i in range(4)]
+    hparts = [pd.DataFrame({"k": f["k"].data.cpu().numpy(), "y": f["y"].data.cpu().numpy()}) for f in small]
+    cpu_dir = os.path.join(tmp, "cfg4mp_cpu")
+    te_stats, te_means = O.target_encoding_fit([h.copy() for h in hparts], ["k"], ["y"],
+                                               os.path.join(cpu_dir, "te"), kfold=5, fold_seed=42)
+    jg_cats = O.join_groupby_fit([h.copy() for h in hparts], [["k"]], ["y"], stats, os.path.join(cpu_dir, "jg"))
+    wf2 = build(os.path.join(tmp, "cfg4mp_par"))
+    wf2.fit(nvt.Dataset(small))
+    worst, nan_mismatch, per_col = 0.0, {}, {}
+    for h, f in zip(hparts, small):
+        got = wf2.transform(f)
+        te_out = O.target_encoding_transform(h.copy(), ["k"], ["y"], te_stats, te_means, kfold=5,
+                                             fold_seed=42, p_smooth=p)
+        jg_out = O.join_groupby_transform(h.copy(), [["k"]], jg_cats)
+        for name, exp in [("TE_k_y", te_out["TE_k_y"])] + [(c, jg_out[c]) for c in jg_out.columns]:
+            gv = got[name].data.cpu().numpy().astype("float64")
+            ev = exp.to_numpy().astype("float64")
+            if name.endswith("_std"):  # (float32 accumulation of the pandas path: see extra_cfg4)
+                tiny = (np.nan_to_num(np.abs(gv), nan=0.0) < 1e-2) & (np.nan_to_num(np.abs(ev), nan=0.0) < 1e-2)
+                tiny &= jg_out["k_count"].to_numpy() >= 2
+                gv, ev = np.where(tiny, 0.0, gv), np.where(tiny, 0.0, ev)
+            bad = int((np.isnan(gv) != np.isnan(ev)).sum())
+            if bad:
+                nan_mismatch[name] = nan_mismatch.get(name, 0) + bad
+            ok = ~np.isnan(ev) & ~np.isnan(gv)
+            if ok.any():
+                rel = float(np.max(np.abs(gv[ok] - ev[ok]) / np.maximum(np.abs(ev[ok]), 1e-3)))
+                per_col[name] = max(per_col.get(name, 0.0), rel)
+    tol = {c: (5e-3 if c.endswith("_std") else 1e-5) for c in per_col}
+    res["parity"] = {"parity_checked_rows": 4 * m, "partitions": 4, "per_column_max_rel_err": per_col,
+                     "tolerance": tol, "nan_mismatch": nan_mismatch,
+                     "parity_ok": bool(all(per_col[c] <= tol[c] for c in per_col) and not nan_mismatch)}
+    return res
+
+
 def _timed_steps(step, steps):
     """(ms per step, profile report of one more step) of a fit + transform closure."""
     from nvtabular_amd import kernels as K
@@ -770,6 +880,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] (TE + JoinGroupby) entry")
     ap.add_argument("--cfg4-rows", type=int, default=20_000_000)
     ap.add_argument("--multipart", type=int, default=8, help="partitions of the cfg3_multipartition entry")
+    ap.add_argument("--cfg4-parts", type=int, default=4)
+    ap.add_argument("--cfg4-part-rows", type=int, default=1 << 28)
     ap.add_argument("--only-extra", default=None, help="run only this extra_configs entry (diagnostic)")
     ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-procs", type=int, default=1, help=argparse.SUPPRESS)
@@ -1101,6 +1213,9 @@ def main():
                                                                         single_ms=ms_per_step)),
                         ("cfg2_dense_ids", lambda: extra_dense_ids(device, tmp, n, single_ms=ms_per_step)),
                         ("cfg4_te_joingroupby", lambda: extra_cfg4(device, tmp, args.cfg4_rows, 1_000_000)),
+                        ("cfg4_multipartition", lambda: extra_cfg4_multipart(
+                            device, tmp, args.cfg4_part_rows, args.cfg4_parts,
+                            single=(extras.get("cfg4_te_joingroupby") or {}).get("rows_per_s"))),
                         ("cfg3_highcard_columns", lambda: extra_cfg3(device, tmp, n)),
                         ("cfg5_multihot", lambda: extra_cfg5(device, tmp))):
             if args.only_extra and key not in args.only_extra.split(","):

@@ -40,6 +40,7 @@ class GroupAgg:
         # unknown -> assume half the rows are distinct (high-cardinality keys are what these
         # operators are used on, and an undersized table costs a full extra pass per retry)
         self.hint = int(hint)
+        self.part_hint = 0  # groups of ONE partition (sizes the sort path's per-partition arrays)
         self.strings: Dict[str, dict] = {}
         self.key_dtypes: Dict[str, object] = {}
         self.val_dtypes: Dict[str, object] = {}  # source dtype of every aggregated column
@@ -88,16 +89,31 @@ class GroupAgg:
         if self.fold:
             fcol = frame[self.fold[0]]
             fold_t = fcol.data if fcol.data.dtype == torch.uint8 and fcol.valid is None else None
-        if (self.table is None and self.sorted_comp is None and len(keys) == 1
+        if (self.table is None and len(keys) == 1
                 and (self.fold_agg is None or self.fold_agg.table is None)
                 and (not self.fold or fold_t is not None)
                 and K.sorted_groupby_eligible(keys[0], kvalid[0], n, kfold)):
             comp = K.sorted_groupby(keys[0], fold_t, kfold, vals, vvalid, sumsq=self.sumsq,
-                                    minmax=self.minmax, cap_hint=self.hint, te_records=True)
+                                    minmax=self.minmax, cap_hint=self.part_hint or self.hint,
+                                    te_records=True)
             if comp is not None:  # (None: int64 keys spanning 2^32 or more)
-                self.hint = max(self.hint, comp["n"])
+                self.part_hint = max(self.part_hint, comp["n"])
+                if self.sorted_comp is None:
+                    self.hint = max(self.hint, comp["n"])
+                    self.sorted_comp = comp
+                    return
+                # a further partition: both sides are dense groups ORDERED BY KEY -- merged by
+                # the merge-path kernel (_mid_level_groupby, categorify.py:1054-1070 under
+                # join_groupby.py:140-173 / target_encoding.py:171-214), still ordered by key: the
+                # fit keeps the sort path (flat index, fused lookups) however many partitions
+                merged = merge_sorted_comps(self.sorted_comp, comp, self.sumsq, self.minmax)
+                if merged is not None:
+                    self.hint = max(self.hint, merged["n"])
+                    self.sorted_comp = merged
+                    return
+                # (int64 key images with different offsets: the hash tables take over)
+                self._demote()
                 self.sorted_comp = comp
-                return
         if self.sorted_comp is not None:
             self._demote()
         if self.fold:
@@ -151,6 +167,71 @@ class GroupAgg:
             for c in list(self.strings):
                 self.strings[c] = dist.merge_string_luts(self.strings[c])
         return comp
+
+
+def merge_sorted_comps(a, b, sumsq=False, minmax=False):
+    """Two sort-path results (K.sorted_groupby: dense groups of ONE int32 key column, ordered by
+    key) -> the same structure for the union of their rows: ONE merge-path pass over the keys
+    (nvt_merge_sorted_many with source maps) + one gather-combine per statistic
+    (nvt_merge_payload: sums / sizes add, min / max combine, per-fold blocks as rows of kfold
+    values, the transform's {sum, count} records as rows of 2 (kfold + 1)).  None when the two
+    sides carry int64 key images with different offsets.  Inside a pass (K.pass_memo) the key
+    merge of a column is shared by every aggregate on it, like the sort itself."""
+    if ("fold" in a) != ("fold" in b):
+        return None
+    memo = K._PASS_MEMO
+    delta = int(b.get("key_offset", 0)) - int(a.get("key_offset", 0))
+    if delta:
+        # int64 key column: the 32-bit image is key - offset and every partition picks its own
+        # offset (its smallest key).  Re-based to the accumulated side's offset when the
+        # partition's keys fit there (one read-back of its first / last key), else no merge.
+        rkey = ("sgb_rebase", b["keys32"].data_ptr(), int(b["n"]), delta)
+        rb = memo.get(rkey) if memo is not None else None
+        if rb is None:
+            ends = K.read_back(torch.stack([b["keys32"][0], b["keys32"][-1]]).to(torch.int64)) if b["n"] else [0, 0]
+            ok = -(1 << 31) <= int(ends[0]) + delta and int(ends[1]) + delta <= (1 << 31) - 1
+            rb = dict(k32=(b["keys32"].to(torch.int64) + delta).to(torch.int32) if ok else None,
+                      keep=b["keys32"])
+            if memo is not None:
+                memo[rkey] = rb
+        if rb["k32"] is None:
+            return None
+        b = dict(b, keys32=rb["k32"])
+    mkey = ("sgb_merge", a["keys32"].data_ptr(), int(a["n"]), b["keys32"].data_ptr(), int(b["n"]))
+    hit = memo.get(mkey) if memo is not None else None
+    if hit is None:
+        (k32, size, sa, sb), = K.merge_sorted_pairs(
+            [((a["keys32"], a["size"]), (b["keys32"], b["size"]))], want_src=True)
+        hit = dict(k32=k32, size=size, sa=sa, sb=sb, shared={},
+                   k64=k32.to(torch.int64) + int(a.get("key_offset", 0)), keep=(a["keys32"], b["keys32"]))
+        if memo is not None:
+            memo[mkey] = hit
+    k32, size, sa, sb = hit["k32"], hit["size"], hit["sa"], hit["sb"]
+    g = int(k32.numel())
+
+    def comb(x, y, op="add", width=1):
+        return K.merge_payload(sa, sb, x.reshape(-1), y.reshape(-1), op, width)
+
+    out = dict(keys=[hit["k64"]], keys32=k32, n=g, sorted=True, shared=hit["shared"],
+               key_offset=a.get("key_offset", 0), size=size, count=size,
+               null_mask=torch.zeros(g, dtype=torch.uint8, device=k32.device),
+               sum=[comb(x, y) for x, y in zip(a["sum"], b["sum"])],
+               sumsq=[comb(x, y) for x, y in zip(a["sumsq"], b["sumsq"])] if sumsq else [],
+               min=[comb(x, y, "min") for x, y in zip(a["min"], b["min"])] if minmax else [],
+               max=[comb(x, y, "max") for x, y in zip(a["max"], b["max"])] if minmax else [])
+    if "fold" in a:
+        fa, fb = a["fold"], b["fold"]
+        kfold = fa["kfold"]
+        if fb["kfold"] != kfold:
+            return None
+        rs = 2 * (kfold + 1)
+        rec = None
+        if fa.get("records") is not None and fb.get("records") is not None:
+            rec = [comb(x, y, "add", rs).view(g, rs) for x, y in zip(fa["records"], fb["records"])]
+        out["fold"] = dict(kfold=kfold, size=comb(fa["size"], fb["size"], "add", kfold),
+                           sum=[comb(x, y, "add", kfold) for x, y in zip(fa["sum"], fb["sum"])],
+                           records=rec)
+    return out
 
 
 def _table_from_comp(comp, nkeys, nvals, sumsq, minmax) -> "K.GroupbyTable":

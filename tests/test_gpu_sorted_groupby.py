@@ -118,22 +118,28 @@ def _frames(n, card, seed, key="int32"):
     return df
 
 
+def _split(df, nparts):
+    cuts = np.linspace(0, len(df), nparts + 1).astype(int)
+    cuts[1:-1] += np.arange(1, nparts) * 1777  # uneven partitions
+    return [df.iloc[a:b].reset_index(drop=True) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
 @pytest.mark.parametrize("key", ["int32", "int64"])
-@pytest.mark.parametrize("nparts", [1, 2])
+@pytest.mark.parametrize("nparts", [1, 2, 3])
 def test_joingroupby_sorted_path_vs_oracle(tmp_path, nparts, key):
     import nvtabular_amd as nvt
     from nvtabular_amd import kernels as K
     from nvtabular_amd import ops
 
-    df = _frames(120_000, 9_000, 21, key)
-    parts = [df] if nparts == 1 else [df.iloc[:70_000].reset_index(drop=True),
-                                      df.iloc[70_000:].reset_index(drop=True)]
+    df = _frames(120_000 if nparts < 3 else 180_000, 9_000, 21, key)
+    parts = _split(df, nparts)
     stats = ["count", "sum", "mean", "std", "var", "min", "max"]
     jg = ops.JoinGroupby(out_path=str(tmp_path / "g"), stats=stats, cont_cols=["x", "y"])
     wf = nvt.Workflow(["k"] >> jg).fit(nvt.Dataset(parts))
     index = jg._device_stats["k"].index
-    # one partition: sorted groups + flat index; two: the first partition's groups were demoted
-    assert isinstance(index, K.FlatIndex) == (nparts == 1)
+    # sorted groups + flat index however many partitions: the partitions' key-ordered groups are
+    # merged by the merge-path kernel (int64 keys: images re-based to the first partition's offset)
+    assert isinstance(index, K.FlatIndex)
     got = wf.transform(nvt.Dataset(parts)).to_ddf().compute()
     cats = O.join_groupby_fit([p.copy() for p in parts], ["k"], ["x", "y"], stats, str(tmp_path / "c"))
     exp = O.join_groupby_transform(df.copy(), ["k"], cats)
@@ -161,20 +167,19 @@ def test_joingroupby_sorted_path_vs_oracle(tmp_path, nparts, key):
 
 @pytest.mark.parametrize("key", ["int32", "int64"])
 @pytest.mark.parametrize("kfold,fold_seed", [(1, None), (5, 42), (3, None)])
-@pytest.mark.parametrize("nparts", [1, 2])
+@pytest.mark.parametrize("nparts", [1, 2, 3])
 def test_target_encoding_sorted_path_vs_oracle(tmp_path, kfold, fold_seed, nparts, key):
     import nvtabular_amd as nvt
     from nvtabular_amd import ops
     from nvtabular_amd.ops.target_encoding import _FoldDense
 
-    df = _frames(100_000, 7_000, 33, key)
-    parts = [df] if nparts == 1 else [df.iloc[:60_000].reset_index(drop=True),
-                                      df.iloc[60_000:].reset_index(drop=True)]
+    df = _frames(100_000 if nparts < 3 else 150_000, 7_000, 33, key)
+    parts = _split(df, nparts)
     te = ops.TargetEncoding(["y", "x"], out_path=str(tmp_path / "g"), kfold=kfold, fold_seed=fold_seed,
                             p_smooth=20)
     wf = nvt.Workflow(["k"] >> te).fit(nvt.Dataset(parts))
-    if kfold > 1:
-        assert isinstance(te._device_stats["__fold___k"], _FoldDense) == (nparts == 1)
+    if kfold > 1:  # dense per-(group, fold) statistics survive the partition merge
+        assert isinstance(te._device_stats["__fold___k"], _FoldDense)
     got = wf.transform(nvt.Dataset(parts)).to_ddf().compute()
     oparts = [p.copy() for p in parts]
     stats, means = O.target_encoding_fit(oparts, ["k"], ["y", "x"], str(tmp_path / "c"), kfold=kfold,
