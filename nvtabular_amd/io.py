@@ -232,6 +232,7 @@ class Dataset:
         * writes ``_metadata`` (parquet summary of all row groups), ``_file_list.txt`` and
           ``_metadata.json`` (file stats + cats / conts / labels) next to the data files.
         """
+        import itertools
         import json
 
         import numpy as np
@@ -289,7 +290,17 @@ class Dataset:
             pending.clear()
 
         shard = (rank, world) if world > 1 else None
-        for i, part in enumerate(self.to_iter(shard=shard)):
+        parts_iter = iter(self.to_iter(shard=shard))
+        first = next(parts_iter, None)
+        plain = None
+        if first is not None and PLAIN_PARQUET and _plain_eligible(first, dtypes) and \
+                not (shuffle == Shuffle.PER_WORKER and k):
+            # fixed-width numeric columns: PLAIN pages written straight from pinned column
+            # buffers (parquet_plain.py) -- no dictionary pass, no compression, no statistics
+            plain = _write_plain(itertools.chain([first], parts_iter), output_path, fname, k, shuffle, dtypes)
+            parts_iter, first = iter(()), None
+        rest = itertools.chain([first], parts_iter) if first is not None else iter(())
+        for i, part in enumerate(rest):
             n = len(part)
             if shuffle is not None and n > 1:
                 part = part.take_rows(_device_permutation(n, part))
@@ -327,6 +338,14 @@ class Dataset:
         # every ParquetWriter appended its FileMetaData on close, in closing order
         for md, j in zip(collector, order):
             md.set_file_path(names[j])
+        if plain is not None:
+            names, rows_in, order = plain
+            collector = []
+            for j in order:
+                md = pq.read_metadata(os.path.join(output_path, names[j]))
+                md.set_file_path(names[j])
+                collector.append(md)
+            schema = pq.read_schema(os.path.join(output_path, names[order[0]])) if order else None
         if world > 1:
             gathered = [None] * world
             import torch.distributed as td
@@ -356,6 +375,173 @@ class Dataset:
             with open(os.path.join(output_path, "_metadata.json"), "w") as f:
                 json.dump(meta, f)
         return None
+
+
+PLAIN_PARQUET = os.environ.get("NVT_PLAIN_PARQUET", "1") != "0"
+PLAIN_WRITE_THREADS = int(os.environ.get("NVT_PARQUET_THREADS", "16"))
+PLAIN_ROW_GROUP = int(os.environ.get("NVT_PARQUET_ROW_GROUP", str(1 << 22)))
+PLAIN_INFLIGHT = int(os.environ.get("NVT_PARQUET_INFLIGHT", "8"))   # row groups being written at once
+LAST_TIMING = {}   # seconds of the last plain write: staging (enqueue + pinned allocation), waiting for copies, writing
+
+
+def _plain_eligible(frame, dtypes) -> bool:
+    """Every column a flat int32 / int64 / float32 / float64 device column (after the requested
+    casts): the hand-written PLAIN writer takes the partition; anything else goes to pyarrow."""
+    import numpy as np
+    import torch
+
+    from .parquet_plain import supported_dtype
+
+    np_of = {torch.int32: "int32", torch.int64: "int64", torch.float32: "float32", torch.float64: "float64"}
+    if len(frame.columns) == 0:
+        return False
+    for name, col in frame.items():
+        if col.strings is not None or col.offsets is not None or col.data.dtype not in np_of:
+            return False
+        if dtypes and name in dtypes and not supported_dtype(np.dtype(dtypes[name])):
+            return False
+    return True
+
+
+def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
+    """Dataset.to_parquet for fixed-width numeric frames: every partition is cut into row groups
+    of PLAIN_ROW_GROUP rows; a row group's columns are copied into pinned host buffers on a side
+    stream (nulls: values compacted and the validity bitmap re-packed on the device first) while
+    the previous row group is written -- all its column chunks at once, by a pool of threads
+    calling pwrite at offsets laid out beforehand (PlainParquetWriter).
+    -> (names {file index: name}, rows {file index: rows}, file indices in order)."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+    import torch
+
+    from . import kernels as K
+    from .device import pack_bitmap_device
+    from .parquet_plain import PlainParquetWriter
+
+    import time
+
+    t_of = {"int32": torch.int32, "int64": torch.int64, "float32": torch.float32, "float64": torch.float64}
+    LAST_TIMING.update(wait_copy_s=0.0, write_s=0.0, stage_s=0.0, total_s=0.0, input_s=0.0, close_s=0.0)
+    t_all = time.perf_counter()
+    copy_s = None
+    writers, names, rows_in = {}, {}, {}
+    staged = deque()
+    inflight = deque()   # (futures, host buffers) of row groups whose column writes are still running
+    touched = set()
+
+    with ThreadPoolExecutor(max_workers=PLAIN_WRITE_THREADS) as pool:
+        def flush_one():
+            j, cols, rows, event, keep = staged.popleft()
+            t0 = time.perf_counter()
+            # the host does not wait for the copies: every column task synchronises with the
+            # event itself before it writes.  Only validity bitmaps must be here already (the
+            # pages are laid out from their popcounts).
+            if event is not None and any(c[2] is not None for c in cols):
+                event.synchronize()
+            ready = event.synchronize if event is not None else None
+            t1 = time.perf_counter()
+            LAST_TIMING["wait_copy_s"] += t1 - t0
+            w = writers.get(j)
+            if w is None:
+                names[j] = fname(j)
+                w = writers[j] = PlainParquetWriter(
+                    os.path.join(output_path, names[j]), [c[0] for c in cols],
+                    [c[1].dtype for c in cols], pool=pool)
+            # the column writes of this row group go to the pool and are NOT waited for: row
+            # groups of other files (other inodes: buffered writes to ONE file serialise on its
+            # inode lock, ~10 GB/s) and the next copies proceed meanwhile
+            futs = w.write_row_group([(c[1], c[2]) for c in cols], rows, wait=False, ready=ready)
+            inflight.append((futs, cols, keep))
+            while len(inflight) > PLAIN_INFLIGHT:
+                for f in inflight.popleft()[0]:
+                    f.result()
+            LAST_TIMING["write_s"] += time.perf_counter() - t1
+            rows_in[j] = rows_in.get(j, 0) + rows
+
+        parts = iter(parts)
+        i = -1
+        while True:
+            t_in = time.perf_counter()
+            part = next(parts, None)
+            LAST_TIMING["input_s"] += time.perf_counter() - t_in
+            if part is None:
+                break
+            i += 1
+            n = len(part)
+            if shuffle is not None and n > 1:
+                part = part.take_rows(_device_permutation(n, part))
+            cols = []
+            for name, col in part.items():
+                col = col.materialize()
+                data = col.data
+                if dtypes and name in dtypes:
+                    data = data.to(t_of[str(np.dtype(dtypes[name]))])
+                mask = K.unpack_bitmap(col.valid, n) if col.valid is not None else None
+                cols.append((name, data, mask))
+            on_gpu = any(c[1].is_cuda for c in cols)
+            if on_gpu and copy_s is None:
+                copy_s = torch.cuda.Stream()
+            if on_gpu:
+                copy_s.wait_stream(torch.cuda.current_stream())
+            pieces = [(i, 0, n)] if k is None else [
+                (j, (n * j) // k, (n * (j + 1)) // k) for j in range(k)]
+            for j, a, b in pieces:
+                if b <= a and j in touched:
+                    continue
+                touched.add(j)
+                for s0 in (range(a, b, PLAIN_ROW_GROUP) if b > a else [a]):
+                    s1 = min(b, s0 + PLAIN_ROW_GROUP)
+                    rows = s1 - s0
+                    host, keep = [], []
+                    t_st = time.perf_counter()
+                    ctx = torch.cuda.stream(copy_s) if on_gpu else _nullcontext()
+                    with ctx:
+                        for name, data, mask in cols:
+                            vals, bm = data[s0:s1], None
+                            if mask is not None:
+                                m = mask[s0:s1]
+                                vals = vals[m]
+                                bm = pack_bitmap_device(m) if m.is_cuda else torch.from_numpy(
+                                    np.packbits(m.numpy(), bitorder="little"))
+                            hv = _to_host(vals)
+                            hb = _to_host(bm) if bm is not None else None
+                            keep.append((vals, bm))
+                            host.append((name, hv.numpy(), hb.numpy() if hb is not None else None))
+                        event = None
+                        if on_gpu:
+                            event = torch.cuda.Event()
+                            event.record(copy_s)
+                    LAST_TIMING["stage_s"] += time.perf_counter() - t_st
+                    staged.append((j, host, rows, event, keep))
+                    flush_one()
+        while staged:
+            flush_one()
+        t_cl = time.perf_counter()
+        for w in writers.values():
+            w.close()
+        LAST_TIMING["close_s"] = time.perf_counter() - t_cl
+    LAST_TIMING["total_s"] = time.perf_counter() - t_all
+    return names, rows_in, sorted(writers)
+
+
+class _nullcontext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _to_host(t):
+    import torch
+
+    if not t.is_cuda:
+        return t.contiguous()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    return h
 
 
 class Shuffle:

@@ -1,0 +1,243 @@
+"""PLAIN / uncompressed parquet files written straight from column buffers.
+
+The output half of the parquet path (reference contract: ``Dataset.to_parquet``,
+merlin-io via tests/unit/workflow/test_cpu_workflow.py:67-81 and
+bench/datasets/tools/nvt_etl.py:154-171).  pyarrow's writer spent the time of a 45 M-row
+Criteo partition set in dictionary building, statistics and compression (5 M rows/s); the
+columns this engine produces are fixed-width numbers (int64 labels, float64 / float32
+normalised values, int32 passthroughs) for which a PLAIN data page is the column buffer itself:
+
+    page = thrift PageHeader | definition levels | values (non-null ones, little endian)
+
+* no nulls: the definition levels are ONE RLE run ("n times 1": a varint and a byte);
+* nulls: the hybrid encoding's bit-packed run at bit width 1 IS the Arrow validity bitmap
+  (LSB first), so the bitmap bytes are written verbatim behind a run header, and the values are
+  compacted on the device before they are copied out (the caller hands over non-null values).
+
+The file layout (magic, row groups of column chunks of pages, thrift-compact FileMetaData
+footer) is written by hand: parquet-format's PageHeader / FileMetaData structures in the
+thrift compact protocol.  Readers: pyarrow / pandas / the reference's merlin-io read these
+files like any other (tests/test_parquet_plain.py reads them back with pyarrow).
+Anything else (strings, lists, booleans, requested dtype casts) stays with pyarrow's writer.
+"""
+from __future__ import annotations
+
+import os
+import struct
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# parquet physical types / thrift compact type ids
+_PQ_TYPE = {np.dtype("int32"): 1, np.dtype("int64"): 2, np.dtype("float32"): 4, np.dtype("float64"): 5}
+_CT_BOOL_TRUE, _CT_I32, _CT_I64, _CT_BINARY, _CT_LIST, _CT_STRUCT = 1, 5, 6, 8, 9, 12
+PAGE_VALUES = 1 << 20          # values per data page (8 MiB of int64)
+ROW_GROUP_ROWS = 1 << 23       # rows per row group
+
+
+def supported_dtype(dt) -> bool:
+    return np.dtype(dt) in _PQ_TYPE
+
+
+def _varint(v: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _zigzag(v: int) -> bytes:
+    return _varint((v << 1) ^ (v >> 63))
+
+
+class _Struct:
+    """Minimal thrift compact-protocol struct writer (fields must be added in ascending id)."""
+
+    def __init__(self):
+        self.b = bytearray()
+        self.last = 0
+
+    def _head(self, fid: int, ctype: int):
+        d = fid - self.last
+        if 0 < d <= 15:
+            self.b.append((d << 4) | ctype)
+        else:
+            self.b.append(ctype)
+            self.b += _zigzag(fid)
+        self.last = fid
+
+    def i32(self, fid, v):
+        self._head(fid, _CT_I32)
+        self.b += _zigzag(int(v))
+        return self
+
+    def i64(self, fid, v):
+        self._head(fid, _CT_I64)
+        self.b += _zigzag(int(v))
+        return self
+
+    def binary(self, fid, s):
+        s = s.encode() if isinstance(s, str) else bytes(s)
+        self._head(fid, _CT_BINARY)
+        self.b += _varint(len(s)) + s
+        return self
+
+    def struct(self, fid, body: bytes):
+        self._head(fid, _CT_STRUCT)
+        self.b += body
+        return self
+
+    def list(self, fid, etype: int, items: Sequence[bytes]):
+        self._head(fid, _CT_LIST)
+        n = len(items)
+        self.b += bytes([(n << 4) | etype]) if n < 15 else bytes([0xF0 | etype]) + _varint(n)
+        for it in items:
+            self.b += it
+        return self
+
+    def done(self) -> bytes:
+        return bytes(self.b) + b"\x00"
+
+
+def _page_header(num_values: int, page_bytes: int) -> bytes:
+    dph = _Struct().i32(1, num_values).i32(2, 0).i32(3, 3).i32(4, 3).done()  # PLAIN, RLE, RLE
+    return _Struct().i32(1, 0).i32(2, page_bytes).i32(3, page_bytes).struct(5, dph).done()
+
+
+def _def_levels(n: int, valid_bytes: Optional[memoryview]) -> Tuple[bytes, Optional[memoryview]]:
+    """Definition levels of one page (max level 1): (prefix bytes, bitmap bytes or None)."""
+    if valid_bytes is None:
+        body = _varint(n << 1) + b"\x01"          # RLE run: n times the value 1
+        return struct.pack("<I", len(body)) + body, None
+    groups = (n + 7) // 8
+    head = _varint((groups << 1) | 1)             # bit-packed run of `groups` groups of 8 levels
+    return struct.pack("<I", len(head) + groups) + head, valid_bytes[:groups]
+
+
+class PlainParquetWriter:
+    """One parquet file of flat int32 / int64 / float32 / float64 columns, every column OPTIONAL
+    (like pyarrow writes nullable Arrow columns), PLAIN encoding, no compression.
+
+    With a thread ``pool`` a row group is written by a pool task: a PLAIN page's size is known
+    before it is written, so the row group is laid out first and its pages go to their offsets
+    with ``os.pwrite`` (which releases the GIL) while the caller stages the next row group or
+    another file."""
+
+    def __init__(self, path: str, names: Sequence[str], dtypes: Sequence, pool=None):
+        self.path = path
+        self.names = list(names)
+        self.dtypes = [np.dtype(d) for d in dtypes]
+        for d in self.dtypes:
+            if d not in _PQ_TYPE:
+                raise TypeError(f"PlainParquetWriter: unsupported dtype {d}")
+        self.fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.pwrite(self.fd, b"PAR1", 0)
+        self.pos = 4
+        self.pool = pool
+        self.row_groups: List[bytes] = []
+        self.num_rows = 0
+        self.pending = []
+
+    def _plan_column(self, values, valid, n, dt, start):
+        """[(offset, bytes-like)] of one column chunk laid out from `start`, and its size."""
+        values = np.ascontiguousarray(values, dtype=dt)
+        vbytes = memoryview(values).cast("B") if values.size else memoryview(b"")
+        vb = memoryview(np.ascontiguousarray(valid)).cast("B") if valid is not None else None
+        segs, at = [], start
+        done_rows, done_vals = 0, 0
+        while True:
+            rows = min(PAGE_VALUES, n - done_rows)
+            if vb is not None:
+                page_valid = vb[done_rows // 8: (done_rows + rows + 7) // 8]
+                nv = int(np.unpackbits(np.frombuffer(page_valid, dtype=np.uint8),
+                                       bitorder="little")[:rows].sum()) if rows else 0
+            else:
+                page_valid, nv = None, rows
+            prefix, bitmap = _def_levels(rows, page_valid)
+            payload = vbytes[done_vals * dt.itemsize: (done_vals + nv) * dt.itemsize]
+            body = len(prefix) + (len(bitmap) if bitmap is not None else 0) + len(payload)
+            head = _page_header(rows, body) + prefix
+            segs.append((at, head))
+            at += len(head)
+            if bitmap is not None and len(bitmap):
+                segs.append((at, bitmap))
+                at += len(bitmap)
+            if len(payload):
+                segs.append((at, payload))
+                at += len(payload)
+            done_rows += rows
+            done_vals += nv
+            if done_rows >= n:
+                break
+        if done_vals != values.size:
+            raise ValueError("PlainParquetWriter: the values do not match the validity bitmap "
+                             f"({values.size} values, {done_vals} valid rows)")
+        return segs, at - start
+
+    def _run(self, segs, ready=None):
+        if ready is not None:
+            ready()   # (e.g. the event behind the device-to-host copy of these buffers)
+        for off, buf in segs:
+            mv = memoryview(buf)
+            while len(mv):          # (pwrite may write less than asked for)
+                k = os.pwrite(self.fd, mv, off)
+                mv, off = mv[k:], off + k
+
+    def write_row_group(self, columns, n: int, wait: bool = True, ready=None):
+        """columns[j] = (values, valid): `values` a 1-D numpy array of the column's dtype holding
+        the NON-NULL values in row order, `valid` None or the Arrow validity bitmap (uint8, LSB
+        first, >= ceil(n / 8) bytes) of the n rows.  wait=False (with a pool): returns the
+        futures of the column writes instead of waiting for them -- the layout is fixed, so later
+        row groups (of this or of other files) can be written meanwhile; the caller keeps the
+        buffers alive until the futures are done, close() waits for whatever is left.
+        ready: called by every column task before it touches its buffers (the VALUES may still
+        be in flight when this returns; validity bitmaps must be complete: pages are laid out
+        from their popcounts)."""
+        chunks, plans = [], []
+        total = 0
+        for (values, valid), name, dt in zip(columns, self.names, self.dtypes):
+            start = self.pos
+            segs, size = self._plan_column(values, valid, n, dt, start)
+            plans.append(segs)
+            self.pos += size
+            meta = (_Struct().i32(1, _PQ_TYPE[dt]).list(2, _CT_I32, [_zigzag(0), _zigzag(3)])
+                    .list(3, _CT_BINARY, [_varint(len(name.encode())) + name.encode()])
+                    .i32(4, 0).i64(5, n).i64(6, size).i64(7, size).i64(9, start).done())
+            chunks.append(_Struct().i64(2, start).struct(3, meta).done())
+            total += size
+        futures = []
+        if self.pool is not None:
+            # ONE task per row group: buffered writes to one file serialise on its inode lock
+            # (11 GB/s on the GPU box whatever the thread count, tools/write_probe.py), so
+            # threads are spent on DIFFERENT files (6 files: 58 GB/s), not on one file's columns
+            futures = [self.pool.submit(self._run, [sg for segs in plans for sg in segs], ready)]
+            if wait:
+                for f in futures:
+                    f.result()
+                futures = []
+            else:
+                self.pending += futures
+        else:
+            for segs in plans:
+                self._run(segs, ready)
+        self.row_groups.append(_Struct().list(1, _CT_STRUCT, chunks).i64(2, total).i64(3, n).done())
+        self.num_rows += n
+        return futures
+
+    def close(self):
+        schema = [_Struct().binary(4, "schema").i32(5, len(self.names)).done()]
+        for name, dt in zip(self.names, self.dtypes):
+            schema.append(_Struct().i32(1, _PQ_TYPE[dt]).i32(3, 1).binary(4, name).done())
+        footer = (_Struct().i32(1, 1).list(2, _CT_STRUCT, schema).i64(3, self.num_rows)
+                  .list(4, _CT_STRUCT, self.row_groups)
+                  .binary(6, "nvtabular_amd plain writer").done())
+        for f in self.pending:
+            f.result()
+        self.pending = []
+        self._run([(self.pos, footer + struct.pack("<I", len(footer)) + b"PAR1")])
+        os.close(self.fd)

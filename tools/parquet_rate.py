@@ -27,7 +27,8 @@ for name, col in frame.items():
 tmp = tempfile.mkdtemp()
 path = os.path.join(tmp, "day0.parquet")
 t0 = time.perf_counter()
-pq.write_table(pa.table(arrays), path, row_group_size=1 << 20, compression=None)
+pq.write_table(pa.table(arrays), path, row_group_size=1 << 20, compression=None, use_dictionary=False,
+               write_statistics=False)
 print(f"wrote {os.path.getsize(path)/1e9:.2f} GB parquet in {time.perf_counter()-t0:.1f} s "
       f"({os.cpu_count()} host cores)", flush=True)
 del frame, arrays
@@ -51,3 +52,12 @@ wf.transform(ds).to_parquet(out_dir)
 dt = time.perf_counter() - t0
 size = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
 print(f"transform + to_parquet: {1e3*dt:.0f} ms, {n/dt/1e6:.1f} M rows/s, {size/1e9:.2f} GB written", flush=True)
+from nvtabular_amd import io as _io
+print("  phases", {k: round(v, 3) for k, v in _io.LAST_TIMING.items()}, flush=True)
+for rep in range(2):
+    import shutil
+    shutil.rmtree(out_dir)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    wf.transform(ds).to_parquet(out_dir)
+    dt = time.perf_counter() - t0
+    print(f"again: {1e3*dt:.0f} ms, {n/dt/1e6:.1f} M rows/s", {k: round(v, 3) for k, v in _io.LAST_TIMING.items()}, flush=True)
