@@ -932,6 +932,86 @@ def eager_artifacts_step_ms(frame, cat_names, cont_names, tmp, steps=2):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
+def collective_selfcheck(device, backend):
+    """Before anything is timed on more than one rank: the collective FORMS dist.py relies on
+    (all_to_all_single with uneven splits, the all-gather(v) written as an all-to-all in which
+    every rank sends its whole tensor to every peer, all_gather of equal shapes, MAX / SUM
+    all-reduce) run once on tiny tensors over the measured backend (nccl = RCCL) AND over a gloo
+    group of the same processes, and must agree element for element.  A wiring problem (IPC mode,
+    device binding, split-size semantics) then shows up as `collective_selfcheck` failing with
+    its reason, not as a hang or a wrong vocabulary minutes into the fit."""
+    import torch.distributed as td
+
+    G, r = td.get_world_size(), td.get_rank()
+    ref = td.new_group(backend="gloo")
+    report = {"backend": backend, "world": G, "ok": False, "checks": []}
+
+    def both(fn):
+        # (gloo rehearsal on one GPU, NVT_BENCH_BACKEND=gloo: both legs are host legs)
+        dev_out = fn(device if backend == "nccl" else torch.device("cpu"), None)
+        cpu_out = fn(torch.device("cpu"), ref)
+        return dev_out.cpu(), cpu_out
+
+    def a2a_uneven(dev, group):
+        send_counts = [(r + 1) * (p + 2) for p in range(G)]           # rows this rank sends to p
+        recv_counts = [(p + 1) * (r + 2) for p in range(G)]
+        send = torch.cat([torch.full((c,), 1000 * r + p, dtype=torch.int64) for p, c in enumerate(send_counts)]).to(dev)
+        out = torch.empty(sum(recv_counts), dtype=torch.int64, device=dev)
+        if dev.type == "cpu":   # gloo has no all_to_all_single on every build: pairwise reference
+            reqs = [td.isend(send[sum(send_counts[:p]): sum(send_counts[:p + 1])].contiguous(), p, group=group)
+                    for p in range(G) if p != r]
+            for p in range(G):
+                lo = sum(recv_counts[:p])
+                if p == r:
+                    out[lo: lo + recv_counts[p]] = send[sum(send_counts[:r]): sum(send_counts[:r + 1])]
+                else:
+                    buf = torch.empty(recv_counts[p], dtype=torch.int64)
+                    td.recv(buf, p, group=group)
+                    out[lo: lo + recv_counts[p]] = buf
+            for q in reqs:
+                q.wait()
+        else:
+            td.all_to_all_single(out, send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
+        return out
+
+    def gather_v(dev, group):
+        mine = torch.arange(3 + 2 * r, dtype=torch.int64, device=dev) + 100 * r
+        sizes = [3 + 2 * p for p in range(G)]
+        if dev.type == "cpu":
+            pad = torch.zeros(max(sizes), dtype=torch.int64)
+            pad[: mine.numel()] = mine
+            bufs = [torch.empty_like(pad) for _ in range(G)]
+            td.all_gather(bufs, pad, group=group)
+            return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+        out = torch.empty(sum(sizes), dtype=torch.int64, device=dev)
+        td.all_to_all_single(out, mine.repeat(G), output_split_sizes=sizes, input_split_sizes=[mine.numel()] * G)
+        return out
+
+    def reduce_max(dev, group):
+        t = torch.tensor([r, -r, 7], dtype=torch.int64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX, group=group)
+        return t
+
+    def reduce_sum(dev, group):
+        t = torch.tensor([1.5 * (r + 1), 2.0], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.SUM, group=group)
+        return t
+
+    try:
+        for name, fn in (("all_to_all_single(uneven)", a2a_uneven), ("all_gather_v", gather_v),
+                         ("all_reduce(MAX)", reduce_max), ("all_reduce(SUM)", reduce_sum)):
+            a, b = both(fn)
+            same = a.shape == b.shape and bool(torch.equal(a, b))
+            report["checks"].append({"collective": name, "equal_to_gloo": same})
+        report["ok"] = all(c["equal_to_gloo"] for c in report["checks"])
+    except Exception as e:
+        report["error"] = repr(e)
+    flag = torch.tensor([1 if report["ok"] else 0], dtype=torch.int64)
+    td.all_reduce(flag, op=td.ReduceOp.MIN, group=ref)
+    report["ok_on_every_rank"] = bool(int(flag.item()))
+    return report
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -995,6 +1075,16 @@ def main():
         else:
             td.init_process_group(backend, rank=rank, world_size=world)
         assert td.get_world_size() == args.gpus, (td.get_world_size(), args.gpus)
+        selfcheck = collective_selfcheck(device, backend)
+        if not selfcheck["ok_on_every_rank"]:
+            if rank == 0:
+                print(json.dumps({"metric": "rows/sec + GB/s (Criteo Categorify+FillMissing+Normalize "
+                                            "fit+transform, HBM-resident)", "value": None,
+                                  "n_gpus": world, "error": "collective self-check failed: the "
+                                  f"{backend} collectives disagree with gloo or raised",
+                                  "collective_selfcheck": selfcheck}))
+            td.destroy_process_group()
+            raise SystemExit(3)
 
     import nvtabular_amd as nvt
     from nvtabular_amd import kernels as K
@@ -1290,6 +1380,8 @@ def main():
                 extras[key] = {"error": repr(e)}
             torch.cuda.empty_cache()
         result["extra_configs"] = extras
+    if world > 1:
+        result["collective_selfcheck"] = selfcheck
     if rank == 0:
         from nvtabular_amd import dist as _d
 

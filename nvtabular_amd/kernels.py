@@ -1821,6 +1821,8 @@ class ExchangeBatch:
         """(count << 32 | key) words grouped by (owner, column); ``starts`` int64[G, ncol] (device)
         = the first position of every group (consumed: advanced to the group ends)."""
         rows = torch.empty(self.total, dtype=torch.int64, device=self.dev)
+        if self.total == 0:
+            return rows  # (a rank that received no partition: nothing to send, nothing to launch)
         a, b = self._owner_args(lo, width)
         check(self.lib.nvt_exchange_scatter(self.cols, self.ncol, a, b, G, starts.data_ptr(),
                                             rows.data_ptr(), stream_ptr()), "nvt_exchange_scatter")

@@ -61,9 +61,27 @@ wf32 = nvt.Workflow(["p", "q", "s", "t"] >> ops.Categorify(out_path=os.path.join
 got32 = wf32.fit_transform(nvt.Dataset(int32_frame(rank))).to_ddf().compute()
 assert _dist.STATS["sorted_merges"] == before["sorted_merges"] + 1, _dist.STATS
 assert _dist.STATS["packed_exchanges"] == before["packed_exchanges"] + 1, _dist.STATS
+# fewer partitions than ranks: a parquet dataset of ONE row group -- rank 1 decodes nothing and
+# passes empty tables into the exchange (they used to be int64 empties that switched that rank
+# alone to the two-word wire format: mismatched byte counts in the all-to-all)
+lone_path = os.path.join(tempfile.gettempdir(), "nvt_multirank_lone.parquet")
+if rank == 0:
+    int32_frame(9, 50_000).to_parquet(lone_path)
+td.barrier()
+before = dict(_dist.STATS)
+wf_lone = nvt.Workflow(["p", "q", "s"] >> ops.Categorify(out_path=os.path.join(tmp, f"l{rank}")))
+lone_ds = nvt.Dataset(lone_path, engine="parquet")
+assert lone_ds.npartitions == 1
+wf_lone.fit(lone_ds)
+assert _dist.STATS["packed_exchanges"] == before["packed_exchanges"] + 1, _dist.STATS   # one-word rows on BOTH ranks
+got_lone = wf_lone.transform(int32_frame(9, 50_000))
 td.barrier()
 # single-process reference on the union (world_size() is 1 inside this block)
 td.destroy_process_group()
+ref_lone = nvt.Workflow(["p", "q", "s"] >> ops.Categorify(out_path=os.path.join(tmp, f"refl{rank}")))
+exp_lone = ref_lone.fit_transform(nvt.Dataset(int32_frame(9, 50_000))).to_ddf().compute()
+for c in ("p", "q", "s"):
+    np.testing.assert_array_equal(got_lone[c].to_numpy(), exp_lone[c].to_numpy(), err_msg="lone " + c)
 full = pd.concat([make(r) for r in range(world)], ignore_index=True)
 ref = nvt.Workflow((["a", "b"] >> ops.Categorify(out_path=os.path.join(tmp, f"ref{rank}")))
                    + (["x"] >> ops.FillMissing() >> ops.Normalize()))

@@ -219,6 +219,9 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
     # shard) and the parity leg (a single-rank fit inside dist.local_only())
     assert rec["roofline"]["per_family"]["count"]["ms_per_step"] > 0
     assert rec["cpu_baseline"]["value"] > 0 and rec["parity"]["parity_ok"] is True
+    # the collective self-check ran before the timing (here gloo against gloo: the code path)
+    sc = rec["collective_selfcheck"]
+    assert sc["ok_on_every_rank"] and len(sc["checks"]) == 4 and all(c["equal_to_gloo"] for c in sc["checks"])
 
 
 def test_fully_staged_encode_with_unseen_keys_and_nulls(tmp_path):
