@@ -107,8 +107,38 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
   }
   std::vector<OrderTail> tails;   // class-255 sorts of the key-sorted vocabularies: one batch
   std::vector<int> tail_cols;
+  // key-sorted vocabularies with a range table (dumped by the counting pass, or flat): ordered
+  // by ONE chain of batched launches on the first internal stream (vocab_order_sorted_batch)
+  // instead of ~10 launches per vocabulary spread over the streams -- the host took as long to
+  // enqueue those as the GPU to run them
+  static const bool batch_order = getenv("NVT_NO_ORDER_BATCH") == nullptr;
+  std::vector<char> batched(ncols > 0 ? ncols : 0, 0);
+  if (batch_order) {
+    std::vector<OrderSortedJob> jobs;
+    std::vector<int> job_cols;
+    for (int i : big) {
+      const nvt_vocab_col &c = cols[i];
+      if (c.src_keys == nullptr || c.table == nullptr || c.range_aux == nullptr || c.n == 0) continue;
+      NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
+      jobs.push_back({(const int32_t *)c.src_keys, c.src_counts, c.n, c.cls_hist, c.n_big, c.max_count,
+                      (int32_t *)c.keys, c.counts, c.sort_tmp, c.first_label, c.table, c.capacity,
+                      c.sentinel_label, c.range_aux, c.range_nb_log2, c.flat_slots});
+      job_cols.push_back(i);
+      batched[i] = 1;
+    }
+    if (!jobs.empty()) {
+      hipStream_t s = fork ? pool->s[0] : main_s;
+      int rc = vocab_order_sorted_batch(jobs.data(), (int)jobs.size(), s);
+      if (rc) return rc;
+      for (int i : job_cols) {
+        rc = finish(cols[i], s);
+        if (rc) return rc;
+      }
+    }
+  }
   for (size_t j = 0; j < big.size(); ++j) {
     const nvt_vocab_col &c = cols[big[j]];
+    if (batched[big[j]]) continue;
     hipStream_t s = fork ? pool->s[j % kSide] : main_s;
     if (c.src_keys != nullptr) {
       // key-sorted list of the range path: one stable counting pass orders it and fills the table

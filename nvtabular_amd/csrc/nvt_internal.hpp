@@ -56,6 +56,27 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
                             void *table, uint64_t capacity, int64_t *sentinel_label,
                             const int32_t *range_aux, int range_nb_log2, hipStream_t s,
                             bool *tail_deferred = nullptr, uint64_t flat_slots = 0);
+// the same for several vocabularies that own a range table (dumped or flat): one launch per
+// stage for ALL of them, class-255 tails included
+struct OrderSortedJob {
+  const int32_t *src_keys;
+  const int64_t *src_cnts;
+  uint64_t n;
+  const unsigned *cls_hist;
+  uint64_t n_big;
+  int64_t max_count;
+  int32_t *out_keys;
+  int64_t *out_cnts;
+  void *tmp;
+  int64_t first_label;
+  void *table;
+  uint64_t capacity;
+  int64_t *sentinel_label;
+  const int32_t *range_aux;
+  int range_nb_log2;
+  uint64_t flat_slots;
+};
+int vocab_order_sorted_batch(const OrderSortedJob *jobs, int njobs, hipStream_t s);
 // the deferred part: sort of the n_big leading entries (class 255) + their labels
 struct OrderTail {
   int32_t *keys;

@@ -934,7 +934,7 @@ __device__ __forceinline__ unsigned cls_digit(uint64_t comp) {
   return 255u - (cnt < 255u ? cnt : 255u);
 }
 
-__global__ __launch_bounds__(kS2BS) void cls_scatter_kernel(
+__device__ __forceinline__ void cls_scatter_body(
     const int32_t *__restrict__ keys, const int64_t *__restrict__ cnts, uint64_t n,
     const unsigned *__restrict__ cls_hist, unsigned *status, unsigned *ticket, int32_t *out_keys,
     int64_t *out_cnts, unsigned long long *table, uint64_t mask, int64_t first_label,
@@ -1074,6 +1074,67 @@ __global__ __launch_bounds__(kS2BS) void cls_scatter_kernel(
   }
 }
 
+__global__ __launch_bounds__(kS2BS) void cls_scatter_kernel(
+    const int32_t *__restrict__ keys, const int64_t *__restrict__ cnts, uint64_t n,
+    const unsigned *__restrict__ cls_hist, unsigned *status, unsigned *ticket, int32_t *out_keys,
+    int64_t *out_cnts, unsigned long long *table, uint64_t mask, int64_t first_label,
+    int64_t *sentinel_label, int32_t *label_of) {
+  cls_scatter_body(keys, cnts, n, cls_hist, status, ticket, out_keys, out_cnts, table, mask,
+                   first_label, sentinel_label, label_of);
+}
+
+// ---- the same ordering for SEVERAL vocabularies per launch --------------------------------
+// A Criteo fit orders 13 key-sorted vocabularies; one launch chain per vocabulary (memsets,
+// scatter, patch / build: ~10 launches each) kept the HOST busy for as long as the kernels ran
+// (~130 launches, 1.0 ms of a 12 ms step).  Here every stage is ONE launch for all vocabularies
+// of the call: the tiles of all lists form one grid (a block finds its vocabulary in a prefix
+// table of 16 entries), streaming stages use blockIdx.y = vocabulary.
+constexpr int kOrdBatch = 16;
+struct OrdJob {
+  const int32_t *keys;
+  const int64_t *cnts;
+  const unsigned *cls_hist;
+  unsigned *status, *ticket;
+  int32_t *out_keys;
+  int64_t *out_cnts;
+  int32_t *label_of;
+  unsigned long long *table;
+  int64_t *sentinel_label;
+  int32_t *aux;
+  unsigned long long *fb_status;
+  unsigned long long n, capacity, nslots, flat_slots, first_label, status_words, fb_words;
+};
+struct OrdBatch {
+  OrdJob j[kOrdBatch];
+  unsigned tile_start[kOrdBatch + 1];
+  unsigned flat_start[kOrdBatch + 1];
+  int njobs;
+};
+__device__ __forceinline__ int ord_job_of(const unsigned *start, int n, unsigned b) {
+  int c = 0;
+  while (c + 1 < n && b >= start[c + 1]) ++c;
+  return c;
+}
+
+__global__ __launch_bounds__(kBlock) void ord_prep_kernel(OrdBatch b) {
+  const OrdJob &j = b.j[blockIdx.y];
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const uint64_t t0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  for (uint64_t i = t0; i < j.status_words; i += stride) j.status[i] = 0;   // + the ticket word
+  for (uint64_t i = t0; i < j.fb_words; i += stride) j.fb_status[i] = 0;
+  if (j.flat_slots) {  // flat table: every slot empty before the build
+    for (uint64_t i = t0; i < j.capacity; i += stride) j.table[i] = kEncEmptySlot;
+  }
+  if (t0 == 0) *j.sentinel_label = -1;
+}
+
+__global__ __launch_bounds__(kS2BS) void cls_scatter_many_kernel(OrdBatch b) {
+  const int ji = ord_job_of(b.tile_start, b.njobs, blockIdx.x);
+  const OrdJob &j = b.j[ji];
+  cls_scatter_body(j.keys, j.cnts, j.n, j.cls_hist, j.status, j.ticket, j.out_keys, j.out_cnts,
+                   nullptr, 0, (int64_t)j.first_label, j.sentinel_label, j.label_of);
+}
+
 // Range table (dumped by the counting pass: slot = {key, position in the key-ordered list}):
 // positions -> labels.  One streaming pass: the slots are in key order, so label_of[] is read
 // front to back as well.
@@ -1127,6 +1188,66 @@ __global__ __launch_bounds__(kBlock) void range_fix_prefix_kernel(
   }
 }
 
+__global__ __launch_bounds__(kBlock) void range_patch_many_kernel(OrdBatch b) {
+  const OrdJob &j = b.j[blockIdx.y];
+  if (j.flat_slots || j.nslots == 0) return;
+  unsigned long long *table = j.table;
+  const int32_t *__restrict__ label_of = j.label_of;
+  const uint64_t nslots = j.nslots;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock * 2;
+  for (uint64_t s0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 2; s0 < nslots; s0 += stride) {
+    ulonglong2 e = *reinterpret_cast<ulonglong2 *>(table + s0);
+    bool dirty = false;
+    if ((int32_t)(uint32_t)e.x != INT32_MIN) {
+      e.x = ((unsigned long long)(uint32_t)label_of[(uint32_t)(e.x >> 32)] << 32) | (uint32_t)e.x;
+      dirty = true;
+    }
+    if ((int32_t)(uint32_t)e.y != INT32_MIN) {
+      e.y = ((unsigned long long)(uint32_t)label_of[(uint32_t)(e.y >> 32)] << 32) | (uint32_t)e.y;
+      dirty = true;
+    }
+    if (dirty) *reinterpret_cast<ulonglong2 *>(table + s0) = e;
+  }
+}
+
+struct FixJob {
+  unsigned long long *table;
+  const int32_t *aux, *vocab;
+  int64_t *sentinel_label;
+  unsigned long long n_big, first_label, table_slots;
+};
+struct FixBatch {
+  FixJob j[kOrdBatch];
+};
+__global__ __launch_bounds__(kBlock) void range_fix_prefix_many_kernel(FixBatch b) {
+  const FixJob &f = b.j[blockIdx.y];
+  const RangeMap map = load_map(f.aux);
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < f.n_big; j += stride) {
+    const int32_t key = f.vocab[j];
+    const int64_t label = (int64_t)f.first_label + (int64_t)j;
+    if (key == INT32_MIN) {
+      *f.sentinel_label = label;
+      continue;
+    }
+    uint64_t s = map.table_slot(key);
+    if (map.flat) {
+      s = flat_find_from(f.table, f.table_slots, s, key, f.table[s]);
+      if (s != ~0ull) f.table[s] = ((unsigned long long)(uint32_t)label << 32) | (uint32_t)key;
+      continue;
+    }
+    while (true) {
+      const unsigned long long e = f.table[s];
+      if ((int32_t)(uint32_t)e == key) {
+        f.table[s] = ((unsigned long long)(uint32_t)label << 32) | (uint32_t)key;
+        break;
+      }
+      if ((int32_t)(uint32_t)e == INT32_MIN) break;
+      ++s;
+    }
+  }
+}
+
 // histogram of min(count, 255) of a (key, count) list that did not come from the range path (the
 // multi-GPU merge gathers key-sorted owner shards): what cls_scatter_kernel needs
 __global__ __launch_bounds__(kBlock) void class_hist_kernel(const int64_t *__restrict__ cnts,
@@ -1160,8 +1281,8 @@ __global__ __launch_bounds__(kBlock) void class_hist_kernel(const int64_t *__res
 // the key or an empty slot, exactly like the dumped tables of the range path (RangeMap.flat).
 // The largest displacement p_i - h_i goes to aux[NVT_FLAT_AUX_MAXDISP]: keys that cluster in
 // their range make long runs, the caller then builds an ordinary hashed table instead.
-__global__ void flat_params_kernel(const int32_t *__restrict__ keys, uint64_t n, uint64_t slots,
-                                   int32_t *aux) {
+__device__ __forceinline__ void flat_params_body(const int32_t *__restrict__ keys, uint64_t n,
+                                                 uint64_t slots, int32_t *aux) {
   // span of the (sorted) keys, the sentinel key (smallest int32, not in the table) left out
   const uint64_t first = (n > 1 && keys[0] == INT32_MIN) ? 1 : 0;
   const uint64_t lo = ukey(keys[first]), hi = ukey(keys[n - 1]);
@@ -1184,11 +1305,15 @@ __global__ void flat_params_kernel(const int32_t *__restrict__ keys, uint64_t n,
   aux[NVT_RANGE_AUX_LO + 6] = keys[0] == INT32_MIN ? 1 : 0;  // position 0 holds the smallest int32 (not in the table)
   aux[NVT_FLAT_AUX_MAXDISP] = 0;
 }
+__global__ void flat_params_kernel(const int32_t *__restrict__ keys, uint64_t n, uint64_t slots,
+                                   int32_t *aux) {
+  flat_params_body(keys, n, slots, aux);
+}
 
 constexpr unsigned long long kFbAgg = 1ull << 62, kFbPrefix = 2ull << 62, kFbMask = (1ull << 62) - 1ull;
 constexpr long long kFbBias = 1ll << 40;  // h - i is > -2^30: biased to an unsigned value
 
-__global__ __launch_bounds__(kS2BS) void flat_build_kernel(
+__device__ __forceinline__ void flat_build_body(
     const int32_t *__restrict__ keys, const int32_t *__restrict__ label_of, uint64_t n,
     int32_t *aux, unsigned long long *status, unsigned *ticket, unsigned long long *table,
     uint64_t table_slots) {
@@ -1277,6 +1402,23 @@ __global__ __launch_bounds__(kS2BS) void flat_build_kernel(
     maxdisp = o > maxdisp ? o : maxdisp;
   }
   if (l == 0 && maxdisp > 0) atomicMax(reinterpret_cast<unsigned *>(aux + NVT_FLAT_AUX_MAXDISP), maxdisp);
+}
+__global__ __launch_bounds__(kS2BS) void flat_build_kernel(
+    const int32_t *__restrict__ keys, const int32_t *__restrict__ label_of, uint64_t n,
+    int32_t *aux, unsigned long long *status, unsigned *ticket, unsigned long long *table,
+    uint64_t table_slots) {
+  flat_build_body(keys, label_of, n, aux, status, ticket, table, table_slots);
+}
+__global__ void flat_params_many_kernel(OrdBatch b) {
+  const OrdJob &j = b.j[blockIdx.x];
+  if (j.flat_slots) flat_params_body(j.keys, j.n, j.flat_slots, j.aux);
+}
+__global__ __launch_bounds__(kS2BS) void flat_build_many_kernel(OrdBatch b) {
+  const int ji = ord_job_of(b.flat_start, b.njobs, blockIdx.x);
+  const OrdJob &j = b.j[ji];
+  const uint64_t ntiles = (j.n + kS2Tile - 1) / kS2Tile;
+  flat_build_body(j.keys, j.label_of, j.n, j.aux, j.fb_status,
+                  reinterpret_cast<unsigned *>(j.fb_status + ntiles), j.table, j.capacity);
 }
 
 // key -> position in the sorted list through a flat range table whose labels are the positions
@@ -1522,6 +1664,106 @@ int vocab_order_from_sorted(const int32_t *src_keys, const int64_t *src_cnts, ui
   return NVT_OK;
 }
 
+// vocab_order_from_sorted for several vocabularies that own a range table (dumped or flat): every
+// stage one launch (ord_prep / cls_scatter_many / flat_params_many + flat_build_many /
+// range_patch_many), then the class-255 tails (one batched small sort + one label launch; a tail
+// too long for the small sort is sorted on its own).
+int vocab_order_sorted_batch(const OrderSortedJob *jobs, int njobs, hipStream_t s) {
+  for (int j0 = 0; j0 < njobs; j0 += kOrdBatch) {
+    const int nj = njobs - j0 < kOrdBatch ? njobs - j0 : kOrdBatch;
+    OrdBatch b;
+    memset(&b, 0, sizeof(b));
+    std::vector<OrderTail> tails;
+    bool any_flat = false, any_ranged = false;
+    for (int i = 0; i < nj; ++i) {
+      const OrderSortedJob &q = jobs[j0 + i];
+      NVT_CHECK_ARG(q.n > 0 && q.n < (1ull << 30), "1 .. 2^30-1 vocabulary entries");
+      NVT_CHECK_ARG(q.n_big <= q.n, "n_big > n");
+      NVT_CHECK_ARG(q.table && q.range_aux && q.tmp && q.sentinel_label, "range table jobs only");
+      const uint64_t ntiles = (q.n + kS2Tile - 1) / kS2Tile;
+      unsigned *status = reinterpret_cast<unsigned *>(q.tmp);
+      uint64_t sort_bytes = 0;
+      if (q.n_big > 1) (void)nvt_vocab_sort_tmp_bytes(4, q.n_big, &sort_bytes);
+      char *sort_tmp = reinterpret_cast<char *>(q.tmp) + pad16(ntiles * 256 * 4 + 64);
+      int32_t *label_of = reinterpret_cast<int32_t *>(sort_tmp + pad16(sort_bytes));
+      OrdJob &o = b.j[i];
+      o.keys = q.src_keys;
+      o.cnts = q.src_cnts;
+      o.cls_hist = q.cls_hist;
+      o.status = status;
+      o.ticket = status + ntiles * 256;
+      o.out_keys = q.out_keys;
+      o.out_cnts = q.out_cnts;
+      o.label_of = label_of;
+      o.table = reinterpret_cast<unsigned long long *>(q.table);
+      o.sentinel_label = q.sentinel_label;
+      o.aux = const_cast<int32_t *>(q.range_aux);
+      o.fb_status = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(label_of) + pad16(q.n * 4));
+      o.n = q.n;
+      o.capacity = q.capacity;
+      o.flat_slots = q.flat_slots;
+      o.nslots = q.flat_slots ? 0 : ((uint64_t)1 << q.range_nb_log2) * kRpRegion + kRpGuard;
+      o.first_label = (unsigned long long)q.first_label;
+      o.status_words = ntiles * 256 + 16;
+      o.fb_words = q.flat_slots ? ntiles + 8 : 0;
+      if (q.flat_slots) {
+        NVT_CHECK_ARG(q.flat_slots >= 64 && q.flat_slots < (1ull << 32), "flat table: 64 .. 2^32-1 slots");
+        NVT_CHECK_ARG(q.capacity >= q.flat_slots + q.n + 64, "flat table: slots + n + 64");
+        any_flat = true;
+      } else {
+        any_ranged = true;
+      }
+      b.tile_start[i + 1] = b.tile_start[i] + (unsigned)ntiles;
+      b.flat_start[i + 1] = b.flat_start[i] + (q.flat_slots ? (unsigned)ntiles : 0u);
+    }
+    b.njobs = nj;
+    {
+      NVT_PROF("vocab_order", 0, s);
+      ord_prep_kernel<<<dim3(any_flat ? 2048 : 64, nj), kBlock, 0, s>>>(b);
+      NVT_CHECK_LAUNCH();
+      cls_scatter_many_kernel<<<b.tile_start[nj], kS2BS, 0, s>>>(b);
+      NVT_CHECK_LAUNCH();
+      if (any_flat) {
+        flat_params_many_kernel<<<nj, 1, 0, s>>>(b);
+        NVT_CHECK_LAUNCH();
+        flat_build_many_kernel<<<b.flat_start[nj], kS2BS, 0, s>>>(b);
+        NVT_CHECK_LAUNCH();
+      }
+      if (any_ranged) {
+        range_patch_many_kernel<<<dim3(1024, nj), kBlock, 0, s>>>(b);
+        NVT_CHECK_LAUNCH();
+      }
+    }
+    for (int i = 0; i < nj; ++i) {
+      const OrderSortedJob &q = jobs[j0 + i];
+      if (q.n_big == 0) continue;
+      if (vocab_sort_small_eligible(4, q.n_big, q.max_count)) {
+        tails.push_back({q.out_keys, q.out_cnts, q.n_big, q.first_label, q.table, q.capacity,
+                         q.sentinel_label, q.range_aux});
+        continue;
+      }
+      // a class 255 beyond the one-workgroup sort (merged multi-partition vocabularies), or of
+      // one entry (nothing to sort)
+      if (q.n_big > 1) {
+        const uint64_t ntiles = (q.n + kS2Tile - 1) / kS2Tile;
+        char *sort_tmp = reinterpret_cast<char *>(q.tmp) + pad16(ntiles * 256 * 4 + 64);
+        int rc = vocab_sort_any(4, q.out_keys, q.out_cnts, q.n_big, q.max_count, sort_tmp, s);
+        if (rc) return rc;
+      }
+      NVT_PROF("encode_build", 0, s);
+      range_fix_prefix_kernel<<<stream_grid(q.n_big, kBlock), kBlock, 0, s>>>(
+          (unsigned long long *)q.table, q.range_aux, q.out_keys, q.n_big, q.first_label,
+          q.sentinel_label, q.capacity);
+      NVT_CHECK_LAUNCH();
+    }
+    if (!tails.empty()) {
+      int rc = vocab_order_tail_batch(tails.data(), (int)tails.size(), s);
+      if (rc) return rc;
+    }
+  }
+  return NVT_OK;
+}
+
 // class 255 of several vocabularies (vocab_order_from_sorted with tail_deferred): ONE batched
 // sort launch (a workgroup per vocabulary) instead of a one-workgroup launch per vocabulary,
 // then the labels of the sorted entries
@@ -1536,13 +1778,28 @@ int vocab_order_tail_batch(const OrderTail *t, int nt, hipStream_t s) {
   int rc = vocab_sort_small_batch(d.data(), nt, s);
   if (rc) return rc;
   NVT_PROF("encode_build", 0, s);
+  // range tables (dumped or flat): the labels of all vocabularies in one launch
+  for (int i0 = 0; i0 < nt;) {
+    FixBatch fb;
+    memset(&fb, 0, sizeof(fb));
+    int nf = 0;
+    uint64_t longest = 0;
+    for (; i0 < nt && nf < kOrdBatch; ++i0) {
+      if (!t[i0].table || !t[i0].range_aux) continue;
+      fb.j[nf++] = {(unsigned long long *)t[i0].table, t[i0].range_aux, t[i0].keys,
+                    t[i0].sentinel_label, t[i0].n_big, (unsigned long long)t[i0].first_label,
+                    t[i0].capacity};
+      longest = t[i0].n_big > longest ? t[i0].n_big : longest;
+    }
+    if (nf) {
+      range_fix_prefix_many_kernel<<<dim3(stream_grid(longest, kBlock), nf), kBlock, 0, s>>>(fb);
+      NVT_CHECK_LAUNCH();
+    }
+  }
   for (int i = 0; i < nt; ++i) {
     if (!t[i].table) continue;
     if (t[i].range_aux) {
-      range_fix_prefix_kernel<<<stream_grid(t[i].n_big, kBlock), kBlock, 0, s>>>(
-          (unsigned long long *)t[i].table, t[i].range_aux, t[i].keys, t[i].n_big, t[i].first_label,
-          t[i].sentinel_label, t[i].capacity);
-      NVT_CHECK_LAUNCH();
+      continue;  // (labelled above)
     } else {
       rc = encode_insert_any(4, t[i].keys, t[i].n_big, t[i].first_label, t[i].table, t[i].capacity,
                              t[i].sentinel_label, s);
