@@ -855,10 +855,28 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
   __shared__ int32_t tk[kHotSlots];
   __shared__ unsigned seen[2048];  // 64 K-bit "seen once" filter
   __shared__ unsigned s_hits, s_rows, s_umin, s_umax;
+  // range path only: how often the sample shows every image slot's key, and a one-row sketch of
+  // the keys that found their bucket full -- a FREQUENT key that lost the race for its bucket
+  // would flood one region of the partition pass (see the rescue below)
+  __shared__ unsigned tcnt[kHotSlots];
+  __shared__ unsigned msk[2048];
+  __shared__ int32_t mk[256];
+  __shared__ unsigned mc[256];
+  __shared__ unsigned s_missed;
+  const bool rescue = batch.c[blockIdx.x].nb_log2 > 0;
   __shared__ uint64_t s_map[4];
   for (int i = threadIdx.x; i < kHotSlots; i += 1024) tk[i] = EMPTY;
   for (int i = threadIdx.x; i < 2048; i += 1024) seen[i] = 0;
+  if (rescue) {
+    for (int i = threadIdx.x; i < kHotSlots; i += 1024) tcnt[i] = 0;
+    for (int i = threadIdx.x; i < 2048; i += 1024) msk[i] = 0;
+    if (threadIdx.x < 256) {
+      mk[threadIdx.x] = EMPTY;
+      mc[threadIdx.x] = 0;
+    }
+  }
   if (threadIdx.x == 0) {
+    s_missed = 0;
     s_hits = s_rows = 0;
     s_umin = 0xFFFFFFFFu;
     s_umax = 0u;
@@ -932,7 +950,18 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
         bool found = false;
 #pragma unroll
         for (int c = 0; c < kHotWidth; ++c) found = found || tk[b + c] == key;
-        if (!found) insert(key, h);
+        bool in = found;
+        if (!found) in = insert(key, h);
+        if (rescue) {
+          if (in) {
+#pragma unroll
+            for (int c = 0; c < kHotWidth; ++c)
+              if (tk[b + c] == key) atomicAdd(&tcnt[b + c], 1u);
+          } else {
+            atomicAdd(&msk[(h * 0x85EBCA6Bu) >> 21], 1u);
+            atomicAdd(&s_missed, 1u);
+          }
+        }
         hits += found;
         rows += 1;
         const unsigned u = (unsigned)key ^ 0x80000000u;
@@ -959,6 +988,63 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
     atomicMax(&s_umax, umax);
   }
   __syncthreads();
+  if (rescue) {
+    // Rescue of frequent keys that are NOT in the image.  The image takes keys first come, so a
+    // key as frequent as 1 % of the rows occasionally finds both slots of its bucket taken by
+    // two rarer keys; all its rows then go through ONE bin of the partition pass and overflow a
+    // (bucket, workgroup) region (2 x the average rows + 64): about one 45 M-row Criteo partition
+    // in a hundred had to be recounted on the sort path for that.  A key whose sample count
+    // reaches rows / (2 * buckets) replaces the rarer occupant of its bucket.  The sketch makes
+    // the common case (nothing to rescue) free: a third sweep of the sample runs only when some
+    // sketch counter stands out from the noise of the one-off keys.
+    const unsigned nbk = 1u << batch.c[blockIdx.x].nb_log2;
+    const unsigned T = max(16u, s_rows / (2u * nbk));
+    const unsigned thr = T + 2u * (s_missed / 2048u);
+    const int any = __syncthreads_or(msk[threadIdx.x] >= thr || msk[threadIdx.x + 1024] >= thr);
+    if (any) {
+      for (unsigned it0 = 0; it0 < S; it0 += kBatch) {
+        load_batch(it0);
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+          const int32_t key = kreg[q];
+          if (key == EMPTY) continue;
+          const uint32_t h = slot_hash(key);
+          if (msk[(h * 0x85EBCA6Bu) >> 21] < thr) continue;
+          const uint32_t b = hot_bucket(h) * kHotWidth;
+          bool found = false;
+#pragma unroll
+          for (int c = 0; c < kHotWidth; ++c) found = found || tk[b + c] == key;
+          if (found) continue;
+          uint32_t m = (h >> 3) & 255u;
+          for (int step = 0; step < 256; ++step, m = (m + 1) & 255u) {  // exact count of the candidates
+            const int32_t prev = atomicCAS(&mk[m], EMPTY, key);
+            if (prev == EMPTY || prev == key) {
+              atomicAdd(&mc[m], 1u);
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int m = 0; m < 256; ++m) {
+          const int32_t key = mk[m];
+          const unsigned c = mc[m];
+          if (key == EMPTY || c < T) continue;
+          const uint32_t b = hot_bucket(slot_hash(key)) * kHotWidth;
+          int worst = 0;
+#pragma unroll
+          for (int w = 1; w < kHotWidth; ++w)
+            if (tcnt[b + w] < tcnt[b + worst]) worst = w;
+          if (tcnt[b + worst] < c) {  // the rarer occupant leaves the image (and goes through the bins)
+            tk[b + worst] = key;
+            tcnt[b + worst] = c;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
   const bool useful = (uint64_t)s_hits * 8 >= (uint64_t)s_rows && s_rows > 0;
   for (int i = threadIdx.x; i < kHotSlots; i += 1024) image[i] = useful ? tk[i] : EMPTY;
   const int nb_log2 = batch.c[blockIdx.x].nb_log2;

@@ -262,7 +262,7 @@ __device__ __forceinline__ void two_buckets(uint32_t h, uint32_t &b1, uint32_t &
 // dumped; nvt_range.hpp): first slot from the monotone map, probing runs forward without
 // wrapping (an empty slot ends every chain).
 template <typename K, typename OUT, bool TWO = false, bool GLOBAL = true, int UU = 2,
-          bool RANGE = false>
+          int RANGE = 0>  // 0: hashed table, 1: bucket regions dumped by the counting pass, 2: flat
 __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
@@ -439,16 +439,26 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
 #pragma unroll
       for (int q = 0; q < NK; ++q) {
         if (!need[q]) continue;
-        if constexpr (RANGE) {
-          if (rmap.flat) {
-            // flat table: runs are in key order -- linear for a few slots, then doubling +
-            // bisection (flat_find_from: keys that cluster in their range sit far from home)
-            const uint64_t at = flat_find_from(reinterpret_cast<const unsigned long long *>(table),
-                                               mask + 1, slot[q], (int32_t)k[q],
-                                               *reinterpret_cast<const unsigned long long *>(&e[q]));
-            if (at != ~0ull) lab[q] = (int64_t)table[at].label;
-            continue;
+        if constexpr (RANGE == 2) {
+          // flat table: a few slots one by one (keys that are spread over their range sit next
+          // to home); a key that is still unresolved then -- its vocabulary clusters in its
+          // range -- is searched by doubling + bisection behind this loop (runs are in key order)
+          int step = 0;
+          while (true) {
+            if (e[q].key == k[q]) {
+              lab[q] = (int64_t)e[q].label;
+              need[q] = false;
+              break;
+            }
+            if (e[q].key == EMPTY) {
+              need[q] = false;
+              break;
+            }
+            if (++step == kFlatLinear) break;   // need[q] stays set: slot[q] is below the key
+            slot[q] = slot[q] + 1;
+            e[q] = table[slot[q]];
           }
+          continue;
         }
         while (true) {  // collisions continue here (load factor <= 0.5: short chains)
           if (e[q].key == k[q]) {
@@ -458,6 +468,21 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
           if (e[q].key == EMPTY) break;
           slot[q] = next_slot(slot[q]);
           e[q] = table[slot[q]];
+        }
+      }
+      if constexpr (RANGE == 2) {
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) any = any || need[q];
+        if (any) {  // (never taken for keys that are spread over their range)
+#pragma unroll   // (static indices: a rolled loop would put k[] / slot[] / lab[] into scratch)
+          for (int q = 0; q < NK; ++q) {
+            if (!need[q]) continue;
+            if (ukey((int32_t)e[q].key) > ukey((int32_t)k[q])) continue;   // already past it: not there
+            const uint64_t at = flat_gallop(reinterpret_cast<const unsigned long long *>(table),
+                                            mask + 1, slot[q], (int32_t)k[q]);
+            if (at != ~0ull) lab[q] = (int64_t)table[at].label;
+          }
         }
       }
     }
@@ -645,14 +670,18 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
         const uint64_t cap2 = (uint64_t)HotCfg<K>::slots / 8 * 7;
         n_hot = (uint32_t)(n_vocab < cap2 ? n_vocab : cap2);
         if (range_aux != nullptr) {
-          if (out_bytes == 8)
-            encode_hot_kernel<K, int64_t, true, true, 2, true><<<hgrid, kEncBS, 0, s>>>(
-                keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
-                reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label, range_aux);
-          else
-            encode_hot_kernel<K, int32_t, true, true, 2, true><<<hgrid, kEncBS, 0, s>>>(
-                keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
-                reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label, range_aux);
+          // capacity > 0: a FLAT range table of `capacity` slots (bounded search); 0: the bucket
+          // regions dumped by the counting pass
+#define NVT_ENC_RANGE(OUTT, KIND)                                                                  \
+  encode_hot_kernel<K, OUTT, true, true, 2, KIND><<<hgrid, kEncBS, 0, s>>>(                         \
+      keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,          \
+      reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux)
+          if (capacity > 0) {
+            if (out_bytes == 8) NVT_ENC_RANGE(int64_t, 2); else NVT_ENC_RANGE(int32_t, 2);
+          } else {
+            if (out_bytes == 8) NVT_ENC_RANGE(int64_t, 1); else NVT_ENC_RANGE(int32_t, 1);
+          }
+#undef NVT_ENC_RANGE
           NVT_CHECK_LAUNCH();
           return NVT_OK;
         }

@@ -57,26 +57,16 @@ struct RangeMap {
 // hundreds of thousands of slots from home; a slot-by-slot walk took minutes per column there.
 // `e0` = the word already loaded from `home`.
 constexpr int kFlatLinear = 8;
-__device__ __forceinline__ uint64_t flat_find_from(const unsigned long long *__restrict__ table,
-                                                   uint64_t slots, uint64_t home, int32_t key,
-                                                   unsigned long long e0) {
+// the rare part:
+// table[lo] is occupied and below `key`; doubling steps, then bisection
+__device__ __forceinline__ uint64_t flat_gallop(const unsigned long long *__restrict__ table,
+                                             uint64_t slots, uint64_t lo, int32_t key) {
   const uint32_t uk = ukey(key);
   auto below = [&](unsigned long long e) {  // occupied and in front of `key`
     const int32_t ek = (int32_t)(uint32_t)e;
     return ek != INT32_MIN && ukey(ek) < uk;
   };
-  uint64_t sl = home;
-  unsigned long long e = e0;
-#pragma unroll 1
-  for (int step = 0; step < kFlatLinear; ++step) {
-    if ((int32_t)(uint32_t)e == key) return sl;
-    if (!below(e)) return ~0ull;
-    if (++sl >= slots) return ~0ull;
-    e = table[sl];
-  }
-  // table[sl - 1] is below the key; find hi with !below(table[hi]) by doubling, then bisect
-  uint64_t lo = sl - 1, width = kFlatLinear;
-  uint64_t hi;
+  uint64_t width = kFlatLinear, hi;
   while (true) {
     hi = lo + width < slots - 1 ? lo + width : slots - 1;
     if (!below(table[hi]) || hi == slots - 1) break;
@@ -89,6 +79,33 @@ __device__ __forceinline__ uint64_t flat_find_from(const unsigned long long *__r
     if (below(table[mid])) lo = mid; else hi = mid;
   }
   return (int32_t)(uint32_t)table[hi] == key ? hi : ~0ull;
+}
+
+// (`word`: receives the {key, label} word of the slot that is returned -- the callers that only
+// read the label need no second load of it)
+__device__ __forceinline__ uint64_t flat_find_from(const unsigned long long *__restrict__ table,
+                                                   uint64_t slots, uint64_t home, int32_t key,
+                                                   unsigned long long e0,
+                                                   unsigned long long *word = nullptr) {
+  uint64_t sl = home;
+  unsigned long long e = e0;
+  int step = 0;
+  while (true) {
+    const int32_t ek = (int32_t)(uint32_t)e;
+    if (ek == key) {
+      if (word) *word = e;
+      return sl;
+    }
+    if (ek == INT32_MIN) return ~0ull;          // an empty slot ends every run
+    if (++step == kFlatLinear) {                // far from home: the keys cluster in their range
+      if (ukey(ek) > ukey(key)) return ~0ull;   // (runs are in key order: already past it)
+      const uint64_t at = flat_gallop(table, slots, sl, key);
+      if (word && at != ~0ull) *word = table[at];
+      return at;
+    }
+    if (++sl >= slots) return ~0ull;
+    e = table[sl];
+  }
 }
 
 __device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {

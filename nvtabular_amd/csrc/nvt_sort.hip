@@ -1455,8 +1455,9 @@ __device__ __forceinline__ int64_t flat_probe(const FlatIndexView &v, const K *_
   if (k == INT32_MIN) return v.has_min ? 0 : -1;
   const uint64_t home = v.map.fine(k);
   if (home >= v.slots) return -1;
-  const uint64_t sl = flat_find_from(v.table, v.slots, home, k, v.table[home]);
-  return sl == ~0ull ? -1 : (int64_t)(uint32_t)(v.table[sl] >> 32);
+  unsigned long long w = 0;
+  const uint64_t sl = flat_find_from(v.table, v.slots, home, k, v.table[home], &w);
+  return sl == ~0ull ? -1 : (int64_t)(uint32_t)(w >> 32);
 }
 
 template <typename K>
