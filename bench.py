@@ -238,17 +238,17 @@ def family_of(scope):
 
 
 def pmc_traffic():
-    """HBM bytes from the committed PMC passes (profiles/r03_pmc_traffic.json: FETCH_SIZE /
+    """HBM bytes from the committed PMC passes (profiles/r04_pmc_traffic.json: FETCH_SIZE /
     WRITE_SIZE collected in separate `rocprofv3 --pmc` passes over this command and corrected
-    per MI355X_MICROARCH.md; made by tools/prof_r03.sh + tools/pmc_summarize.py).  PMC cannot be
+    per MI355X_MICROARCH.md; made by tools/prof_r04.sh + tools/pmc_summarize.py).  PMC cannot be
     sampled from inside the timed run, so these are the figures of the same command at the same
     size.  -> {"families": {family: bytes per step}, "step": bytes per step} or None."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        d["source"] = ("committed profile profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of "
-                       "this command at this size, tools/prof_r03.sh; NOT collected in this run)")
+        d["source"] = ("committed profile profiles/r04_pmc_traffic.json (rocprofv3 --pmc passes of "
+                       "this command at this size, tools/prof_r04.sh; NOT collected in this run)")
         return d
     except Exception:
         return None

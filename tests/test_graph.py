@@ -254,3 +254,18 @@ def test_groupby_schema_and_selector_cols():
     assert not out["y-first"].is_list
     with pytest.raises(NotImplementedError):
         ops.Groupby(groupby_cols=["a"], aggs="median")
+
+
+def test_import_nvtabular_resolves_to_this_engine():
+    """Existing scripts import `nvtabular`: the alias package hands them nvtabular_amd's modules."""
+    import nvtabular as nvt
+    import nvtabular_amd
+    from nvtabular import ops
+    from nvtabular.ops import Categorify, Normalize
+    from nvtabular.ops.categorify import get_embedding_sizes
+
+    assert nvt is nvtabular_amd and ops is nvtabular_amd.ops
+    assert Categorify is nvtabular_amd.ops.Categorify and Normalize is nvtabular_amd.ops.Normalize
+    assert callable(get_embedding_sizes)
+    graph = ["a", "b"] >> ops.Categorify() 
+    assert nvt.Workflow(graph).output_node is not None and hasattr(nvt, "Dataset")
