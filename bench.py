@@ -746,6 +746,7 @@ def extra_dense_ids(device, tmp, rows, steps=5, single_ms=None):
         "counting_paths": paths,
         "range_path_banned_columns": sorted(op._no_range),
         "range_overflows": len(op._range_failures),
+        "range_overflow_bits": sorted({(h, b) for h, b, _ in op._range_failures}),
         "per_family_ms": {k: round(v, 3) for k, v in sorted(fam.items())},
         "parity": property_checks(wf, [frame], [out], cat_names, cont_names),
     }

@@ -142,6 +142,9 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
 #define NVT_PATH_HOT 16
 #define NVT_HOT_IMAGE_WORDS 8192
 #define NVT_PATH_RANGE 9
+#define NVT_PATH_PIECES 0x10000     /* with NVT_PATH_RANGE: let the sample decide on a piecewise map
+                                       (sampled quantile splitters) -- for keys that are not spread
+                                       over their range; asked for after the linear map overflowed */
 #define NVT_PATH_SORT 10            /* int32 keys, no weights, any number of distinct keys: radix sort of
                                        the rows + run lengths; key-sorted output like the range path;
                                        hot_image = uint32[256] receiving the histogram of min(count, 255) */
@@ -151,7 +154,10 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
 #define NVT_RANGE_AUX_HIST 8208     /*   uint32[256] histogram of min(count, 255)             */
 #define NVT_RANGE_AUX_HOTSTART 8464 /*   uint32[1025]: hot image slots by bucket (CSR offsets) */
 #define NVT_RANGE_AUX_HOTORDER 9504 /*   uint16[8192]: the image slots in bucket order         */
-#define NVT_RANGE_AUX_WORDS (9504 + 4096)
+#define NVT_RANGE_AUX_PW 13600      /*   piecewise map (keys not spread over their range): u32
+                                       splitters[65], mul[64], shift flags[2]; word LO + 7 = fine
+                                       slots per piece (0: the linear map)                      */
+#define NVT_RANGE_AUX_WORDS (13600 + 256)
 int nvt_dense_count_ws_bytes(int key_bytes, uint64_t n, int path, int weighted, uint64_t *bytes);
 int nvt_dense_count_i32(const int32_t *keys, const uint8_t *valid, const int64_t *weights,
                         uint64_t n, int path, void *ws, int32_t *out_keys, int64_t *out_counts,

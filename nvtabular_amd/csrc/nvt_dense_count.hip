@@ -839,7 +839,13 @@ struct HotSampleCol {
   uint64_t n;
   int32_t *image;
   int nb_log2;  // > 0: also derive the key ranges of the range path (image[NVT_RANGE_AUX_*])
+  int pieces;   // range path: also decide on the piecewise map (NVT_PATH_PIECES: after an overflow)
 };
+#ifdef NVT_NO_PIECEWISE
+constexpr bool kPiecewise = false;
+#else
+constexpr bool kPiecewise = true;
+#endif
 constexpr int kHotBatch = 32;
 struct HotSampleBatch {
   HotSampleCol c[kHotBatch];
@@ -864,7 +870,9 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
   __shared__ unsigned mc[256];
   __shared__ unsigned s_missed;
   const bool rescue = batch.c[blockIdx.x].nb_log2 > 0;
-  __shared__ uint64_t s_map[4];
+  __shared__ uint64_t s_map[5];
+  unsigned pmb[kHotSlots / 1024], pmr[kHotSlots / 1024];
+  bool pieces_done = false;
   for (int i = threadIdx.x; i < kHotSlots; i += 1024) tk[i] = EMPTY;
   for (int i = threadIdx.x; i < 2048; i += 1024) seen[i] = 0;
   if (rescue) {
@@ -1076,20 +1084,90 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
     image[NVT_RANGE_AUX_LO + 3] = (int32_t)(uint32_t)(mul >> 32);
     image[NVT_RANGE_AUX_LO + 4] = sh;
     image[NVT_RANGE_AUX_LO + 5] = 0;  // bucket-region table layout (nvt_range.hpp)
+    image[NVT_RANGE_AUX_LO + 7] = 0;  // linear map (the piecewise form is decided below)
     s_map[0] = lo;
     s_map[1] = span;
     s_map[2] = mul;
     s_map[3] = (uint64_t)sh;
   }
+  if (nb_log2 >= 6 && kPiecewise && batch.c[blockIdx.x].pieces) {
+    // ---- piecewise map: the caller put kRpPieces + 1 splitters (order-preserving u32 images,
+    // strictly increasing) into the aux block -- taken from an EXACT key-ordered (key, count)
+    // list of an earlier pass over this column (kernels.range_splitters: rows and distinct keys
+    // blended, so that no piece holds more than ~2x the average of either).  A sample of a few
+    // thousand rows cannot do this: nearly every cold key is a singleton in it, so it sees rows,
+    // not distinct keys, and the tail pieces of a dense-id column came out with 3.5x the average
+    // number of distinct keys (tools/pieces_probe.py).  Here: multipliers + the CSR of the hot keys.
+    __shared__ uint32_t s_pw[2 * kRpPieces + 3];
+    for (int p = threadIdx.x; p <= kRpPieces; p += 1024)
+      s_pw[p] = (uint32_t)image[NVT_RANGE_AUX_PW + p];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t S = 1u << (nb_log2 + 8);   // fine slots per piece = buckets / 64 x 16384
+      bool ok = true;
+      for (int p = 0; p < kRpPieces; ++p) ok = ok && s_pw[p + 1] > s_pw[p];
+      if (ok) {
+        uint32_t flags[2] = {0u, 0u};
+        for (int p = 0; p < kRpPieces; ++p) {
+          const uint32_t w = s_pw[p + 1] - s_pw[p];
+          uint32_t mulp;
+          if (w > S) {
+            mulp = (uint32_t)((((uint64_t)S) << 32) / w);
+            flags[p >> 5] |= 1u << (p & 31);
+          } else {  // fewer keys than slots: 16-bit fixed point (an integer factor S / w would leave
+                    // up to half of the piece's slots unused and its first buckets overfull)
+            const uint64_t m16 = (((uint64_t)S) << 16) / w;
+            mulp = (uint32_t)(m16 < 0xFFFFFFFFull ? m16 : 0xFFFFFFFFull);
+          }
+          s_pw[kRpPwMul + p] = mulp;
+        }
+        s_pw[kRpPwSh] = flags[0];
+        s_pw[kRpPwSh + 1] = flags[1];
+        s_map[4] = S;
+      } else {
+        s_map[4] = 0;   // (malformed splitters: the linear map)
+      }
+    }
+    __syncthreads();
+    if (s_map[4]) {
+      for (int p = threadIdx.x; p < 2 * kRpPieces + 3; p += 1024) image[NVT_RANGE_AUX_PW + p] = (int32_t)s_pw[p];
+      if (threadIdx.x == 0) image[NVT_RANGE_AUX_LO + 7] = (int32_t)s_map[4];
+    }
+    __syncthreads();
+    // (the CSR below maps the hot keys with the map that was just decided)
+    if (s_map[4]) {
+      RangeMap pm;
+      pm.ulo = 0; pm.span = 0; pm.mul = 0; pm.sh = 0; pm.flat = 0;
+      pm.piece_slots = (uint32_t)s_map[4];
+      pm.pw = s_pw;
+      unsigned *bcnt = seen;
+      for (int i = threadIdx.x; i < 1025; i += 1024) bcnt[i] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kHotSlots / 1024; ++q) {
+        const int i = q * 1024 + threadIdx.x;
+        const int32_t key = useful ? tk[i] : EMPTY;
+        pmb[q] = 0xFFFFFFFFu;
+        if (key != EMPTY) {
+          pmb[q] = pm.fine(key) >> 14;
+          pmr[q] = atomicAdd(&bcnt[pmb[q]], 1u);
+        }
+      }
+      pieces_done = true;
+    }
+  } else if (nb_log2 > 0 && threadIdx.x == 0) {
+    s_map[4] = 0;
+  }
   if (nb_log2 > 0) {
     // the image slots indexed by range bucket (counting sort): the per-bucket count workgroup
     // of the range path picks up its hot keys without scanning the whole image
     unsigned *bcnt = seen;  // 2048 words, free again
+    unsigned myb[kHotSlots / 1024], myr[kHotSlots / 1024];
+    if (!pieces_done) {
     for (int i = threadIdx.x; i < 1025; i += 1024) bcnt[i] = 0;
     __syncthreads();
     const uint64_t lo = s_map[0], span = s_map[1], mul = s_map[2];
     const int sh = (int)s_map[3];
-    unsigned myb[kHotSlots / 1024], myr[kHotSlots / 1024];
 #pragma unroll
     for (int q = 0; q < kHotSlots / 1024; ++q) {
       const int i = q * 1024 + threadIdx.x;
@@ -1101,6 +1179,13 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
         d = d < span ? d : span;
         myb[q] = (unsigned)(((d * mul) >> sh) >> 14);
         myr[q] = atomicAdd(&bcnt[myb[q]], 1u);
+      }
+    }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kHotSlots / 1024; ++q) {
+        myb[q] = pmb[q];
+        myr[q] = pmr[q];
       }
     }
     __syncthreads();
@@ -2200,7 +2285,7 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
           w.hot_image = hot_image_ext;  // sampled by nvt_dense_count_many ahead of the pipelines
         } else {
           HotSampleBatch hb;
-          hb.c[0] = {(const int32_t *)keys, valid, n, w.hot_image, 0};
+          hb.c[0] = {(const int32_t *)keys, valid, n, w.hot_image, 0, 0};
           hot_sample_kernel<<<1, 1024, 0, s>>>(hb);
           NVT_CHECK_LAUNCH();
         }
@@ -2388,7 +2473,8 @@ int nvt_dense_count_many(const nvt_count_col *cols, int ncols, void *stream) {
       if (!((c.path & NVT_PATH_HOT) || range) || c.key_bytes != 4 || c.weights || c.n == 0 ||
           !c.hot_image)
         continue;
-      hb.c[nh++] = {(const int32_t *)c.keys, c.valid, c.n, c.hot_image, range ? (c.path >> 8) & 0xFF : 0};
+      hb.c[nh++] = {(const int32_t *)c.keys, c.valid, c.n, c.hot_image, range ? (c.path >> 8) & 0xFF : 0,
+                    (range && (c.path & NVT_PATH_PIECES)) ? 1 : 0};
       if (nh == kHotBatch) {
         int rc = flush();
         if (rc) return rc;

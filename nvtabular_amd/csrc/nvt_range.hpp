@@ -26,14 +26,43 @@ __device__ __forceinline__ uint32_t ukey(int32_t k) { return (uint32_t)k ^ 0x800
 // mul < 2^32 in both forms, so the map is ONE 32 x 32-bit multiply per key (high half or low
 // half of the product; the 64-bit form cost two v_mad_u64_u32 and a 64-bit shift per key in the
 // partition, count and encode kernels).
+// Piecewise form (round 4): keys that are NOT spread over their range (dense, frequency-ordered
+// ids: most of the rows and most of the distinct keys sit in a sliver of [min, max]) overflow the
+// equal-width buckets of the linear map.  The sample kernel then cuts the key range into
+// kRpPieces pieces at quantiles of its cold sample (rows and distinct keys blended, so that
+// neither the rows nor the keys of a piece exceed twice the average) and every piece maps
+// linearly onto an equal share of the fine slots: still monotone, buckets balanced for any key
+// distribution.  pw (in the column's aux block): u32 splitters[kRpPieces + 1], u32 mul[kRpPieces],
+// u32 shflags[2] (bit p set: wide piece, high half of the 32 x 32 product; clear: 16-bit fixed point).
+constexpr int kRpPieces = 64;
+constexpr int kRpPwMul = kRpPieces + 1, kRpPwSh = 2 * kRpPieces + 1;
 struct RangeMap {
   uint32_t ulo, span;
   uint32_t mul;
   int sh;  // 32 or 0
   int flat;  // 1: the table is ONE run of F slots (+ tail), slot = f (vocabulary tables built from a
              //    key-sorted list: flat_build_kernel); 0: bucket regions dumped by the counting pass
+  uint32_t piece_slots;      // 0: linear map; else fine slots per piece (the piecewise form)
+  const uint32_t *pw;        // piecewise parameters (global or LDS)
   __device__ __forceinline__ uint32_t fine(int32_t key) const {
     const uint32_t u = ukey(key);
+    if (piece_slots) {
+      // piece p: splitters[p] <= u < splitters[p + 1] (keys outside the sampled range clamp)
+      unsigned p = 0;
+#pragma unroll
+      for (unsigned step = kRpPieces / 2; step > 0; step >>= 1)
+        p += (u >= pw[p + step]) ? step : 0u;
+      const uint32_t s0 = pw[p], s1 = pw[p + 1];
+      uint32_t d = u > s0 ? u - s0 : 0u;
+      d = d < s1 - s0 - 1u ? d : s1 - s0 - 1u;
+      const uint32_t m = pw[kRpPwMul + p];
+      const bool hi = (pw[kRpPwSh + (p >> 5)] >> (p & 31)) & 1u;
+      // wide piece (more keys than slots): high half of d * (S << 32) / width; narrow piece
+      // (dense ids: fewer keys than slots): 16-bit fixed point, (d * ((S << 16) / width)) >> 16
+      uint32_t f = hi ? __umulhi(d, m) : (uint32_t)(((uint64_t)d * m) >> 16);
+      f = f < piece_slots - 1u ? f : piece_slots - 1u;
+      return p * piece_slots + f;
+    }
     uint32_t d = u > ulo ? u - ulo : 0u;
     d = d < span ? d : span;
     return sh ? __umulhi(d, mul) : d * mul;
@@ -115,6 +144,10 @@ __device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {
   m.mul = (uint32_t)aux[NVT_RANGE_AUX_LO + 2];  // (word + 3: the high half, always 0)
   m.sh = aux[NVT_RANGE_AUX_LO + 4];
   m.flat = aux[NVT_RANGE_AUX_LO + 5];
+  // (word + 6: FlatIndex's has-min flag; word + 7: fine slots per piece, 0 = linear.  Flat tables
+  // never use pieces: their aux blocks end before the piecewise parameters)
+  m.piece_slots = m.flat ? 0u : (uint32_t)aux[NVT_RANGE_AUX_LO + 7];
+  m.pw = reinterpret_cast<const uint32_t *>(aux + NVT_RANGE_AUX_PW);
   return m;
 }
 

@@ -350,7 +350,10 @@ PATH_P3_MAX_DISTINCT = 60_000_000
 # pass by key range + per-bucket tables emitted in key order.  Buckets are sized for <= ~5000
 # distinct keys (16384-slot tables addressed by a monotone function of the key want a low load).
 PATH_RANGE = 9
-RANGE_AUX_WORDS, RANGE_AUX_HIST = 9504 + 4096, 8208   # include/nvt_hip.h NVT_RANGE_AUX_*
+PATH_PIECES = 0x10000   # include/nvt_hip.h NVT_PATH_PIECES
+USE_PIECES = os.environ.get("NVT_RANGE_PIECES", "1") != "0"
+RANGE_AUX_WORDS, RANGE_AUX_HIST = 13600 + 256, 8208   # include/nvt_hip.h NVT_RANGE_AUX_*
+RANGE_AUX_PW, RANGE_PIECES = 13600, 64   # include/nvt_hip.h NVT_RANGE_AUX_PW, nvt_range.hpp kRpPieces
 RANGE_KEYS_PER_BUCKET = 5000
 PATH_RANGE_MAX_DISTINCT = int(os.environ.get("NVT_RANGE_MAX", 6_500_000))
 USE_RANGE = os.environ.get("NVT_RANGE", "1") != "0"
@@ -416,13 +419,17 @@ class DenseCountJob:
     """One column's groupby-size, launched asynchronously; ``dense_count_many`` reads all
     jobs' state words back with a single device->host copy."""
 
-    def __init__(self, keys, valid, weights=None, hint: int = 0, allow_range: bool = True):
+    def __init__(self, keys, valid, weights=None, hint: int = 0, allow_range: bool = True,
+                 pieces=None):
         _lib.require_gpu()
         self.want_table = True    # range path: also dump the count tables as the encode table
         self.range_table = None
         self.allow_range = allow_range  # False: the range path overflowed on this column before
         self.range_failed = False
         self.range_fail_bits = 0
+        # range path with a piecewise map (NVT_PATH_PIECES): `pieces` = int32[65] splitters
+        # (range_splitters) of a column whose keys are not spread over their range
+        self.pieces = pieces if USE_PIECES else None
         self.min_range_bits = 8
         self.lib = _lib.load()
         self.keys = aligned(keys)
@@ -447,7 +454,7 @@ class DenseCountJob:
 
     def _launch_path_of(self, path: int) -> int:
         if path == PATH_RANGE:
-            return PATH_RANGE | (self.range_bits() << 8)
+            return PATH_RANGE | (self.range_bits() << 8) | (PATH_PIECES if self.pieces is not None else 0)
         eligible = path in (1, 2, 3) and self.kb == 4 and self.weights is None
         hot = HOT_FILTER if self.hot is None else self.hot
         return path | PATH_HOT if (eligible and hot) else path
@@ -494,6 +501,8 @@ class DenseCountJob:
         elif path == PATH_RANGE:
             # aux block: hot image + range parameters (sample kernel) + class histogram
             self.hot_image = torch.empty(RANGE_AUX_WORDS, dtype=torch.int32, device=self.dev)
+            if self.pieces is not None:
+                self.hot_image[RANGE_AUX_PW:RANGE_AUX_PW + RANGE_PIECES + 1] = self.pieces
             desc.hot_image = self.hot_image.data_ptr()
             if self.want_table:
                 # the per-bucket count tables, dumped: the column's encode table (range table)
@@ -564,7 +573,8 @@ class DenseCountJob:
                            dict(path=self.path, distinct=m, max_count=max_count,
                                 rows=st[_lib.ST_ROWS], sorted_by_key=True, cls_hist=self.hot_image,
                                 n_big=st[_lib.ST_BIG], range_failed=self.range_failed,
-                                range_fail_bits=self.range_fail_bits))
+                                range_fail_bits=self.range_fail_bits,
+                                range_pieces=self.pieces is not None))
             return True
         if self.path == PATH_RANGE:
             # key-ordered list (the sentinel key, smallest int32, already leads it) + what the
@@ -575,7 +585,9 @@ class DenseCountJob:
                                 cls_hist=self.hot_image[RANGE_AUX_HIST:RANGE_AUX_HIST + 256],
                                 n_big=st[_lib.ST_BIG], range_aux=self.hot_image,
                                 range_table=self.range_table,
-                                range_bits=self.table_bits if self.range_table is not None else 0))
+                                range_bits=self.table_bits if self.range_table is not None else 0,
+                                range_pieces=self.pieces is not None,
+                                range_fail_bits=self.range_fail_bits))
             return True
         if st[_lib.ST_SENTINEL] > 0:
             self.out_k[m] = INT32_MIN if self.kb == 4 else INT64_MIN
@@ -914,6 +926,50 @@ def merge_sorted_tree(col_lists):
         out.append(lists[0] if lists else (torch.empty(0, dtype=torch.int32, device=dev),
                                            torch.empty(0, dtype=torch.int64, device=dev)))
     return out
+
+
+def range_splitters(keys: torch.Tensor, counts: torch.Tensor, rows: int = 0):
+    """int32[65] splitters of the piecewise range map (NVT_PATH_PIECES) from an EXACT key-ordered
+    (key, count) list of the column (what the sort path returns after the linear map
+    overflowed), or None when the list is too short to need them.
+
+    The range path wants buckets with at most ~2x the average of (a) the rows that go through
+    the partition bins and (b) the distinct keys of a bucket table.  Every key gets the weight
+    1/3 x its share of the bin rows (the ~8192 most frequent keys, which the hot image mostly
+    absorbs, count with a third of their rows) + 2/3 x its share of the distinct keys (1 / entries); splitter p
+    is the key at which the running weight reaches p / 64.  Values are the order-preserving
+    uint32 images of the keys (key ^ 2^31), stored in an int32 tensor.  One read-back."""
+    n = int(keys.numel())
+    if n < 4096 or keys.dtype != torch.int32:
+        return None
+    k64 = keys.to(torch.int64)
+    if int(k64[0].item()) == INT32_MIN:   # the sentinel key leads the list and is not in any table
+        k64, counts, n = k64[1:], counts[1:], n - 1
+    c = counts.to(torch.float64)
+    rows = rows or float(c.sum().item())
+    # rows that go through the bins = rows of the keys that are NOT in the hot image.  The image
+    # (hot_sample_kernel) takes the keys the 64 K-row sample shows twice, the most frequent ones
+    # first; a key with lam expected sample hits is in with about P(Poisson(lam) >= 2), less the
+    # bucket conflicts of the late-comers (2-slot buckets: ~15 %); lam >= 8: practically always
+    lam = c * (65536.0 / max(float(rows), 1.0))
+    p_in = torch.where(lam >= 8.0, torch.full_like(c, 0.98),
+                       0.85 * (1.0 - torch.exp(-lam) * (1.0 + lam)))
+    w_rows = c * (1.0 - p_in)
+    tot = w_rows.sum()
+    w = (2.0 / 3.0) / n + torch.where(tot > 0, w_rows / torch.clamp(tot, min=1.0) / 3.0, torch.zeros_like(c) + (1.0 / 3.0) / n)
+    cum = torch.cumsum(w, 0)
+    cum = cum / cum[-1]
+    targets = torch.arange(1, RANGE_PIECES, dtype=torch.float64, device=keys.device) / RANGE_PIECES
+    idx = torch.searchsorted(cum, targets).clamp_(max=n - 1)
+    u = (torch.cat([k64[:1], k64[idx], k64[-1:] + 1]) + (1 << 31))
+    host = read_back(u).tolist()
+    for p in range(1, RANGE_PIECES + 1):      # strictly increasing (degenerate pieces: one key wide)
+        if host[p] <= host[p - 1]:
+            host[p] = host[p - 1] + 1
+    if host[-1] > 0xFFFFFFFF:
+        return None
+    arr = torch.tensor(host, dtype=torch.int64, device=keys.device)
+    return torch.where(arr >= (1 << 31), arr - (1 << 32), arr).to(torch.int32)   # the u32 bit pattern
 
 
 def class_hist(counts: torch.Tensor) -> torch.Tensor:

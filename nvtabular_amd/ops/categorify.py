@@ -183,6 +183,7 @@ class Categorify(StatOperator):
         self._range_oks: Dict[str, int] = {}   # partitions each column counted on the range path
         self._flat_unchecked: List[str] = []   # flat range tables whose displacement is still unread
         self._no_flat = set()                  # vocabularies whose keys cluster: hashed tables
+        self._range_pieces: Dict[str, object] = {}   # column -> int32[65] splitters (NVT_PATH_PIECES)
         self._lazy_finalize = None  # (groups, options, base) of a fit whose ordering is deferred
         self._writer_cache: Dict[str, bool] = {}
         self.vocabs = {}
@@ -260,7 +261,8 @@ class Categorify(StatOperator):
             # categorify.py:955); the one readback of all state words happens in
             # _absorb_pending (next partition / fit_end)
             jobs = [K.DenseCountJob(k, v, None, hint=self._cap_hints.get(hkey, 0),
-                                    allow_range=hkey not in self._no_range)
+                                    allow_range=hkey not in self._no_range,
+                                    pieces=self._range_pieces.get(hkey))
                     for _, hkey, k, v in specs]
             with K.annotate("top_level_groupby"):
                 return K.CountBatch(jobs), [(g, hkey) for g, hkey, _, _ in specs]
@@ -303,6 +305,19 @@ class Categorify(StatOperator):
                     self._no_range.add(hkey)
             elif info["path"] == K.PATH_RANGE:
                 self._range_oks[hkey] = self._range_oks.get(hkey, 0) + 1
+            if info.get("range_failed") and info.get("sorted_by_key") and K.USE_PIECES \
+                    and dk.dtype == torch.int32:
+                # the linear range map overflowed (keys not spread over their range: dense /
+                # frequency-ordered ids) and the sort path delivered the exact key-ordered list:
+                # splitters of a piecewise map from it; the column's next partitions / fits take
+                # the range path with them, and the overflow is not held against the column
+                sp = None if info.get("range_pieces") else K.range_splitters(dk, dc)
+                if info.get("range_pieces"):
+                    self._range_pieces.pop(hkey, None)   # overflowed WITH splitters: counts as a failure
+                if sp is not None:
+                    self._range_pieces[hkey] = sp
+                    self._no_range.discard(hkey)
+                    self._range_failures = [f for f in self._range_failures if f[0] != hkey]
             srt = bool(info.get("sorted_by_key")) and dk.dtype == torch.int32
             g.nulls += nulls
             g.valid_rows += info["rows"] - nulls

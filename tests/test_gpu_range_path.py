@@ -219,3 +219,50 @@ def test_flat_table_falls_back_to_a_hashed_table_for_clustered_keys(tmp_path):
             np.testing.assert_array_equal(got, exp)
     finally:
         K.PATH_RANGE_MAX_DISTINCT = old
+
+
+def test_dense_ids_take_the_range_path_with_splitters(tmp_path):
+    """Dense frequency-ordered ids (id = rank, power law): the linear range map overflows, the
+    sort path delivers the exact list, kernels.range_splitters turns it into a piecewise map and
+    the NEXT fit counts the column on the range path (NVT_PATH_PIECES) -- count, ordering, the
+    dumped table addressed through the piecewise map and the encode all agree with the oracle."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K, ops
+    from nvtabular_amd.device import DeviceColumn, DeviceFrame
+
+    rng = np.random.default_rng(12)
+    n, card, s = 3_000_000, 2_000_000, 1.1
+    u = rng.random(n)
+    ids = np.floor(((card ** (1.0 - s) - 1.0) * u + 1.0) ** (1.0 / (1.0 - s))).clip(1, card).astype(np.int32)
+    ids[5] = np.iinfo(np.int32).min   # the sentinel key leads the sorted list
+    frame = DeviceFrame({"c": DeviceColumn(torch.from_numpy(ids).cuda())})
+    op = ops.Categorify(out_path=str(tmp_path / "g"))
+    wf = nvt.Workflow(["c"] >> op)
+    wf.fit(nvt.Dataset(frame))
+    first = op._last_paths["c#0"]
+    got1 = wf.transform(frame)["c"].data.cpu().numpy()
+    wf.fit(nvt.Dataset(frame))
+    got2 = wf.transform(frame)["c"].data.cpu().numpy()
+    df = pd.DataFrame({"c": ids})
+    paths = O.categorify_fit([df], ["c"], str(tmp_path / "c"), tie_break="stable")
+    exp = O.categorify_transform(df, ["c"], paths)["c"].to_numpy()
+    np.testing.assert_array_equal(got1, exp)
+    np.testing.assert_array_equal(got2, exp)
+    if first == K.PATH_SORT:   # the linear map overflowed on the first fit (expected for these ids)
+        assert "c#0" in op._range_pieces and op._last_paths["c#0"] == K.PATH_RANGE
+        assert "c#0" not in op._no_range
+
+
+def test_range_splitters_balance_rows_and_keys():
+    from nvtabular_amd import kernels as K
+
+    rng = np.random.default_rng(2)
+    keys = np.unique(np.concatenate([np.arange(1, 200_000), rng.integers(200_000, 2**31 - 1, 300_000)])).astype(np.int32)
+    counts = np.maximum(1, (3e6 / np.arange(1, keys.size + 1) ** 1.1)).astype(np.int64)
+    sp = K.range_splitters(torch.from_numpy(keys).cuda(), torch.from_numpy(counts).cuda())
+    u = sp.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert u.size == 65 and (np.diff(u) > 0).all()
+    assert u[0] == int(keys[0]) + 2**31 and u[-1] == int(keys[-1]) + 2**31 + 1
+    piece = np.searchsorted(u, keys.astype(np.int64) + 2**31, side="right") - 1
+    distinct = np.bincount(piece, minlength=64)
+    assert distinct.max() <= 2.0 * keys.size / 64      # <= 1.5 x by construction, 2 x with slack
