@@ -271,7 +271,9 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     const int32_t *__restrict__ range_aux = nullptr) {
   constexpr bool global_needed = GLOBAL;
   RangeMap rmap = {0u, 0u, 0u, 0, 0};
+  __shared__ uint32_t s_pieces[RANGE == 1 ? kRpPwWords : 1];
   if constexpr (RANGE) rmap = load_map(range_aux);
+  if constexpr (RANGE == 1) stage_pieces(rmap, s_pieces, threadIdx.x, kEncBS);  // (barrier below)
   auto first_slot = [&](K key) -> uint64_t {
     if constexpr (RANGE) return rmap.table_slot((int32_t)key);
     return (uint64_t)slot_hash(key) & mask;

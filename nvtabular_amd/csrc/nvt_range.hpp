@@ -137,6 +137,16 @@ __device__ __forceinline__ uint64_t flat_find_from(const unsigned long long *__r
   }
 }
 
+// the piecewise parameters staged in LDS (`lds`: kRpPwWords words; every thread of the workgroup
+// calls this, a barrier follows in the caller before the map is used): six dependent reads per
+// key come from LDS instead of the vector cache
+constexpr int kRpPwWords = 2 * kRpPieces + 3;
+__device__ __forceinline__ void stage_pieces(RangeMap &m, uint32_t *lds, unsigned tid, unsigned nthreads) {
+  if (!m.piece_slots) return;
+  for (unsigned i = tid; i < (unsigned)kRpPwWords; i += nthreads) lds[i] = m.pw[i];
+  m.pw = lds;
+}
+
 __device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {
   RangeMap m;
   m.ulo = (uint32_t)aux[NVT_RANGE_AUX_LO];

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
     s_sent = 0;
     s_ovf = 0;
   }
-  const RangeMap map = load_map(aux);
+  RangeMap map = load_map(aux);
+  __shared__ uint32_t s_pieces[kRpPwWords];
+  stage_pieces(map, s_pieces, threadIdx.x, kRpBS);
   __syncthreads();
 
   // flush every bin that holds >= kRpLine keys (or, with `all`, whatever it holds): one
@@ -326,7 +328,9 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
   __syncthreads();
   const unsigned b = s_b, NB = 1u << nb_log2;
   const unsigned lane = lane_id(), w = threadIdx.x / kWave;
-  const RangeMap map = load_map(aux);
+  RangeMap map = load_map(aux);
+  __shared__ uint32_t s_pieces[kRpPwWords];
+  stage_pieces(map, s_pieces, threadIdx.x, kRpBS);  // (barriers follow before the first use)
 #ifdef NVT_RANGE_TIMING
   long long tm[8];
   int tmi = 0;
