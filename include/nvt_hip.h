@@ -407,6 +407,12 @@ int nvt_count_merge_sorted_ws_bytes(uint64_t n, uint64_t *bytes);
 int nvt_count_merge_sorted(const int64_t *rows, uint64_t n, const uint64_t *seg_off, int nseg,
                            int ncol, int32_t *out_keys, int64_t *out_col, double *out_sum,
                            uint64_t *state, void *ws, void *stream);
+/* Seeded TargetEncoding folds (target_encoding.py:427-439: numpy.random.RandomState(seed)
+ * .choice(arange(kfold), n)) on the device: MT19937 seeded by init_genrand(seed), 32-bit draws
+ * masked to the next 2^k - 1 and rejected while >= kfold -- out[i] (uint8) = the i-th accepted
+ * value, bit for bit numpy's sequence.  One workgroup walks the generator (it is sequential);
+ * kfold <= 128. */
+int nvt_fold_mt19937(uint32_t seed, int kfold, uint64_t n, uint8_t *out, void *stream);
 /* ---- tree merge of KEY-SORTED partial results (multi-partition fit) ------------------------
  * Replaces the concat + re-groupby of _mid_level_groupby (categorify.py:1054-1070) inside the
  * tree of categorify.py:1423-1478 -- and the same tree under join_groupby.py:140-173 /

@@ -116,6 +116,7 @@ SIGNATURES = {
     "nvt_flat_lookup": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _vp],
     "nvt_widen_i64": [_vp, _i32, _u64, _vp, _vp],
     "nvt_popcount": [_vp, _u64, _vp, _vp],
+    "nvt_fold_mt19937": [_u32, _i32, _u64, _vp, _vp],
 }
 
 

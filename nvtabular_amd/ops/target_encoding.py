@@ -32,6 +32,7 @@ def _add_fold(n, kfold, fold_seed=None) -> np.ndarray:
 
 
 _FOLD_CACHE = {}  # (kfold, fold_seed, device) -> uint8 tensor of the longest partition seen
+DEVICE_FOLDS = os.environ.get("NVT_DEVICE_FOLDS", "1") != "0"
 
 
 def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
@@ -39,10 +40,11 @@ def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
 
     fold_seed None: ``arange(n) % kfold`` is generated on the device (no host traffic).
     Seeded folds must be numpy's MT19937 stream to stay bit-identical to the reference
-    (target_encoding.py:436-439), so they are drawn on the host -- but the reference re-seeds
-    per partition, i.e. every partition gets the SAME sequence (a shorter partition a prefix of
-    it): the column is generated and uploaded once per (kfold, seed, device) and sliced
-    afterwards instead of 1 B/row over PCIe for every partition of every pass."""
+    (target_encoding.py:436-439): regenerated on the device (nvt_fold_mt19937: init_genrand +
+    masked rejection, bit-checked against numpy in tests/test_gpu_sorted_groupby.py; the host
+    draws them only for seeds / kfold outside the kernel's range).  The reference re-seeds per
+    partition, i.e. every partition gets the SAME sequence (a shorter partition a prefix of it):
+    the column is generated once per (kfold, seed, device) and sliced afterwards."""
     if fold_seed is None:
         # the reference's arange is created IN the fold dtype (min_scalar_type(kfold * 2), uint8
         # for any sane kfold) and wraps: fold = (i mod 2^bits) mod kfold, not i mod kfold
@@ -54,8 +56,18 @@ def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
     key = (int(kfold), int(fold_seed), str(device))
     cached = _FOLD_CACHE.get(key)
     if cached is None or cached.numel() < n:
-        f = _add_fold(n, kfold, fold_seed).astype(np.uint8)
-        cached = _FOLD_CACHE[key] = torch.from_numpy(f).to(device)
+        seed = int(fold_seed)
+        if DEVICE_FOLDS and 1 <= kfold <= 128 and 0 <= seed < 2**32 and torch.device(device).type == "cuda":
+            # numpy's stream regenerated on the device (nvt_fold_mt19937): no O(rows) host work
+            # and no copy; (a little head room: a longer partition later extends, not restarts)
+            m = int(n) + int(n) // 16
+            cached = torch.empty(m, dtype=torch.uint8, device=device)
+            K.check(K._lib.load().nvt_fold_mt19937(seed, int(kfold), m, cached.data_ptr(), K.stream_ptr()),
+                    "nvt_fold_mt19937")
+        else:
+            f = _add_fold(n, kfold, fold_seed).astype(np.uint8)
+            cached = torch.from_numpy(f).to(device)
+        _FOLD_CACHE[key] = cached
     return DeviceColumn(cached[:n])
 
 

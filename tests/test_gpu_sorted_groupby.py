@@ -467,3 +467,17 @@ def test_clustered_keys_fall_back_to_a_hashed_index(tmp_path):
     np.testing.assert_array_equal(got["k_count"].to_numpy(), exp_j["k_count"].to_numpy())
     np.testing.assert_allclose(got["k_x_mean"].to_numpy(), exp_j["k_x_mean"].to_numpy(), rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(got["TE_k_y"].to_numpy(), exp_t["TE_k_y"].to_numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("kfold,seed", [(5, 42), (3, 7), (8, 1), (2, 0), (16, 123), (10, 2**32 - 1), (100, 5)])
+def test_device_folds_are_numpys_mt19937_stream(kfold, seed):
+    """nvt_fold_mt19937 == numpy.random.RandomState(seed).choice(arange(kfold), n), bit for bit
+    (target_encoding.py:427-439), incl. lengths that end inside a 624-word state."""
+    from nvtabular_amd import kernels as K
+
+    for n in (1, 623, 624, 625, 200_001):
+        out = torch.empty(n, dtype=torch.uint8, device="cuda")
+        K.check(K._lib.load().nvt_fold_mt19937(seed, kfold, n, out.data_ptr(), K.stream_ptr()))
+        typ = np.min_scalar_type(kfold * 2)
+        exp = np.random.RandomState(seed).choice(np.arange(kfold, dtype=typ), n)
+        np.testing.assert_array_equal(out.cpu().numpy(), exp.astype(np.uint8))
