@@ -611,6 +611,9 @@ typedef struct nvt_vocab_col {
 } nvt_vocab_col;
 #define NVT_FLAT_AUX_WORDS (NVT_RANGE_AUX_LO + 16)
 #define NVT_FLAT_AUX_MAXDISP (NVT_RANGE_AUX_LO + 8)
+#define NVT_FLAT_AUX_NULLGROUP (NVT_RANGE_AUX_LO + 10)  /* nvt_flat_lookup*: 1 + the group of rows whose
+                                                          key is null (0: none, such rows miss); set
+                                                          by the caller after nvt_flat_index_build */
 int nvt_vocab_order_tmp_bytes(uint64_t n, uint64_t n_big, uint64_t *bytes);
 /* hist[c] = entries with min(counts[i], 255) == c, for a key-sorted list that did not come from
  * the range path (multi-GPU: gathered owner shards); hist[255] = n_big */

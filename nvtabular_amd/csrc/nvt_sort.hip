@@ -1429,6 +1429,7 @@ struct FlatIndexView {
   RangeMap map;
   int64_t offset;  // table key = column key - offset (0 for int32 columns)
   bool has_min;
+  int64_t null_group;  // group of the rows whose key is null (-1: none; aux word LO + 10 holds it + 1)
   const unsigned long long *table;
   uint64_t slots;
 };
@@ -1440,6 +1441,7 @@ __device__ __forceinline__ FlatIndexView flat_view(const int32_t *__restrict__ a
   v.map = load_map(aux);
   v.offset = offset;
   v.has_min = aux[NVT_RANGE_AUX_LO + 6] != 0;
+  v.null_group = (int64_t)aux[NVT_RANGE_AUX_LO + 10] - 1;
   v.table = table;
   v.slots = slots;
   return v;
@@ -1449,8 +1451,9 @@ template <typename K>
 __device__ __forceinline__ int64_t flat_probe(const FlatIndexView &v, const K *__restrict__ keys,
                                               const uint8_t *__restrict__ valid, uint64_t i) {
   int64_t kv;
+  if (!bit_valid(valid, i)) return v.null_group;   // null keys are one group (groupby dropna=False)
   if (__builtin_sub_overflow((int64_t)keys[i], v.offset, &kv)) return -1;
-  if (!bit_valid(valid, i) || kv < (int64_t)INT32_MIN || kv > (int64_t)INT32_MAX) return -1;
+  if (kv < (int64_t)INT32_MIN || kv > (int64_t)INT32_MAX) return -1;
   const int32_t k = (int32_t)kv;
   if (k == INT32_MIN) return v.has_min ? 0 : -1;
   const uint64_t home = v.map.fine(k);

@@ -1978,6 +1978,11 @@ class FlatIndex:
                                        stream_ptr()), "nvt_flat_index_build")
         self._ok = None
 
+    def set_null_group(self, group: int):
+        """Rows whose key is null look up `group` (JoinGroupby / TargetEncoding keep null keys as
+        one group, like the reference's groupby(dropna=False)); without it they miss."""
+        self.aux[self.FLAT_AUX_MAXDISP + 2] = int(group) + 1   # NVT_FLAT_AUX_NULLGROUP
+
     def ok(self) -> bool:
         """False when the keys cluster in their range (an entry further than MAX_DISPLACEMENT
         slots from its home slot): the caller builds a hashed index instead.  One read-back."""

@@ -73,7 +73,7 @@ class GroupAgg:
 
     def _demote(self):
         """A second partition arrives: the sorted groups of the first become hash tables."""
-        comp, self.sorted_comp = self.sorted_comp, None
+        comp, self.sorted_comp = with_null_group(self.sorted_comp), None
         self.table = _table_from_comp(comp, 1, len(self.val_cols), self.sumsq, self.minmax)
         if "fold" in comp:
             self._fold_classic().table = _table_from_comp(fold_sparse(comp), 2, len(self.val_cols),
@@ -89,13 +89,25 @@ class GroupAgg:
         if self.fold:
             fcol = frame[self.fold[0]]
             fold_t = fcol.data if fcol.data.dtype == torch.uint8 and fcol.valid is None else None
-        if (self.table is None and len(keys) == 1
-                and (self.fold_agg is None or self.fold_agg.table is None)
-                and (not self.fold or fold_t is not None)
-                and K.sorted_groupby_eligible(keys[0], kvalid[0], n, kfold)):
-            comp = K.sorted_groupby(keys[0], fold_t, kfold, vals, vvalid, sumsq=self.sumsq,
+        nullgrp = None
+        sort_ok = (self.table is None and len(keys) == 1
+                   and (self.fold_agg is None or self.fold_agg.table is None)
+                   and (not self.fold or fold_t is not None))
+        s_keys, s_kvalid, s_vals, s_vvalid, s_fold, s_n = keys, kvalid, vals, vvalid, fold_t, n
+        if sort_ok and kvalid[0] is not None and NULL_KEY_GROUP and \
+                K.sorted_groupby_eligible(keys[0], None, n, kfold):
+            # null KEYS: their rows are one group of their own (the reference groups with
+            # dropna=False, categorify.py:1013-1018).  The sort path takes the rows WITH a key
+            # (compacted: torch plumbing, one pass per column); the null rows are reduced on the
+            # side and travel with the result as comp["nullgrp"]
+            s_keys, s_kvalid, s_vals, s_vvalid, s_fold, nullgrp, s_n = _split_null_keys(
+                keys[0], kvalid[0], vals, vvalid, fold_t, kfold, self.sumsq, self.minmax)
+        if sort_ok and K.sorted_groupby_eligible(s_keys[0], s_kvalid[0], s_n, kfold):
+            comp = K.sorted_groupby(s_keys[0], s_fold, kfold, s_vals, s_vvalid, sumsq=self.sumsq,
                                     minmax=self.minmax, cap_hint=self.part_hint or self.hint,
                                     te_records=True)
+            if comp is not None and nullgrp is not None:
+                comp["nullgrp"] = nullgrp
             if comp is not None:  # (None: int64 keys spanning 2^32 or more)
                 self.part_hint = max(self.part_hint, comp["n"])
                 if self.sorted_comp is None:
@@ -143,7 +155,8 @@ class GroupAgg:
         from .. import dist
 
         if self.sorted_comp is not None:
-            comp = self.sorted_comp
+            null_at = int(self.sorted_comp["n"]) if "nullgrp" in self.sorted_comp else -1
+            comp = with_null_group(self.sorted_comp)
             if dist.world_size() > 1:
                 if "fold" in comp:
                     # the ranks merge compacted groups: the dense per-(group, fold) statistics
@@ -155,6 +168,8 @@ class GroupAgg:
             elif len(self.key_cols) == 1 and "keys32" in comp:
                 index = K.flat_index_for(comp)
                 if index.ok():  # else: _Stats builds a hashed index from the keys
+                    if null_at >= 0 and int(comp["n"]) > null_at:
+                        index.set_null_group(null_at)   # rows with a null key look up the last group
                     comp["index_table"] = index
             return comp
         if self.table is None:
@@ -167,6 +182,110 @@ class GroupAgg:
             for c in list(self.strings):
                 self.strings[c] = dist.merge_string_luts(self.strings[c])
         return comp
+
+
+NULL_KEY_GROUP = True
+
+
+def _split_null_keys(key, valid, vals, vvalid, fold_t, kfold, sumsq, minmax):
+    """(keys, key validity, values, value validity, folds) of the rows WITH a key, the statistics
+    of the rows without one ("nullgrp"), and the number of rows kept."""
+    from ..device import pack_bitmap_device
+
+    n = int(key.numel())
+    has = K.unpack_bitmap(valid, n)
+    inv = ~has
+    dev = key.device
+    cvals, cvv, nsum, nsq, nmin, nmax = [], [], [], [], [], []
+    f64 = torch.float64
+    ninf = torch.tensor(float("inf"), dtype=f64, device=dev)
+    size = inv.sum().to(torch.int64)
+    fold64 = fold_t.to(torch.int64) if fold_t is not None else None
+    fsum = []
+    for v, vv in zip(vals, vvalid):
+        x = v.to(f64)
+        ok = inv & ~torch.isnan(x)
+        if vv is not None:
+            vok = K.unpack_bitmap(vv, n)
+            ok = ok & vok
+            cvv.append(pack_bitmap_device(vok[has]))
+        else:
+            cvv.append(None)
+        cvals.append(v[has])
+        xz = torch.where(ok, x, torch.zeros((), dtype=f64, device=dev))
+        nsum.append(xz.sum())
+        if sumsq:
+            nsq.append((xz * xz).sum())
+        if minmax:
+            mn = torch.where(ok, x, ninf).min() if n else ninf
+            mx = torch.where(ok, x, -ninf).max() if n else -ninf
+            nan = torch.tensor(float("nan"), dtype=f64, device=dev)
+            nmin.append(torch.where(torch.isinf(mn), nan, mn))   # (no value: NaN, as nvt_gb_compact)
+            nmax.append(torch.where(torch.isinf(mx), nan, mx))
+        if fold64 is not None and kfold > 1:
+            fsum.append(torch.bincount(fold64[ok], weights=x[ok], minlength=kfold).to(f64))
+    grp = dict(size=size, sum=nsum, sumsq=nsq, min=nmin, max=nmax)
+    if fold64 is not None and kfold > 1:
+        grp["fold"] = dict(size=torch.bincount(fold64[inv], minlength=kfold).to(torch.int64), sum=fsum)
+    return ([key[has]], [None], cvals, cvv, fold_t[has] if fold_t is not None else None, grp,
+            int(n - int(size.item())))
+
+
+def _merge_null_groups(x, y):
+    if x is None or y is None:
+        return x if y is None else y
+
+    def mm(a, b, op):
+        pick = torch.minimum if op == "min" else torch.maximum
+        return torch.where(torch.isnan(a), b, torch.where(torch.isnan(b), a, pick(a, b)))
+
+    out = dict(size=x["size"] + y["size"], sum=[a + b for a, b in zip(x["sum"], y["sum"])],
+               sumsq=[a + b for a, b in zip(x["sumsq"], y["sumsq"])],
+               min=[mm(a, b, "min") for a, b in zip(x["min"], y["min"])],
+               max=[mm(a, b, "max") for a, b in zip(x["max"], y["max"])])
+    if "fold" in x and "fold" in y:
+        out["fold"] = dict(size=x["fold"]["size"] + y["fold"]["size"],
+                           sum=[a + b for a, b in zip(x["fold"]["sum"], y["fold"]["sum"])])
+    return out
+
+
+def with_null_group(comp):
+    """The sort-path result with the group of the null-key rows (comp["nullgrp"]) appended as its
+    LAST group (null_mask 1, key 0): what the artifacts, the hash tables and the ranks' merge
+    consume.  keys32 (the flat index's keys) stays as it is: the index sends null rows to the
+    group through FlatIndex.set_null_group."""
+    g0 = comp.get("nullgrp")
+    if g0 is None or int(g0["size"].item()) == 0:
+        return {k: v for k, v in comp.items() if k != "nullgrp"}
+    dev = comp["size"].device
+    one = lambda t, dt: t.reshape(1).to(dt)  # noqa: E731
+    out = {k: v for k, v in comp.items() if k != "nullgrp"}
+    out["keys"] = [torch.cat([comp["keys"][0], torch.zeros(1, dtype=torch.int64, device=dev)])]
+    out["null_mask"] = torch.cat([comp["null_mask"], torch.ones(1, dtype=torch.uint8, device=dev)])
+    out["size"] = torch.cat([comp["size"], one(g0["size"], torch.int64)])
+    # "count" is the count of the KEY column (categorify.py:1004-1018: agg_dict[key] = ["count"]),
+    # which skips nulls: 0 for the group of the null keys, whatever its size
+    out["count"] = torch.cat([comp["size"], torch.zeros(1, dtype=torch.int64, device=dev)])
+    for name in ("sum", "sumsq", "min", "max"):
+        out[name] = [torch.cat([a, one(b, torch.float64)]) for a, b in zip(comp[name], g0[name])]
+    out["n"] = int(comp["n"]) + 1
+    if "fold" in comp and "fold" in g0:
+        f, gf = comp["fold"], g0["fold"]
+        kfold = f["kfold"]
+        rec = None
+        if f.get("records") is not None:
+            rec = []
+            for j, r in enumerate(f["records"]):
+                row = torch.empty(2 * (kfold + 1), dtype=torch.float64, device=dev)
+                # the reference's counts: the per-key table counts the KEY column (0 for the null
+                # keys), the [fold, key] table counts its FIRST key column, the fold (= the rows)
+                row.zero_()
+                row[0] = g0["sum"][j]
+                row[2::2], row[3::2] = gf["sum"][j], gf["size"].to(torch.float64)
+                rec.append(torch.cat([r, row.reshape(1, -1)]))
+        out["fold"] = dict(kfold=kfold, size=torch.cat([f["size"], gf["size"]]),
+                           sum=[torch.cat([a, b]) for a, b in zip(f["sum"], gf["sum"])], records=rec)
+    return out
 
 
 def merge_sorted_comps(a, b, sumsq=False, minmax=False):
@@ -212,6 +331,7 @@ def merge_sorted_comps(a, b, sumsq=False, minmax=False):
     def comb(x, y, op="add", width=1):
         return K.merge_payload(sa, sb, x.reshape(-1), y.reshape(-1), op, width)
 
+    ng = _merge_null_groups(a.get("nullgrp"), b.get("nullgrp"))
     out = dict(keys=[hit["k64"]], keys32=k32, n=g, sorted=True, shared=hit["shared"],
                key_offset=a.get("key_offset", 0), size=size, count=size,
                null_mask=torch.zeros(g, dtype=torch.uint8, device=k32.device),
@@ -231,6 +351,8 @@ def merge_sorted_comps(a, b, sumsq=False, minmax=False):
         out["fold"] = dict(kfold=kfold, size=comb(fa["size"], fb["size"], "add", kfold),
                            sum=[comb(x, y, "add", kfold) for x, y in zip(fa["sum"], fb["sum"])],
                            records=rec)
+    if ng is not None:
+        out["nullgrp"] = ng
     return out
 
 
@@ -250,8 +372,9 @@ def fold_sparse(comp):
     kfold = f["kfold"]
     idx = torch.nonzero(f["size"] > 0).squeeze(1)
     size = f["size"][idx]
+    # (bit 1 = the key column of the [fold, key] tuple: set for the group of the null-key rows)
     return dict(keys=[idx % kfold, comp["keys"][0][idx // kfold]],
-                null_mask=torch.zeros(idx.numel(), dtype=torch.uint8, device=idx.device),
+                null_mask=(comp["null_mask"][idx // kfold].to(torch.uint8) << 1),
                 size=size, count=size, sum=[c[idx] for c in f["sum"]], sumsq=[], min=[], max=[],
                 n=int(idx.numel()))
 

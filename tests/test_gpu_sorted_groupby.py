@@ -481,3 +481,47 @@ def test_device_folds_are_numpys_mt19937_stream(kfold, seed):
         typ = np.min_scalar_type(kfold * 2)
         exp = np.random.RandomState(seed).choice(np.arange(kfold, dtype=typ), n)
         np.testing.assert_array_equal(out.cpu().numpy(), exp.astype(np.uint8))
+
+
+@pytest.mark.parametrize("nparts", [1, 3])
+def test_null_keys_are_one_group_on_the_sort_path(tmp_path, nparts):
+    """A nullable int32 key column: the rows without a key form one group (the reference groups
+    with dropna=False) -- reduced beside the sort path, appended as the last group, looked up
+    through FlatIndex.set_null_group.  JoinGroupby statistics and TargetEncoding (with folds)
+    against the oracle, over one and three partitions."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+    from nvtabular_amd.ops.target_encoding import _FoldDense
+
+    df = _frames(150_000, 6_000, 91)
+    rng = np.random.default_rng(3)
+    df["k"] = pd.array(df["k"].to_numpy(), dtype="Int32")
+    df.loc[rng.random(len(df)) < 0.07, "k"] = pd.NA
+    parts = _split(df, nparts)
+    stats = ["count", "sum", "mean", "min", "max"]
+    jg = ops.JoinGroupby(out_path=str(tmp_path / "jg"), stats=stats, cont_cols=["x", "y"])
+    te = ops.TargetEncoding(["y"], out_path=str(tmp_path / "te"), kfold=5, fold_seed=42, p_smooth=20)
+    wf = nvt.Workflow((["k"] >> jg) + (["k"] >> te)).fit(nvt.Dataset(parts))
+    assert isinstance(jg._device_stats["k"].index, K.FlatIndex)
+    assert isinstance(te._device_stats["__fold___k"], _FoldDense)
+    got = wf.transform(nvt.Dataset(parts)).to_ddf().compute()
+    oparts = [p.copy() for p in parts]
+    for p in oparts:   # what pandas' parquet reader hands the reference: float64 with NaN
+        p["k"] = p["k"].astype("float64")
+    cats = O.join_groupby_fit([p.copy() for p in oparts], ["k"], ["x", "y"], stats, str(tmp_path / "c"))
+    exp = O.join_groupby_transform(pd.concat(oparts, ignore_index=True), ["k"], cats)
+    for c in exp.columns:
+        if c.endswith("_count"):
+            np.testing.assert_array_equal(got[c].to_numpy(), exp[c].to_numpy(), err_msg=c)
+        else:
+            np.testing.assert_allclose(got[c].to_numpy().astype("float64"), exp[c].to_numpy().astype("float64"),
+                                       rtol=2e-5, atol=1e-6, err_msg=c)
+    tstats, means = O.target_encoding_fit([p.copy() for p in oparts], ["k"], ["y"], str(tmp_path / "ct"),
+                                          kfold=5, fold_seed=42)
+    texp = pd.concat([O.target_encoding_transform(p[["k", "y"]].copy(), ["k"], ["y"], tstats, means, kfold=5,
+                                                  fold_seed=42, p_smooth=20) for p in oparts], ignore_index=True)
+    np.testing.assert_allclose(got["TE_k_y"].to_numpy(), texp["TE_k_y"].to_numpy(), rtol=1e-5, atol=1e-6)
+    isnull = pd.concat(parts, ignore_index=True)["k"].isna().to_numpy()
+    assert isnull.any() and np.isfinite(got["k_x_sum"].to_numpy()[isnull]).all()   # the null group has statistics
+    assert (got["k_count"].to_numpy()[isnull] == 0).all()   # ... and the count of its (null) keys is 0
