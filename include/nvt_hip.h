@@ -150,7 +150,7 @@ int nvt_count_compact_i64(const void *table, uint64_t capacity, int64_t *out_key
                                        hot_image = uint32[256] receiving the histogram of min(count, 255) */
 #define NVT_RANGE_WGS 256           /* partition workgroups = runs per bucket                 */
 #define NVT_RANGE_AUX_LO 8192       /* aux words behind the hot image: range origin (biased),
-                                       span, multiplier (2 words), shift of the monotone map   */
+                                       span, multiplier, 0, pre-shift of the monotone map (nvt_range.hpp) */
 #define NVT_RANGE_AUX_HIST 8208     /*   uint32[256] histogram of min(count, 255)             */
 #define NVT_RANGE_AUX_HOTSTART 8464 /*   uint32[1025]: hot image slots by bucket (CSR offsets) */
 #define NVT_RANGE_AUX_HOTORDER 9504 /*   uint16[8192]: the image slots in bucket order         */

@@ -258,13 +258,29 @@ constexpr int kRanges = 256;    // home ranges per table
 constexpr int kMergeBS = 256, kMergeSlots = 512;
 constexpr unsigned kRepFill = 256;  // replicate hot keys per lane group while fill <= this
 
+// hash of stage 1: home slot from bits >= kStageHomeShift, key class from the (up to 3) bits
+// at kStageClassShift
+#ifndef NVT_STAGE_FMIX
+__device__ __forceinline__ uint32_t stage_hash(int32_t key) { return mul24_hash(key); }
+template <typename K>
+struct StageBits {
+  static constexpr int home = sizeof(K) == 4 ? 18 : 17, cls = sizeof(K) == 4 ? 15 : 0;
+};
+#else
+__device__ __forceinline__ uint32_t stage_hash(int32_t key) { return slot_hash(key); }
+template <typename K>
+struct StageBits {
+  static constexpr int home = 17, cls = 0;
+};
+#endif
+__device__ __forceinline__ uint64_t stage_hash(int64_t key) { return slot_hash(key); }
 template <typename K, int SLOTS>
 __device__ __forceinline__ uint32_t home_slot(K key) {
-  return (uint32_t)(slot_hash(key) >> 17) & (SLOTS - 1);
+  return (uint32_t)(stage_hash(key) >> StageBits<K>::home) & (SLOTS - 1);
 }
 template <typename K>
 __device__ __forceinline__ uint32_t key_class(K key, unsigned split_mask) {
-  return (uint32_t)slot_hash(key) & split_mask;
+  return (uint32_t)(stage_hash(key) >> StageBits<K>::cls) & split_mask;
 }
 
 template <typename K, typename C, int SLOTS>
@@ -312,9 +328,9 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
       if (q == 0) my_sent += w;
       return;
     }
-    const auto h = slot_hash(key);
-    if (((uint32_t)h & split_mask) != q) return;
-    if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, key, (C)w, (uint32_t)(h >> 17) + rep))
+    const auto h = stage_hash(key);
+    if (((uint32_t)(h >> StageBits<K>::cls) & split_mask) != q) return;
+    if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, key, (C)w, (uint32_t)(h >> StageBits<K>::home) + rep))
       failed = true;
   };
   const uint64_t stride = (uint64_t)kSlabs * kStageBS;
@@ -393,10 +409,10 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
           const int qi = u * VEC + j;
           const bool v = (bits >> j) & 1;
           const bool is_sent = v & (kq[qi] == EMPTY);
-          const auto h = slot_hash(kq[qi]);
-          const bool lv = v & !is_sent & (((uint32_t)h & split_mask) == q);
+          const auto h = stage_hash(kq[qi]);
+          const bool lv = v & !is_sent & (((uint32_t)(h >> StageBits<K>::cls) & split_mask) == q);
           nsent += is_sent ? 1u : 0u;
-          hq[qi] = lv ? (((uint32_t)(h >> 17) + rep) & (SLOTS - 1)) : 0u;
+          hq[qi] = lv ? (((uint32_t)(h >> StageBits<K>::home) + rep) & (SLOTS - 1)) : 0u;
           live |= (lv ? 1u : 0u) << qi;
         }
       }
@@ -816,7 +832,7 @@ constexpr int kHotBuckets = kHotSlots / kHotWidth;
 constexpr int kHotBlocks = 256;         // histogram workgroups (one per CU: 130 KiB of LDS each)
 constexpr int kHotSampleBlocks = 64;    // x 1024 rows
 
-__device__ __forceinline__ uint32_t hot_bucket(uint32_t h) { return (h >> 13) & (kHotBuckets - 1); }
+__device__ __forceinline__ uint32_t hot_bucket(int32_t key) { return hot_image_bucket(key, kHotBuckets - 1); }
 // slot of `key` in its bucket (already loaded), or -1
 __device__ __forceinline__ int hot_find(const int2 &b, int32_t key, uint32_t base) {
   int slot = -1;
@@ -894,8 +910,8 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
   const uint64_t nblk = (n + 1023) / 1024;
   const unsigned S = (unsigned)(nblk < (uint64_t)kHotSampleBlocks ? nblk : kHotSampleBlocks);
   const uint64_t step = (S ? nblk / S : 1) * 1024;  // rows between the starts of sampled blocks
-  auto insert = [&](int32_t key, uint32_t h) -> bool {
-    const uint32_t b = hot_bucket(h) * kHotWidth;
+  auto insert = [&](int32_t key, uint32_t) -> bool {
+    const uint32_t b = hot_bucket(key) * kHotWidth;
 #pragma unroll
     for (int c = 0; c < kHotWidth; ++c) {
       const int32_t prev = atomicCAS(&tk[b + c], EMPTY, key);
@@ -953,8 +969,8 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
     for (int q = 0; q < kBatch; ++q) {
       const int32_t key = kreg[q];
       if (key != EMPTY) {
-        const uint32_t h = slot_hash(key);
-        const uint32_t b = hot_bucket(h) * kHotWidth;
+        const uint32_t h = slot_hash(key);  // (the sketch of the rescue below)
+        const uint32_t b = hot_bucket(key) * kHotWidth;
         bool found = false;
 #pragma unroll
         for (int c = 0; c < kHotWidth; ++c) found = found || tk[b + c] == key;
@@ -1018,7 +1034,7 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
           if (key == EMPTY) continue;
           const uint32_t h = slot_hash(key);
           if (msk[(h * 0x85EBCA6Bu) >> 21] < thr) continue;
-          const uint32_t b = hot_bucket(h) * kHotWidth;
+          const uint32_t b = hot_bucket(key) * kHotWidth;
           bool found = false;
 #pragma unroll
           for (int c = 0; c < kHotWidth; ++c) found = found || tk[b + c] == key;
@@ -1039,7 +1055,7 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
           const int32_t key = mk[m];
           const unsigned c = mc[m];
           if (key == EMPTY || c < T) continue;
-          const uint32_t b = hot_bucket(slot_hash(key)) * kHotWidth;
+          const uint32_t b = hot_bucket(key) * kHotWidth;
           int worst = 0;
 #pragma unroll
           for (int w = 1; w < kHotWidth; ++w)
@@ -1069,19 +1085,13 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
     lo = lo > pad ? lo - pad : 0;
     hi = hi + pad < 0xFFFFFFFFull ? hi + pad : 0xFFFFFFFFull;
     const uint64_t span = hi - lo, F = 1ull << (nb_log2 + 14);
-    uint64_t mul;
+    uint32_t mul;
     int sh;
-    if (span + 1 > F) {  // (strictly: mul < 2^32, RangeMap multiplies 32 x 32 bits)
-      mul = (F << 32) / (span + 1);
-      sh = 32;
-    } else {
-      mul = F / (span + 1);
-      sh = 0;
-    }
+    range_map_params(span, F, &mul, &sh);
     image[NVT_RANGE_AUX_LO] = (int32_t)(uint32_t)lo;
     image[NVT_RANGE_AUX_LO + 1] = (int32_t)(uint32_t)span;
-    image[NVT_RANGE_AUX_LO + 2] = (int32_t)(uint32_t)mul;
-    image[NVT_RANGE_AUX_LO + 3] = (int32_t)(uint32_t)(mul >> 32);
+    image[NVT_RANGE_AUX_LO + 2] = (int32_t)mul;
+    image[NVT_RANGE_AUX_LO + 3] = 0;
     image[NVT_RANGE_AUX_LO + 4] = sh;
     image[NVT_RANGE_AUX_LO + 5] = 0;  // bucket-region table layout (nvt_range.hpp)
     image[NVT_RANGE_AUX_LO + 7] = 0;  // linear map (the piecewise form is decided below)
@@ -1177,7 +1187,7 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
         const uint64_t u = (uint32_t)key ^ 0x80000000u;
         uint64_t d = u > lo ? u - lo : 0;
         d = d < span ? d : span;
-        myb[q] = (unsigned)(((d * mul) >> sh) >> 14);
+        myb[q] = (unsigned)((((d << sh) * mul) >> 32) >> 14);  // RangeMap::fine
         myr[q] = atomicAdd(&bcnt[myb[q]], 1u);
       }
     }
@@ -1283,7 +1293,7 @@ __global__ __launch_bounds__(1024) void part_hist_hot_kernel(
       uint32_t sa[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        sa[j] = hot_bucket(slot_hash(kv[j]));
+        sa[j] = hot_bucket(kv[j]);
         bk[j] = tk[sa[j]];
       }
       unsigned cold_bits = 0;

@@ -248,11 +248,35 @@ struct HotCfg<int64_t> {
 // table can be filled to 7/8: 14336 hot keys instead of 4096, 15-20 % fewer rows go on to the
 // table in HBM.  A key that finds both buckets full is simply not cached (the global table
 // holds every key).
-template <int NB>
-__device__ __forceinline__ void two_buckets(uint32_t h, uint32_t &b1, uint32_t &b2) {
+template <int NB, typename K>
+__device__ __forceinline__ void two_buckets(K key, uint32_t &b1, uint32_t &b2) {
+#ifndef NVT_ENC_NO_MUL24
+  if constexpr (sizeof(K) == 4) {
+    // both bucket indices from 24-bit multiplies of the same two words (nvt_common.hpp:
+    // mul24_hash; fmix32 + a third 32-bit multiply were ~28 issue slots per key, this is ~10)
+    static_assert(NB <= 8192, "13 index bits");
+    const uint32_t k = (uint32_t)key, lo = k ^ (k >> 7), hi = k >> 8;
+    b1 = ((__umul24(hi, 0x5BD1E9u) + __umul24(lo, 0x9E3779u)) >> 19) & (NB - 1);
+    b2 = ((__umul24(hi, 0x7FEB35u) + __umul24(lo, 0x846CA7u)) >> 19) & (NB - 1);
+    b2 = b2 == b1 ? b1 ^ 1u : b2;
+    return;
+  }
+#endif
+  const uint32_t h = (uint32_t)slot_hash(key);
   b1 = (h >> 13) & (NB - 1);
   b2 = (((h ^ (h >> 15)) * 0x2C1B3C6Du) >> 17) & (NB - 1);
   b2 = b2 == b1 ? b1 ^ 1u : b2;
+}
+// first slot of the linear-probing LDS table
+template <int SLOTS, typename K>
+__device__ __forceinline__ uint32_t lds_home(K key) {
+#ifndef NVT_ENC_NO_MUL24
+  if constexpr (sizeof(K) == 4) {
+    static_assert(SLOTS <= 16384, "14 index bits");
+    return (mul24_hash((int32_t)key) >> 18) & (SLOTS - 1);
+  }
+#endif
+  return (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
 }
 
 // GLOBAL = false: the whole vocabulary is staged (no table in HBM): the probe phases and their
@@ -303,7 +327,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     }
     if constexpr (TWO) {
       uint32_t b1, b2;
-      two_buckets<SLOTS / 2>((uint32_t)slot_hash(key), b1, b2);
+      two_buckets<SLOTS / 2>(key, b1, b2);
       const uint32_t cand[4] = {2 * b1, 2 * b1 + 1, 2 * b2, 2 * b2 + 1};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
       }
       continue;  // all four slots taken: not cached
     }
-    uint32_t s = (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
+    uint32_t s = lds_home<SLOTS>(key);
     while (true) {
       K prev = (K)atomicCAS(reinterpret_cast<C *>(&lt[s].key), (C)EMPTY, (C)key);
       if (prev == EMPTY || prev == key) {
@@ -333,7 +357,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
   auto hot_lookup = [&](K key) -> int64_t {
     if constexpr (TWO) {
       uint32_t b1, b2;
-      two_buckets<SLOTS / 2>((uint32_t)slot_hash(key), b1, b2);
+      two_buckets<SLOTS / 2>(key, b1, b2);
       const int4 a = reinterpret_cast<const int4 *>(lt)[b1];
       const int4 c = reinterpret_cast<const int4 *>(lt)[b2];
       int lab = -1;
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
       lab = c.z == (int)key ? c.w : lab;
       return (int64_t)lab;
     }
-    uint32_t s = (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
+    uint32_t s = lds_home<SLOTS>(key);
     while (true) {
       EncSlot<K> e = lt[s];
       if (e.key == key) return (int64_t)e.label;

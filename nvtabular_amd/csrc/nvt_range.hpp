@@ -19,13 +19,36 @@ constexpr unsigned long long kEncEmptySlot =
 __device__ __forceinline__ uint32_t ukey(int32_t k) { return (uint32_t)k ^ 0x80000000u; }
 
 // key -> "fine slot" f in [0, NB * 16384): bucket = f >> 14, home slot = f & 16383.
-// f = (min(max(u - ulo, 0), span) * mul) >> sh with (mul, sh) chosen by the sample kernel so
-// that the padded span of the sampled keys covers ALL buckets evenly (a power-of-two bucket
-// width left up to half of them empty): span + 1 > F = NB * 16384: mul = F * 2^32 / (span + 1),
-// sh = 32; smaller spans (dense ids): mul = F / (span + 1), sh = 0 -- keys spread with gaps.
-// mul < 2^32 in both forms, so the map is ONE 32 x 32-bit multiply per key (high half or low
-// half of the product; the 64-bit form cost two v_mad_u64_u32 and a 64-bit shift per key in the
-// partition, count and encode kernels).
+// f = high half of ((min(max(u - ulo, 0), span) << sh) * mul) with (mul, sh) chosen by the sample
+// kernel so that the padded span of the sampled keys covers ALL buckets evenly (a power-of-two
+// bucket width left up to half of them empty): span + 1 > F = NB * 16384: mul = F * 2^32 /
+// (span + 1), sh = 0; smaller spans (dense ids): the integer factor m = F / (span + 1) as
+// mul = m << (32 - sh), sh = bit length of m -- exactly d * m, keys spread with gaps.  ONE 32 x 32
+// bit multiply per key, the same instruction in both forms (the kernels used to compute the high
+// AND the low product and select: integer multiplies are quarter-rate instructions, and these
+// loops are bound by instruction issue).
+__host__ __device__ inline void range_map_params(uint64_t span, uint64_t F, uint32_t *mul, int *sh) {
+  if (span + 1 > F) {
+    *mul = (uint32_t)((F << 32) / (span + 1));
+    *sh = 0;
+    return;
+  }
+  uint64_t m = F / (span + 1);  // >= 1
+  auto bits = [](uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };
+  int b = bits(m);
+  // (d << sh) must stay below 2^32 for every d <= span; a smaller factor only spreads less
+  while (b > 0 && (b > 31 || (span >> (32 - b)) != 0)) {
+    m >>= 1;
+    b = bits(m);
+  }
+  if (m == 0) {  // a span of >= 2^31 keys in a table that large: f = d - 1 (monotone, < F)
+    *mul = 0xFFFFFFFFu;
+    *sh = 0;
+    return;
+  }
+  *mul = (uint32_t)(m << (32 - b));
+  *sh = b;
+}
 // Piecewise form (round 4): keys that are NOT spread over their range (dense, frequency-ordered
 // ids: most of the rows and most of the distinct keys sit in a sliver of [min, max]) overflow the
 // equal-width buckets of the linear map.  The sample kernel then cuts the key range into
@@ -39,7 +62,7 @@ constexpr int kRpPwMul = kRpPieces + 1, kRpPwSh = 2 * kRpPieces + 1;
 struct RangeMap {
   uint32_t ulo, span;
   uint32_t mul;
-  int sh;  // 32 or 0
+  int sh;  // pre-shift of the key offset (0: wide spans)
   int flat;  // 1: the table is ONE run of F slots (+ tail), slot = f (vocabulary tables built from a
              //    key-sorted list: flat_build_kernel); 0: bucket regions dumped by the counting pass
   uint32_t piece_slots;      // 0: linear map; else fine slots per piece (the piecewise form)
@@ -65,7 +88,7 @@ struct RangeMap {
     }
     uint32_t d = u > ulo ? u - ulo : 0u;
     d = d < span ? d : span;
-    return sh ? __umulhi(d, mul) : d * mul;
+    return __umulhi(d << sh, mul);
   }
   __device__ __forceinline__ uint32_t bucket(int32_t key) const { return fine(key) >> 14; }
   __device__ __forceinline__ uint32_t slot(int32_t key) const { return fine(key) & (kRpSlots - 1); }

@@ -59,7 +59,7 @@ constexpr int kRpProbe = 512;
 constexpr unsigned long long kStAgg = 1ull << 62, kStPrefix = 2ull << 62,
                              kStMask = (1ull << 62) - 1ull;
 
-__device__ __forceinline__ uint32_t hot_bucket_r(uint32_t h) { return (h >> 13) & (kHotBucketsR - 1); }
+__device__ __forceinline__ uint32_t hot_bucket_r(int32_t key) { return hot_image_bucket(key, kHotBucketsR - 1); }
 
 
 // ---------------------------------------------------------------------------------------------
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
   __shared__ unsigned tc[kHotSlotsR];
   __shared__ int32_t bins[kRpBinWords];
   __shared__ unsigned fill[1 << kRpMaxNbLog2], flushed[1 << kRpMaxNbLog2];
+  __shared__ unsigned scratch[kWave];  // one word per lane: target of the adds of non-hits
   __shared__ unsigned long long s_nulls, s_sent;
   __shared__ unsigned s_ovf;
-  __shared__ unsigned scratch[kWave];  // one word per lane: target of the adds of non-hits
   const unsigned NB = 1u << nb_log2, CAP = (unsigned)kRpBinWords >> nb_log2;
   const unsigned g = blockIdx.x, lane = lane_id();
   for (int i = threadIdx.x; i < kHotBucketsR; i += kRpBS)
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
       uint32_t sa[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        sa[j] = hot_bucket_r(slot_hash(kv[4 * u + j]));
+        sa[j] = hot_bucket_r(kv[4 * u + j]);
         hb[j] = tk[sa[j]];
       }
 #pragma unroll

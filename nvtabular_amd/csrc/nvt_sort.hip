@@ -1287,19 +1287,13 @@ __device__ __forceinline__ void flat_params_body(const int32_t *__restrict__ key
   const uint64_t first = (n > 1 && keys[0] == INT32_MIN) ? 1 : 0;
   const uint64_t lo = ukey(keys[first]), hi = ukey(keys[n - 1]);
   const uint64_t span = hi - lo, F = slots;  // any slot count < 2^32 (no power of two needed)
-  uint64_t mul;
+  uint32_t mul;
   int sh;
-  if (span + 1 > F) {  // (strictly: mul < 2^32, RangeMap multiplies 32 x 32 bits)
-    mul = (F << 32) / (span + 1);
-    sh = 32;
-  } else {
-    mul = F / (span + 1);
-    sh = 0;
-  }
+  range_map_params(span, F, &mul, &sh);
   aux[NVT_RANGE_AUX_LO] = (int32_t)(uint32_t)lo;
   aux[NVT_RANGE_AUX_LO + 1] = (int32_t)(uint32_t)span;
-  aux[NVT_RANGE_AUX_LO + 2] = (int32_t)(uint32_t)mul;
-  aux[NVT_RANGE_AUX_LO + 3] = (int32_t)(uint32_t)(mul >> 32);
+  aux[NVT_RANGE_AUX_LO + 2] = (int32_t)mul;
+  aux[NVT_RANGE_AUX_LO + 3] = 0;
   aux[NVT_RANGE_AUX_LO + 4] = sh;
   aux[NVT_RANGE_AUX_LO + 5] = 1;  // flat layout
   aux[NVT_RANGE_AUX_LO + 6] = keys[0] == INT32_MIN ? 1 : 0;  // position 0 holds the smallest int32 (not in the table)

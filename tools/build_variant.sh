@@ -1,9 +1,15 @@
 #!/bin/bash
-# build_variant.sh <name> <file.hip> <extra flags...>: libnvt_hip_<name>.so with one object rebuilt
+# build_variant.sh <name> <file.hip[,file2.hip,...]> <extra flags...>: libnvt_hip_<name>.so with the
+# listed objects rebuilt with the extra flags (the rest are the default build's objects)
 set -e
 cd $(dirname $0)/../nvtabular_amd/csrc
-name=$1; src=$2; shift 2
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $src -o /tmp/variant_$name.o
-objs=$(ls *.o | grep -v "^${src%.hip}.o$")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/variant_$name.o -ldl -o ../libnvt_hip_$name.so
+name=$1; srcs=${2//,/ }; shift 2
+skip=""; new=""
+for src in $srcs; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $src -o /tmp/variant_${name}_${src%.hip}.o
+  skip="$skip ${src%.hip}.o"; new="$new /tmp/variant_${name}_${src%.hip}.o"
+done
+objs=""
+for o in *.o; do case " $skip " in *" $o "*) ;; *) objs="$objs $o";; esac; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $new -ldl -o ../libnvt_hip_$name.so
 echo built ../libnvt_hip_$name.so
