@@ -431,6 +431,7 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
         atomicAdd(&lcnt[hit ? hq[qi] : (uint32_t)SLOTS + lane_id()], (C)1);
         missbits |= ((lv & !hit) ? 1u : 0u) << qi;
       }
+#ifdef NVT_STAGE_SPARSE_MISS
       if (missbits) {
 #pragma unroll
         for (int qi = 0; qi < NKB; ++qi)
@@ -438,6 +439,27 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
               !lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, kq[qi], (C)1, hq[qi]))
             failed = true;
       }
+#else
+      // The probe chain of a miss is a loop of dependent LDS round trips, and with a few percent
+      // of misses SOME lane misses at every one of the NKB key positions: walked position by
+      // position the wave paid NKB chains per batch with a handful of lanes active in each.
+      // Every lane walks ITS next miss instead: as many chains as the unluckiest lane has
+      // misses (2-3 of 8 at a 7 % miss rate).
+      while (__any(missbits != 0)) {
+        if (missbits) {
+          const int qm = (int)__ffs((int)missbits) - 1;
+          K mk = kq[0];
+          uint32_t mh = hq[0];
+#pragma unroll
+          for (int qi = 1; qi < NKB; ++qi) {
+            mk = qm == qi ? kq[qi] : mk;
+            mh = qm == qi ? hq[qi] : mh;
+          }
+          missbits &= missbits - 1u;
+          if (!lds_add<K, C, SLOTS>(lkeys, lcnt, &lfill, mk, (C)1, mh)) failed = true;
+        }
+      }
+#endif
     }
     for (uint64_t i = nvec * VEC + first; i < n; i += stride) {
       if (bit_valid(valid, i))

@@ -69,7 +69,15 @@ template <int U>
 __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
     const int32_t *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const int32_t *__restrict__ aux, int nb_log2, uint32_t region_cap, int32_t *__restrict__ regions,
-    uint32_t *__restrict__ fills, unsigned *__restrict__ hot_cnt, uint64_t *state) {
+    uint32_t *__restrict__ fills, unsigned *__restrict__ hot_cnt, uint64_t *state,
+    unsigned long long *__restrict__ clr_status, unsigned *__restrict__ clr_hist) {
+  // what pass 2 expects cleared (two memset launches per column otherwise): the look-back status
+  // words with the ticket behind them, and the class histogram
+  {
+    const unsigned nst = (1u << nb_log2) + 8u;  // + 64 bytes: the ticket
+    for (unsigned i = blockIdx.x * kRpBS + threadIdx.x; i < nst; i += kRpG * kRpBS) clr_status[i] = 0ull;
+    if (blockIdx.x == kRpG - 1 && threadIdx.x < 256) clr_hist[threadIdx.x] = 0u;
+  }
   __shared__ int2 tk[kHotBucketsR];
   __shared__ unsigned tc[kHotSlotsR];
   __shared__ int32_t bins[kRpBinWords];
@@ -376,7 +384,10 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
     for (int q = 0; q < RPW; ++q) pre[q + 1] = pre[q] + run_len[w * RPW + q];
     const unsigned total = pre[RPW];
     const int32_t *rbase = regions + ((uint64_t)b * kRpG + w * RPW) * region_cap;
-    constexpr int GB = 8;
+#ifndef NVT_RP_GB
+#define NVT_RP_GB 8
+#endif
+    constexpr int GB = NVT_RP_GB;
     for (unsigned f0 = 0; f0 < total && !failed; f0 += GB * kWave) {
       int32_t kk[GB];
 #pragma unroll
@@ -687,8 +698,6 @@ int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int n
   range_ws_layout(n, nb_log2, (char *)wsp, &w);
   const unsigned NB = 1u << nb_log2;
   const uint32_t cap = range_region_cap(n, nb_log2);
-  NVT_CHECK_HIP(hipMemsetAsync(w.status, 0, (uint64_t)NB * 8 + 64, s));
-  NVT_CHECK_HIP(hipMemsetAsync(aux + NVT_RANGE_AUX_HIST, 0, 256 * 4, s));
   static const bool debug = getenv("NVT_RANGE_DEBUG") != nullptr;
   auto mark = [&](const char *what) {
     if (debug) {
@@ -707,16 +716,21 @@ int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int n
             (unsigned long long)(uint32_t)prm[2] | ((unsigned long long)(uint32_t)prm[3] << 32), prm[4],
             wsp, (void *)w.regions, (void *)w.fills, (void *)w.hot_cnt, (void *)aux);
   }
+  unsigned *hist = (unsigned *)(aux + NVT_RANGE_AUX_HIST);
+#ifdef NVT_RP_MEMSET
+  NVT_CHECK_HIP(hipMemsetAsync(w.status, 0, (uint64_t)NB * 8 + 64, s));
+  NVT_CHECK_HIP(hipMemsetAsync(aux + NVT_RANGE_AUX_HIST, 0, 256 * 4, s));
+#endif
   static const int upr = getenv("NVT_RANGE_U") ? atoi(getenv("NVT_RANGE_U")) : NVT_RANGE_U;
   if (upr == 4)
     rp_partition_kernel<4><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
-                                                  w.fills, w.hot_cnt, state);
+                                                  w.fills, w.hot_cnt, state, w.status, hist);
   else if (upr == 1)
     rp_partition_kernel<1><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
-                                                  w.fills, w.hot_cnt, state);
+                                                  w.fills, w.hot_cnt, state, w.status, hist);
   else
     rp_partition_kernel<2><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
-                                                  w.fills, w.hot_cnt, state);
+                                                  w.fills, w.hot_cnt, state, w.status, hist);
   NVT_CHECK_LAUNCH();
   mark("partition");
   hot_totals_kernel<<<kHotSlotsR / 64, 64 * kTotGroups, 0, s>>>(w.hot_cnt, kRpG, w.hot_tot);
