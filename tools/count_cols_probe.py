@@ -32,6 +32,6 @@ for j, (name, col) in enumerate(frame.items()):
         res = K.dense_count_many([job])[0]
         hint = int(res[3]["distinct"]) if isinstance(res[3], dict) and "distinct" in res[3] else int(res[0].numel())
         torch.cuda.synchronize()
+    lib.nvt_fold_mt19937(1, 2, 100 + j, mark.data_ptr(), s)   # end of this column's timed passes
+    torch.cuda.synchronize()
     print(name, "distinct", hint, "path", job.path, "bits", job.range_bits() if job.path == K.PATH_RANGE else "-", flush=True)
-lib.nvt_fold_mt19937(1, 2, 1000, mark.data_ptr(), s)
-torch.cuda.synchronize()
