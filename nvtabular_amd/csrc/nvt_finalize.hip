@@ -23,6 +23,7 @@
 namespace nvt {
 namespace {
 constexpr int kSide = kSideStreams;
+constexpr uint64_t kOrderBatchMaxEntries = 1ull << 23;
 }  // namespace
 }  // namespace nvt
 
@@ -119,6 +120,10 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
     for (int i : big) {
       const nvt_vocab_col &c = cols[i];
       if (c.src_keys == nullptr || c.table == nullptr || c.range_aux == nullptr || c.n == 0) continue;
+      // (tens of millions of entries: the launches are not what such a vocabulary waits for, and
+      // on a stream of its own its encode starts while the next one is still being ordered --
+      // four 36 M-entry vocabularies: 14.3 ms of GPU time per step against 15.7 in one batch)
+      if (c.n > kOrderBatchMaxEntries) continue;
       NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
       jobs.push_back({(const int32_t *)c.src_keys, c.src_counts, c.n, c.cls_hist, c.n_big, c.max_count,
                       (int32_t *)c.keys, c.counts, c.sort_tmp, c.first_label, c.table, c.capacity,
