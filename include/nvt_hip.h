@@ -455,6 +455,11 @@ int nvt_merge_payload(const int32_t *src_a, const int32_t *src_b, uint64_t n, in
  *   nvt_exchange_scatter  rows_out = (count << 32 | key) words grouped by (owner, column);
  *                         cursors uint64[G][ncol] (device) = the start of every group, advanced by
  *                         the call; the order inside a group is unspecified (counts < 2^31)
+ *   nvt_exchange_pack_ordered  the same send buffer for KEY-SORTED lists: a group is a contiguous
+ *                         slice of its column, row r of the column goes to start[cell] + (r -
+ *                         first_row[cell]) -- every group arrives in key order and the owner merges
+ *                         sorted runs (nvt_merge_sorted_many) instead of sorting; first_row / start:
+ *                         device uint64[G][ncol]
  *   nvt_exchange_unpack   n gathered words in nseg segments [seg_off[s], seg_off[s + 1]) ->
  *                         keys_out / counts_out at dst_off[s] + (position in the segment)
  * lo / width: HOST arrays; seg_off / dst_off: device arrays.  No host synchronisation. */
@@ -468,6 +473,9 @@ int nvt_exchange_hist(const nvt_xcol *cols, int ncol, const int64_t *lo, const u
                       uint64_t *send_mat, void *stream);
 int nvt_exchange_scatter(const nvt_xcol *cols, int ncol, const int64_t *lo, const uint64_t *width, int G,
                          uint64_t *cursors, int64_t *rows_out, void *stream);
+int nvt_exchange_pack_ordered(const nvt_xcol *cols, int ncol, const int64_t *lo, const uint64_t *width,
+                              int G, const uint64_t *first_row, const uint64_t *start, int64_t *rows_out,
+                              void *stream);
 int nvt_exchange_unpack(const int64_t *words, uint64_t n, const uint64_t *seg_off, const uint64_t *dst_off,
                         int nseg, int32_t *keys_out, int64_t *counts_out, void *stream);
 /* key -> position in an ascending int32 key list (the group ids of nvt_sgb_regroup) through

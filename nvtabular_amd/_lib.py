@@ -108,6 +108,7 @@ SIGNATURES = {
     "nvt_exchange_ranges": [_vp, _i32, _vp, _vp],
     "nvt_exchange_hist": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp],
     "nvt_exchange_scatter": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp, _vp],
+    "nvt_exchange_pack_ordered": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp, _vp, _vp],
     "nvt_exchange_unpack": [_vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp],
     "nvt_count_merge_sorted_ws_bytes": [_u64, C.POINTER(_u64)],
     "nvt_count_merge_sorted": [_vp, _u64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],

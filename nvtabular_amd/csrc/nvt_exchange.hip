@@ -167,6 +167,28 @@ __global__ __launch_bounds__(kBlock) void x_group_kernel(XBatch b, unsigned long
   }
 }
 
+// KEY-SORTED lists: the rows of an (owner, column) group are a contiguous slice of the column
+// (the owner is monotone in the key), so the position of a row in the send buffer follows from
+// its index alone -- no cursors, no atomics, and the slice arrives IN KEY ORDER: the owner then
+// merges G sorted runs per column (nvt_merge_sorted_many) instead of sorting what it received.
+// first_row[cell] = rows of the column in front of the slice, start[cell] = first position of
+// the group in rows_out.
+__global__ __launch_bounds__(kBlock) void x_pack_ordered_kernel(XBatch b,
+                                                                const uint64_t *__restrict__ first_row,
+                                                                const uint64_t *__restrict__ start,
+                                                                int64_t *__restrict__ rows_out) {
+  const uint64_t n = b.pre[b.ncol];
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int c = x_col_of(b, i);
+    const uint64_t r = i - b.pre[c];
+    const int32_t k = b.keys[c][r];
+    const unsigned cell = x_owner(b, c, k) * (unsigned)b.ncol + (unsigned)c;
+    rows_out[start[cell] + (r - first_row[cell])] =
+        (int64_t)(((uint64_t)b.cnts[c][r] << 32) | (uint64_t)(uint32_t)k);
+  }
+}
+
 // the all-gathered words (rank-major, column-minor segments) -> column-major: segment s goes to
 // [dst_off[s], ...) of keys_out / cnts_out, so every column is one contiguous, key-ordered list
 __global__ __launch_bounds__(kBlock) void x_unpack_kernel(const int64_t *__restrict__ words, uint64_t n,
@@ -256,6 +278,22 @@ int nvt_exchange_scatter(const nvt_xcol *cols, int ncol, const int64_t *lo, cons
   NVT_PROF("exchange_prep", b.pre[ncol] * 20ull, s);
   x_group_kernel<true><<<stream_grid(b.pre[ncol], kXTile, 4), kBlock, 0, s>>>(
       b, (unsigned long long *)cursors, rows_out);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_exchange_pack_ordered(const nvt_xcol *cols, int ncol, const int64_t *lo, const uint64_t *width,
+                              int G, const uint64_t *first_row, const uint64_t *start, int64_t *rows_out,
+                              void *stream) {
+  NVT_CHECK_ARG(first_row && start && rows_out && lo && width, "null pointer");
+  NVT_CHECK_ARG(G >= 1 && (int64_t)G * ncol <= kXMaxCells, "ranks x columns must be <= 4096");
+  XBatch b;
+  int rc = fill_batch(b, cols, ncol, lo, width, G);
+  if (rc) return rc;
+  if (b.pre[ncol] == 0) return NVT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("exchange_prep", b.pre[ncol] * 20ull, s);
+  x_pack_ordered_kernel<<<stream_grid(b.pre[ncol], kBlock * 4), kBlock, 0, s>>>(b, first_row, start, rows_out);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

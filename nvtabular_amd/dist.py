@@ -6,11 +6,16 @@ tree reduce over TCP/UCX and a disk round trip (categorify.py:1423-1529).  Here
 each rank keeps its partial tables in HBM and the merge is ONE exchange per fit:
 
   Categorify / JoinGroupby / TargetEncoding fit
-      owner(key) = h32(key) % world          (hash-partitioned, like split_out)
+      owner(key) = key range r of `world` equal ranges of the column's global key span
+                   (monotone in the key: a key-sorted list splits into contiguous slices, the
+                   owners' shards concatenate to a key-sorted union; groupby rows: h32 % world)
       all-to-all(v) of the (key, count[, sums...]) rows to their owners   <- xGMI, all 7 links busy
-      owner-side merge (nvt_count_merge_* / nvt_gb_merge)
+      owner-side merge: a merge tree over the G key-ordered runs of every column
+                   (nvt_merge_sorted_many; lists that arrive unordered: one sort,
+                   nvt_count_merge_sorted; groupby rows: nvt_gb_merge)
       all-gather of the merged shards -> every rank holds the full table and runs the
-      same deterministic finalisation (sort, thresholds), so vocabularies are identical
+      same deterministic finalisation (one-pass ordering, thresholds), so vocabularies are
+      identical; the class histograms the ordering needs are summed over the owners
   Normalize.fit / target means
       all-reduce(sum) of the 3*K float64 moment vector (latency-bound, 312 B for K=13)
 
@@ -336,6 +341,35 @@ PACK_COUNT_ROWS = True  # (tests switch it off to drive the two-word format with
 STATS = {"packed_exchanges": 0, "plain_exchanges": 0, "sorted_merges": 0}  # diagnostics
 MERGE_BY_SORTING = True
 HIP_EXCHANGE = True  # batched nvt_exchange_* launches around the collectives (int32 keys on the GPU)
+# Key-sorted lists (what the range / sort paths and the partition merge produce) travel as
+# contiguous slices in key order, and the owner MERGES the G sorted runs of a column
+# (nvt_merge_sorted_many) instead of sorting everything it received; lists that are not sorted
+# (the LDS-resident counting paths: a few thousand keys) are sorted on the sender first.
+ORDERED_EXCHANGE = True
+SMALL_SORT_MAX = 1 << 18   # entries of unsorted lists one tagged sort may take on the sender
+STATS["ordered_exchanges"] = 0
+
+
+def _sort_unsorted_lists(tables, sorted_by_key):
+    """The lists flagged unsorted ordered by key with ONE sort of (column << 32 | biased key)
+    words; None when they hold more than SMALL_SORT_MAX entries (the caller keeps the unordered
+    exchange)."""
+    todo = [j for j, (k, _, _) in enumerate(tables) if not sorted_by_key[j] and int(k.numel()) > 1]
+    if not todo:
+        return tables
+    lens = [int(tables[j][0].numel()) for j in todo]
+    if sum(lens) > SMALL_SORT_MAX:
+        return None
+    words = torch.cat([(tables[j][0].to(torch.int64) + (1 << 31)) | (i << 32) for i, j in enumerate(todo)])
+    cnts = torch.cat([tables[j][1].to(torch.int64) for j in todo])
+    words, order = torch.sort(words)
+    cnts = cnts[order]
+    keys = ((words & 0xFFFFFFFF) - (1 << 31)).to(torch.int32)
+    out, at = list(tables), 0
+    for j, n in zip(todo, lens):
+        out[j] = (keys[at:at + n], cnts[at:at + n], tables[j][2])
+        at += n
+    return out
 
 
 def _pack_kc(k64: torch.Tensor, c64: torch.Tensor) -> torch.Tensor:
@@ -369,8 +403,13 @@ _sort_by_key_fn: Callable = _sort_by_key_default
 _class_hist_fn: Callable = _class_hist_default
 
 
-def merge_counts_many(tables):
+def merge_counts_many(tables, sorted_by_key=None):
     """ONE exchange for all the (key -> count) tables of a fit.
+
+    ``sorted_by_key[j]``: the list of column j is in ascending key order without duplicates on
+    THIS rank (default: unknown = no).  When every column is (or, for short lists, can cheaply be
+    made) key-sorted on every rank, groups travel in key order and the owners merge sorted runs
+    (ORDERED_EXCHANGE; the decision rides on the MAX all-reduce of the key ranges).
 
     ``tables`` = [(keys, counts, scalars)] per column, ``scalars`` a list of ints that are
     summed over the ranks (null rows, valid rows, ...).  Every column's rows travel in the
@@ -414,6 +453,15 @@ def merge_counts_many(tables):
     wide_local = [int(n > 0 and dt != torch.int32) for dt, n in zip(dtypes, lens)]
     if not any(wide_local):
         tables = [(k if k.dtype == torch.int32 else k.to(torch.int32), c, sc) for k, c, sc in tables]
+    # key order of the local lists (the ordered exchange needs it on every rank)
+    flags = list(sorted_by_key) if sorted_by_key is not None else [False] * ncol
+    flags = [bool(f) or n <= 1 for f, n in zip(flags, lens)]
+    unsorted_local = 1
+    if (ORDERED_EXCHANGE and dev.type == "cuda" and HIP_EXCHANGE and not any(wide_local)
+            and _merge_counts_many_fn is _hip_merge_counts_many):
+        made = _sort_unsorted_lists(tables, flags)
+        if made is not None:
+            tables, unsorted_local = made, 0
     # ---- global key range per column ---------------------------------------------------
     big = torch.iinfo(torch.int64).max
     # device path: all columns int32 on the GPU -- every step around the collectives is ONE
@@ -425,9 +473,11 @@ def merge_counts_many(tables):
 
         if ncol <= K.EXCHANGE_MAX_COLS and G * ncol <= K.EXCHANGE_MAX_CELLS:
             xb = K.ExchangeBatch([(k, c.to(torch.int64)) for k, c, _ in tables])
-    # (-min, max, rows counted on this rank, holds non-int32 keys): one MAX reduce
-    rng = torch.empty(ncol, 4, dtype=torch.int64, device=dev)
+    # (-min, max, rows counted on this rank, holds non-int32 keys, holds lists that are not in key
+    # order): one MAX reduce
+    rng = torch.empty(ncol, 5, dtype=torch.int64, device=dev)
     rng[:, 3] = torch.tensor(wide_local, dtype=torch.int64).to(dev)
+    rng[:, 4] = unsorted_local
     if xb is not None:
         rng[:, :3] = xb.ranges()
         k64s = None
@@ -459,8 +509,9 @@ def merge_counts_many(tables):
     if xb is not None and not packed:  # (counts too large for one word: the general path)
         xb = None
         k64s = [k.to(torch.int64) for k, _, _ in tables]
+    ordered = xb is not None and not any(r[4] > 0 for r in rng_h)   # the same on every rank
     if xb is not None:
-        send_mat, recv_mat, send_h, recv_h, recv = _exchange_rows_hip(xb, rng_h, G, ncol)
+        send_mat, recv_mat, send_h, recv_h, recv = _exchange_rows_hip(xb, rng_h, G, ncol, ordered)
     else:
         send_mat, recv_mat, send_h, recv_h, recv = _exchange_rows_torch(
             tables, k64s, lens, rng_h, G, ncol, dev, packed)
@@ -469,8 +520,12 @@ def merge_counts_many(tables):
     off = torch.zeros(G * ncol + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
     off = off.tolist()
-    sorted_merge, results, packed_all = None, {}, None
-    if packed and recv.is_cuda and _merge_counts_many_fn is _hip_merge_counts_many and MERGE_BY_SORTING:
+    sorted_merge, results, packed_all, own_hist = None, {}, None, None
+    if ordered:
+        # G key-ordered runs per column: merge tree (one launch pair per level for all columns)
+        sorted_merge, packed_all, packed_len, own_hist = _merge_sorted_runs(recv, off, G, ncol)
+        STATS["ordered_exchanges"] += 1
+    elif packed and recv.is_cuda and _merge_counts_many_fn is _hip_merge_counts_many and MERGE_BY_SORTING:
         from . import kernels as K
 
         if 0 < recv.numel() <= K.MERGE_SORTED_MAX_ROWS and ncol <= K.MERGE_SORTED_MAX_COLS:
@@ -480,12 +535,48 @@ def merge_counts_many(tables):
             STATS["sorted_merges"] += 1
     return _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted_merge,
                                 packed_all, packed_len if sorted_merge is not None else None,
-                                xb is not None)
+                                xb is not None, own_hist)
 
 
-def _exchange_rows_hip(xb, rng_h, G, ncol):
+def _merge_sorted_runs(recv, off, G, ncol):
+    """Owner side of the ordered exchange: the received words lie in (source, column) segments,
+    every segment in key order.  -> (True, the merged rows of all columns as one array of words,
+    column after column, their lengths, int64[ncol, 256] class histogram of this owner's share)."""
+    from . import kernels as K
+
+    dev = recv.device
+    dst, runs, at = [0] * (G * ncol), [[] for _ in range(ncol)], 0
+    for j in range(ncol):
+        for src in range(G):
+            sgm = src * ncol + j
+            n = off[sgm + 1] - off[sgm]
+            dst[sgm] = at
+            if n:
+                runs[j].append((at, n))
+            at += (n + 3) // 4 * 4   # every run starts on a 16-byte boundary of both arrays
+    keys_all, cnts_all = K.exchange_unpack(recv, off, dst, at)
+    merged = K.merge_sorted_tree([[(keys_all[a:a + n], cnts_all[a:a + n]) for a, n in r] for r in runs])
+    lens = [int(k.numel()) for k, _ in merged]
+    hist32 = torch.zeros(ncol, 256, dtype=torch.int32, device=dev)
+    for j, (_, c) in enumerate(merged):
+        if lens[j]:
+            K.class_hist(c, out=hist32[j])
+    hist = hist32.to(torch.int64) & 0xFFFFFFFF
+    if sum(lens) == 0:
+        return True, torch.empty(0, dtype=torch.int64, device=dev), lens, hist
+    xm = K.ExchangeBatch([(k, c) for k, c in merged])
+    starts = torch.zeros(1, ncol, dtype=torch.int64)
+    starts[0, 1:] = torch.cumsum(torch.tensor(lens[:-1], dtype=torch.int64), 0)
+    packed_all = xm.pack_ordered([0] * ncol, [1] * ncol, 1, starts.to(dev),
+                                 torch.zeros(1, ncol, dtype=torch.int64, device=dev))
+    return True, packed_all, lens, hist
+
+
+def _exchange_rows_hip(xb, rng_h, G, ncol, ordered=False):
     """Send side on the device path: count matrix, send buffer grouped by (owner, column), the
-    all-to-all(v).  (The order of the rows inside a group is unspecified: the owner sorts.)"""
+    all-to-all(v).  ordered: every list is key-sorted -- a group is a contiguous slice of its
+    column and is copied in key order (the owner merges sorted runs); else the order of the rows
+    inside a group is unspecified (cursor atomics) and the owner sorts."""
     big = torch.iinfo(torch.int64).max
     los, widths = [], []
     for j in range(ncol):
@@ -504,7 +595,11 @@ def _exchange_rows_hip(xb, rng_h, G, ncol):
     send_h, recv_h = send_mat.cpu(), recv_mat.cpu()
     starts = torch.zeros(G * ncol, dtype=torch.int64)
     starts[1:] = torch.cumsum(send_h.reshape(-1), 0)[:-1]
-    rows = xb.scatter(los, widths, G, starts.to(send_mat.device))
+    if ordered:
+        first_row = torch.cumsum(send_mat, 0) - send_mat   # rows of the column in front of the slice
+        rows = xb.pack_ordered(los, widths, G, starts.to(send_mat.device).view(G, ncol), first_row.contiguous())
+    else:
+        rows = xb.scatter(los, widths, G, starts.to(send_mat.device))
     recv = _all_to_all_v(rows, send_h.sum(1).tolist(), recv_h.sum(1).tolist())
     return send_mat, recv_mat, send_h, recv_h, recv
 
@@ -549,7 +644,7 @@ def _exchange_rows_torch(tables, k64s, lens, rng_h, G, ncol, dev, packed):
 
 
 def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted_merge, packed_all,
-                         packed_len, device_path):
+                         packed_len, device_path, own_hist=None):
     """Owner-side merge (when the sorted merge did not already do it), all-gather of the merged
     shards, the per-column lists every rank ends with."""
     results = {}
@@ -591,7 +686,14 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
     nsc = max(len(sc) for _, _, sc in tables)
     scal = torch.tensor([list(sc) + [0] * (nsc - len(sc)) for _, _, sc in tables],
                         dtype=torch.int64, device=dev)
+    hist_all = None
+    if own_hist is not None:
+        # the class histogram of a merged list = the sum of the owners' (every key has ONE owner):
+        # each rank histograms 1 / G of the union and the sums ride on this all-reduce
+        scal = torch.cat([scal, own_hist], dim=1)
     _all_reduce(scal)
+    if own_hist is not None:
+        hist_all = scal[:, nsc:].to(torch.int32).contiguous()
     scal = scal.cpu().tolist()
     out = []
     unpacked = None
@@ -624,11 +726,14 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
                 keys, counts = seg[:, 0].contiguous().to(dtypes[j]), seg[:, 1].contiguous()
         info = None
         if keys.numel():
-            hist = _class_hist_fn(counts)
-            info = dict(sorted_by_key=True, cls_hist=hist, n_big=None, merged=True)
+            if hist_all is not None:
+                info = dict(sorted_by_key=True, cls_hist=hist_all[j], n_big=int(scal[j][nsc + 255]) & 0xFFFFFFFF,
+                            merged=True)
+            else:
+                info = dict(sorted_by_key=True, cls_hist=_class_hist_fn(counts), n_big=None, merged=True)
         out.append((keys, counts, scal[j][: len(tables[j][2])], info))
     # n_big of every column: ONE read-back of the 256th histogram words
-    infos = [o[3] for o in out if o[3] is not None]
+    infos = [o[3] for o in out if o[3] is not None and o[3]["n_big"] is None]
     if infos:
         nb = torch.stack([i["cls_hist"][255] for i in infos]).to(torch.int64).cpu().tolist()
         for i, v in zip(infos, nb):

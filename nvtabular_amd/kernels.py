@@ -843,25 +843,39 @@ def merge_sorted_pairs(pairs, want_src: bool = False):
     descs = (_lib.MergeCol * len(pairs))()
     out_n = torch.empty(len(pairs), dtype=torch.int64, device=dev)
     outs, keep = [], []
+    # ONE output buffer per array for the whole call (a multi-GPU owner merges ~100 pairs per
+    # level: four allocations per pair were most of the call), every pair on a 16-byte boundary
+    sizes, offs, tot = [], [], 0
+    for (ka, _), (kb, _) in pairs:
+        n_ab = int(ka.numel()) + int(kb.numel())
+        if n_ab > MERGE_SORTED_MAX_TOTAL:
+            raise _lib.NvtHipError("merge_sorted_pairs: more than 2^31 - 1 entries in one merge")
+        sizes.append(n_ab)
+        offs.append(tot)
+        tot += (max(n_ab, 1) + 3) // 4 * 4   # (at least one element: an empty pair must still look
+                                            # like "with src maps" to the library)
+    with_counts = any(ca is not None or cb is not None for (_, ca), (_, cb) in pairs)
+    ok_all = torch.empty(tot, dtype=torch.int32, device=dev)
+    oc_all = torch.empty(tot, dtype=torch.int64, device=dev) if with_counts else None
+    sa_all = torch.empty(tot, dtype=torch.int32, device=dev) if want_src else None
+    sb_all = torch.empty(tot, dtype=torch.int32, device=dev) if want_src else None
+    pk, pc = ok_all.data_ptr(), oc_all.data_ptr() if oc_all is not None else 0
+    psa, psb = (sa_all.data_ptr(), sb_all.data_ptr()) if want_src else (0, 0)
+    pn = out_n.data_ptr()
     for i, (d, ((ka, ca), (kb, cb))) in enumerate(zip(descs, pairs)):
         assert ka.dtype == torch.int32 and kb.dtype == torch.int32
         ka, kb = ka.contiguous(), kb.contiguous()
         ca = ca.contiguous() if ca is not None else None
         cb = cb.contiguous() if cb is not None else None
         na, nb = int(ka.numel()), int(kb.numel())
-        if na + nb > MERGE_SORTED_MAX_TOTAL:
-            raise _lib.NvtHipError("merge_sorted_pairs: more than 2^31 - 1 entries in one merge")
-        ok = torch.empty(na + nb, dtype=torch.int32, device=dev)
-        oc = torch.empty(na + nb, dtype=torch.int64, device=dev) if (ca is not None or cb is not None) else None
-        # (at least one element: an empty pair must still look like "with src maps" to the library)
-        sa = torch.empty(max(na + nb, 1), dtype=torch.int32, device=dev) if want_src else None
-        sb = torch.empty(max(na + nb, 1), dtype=torch.int32, device=dev) if want_src else None
+        has_c = ca is not None or cb is not None
+        o = offs[i]
         d.a_keys, d.a_counts, d.na = ptr(ka) if na else None, ptr(ca) if na else None, na
         d.b_keys, d.b_counts, d.nb = ptr(kb) if nb else None, ptr(cb) if nb else None, nb
-        d.out_keys, d.out_counts = ptr(ok), ptr(oc)
-        d.src_a, d.src_b = ptr(sa), ptr(sb)
-        d.out_n = out_n[i:].data_ptr()
-        outs.append((ok, oc, sa, sb))
+        d.out_keys, d.out_counts = pk + 4 * o, (pc + 8 * o) if has_c else None
+        d.src_a, d.src_b = (psa + 4 * o, psb + 4 * o) if want_src else (None, None)
+        d.out_n = pn + 8 * i
+        outs.append((o, has_c))
         keep.append((ka, kb, ca, cb))
     need = C.c_uint64()
     check(lib.nvt_merge_sorted_ws_bytes(descs, len(pairs), C.byref(need)), "nvt_merge_sorted_ws_bytes")
@@ -870,12 +884,12 @@ def merge_sorted_pairs(pairs, want_src: bool = False):
           "nvt_merge_sorted_many")
     ns = read_back(out_n).tolist()
     res = []
-    for (ok, oc, sa, sb), n in zip(outs, ns):
+    for (o, has_c), n in zip(outs, ns):
         n = int(n)
         if want_src:
-            res.append((ok[:n], oc[:n] if oc is not None else None, sa[:n], sb[:n]))
+            res.append((ok_all[o:o + n], oc_all[o:o + n] if has_c else None, sa_all[o:o + n], sb_all[o:o + n]))
         else:
-            res.append((ok[:n], oc[:n] if oc is not None else None))
+            res.append((ok_all[o:o + n], oc_all[o:o + n] if has_c else None))
     return res
 
 
@@ -972,10 +986,10 @@ def range_splitters(keys: torch.Tensor, counts: torch.Tensor, rows: int = 0):
     return torch.where(arr >= (1 << 31), arr - (1 << 32), arr).to(torch.int32)   # the u32 bit pattern
 
 
-def class_hist(counts: torch.Tensor) -> torch.Tensor:
+def class_hist(counts: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """int32[256] histogram of min(count, 255) on the device (nvt_class_hist): the input of the
-    one-pass ordering of a key-sorted (key, count) list."""
-    hist = torch.empty(256, dtype=torch.int32, device=counts.device)
+    one-pass ordering of a key-sorted (key, count) list.  out: a contiguous int32[256] to fill."""
+    hist = out if out is not None else torch.empty(256, dtype=torch.int32, device=counts.device)
     counts = counts.contiguous()
     check(_lib.load().nvt_class_hist(ptr(counts) if counts.numel() else None, counts.numel(),
                                      hist.data_ptr(), stream_ptr()), "nvt_class_hist")
@@ -1882,6 +1896,20 @@ class ExchangeBatch:
         a, b = self._owner_args(lo, width)
         check(self.lib.nvt_exchange_scatter(self.cols, self.ncol, a, b, G, starts.data_ptr(),
                                             rows.data_ptr(), stream_ptr()), "nvt_exchange_scatter")
+        return rows
+
+
+    def pack_ordered(self, lo, width, G, starts: torch.Tensor, first_row: torch.Tensor) -> torch.Tensor:
+        """The send buffer of KEY-SORTED lists: group (g, j) = the contiguous slice of column j
+        whose keys rank g owns, copied in key order to ``starts[g, j]``; ``first_row[g, j]`` =
+        rows of column j in front of the slice (both int64[G, ncol] on the device).  No atomics."""
+        rows = torch.empty(self.total, dtype=torch.int64, device=self.dev)
+        if self.total == 0:
+            return rows
+        a, b = self._owner_args(lo, width)
+        check(self.lib.nvt_exchange_pack_ordered(self.cols, self.ncol, a, b, G, first_row.data_ptr(),
+                                                 starts.data_ptr(), rows.data_ptr(), stream_ptr()),
+              "nvt_exchange_pack_ordered")
         return rows
 
 

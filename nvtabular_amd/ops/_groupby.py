@@ -372,9 +372,12 @@ def fold_sparse(comp):
     kfold = f["kfold"]
     idx = torch.nonzero(f["size"] > 0).squeeze(1)
     size = f["size"][idx]
+    nm = comp.get("null_mask")   # (sort-path groups without a null-key group carry none)
+    if nm is None:
+        nm = torch.zeros(comp["n"], dtype=torch.uint8, device=size.device)
     # (bit 1 = the key column of the [fold, key] tuple: set for the group of the null-key rows)
     return dict(keys=[idx % kfold, comp["keys"][0][idx // kfold]],
-                null_mask=(comp["null_mask"][idx // kfold].to(torch.uint8) << 1),
+                null_mask=(nm[idx // kfold].to(torch.uint8) << 1),
                 size=size, count=size, sum=[c[idx] for c in f["sum"]], sumsq=[], min=[], max=[],
                 n=int(idx.numel()))
 

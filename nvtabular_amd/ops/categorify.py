@@ -443,8 +443,11 @@ class Categorify(StatOperator):
         if dist.world_size() > 1:
             # ONE exchange for every single-vocabulary group of this fit (dist.merge_counts_many)
             singles = [g for g in groups if not g.combo]
-            tabs = []
+            tabs, key_sorted = [], []
             for g in singles:
+                # (range / sort path lists and merged partitions are in key order: they travel as
+                # contiguous slices and the owners merge sorted runs)
+                key_sorted.append(g.table is not None and g.sorted is not None and g.sorted[0] is g.table[0])
                 if g.table is None:
                     dev = torch.device("cuda", torch.cuda.current_device())
                     k = torch.empty(0, dtype=torch.int64, device=dev)
@@ -459,7 +462,7 @@ class Categorify(StatOperator):
                 has_str = int(any(c_ in g.strings for c_ in g.cols))
                 tabs.append((k, c, [int(g.nulls), int(g.valid_rows), int(mx), has_str]))
             if tabs:
-                for g, (k, c, sc, info) in zip(singles, dist.merge_counts_many(tabs)):
+                for g, (k, c, sc, info) in zip(singles, dist.merge_counts_many(tabs, key_sorted)):
                     g.table = (k, c, sc[2])  # the sum of the per-rank maxima bounds the max count
                     g.nulls, g.valid_rows = sc[0], sc[1]
                     g.any_rank_strings = sc[3] > 0

@@ -59,8 +59,20 @@ from nvtabular_amd import dist as _dist
 before = dict(_dist.STATS)
 wf32 = nvt.Workflow(["p", "q", "s", "t"] >> ops.Categorify(out_path=os.path.join(tmp, f"i{rank}")))
 got32 = wf32.fit_transform(nvt.Dataset(int32_frame(rank))).to_ddf().compute()
-assert _dist.STATS["sorted_merges"] == before["sorted_merges"] + 1, _dist.STATS
+# key-sorted lists (range / sort path) + short unsorted ones: groups travel in key order and the
+# owners merge sorted runs (no sort of the received rows)
+assert _dist.STATS["ordered_exchanges"] == before["ordered_exchanges"] + 1, _dist.STATS
+assert _dist.STATS["sorted_merges"] == before["sorted_merges"], _dist.STATS
 assert _dist.STATS["packed_exchanges"] == before["packed_exchanges"] + 1, _dist.STATS
+# the unordered exchange (cursor scatter, owner merge by sorting) stays the fallback: same labels
+_dist.ORDERED_EXCHANGE = False
+before = dict(_dist.STATS)
+wf32u = nvt.Workflow(["p", "q", "s", "t"] >> ops.Categorify(out_path=os.path.join(tmp, f"iu{rank}")))
+got32u = wf32u.fit_transform(nvt.Dataset(int32_frame(rank))).to_ddf().compute()
+assert _dist.STATS["sorted_merges"] == before["sorted_merges"] + 1, _dist.STATS
+_dist.ORDERED_EXCHANGE = True
+for c in ("p", "q", "s", "t"):
+    np.testing.assert_array_equal(got32u[c].to_numpy(), got32[c].to_numpy(), err_msg="unordered " + c)
 # fewer partitions than ranks: a parquet dataset of ONE row group -- rank 1 decodes nothing and
 # passes empty tables into the exchange (they used to be int64 empties that switched that rank
 # alone to the two-word wire format: mismatched byte counts in the all-to-all)

@@ -72,3 +72,22 @@ for j in range(ncol):
     for r in range(G):
         dst[r * ncol + j] = (j * G + r) * seg
 T("exchange_unpack", lambda: K.exchange_unpack(every[: goff[-1]], goff, dst, goff[-1]))
+
+print("---- ordered exchange (key-sorted lists: slices in key order, owners merge sorted runs) ----")
+from nvtabular_amd import dist as D
+starts_d = starts.to(dev).view(G, ncol)
+first_row = (torch.cumsum(mat, 0) - mat).contiguous()
+T("ExchangeBatch.pack_ordered", lambda: xb.pack_ordered(los, widths, G, starts_d, first_row))
+# what an owner receives: per column G key-ordered runs of ~n / G entries with interleaved keys
+pieces, roff = [], [0]
+for src in range(G):
+    for k, c in cols:
+        pieces.append((c[src::G] << 32) | (k[src::G].to(torch.int64) & 0xFFFFFFFF))
+        roff.append(roff[-1] + int(pieces[-1].numel()))
+recv_o = torch.cat(pieces)
+T("_merge_sorted_runs (unpack + merge tree + class hist + pack)", lambda: D._merge_sorted_runs(recv_o, roff, G, ncol))
+T("  of which exchange_unpack", lambda: K.exchange_unpack(recv_o, roff, [roff[s] for s in range(G * ncol)], roff[-1]))
+ka, ca = K.exchange_unpack(recv_o, roff, [roff[s] for s in range(G * ncol)], roff[-1])
+lists = [[(ka[roff[src * ncol + j]:roff[src * ncol + j + 1]], ca[roff[src * ncol + j]:roff[src * ncol + j + 1]])
+          for src in range(G)] for j in range(ncol)]
+T("  of which merge_sorted_tree", lambda: K.merge_sorted_tree(lists))
