@@ -538,15 +538,32 @@ def merge_counts_many(tables, sorted_by_key=None):
                                 xb is not None, own_hist)
 
 
+SMALL_MERGE_MAX = 1 << 16  # received entries of a column up to which its runs are merged by sorting
+
+
 def _merge_sorted_runs(recv, off, G, ncol):
     """Owner side of the ordered exchange: the received words lie in (source, column) segments,
     every segment in key order.  -> (True, the merged rows of all columns as one array of words,
-    column after column, their lengths, int64[ncol, 256] class histogram of this owner's share)."""
+    column after column, their lengths, int64[ncol, 256] class histogram of this owner's share).
+    Columns with many entries: merge tree over their G runs (one launch pair per level for all of
+    them); columns with a few thousand entries (half of a Criteo schema, and 7 of every 14 pairs
+    of the tree -- whose cost for them is the Python that describes the pairs): ONE sort of
+    (column << 32 | key) words of all of them + a segmented sum."""
     from . import kernels as K
 
     dev = recv.device
-    dst, runs, at = [0] * (G * ncol), [[] for _ in range(ncol)], 0
-    for j in range(ncol):
+    tot = [sum(off[src * ncol + j + 1] - off[src * ncol + j] for src in range(G)) for j in range(ncol)]
+    small = [j for j in range(ncol) if 0 < tot[j] <= SMALL_MERGE_MAX]
+    big = [j for j in range(ncol) if tot[j] > SMALL_MERGE_MAX]
+    dst, runs, at = [0] * (G * ncol), {j: [] for j in big}, 0
+    for j in small:      # the small columns first, their runs back to back: one slice holds them all
+        for src in range(G):
+            sgm = src * ncol + j
+            dst[sgm] = at
+            at += off[sgm + 1] - off[sgm]
+    n_small = at
+    at = (at + 3) // 4 * 4
+    for j in big:
         for src in range(G):
             sgm = src * ncol + j
             n = off[sgm + 1] - off[sgm]
@@ -555,7 +572,24 @@ def _merge_sorted_runs(recv, off, G, ncol):
                 runs[j].append((at, n))
             at += (n + 3) // 4 * 4   # every run starts on a 16-byte boundary of both arrays
     keys_all, cnts_all = K.exchange_unpack(recv, off, dst, at)
-    merged = K.merge_sorted_tree([[(keys_all[a:a + n], cnts_all[a:a + n]) for a, n in r] for r in runs])
+    empty = (torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int64, device=dev))
+    merged = [empty] * ncol
+    if big:
+        for j, m in zip(big, K.merge_sorted_tree([[(keys_all[a:a + n], cnts_all[a:a + n]) for a, n in runs[j]]
+                                                  for j in big])):
+            merged[j] = m
+    if small:
+        tags = torch.repeat_interleave(torch.arange(len(small), dtype=torch.int64, device=dev),
+                                       torch.tensor([tot[j] for j in small], dtype=torch.int64, device=dev))
+        words = (keys_all[:n_small].to(torch.int64) + (1 << 31)) | (tags << 32)
+        words, order = torch.sort(words)
+        uniq, inv = torch.unique_consecutive(words, return_inverse=True)
+        sums = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).index_add_(0, inv, cnts_all[:n_small][order])
+        bounds = torch.searchsorted(uniq, torch.arange(len(small) + 1, dtype=torch.int64, device=dev) << 32)
+        bounds = bounds.cpu().tolist()
+        mkeys = ((uniq & 0xFFFFFFFF) - (1 << 31)).to(torch.int32)
+        for i, j in enumerate(small):
+            merged[j] = (mkeys[bounds[i]:bounds[i + 1]], sums[bounds[i]:bounds[i + 1]])
     lens = [int(k.numel()) for k, _ in merged]
     hist32 = torch.zeros(ncol, 256, dtype=torch.int32, device=dev)
     for j, (_, c) in enumerate(merged):

@@ -178,3 +178,30 @@ def test_merge_counts_world2_gloo(world):
         got32 = pd.Series(m[4], index=m[3]).sort_index()
         np.testing.assert_array_equal(got32.index.to_numpy(), exp32.index.to_numpy())
         np.testing.assert_array_equal(got32.to_numpy(), exp32.to_numpy())
+
+
+def test_sort_unsorted_lists_orders_only_the_flagged_lists():
+    """dist._sort_unsorted_lists (sender side of the ordered exchange): lists flagged unsorted come
+    back in key order with their counts, the others untouched; too many entries -> None."""
+    from nvtabular_amd import dist
+
+    rng = np.random.default_rng(3)
+    k0 = torch.tensor(np.sort(rng.choice(10**6, 500, replace=False)) - 500_000, dtype=torch.int32)
+    k1 = torch.tensor(rng.permutation(2000)[:700] - 1000, dtype=torch.int32)
+    k2 = torch.tensor([np.iinfo(np.int32).max, np.iinfo(np.int32).min, 0, -1, 7], dtype=torch.int32)
+    tabs = [(k0, torch.arange(500), [1]), (k1, torch.arange(700) * 3, [2]), (k2, torch.tensor([5, 4, 3, 2, 1]), [3]),
+            (torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int64), [4])]
+    out = dist._sort_unsorted_lists(tabs, [True, False, False, True])
+    assert out[0][0] is k0 and out[3][0] is tabs[3][0]
+    for j in (1, 2):
+        k, c, sc = out[j]
+        order = np.argsort(tabs[j][0].numpy(), kind="stable")
+        np.testing.assert_array_equal(k.numpy(), tabs[j][0].numpy()[order])
+        np.testing.assert_array_equal(c.numpy(), tabs[j][1].numpy()[order])
+        assert k.dtype == torch.int32 and sc == tabs[j][2]
+    old = dist.SMALL_SORT_MAX
+    try:
+        dist.SMALL_SORT_MAX = 100
+        assert dist._sort_unsorted_lists(tabs, [True, False, False, True]) is None
+    finally:
+        dist.SMALL_SORT_MAX = old
