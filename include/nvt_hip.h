@@ -413,6 +413,18 @@ int nvt_count_merge_sorted(const int64_t *rows, uint64_t n, const uint64_t *seg_
  * value, bit for bit numpy's sequence.  One workgroup walks the generator (it is sequential);
  * kfold <= 128. */
 int nvt_fold_mt19937(uint32_t seed, int kfold, uint64_t n, uint8_t *out, void *stream);
+/* Distinct keys of the first n rows of every column, ESTIMATED (HyperLogLog, 4096 registers: 1.6 %
+ * standard error, small counts by linear counting), and the valid rows among them: what steers
+ * the first counting path of a fit that has no cardinality hints (the role of the reference's
+ * `cat_cache` / `tree_width` heuristics around categorify.py:1423-1478: sizing, never results).
+ * out uint64[ncols][2] = {estimate, valid rows} (device).  One launch for all columns. */
+typedef struct nvt_prefix_col {
+  const void *keys;       /* int32 (key_bytes 4) or int64 (8) */
+  const uint8_t *valid;   /* Arrow validity bitmap or NULL */
+  uint64_t n;             /* rows to look at */
+  int key_bytes;
+} nvt_prefix_col;
+int nvt_prefix_distinct(const nvt_prefix_col *cols, int ncols, uint64_t *out, void *stream);
 /* ---- tree merge of KEY-SORTED partial results (multi-partition fit) ------------------------
  * Replaces the concat + re-groupby of _mid_level_groupby (categorify.py:1054-1070) inside the
  * tree of categorify.py:1423-1478 -- and the same tree under join_groupby.py:140-173 /

@@ -118,7 +118,12 @@ SIGNATURES = {
     "nvt_widen_i64": [_vp, _i32, _u64, _vp, _vp],
     "nvt_popcount": [_vp, _u64, _vp, _vp],
     "nvt_fold_mt19937": [_u32, _i32, _u64, _vp, _vp],
+    "nvt_prefix_distinct": [_vp, _i32, _vp, _vp],
 }
+
+
+class PrefixCol(C.Structure):
+    _fields_ = [("keys", _vp), ("valid", _vp), ("n", _u64), ("key_bytes", _i32)]
 
 
 class XCol(C.Structure):
