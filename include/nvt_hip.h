@@ -481,6 +481,9 @@ typedef struct nvt_xcol {
   uint64_t n;
 } nvt_xcol;
 int nvt_exchange_ranges(const nvt_xcol *cols, int ncol, int64_t *rng, void *stream);
+/* the same for KEY-SORTED lists: {-first key, last key, 0} (no pass over the lists; the caller
+ * supplies its own bound of the rows counted) */
+int nvt_exchange_ranges_sorted(const nvt_xcol *cols, int ncol, int64_t *rng, void *stream);
 int nvt_exchange_hist(const nvt_xcol *cols, int ncol, const int64_t *lo, const uint64_t *width, int G,
                       uint64_t *send_mat, void *stream);
 int nvt_exchange_scatter(const nvt_xcol *cols, int ncol, const int64_t *lo, const uint64_t *width, int G,

@@ -106,6 +106,7 @@ SIGNATURES = {
     "nvt_flat_lookup_te": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _i32, _vp, _dbl, _dbl, _vp,
                            _i32, _vp],
     "nvt_exchange_ranges": [_vp, _i32, _vp, _vp],
+    "nvt_exchange_ranges_sorted": [_vp, _i32, _vp, _vp],
     "nvt_exchange_hist": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp],
     "nvt_exchange_scatter": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp, _vp],
     "nvt_exchange_pack_ordered": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp, _vp, _vp],

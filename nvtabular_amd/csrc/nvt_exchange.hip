@@ -112,6 +112,16 @@ __global__ __launch_bounds__(kBlock) void x_ranges_kernel(XBatch b, long long *_
   }
 }
 
+// key-sorted lists: the range is the first and the last key (rows: the caller's bound)
+__global__ void x_ranges_sorted_kernel(XBatch b, long long *__restrict__ rng) {
+  for (int j = threadIdx.x; j < b.ncol; j += blockDim.x) {
+    const uint64_t n = b.pre[j + 1] - b.pre[j];
+    rng[3 * j + 0] = n ? -(long long)b.keys[j][0] : -INT64_MAX;
+    rng[3 * j + 1] = n ? (long long)b.keys[j][n - 1] : -INT64_MAX;
+    rng[3 * j + 2] = 0;
+  }
+}
+
 // SCATTER = false: send_mat[g * ncol + c] += rows of column c owned by rank g.
 // SCATTER = true: `cursor` holds the start of every (owner, column) group in `rows_out` (and is
 // advanced); the order of the rows inside a group is whatever the workgroups make it.
@@ -245,6 +255,16 @@ int nvt_exchange_ranges(const nvt_xcol *cols, int ncol, int64_t *rng, void *stre
   NVT_CHECK_LAUNCH();
   if (b.pre[ncol] == 0) return NVT_OK;
   x_ranges_kernel<<<stream_grid(b.pre[ncol], kXTile, 4), kBlock, 0, s>>>(b, (long long *)rng);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_exchange_ranges_sorted(const nvt_xcol *cols, int ncol, int64_t *rng, void *stream) {
+  NVT_CHECK_ARG(rng, "null out");
+  XBatch b;
+  int rc = fill_batch(b, cols, ncol, nullptr, nullptr, 1);
+  if (rc) return rc;
+  x_ranges_sorted_kernel<<<1, 64, 0, (hipStream_t)stream>>>(b, (long long *)rng);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

@@ -403,13 +403,16 @@ _sort_by_key_fn: Callable = _sort_by_key_default
 _class_hist_fn: Callable = _class_hist_default
 
 
-def merge_counts_many(tables, sorted_by_key=None):
+def merge_counts_many(tables, sorted_by_key=None, rows_bound=None):
     """ONE exchange for all the (key -> count) tables of a fit.
 
     ``sorted_by_key[j]``: the list of column j is in ascending key order without duplicates on
     THIS rank (default: unknown = no).  When every column is (or, for short lists, can cheaply be
     made) key-sorted on every rank, groups travel in key order and the owners merge sorted runs
     (ORDERED_EXCHANGE; the decision rides on the MAX all-reduce of the key ranges).
+    ``rows_bound[j]``: an upper bound of the sum of the counts of column j on this rank (the rows
+    it fitted); with it and sorted lists the key ranges are the first and last keys and no pass
+    over the lists is needed for them.
 
     ``tables`` = [(keys, counts, scalars)] per column, ``scalars`` a list of ints that are
     summed over the ranks (null rows, valid rows, ...).  Every column's rows travel in the
@@ -479,7 +482,11 @@ def merge_counts_many(tables, sorted_by_key=None):
     rng[:, 3] = torch.tensor(wide_local, dtype=torch.int64).to(dev)
     rng[:, 4] = unsorted_local
     if xb is not None:
-        rng[:, :3] = xb.ranges()
+        if unsorted_local == 0 and rows_bound is not None:
+            rng[:, :3] = xb.ranges_sorted()
+            rng[:, 2] = torch.tensor([int(b) for b in rows_bound], dtype=torch.int64).to(dev)
+        else:
+            rng[:, :3] = xb.ranges()
         k64s = None
     else:
         k64s = [k.to(torch.int64) for k, _, _ in tables]

@@ -1894,6 +1894,13 @@ class ExchangeBatch:
               "nvt_exchange_ranges")
         return rng
 
+    def ranges_sorted(self) -> torch.Tensor:
+        """The same for KEY-SORTED lists: (-first key, last key, 0) -- no pass over the lists."""
+        rng = torch.empty((self.ncol, 3), dtype=torch.int64, device=self.dev)
+        check(self.lib.nvt_exchange_ranges_sorted(self.cols, self.ncol, rng.data_ptr(), stream_ptr()),
+              "nvt_exchange_ranges_sorted")
+        return rng
+
     def _owner_args(self, lo, width):
         return ((C.c_int64 * self.ncol)(*[int(v) for v in lo]),
                 (C.c_uint64 * self.ncol)(*[max(1, int(v)) for v in width]))

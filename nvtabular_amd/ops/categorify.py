@@ -443,7 +443,7 @@ class Categorify(StatOperator):
         if dist.world_size() > 1:
             # ONE exchange for every single-vocabulary group of this fit (dist.merge_counts_many)
             singles = [g for g in groups if not g.combo]
-            tabs, key_sorted = [], []
+            tabs, key_sorted, bounds = [], [], []
             for g in singles:
                 # (range / sort path lists and merged partitions are in key order: they travel as
                 # contiguous slices and the owners merge sorted runs)
@@ -461,8 +461,9 @@ class Categorify(StatOperator):
                 # non-collective fast path while the others waited in all_gather_object)
                 has_str = int(any(c_ in g.strings for c_ in g.cols))
                 tabs.append((k, c, [int(g.nulls), int(g.valid_rows), int(mx), has_str]))
+                bounds.append(int(g.valid_rows))   # = the sum of this rank's counts of the group
             if tabs:
-                for g, (k, c, sc, info) in zip(singles, dist.merge_counts_many(tabs, key_sorted)):
+                for g, (k, c, sc, info) in zip(singles, dist.merge_counts_many(tabs, key_sorted, bounds)):
                     g.table = (k, c, sc[2])  # the sum of the per-rank maxima bounds the max count
                     g.nulls, g.valid_rows = sc[0], sc[1]
                     g.any_rank_strings = sc[3] > 0
