@@ -493,6 +493,11 @@ int nvt_exchange_pack_ordered(const nvt_xcol *cols, int ncol, const int64_t *lo,
                               void *stream);
 int nvt_exchange_unpack(const int64_t *words, uint64_t n, const uint64_t *seg_off, const uint64_t *dst_off,
                         int nseg, int32_t *keys_out, int64_t *counts_out, void *stream);
+/* nvt_exchange_unpack with one int32 of payload per word (extra[i] travels with words[i]: the
+ * labels of the distributed vocabulary ordering, nvt_vocab_label_shard) */
+int nvt_exchange_unpack2(const int64_t *words, const int32_t *extra, uint64_t n, const uint64_t *seg_off,
+                         const uint64_t *dst_off, int nseg, int32_t *keys_out, int64_t *counts_out,
+                         int32_t *extra_out, void *stream);
 /* key -> position in an ascending int32 key list (the group ids of nvt_sgb_regroup) through
  * a flat range table laid out from the list in one pass (no inserts): replaces
  * nvt_gb_index_build + nvt_gb_lookup for such groups (join_groupby.py:198-203,
@@ -631,6 +636,12 @@ typedef struct nvt_vocab_col {
    * and, in word NVT_FLAT_AUX_MAXDISP, the longest displacement of an entry from its home slot
    * (large: the keys cluster in their range, build an ordinary table with nvt_encode_build_*) */
   uint64_t flat_slots;
+  /* with a key-sorted source: the 0-based position of every source entry in the vocabulary order
+   * (int32[n]; multi-GPU fits label their shards on the owners, nvt_vocab_label_shard).  cls_hist
+   * / n_big are then ignored: (keys, counts) are filled by one scatter and the table (flat, or
+   * hashed when flat_slots == 0) is built from the labels -- no ordering pass.  sort_tmp:
+   * nvt_vocab_order_tmp_bytes(n, 0) bytes. */
+  const int32_t *src_labels;
 } nvt_vocab_col;
 #define NVT_FLAT_AUX_WORDS (NVT_RANGE_AUX_LO + 16)
 #define NVT_FLAT_AUX_MAXDISP (NVT_RANGE_AUX_LO + 8)
@@ -638,6 +649,20 @@ typedef struct nvt_vocab_col {
                                                           key is null (0: none, such rows miss); set
                                                           by the caller after nvt_flat_index_build */
 int nvt_vocab_order_tmp_bytes(uint64_t n, uint64_t n_big, uint64_t *bytes);
+/* One rank's SHARD (a key range) of a key-sorted (key, count) list that is ordered "count
+ * descending, key ascending" as a whole (categorify.py:1300,1316): label_of[i] = the 0-based
+ * position of entry i in the order of the UNION for entries with count < 255, -1 for the others,
+ * which are written out compacted in key order (big_keys / big_counts / big_src = their positions
+ * in the shard; the caller gathers all ranks' and sorts them exactly).  class_base_diff
+ * uint32[256], indexed by class c = min(count, 255): with base(c) = (entries of the union in
+ * classes 255 .. c + 1) + (entries of class c on the ranks in front of this one), the value at c is
+ * base(c - 1) - base(c) modulo 2^32 for 2 <= c <= 254, base(254) at 255, anything at 1 (the kernel's
+ * exclusive prefix over the classes 255, 254, ... reproduces the bases).  tmp:
+ * nvt_vocab_order_tmp_bytes(n, 0) bytes; big_* hold as many entries as the shard has with count >=
+ * 255. */
+int nvt_vocab_label_shard(const int32_t *keys, const int64_t *counts, uint64_t n, const uint32_t *class_base_diff,
+                          void *tmp, int32_t *label_of, int32_t *big_keys, int64_t *big_counts,
+                          int32_t *big_src, void *stream);
 /* hist[c] = entries with min(counts[i], 255) == c, for a key-sorted list that did not come from
  * the range path (multi-GPU: gathered owner shards); hist[255] = n_big */
 int nvt_class_hist(const int64_t *counts, uint64_t n, uint32_t *hist, void *stream);

@@ -120,6 +120,8 @@ SIGNATURES = {
     "nvt_popcount": [_vp, _u64, _vp, _vp],
     "nvt_fold_mt19937": [_u32, _i32, _u64, _vp, _vp],
     "nvt_prefix_distinct": [_vp, _i32, _vp, _vp],
+    "nvt_vocab_label_shard": [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nvt_exchange_unpack2": [_vp, _vp, _u64, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
 }
 
 
@@ -156,7 +158,7 @@ class VocabCol(C.Structure):
                 ("first_label", _i64), ("table", _vp), ("capacity", _u64),
                 ("sentinel_label", _vp), ("ready_event", _vp), ("src_keys", _vp),
                 ("src_counts", _vp), ("cls_hist", _vp), ("n_big", _u64), ("range_aux", _vp),
-                ("range_nb_log2", C.c_int32), ("flat_slots", C.c_uint64)]
+                ("range_nb_log2", C.c_int32), ("flat_slots", C.c_uint64), ("src_labels", _vp)]
 
 
 class MergeCol(C.Structure):

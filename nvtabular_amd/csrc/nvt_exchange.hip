@@ -220,6 +220,29 @@ __global__ __launch_bounds__(kBlock) void x_unpack_kernel(const int64_t *__restr
   }
 }
 
+// the same with a second payload: one int32 per word (labels of the distributed ordering)
+__global__ __launch_bounds__(kBlock) void x_unpack2_kernel(const int64_t *__restrict__ words,
+                                                           const int32_t *__restrict__ extra, uint64_t n,
+                                                           const uint64_t *__restrict__ seg_off,
+                                                           const uint64_t *__restrict__ dst_off, int nseg,
+                                                           int32_t *__restrict__ keys_out,
+                                                           int64_t *__restrict__ cnts_out,
+                                                           int32_t *__restrict__ extra_out) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    int lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seg_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint64_t d = dst_off[lo] + (i - seg_off[lo]);
+    const int64_t w = words[i];
+    keys_out[d] = (int32_t)(uint32_t)(uint64_t)w;
+    cnts_out[d] = w >> 32;
+    extra_out[d] = extra[i];
+  }
+}
+
 static int fill_batch(XBatch &b, const nvt_xcol *cols, int ncol, const int64_t *lo, const uint64_t *width,
                       int G) {
   NVT_CHECK_ARG(cols && ncol >= 1 && ncol <= kXMaxCols, "1..64 columns");
@@ -326,6 +349,20 @@ int nvt_exchange_unpack(const int64_t *words, uint64_t n, const uint64_t *seg_of
   NVT_PROF("exchange_unpack", n * 20ull, s);
   x_unpack_kernel<<<stream_grid(n, kBlock * 4), kBlock, 0, s>>>(words, n, seg_off, dst_off, nseg, keys_out,
                                                              counts_out);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_exchange_unpack2(const int64_t *words, const int32_t *extra, uint64_t n, const uint64_t *seg_off,
+                         const uint64_t *dst_off, int nseg, int32_t *keys_out, int64_t *counts_out,
+                         int32_t *extra_out, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(words && extra && seg_off && dst_off && keys_out && counts_out && extra_out && nseg >= 1,
+                "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("exchange_unpack", n * 28ull, s);
+  x_unpack2_kernel<<<stream_grid(n, kBlock * 4), kBlock, 0, s>>>(words, extra, n, seg_off, dst_off, nseg,
+                                                              keys_out, counts_out, extra_out);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

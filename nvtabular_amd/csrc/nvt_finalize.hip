@@ -56,8 +56,8 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
     NVT_CHECK_ARG(c.key_bytes == 4 || c.key_bytes == 8, "key_bytes must be 4 or 8");
     NVT_CHECK_ARG(c.n <= 1 || (c.keys && c.counts), "null keys/counts");
     NVT_CHECK_ARG(c.table == nullptr || c.sentinel_label, "table without sentinel_label");
-    NVT_CHECK_ARG(c.src_keys == nullptr || (c.key_bytes == 4 && c.src_counts && c.cls_hist),
-                  "key-sorted source: int32 keys with src_counts and cls_hist");
+    NVT_CHECK_ARG(c.src_keys == nullptr || (c.key_bytes == 4 && c.src_counts && (c.cls_hist || c.src_labels)),
+                  "key-sorted source: int32 keys with src_counts and cls_hist (or src_labels)");
     if (c.src_keys == nullptr && vocab_sort_small_eligible(c.key_bytes, c.n, c.max_count))
       small.push_back(i);
     else
@@ -120,6 +120,7 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
     for (int i : big) {
       const nvt_vocab_col &c = cols[i];
       if (c.src_keys == nullptr || c.table == nullptr || c.range_aux == nullptr || c.n == 0) continue;
+      if (c.src_labels != nullptr) continue;   // (labelled already: no ordering pass at all)
       // (tens of millions of entries: the launches are not what such a vocabulary waits for, and
       // on a stream of its own its encode starts while the next one is still being ordered --
       // four 36 M-entry vocabularies: 14.3 ms of GPU time per step against 15.7 in one batch)
@@ -145,6 +146,20 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
     const nvt_vocab_col &c = cols[big[j]];
     if (batched[big[j]]) continue;
     hipStream_t s = fork ? pool->s[j % kSide] : main_s;
+    if (c.src_keys != nullptr && c.src_labels != nullptr) {
+      // key-sorted list with the vocabulary position of every entry (multi-GPU: the owners
+      // labelled their shards): one scatter + the table build
+      NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
+      int rc = vocab_from_labels((const int32_t *)c.src_keys, c.src_counts, c.src_labels, c.n,
+                                 (int32_t *)c.keys, c.counts, c.sort_tmp, c.first_label, c.table,
+                                 c.capacity, c.sentinel_label, c.range_aux, c.flat_slots, s);
+      if (rc) return rc;
+      if (c.ready_event) {
+        NVT_CHECK_HIP(hipEventRecord((hipEvent_t)c.ready_event, s));
+      } else if (s != main_s)
+        need_join = true;
+      continue;
+    }
     if (c.src_keys != nullptr) {
       // key-sorted list of the range path: one stable counting pass orders it and fills the table
       NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");

@@ -77,6 +77,12 @@ struct OrderSortedJob {
   uint64_t flat_slots;
 };
 int vocab_order_sorted_batch(const OrderSortedJob *jobs, int njobs, hipStream_t s);
+// key-sorted list whose entries carry their 0-based position in the vocabulary order (multi-GPU:
+// labelled shard by shard on the owners): ordered arrays + table without any ordering pass
+int vocab_from_labels(const int32_t *src_keys, const int64_t *src_cnts, const int32_t *labels, uint64_t n,
+                      int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label, void *table,
+                      uint64_t capacity, int64_t *sentinel_label, const int32_t *range_aux,
+                      uint64_t flat_slots, hipStream_t s);
 // the deferred part: sort of the n_big leading entries (class 255) + their labels
 struct OrderTail {
   int32_t *keys;

@@ -938,7 +938,10 @@ __device__ __forceinline__ void cls_scatter_body(
     const int32_t *__restrict__ keys, const int64_t *__restrict__ cnts, uint64_t n,
     const unsigned *__restrict__ cls_hist, unsigned *status, unsigned *ticket, int32_t *out_keys,
     int64_t *out_cnts, unsigned long long *table, uint64_t mask, int64_t first_label,
-    int64_t *sentinel_label, int32_t *label_of) {
+    int64_t *sentinel_label, int32_t *label_of, int32_t *big_src = nullptr) {
+  // big_src set (a SHARD of a list that several ranks own, nvt_vocab_label_shard): only the
+  // entries of class 255 are written out (compacted in key order at the front of out_*, with
+  // their positions in the shard), every other entry only gets its label
   constexpr int NW = kS2BS / kWave;
   __shared__ unsigned wcnt[NW][256];
   __shared__ unsigned goff[256];
@@ -1046,6 +1049,7 @@ __device__ __forceinline__ void cls_scatter_body(
       // range table: label of the entry at position i of the key-ordered list (class 255 is
       // labelled after its own sort: -1 here)
       if (label_of != nullptr) label_of[i] = d != 0 ? (int32_t)(first_label + goff[d] + sidx) : -1;
+      if (big_src != nullptr && d == 0) big_src[goff[0] + sidx] = (int32_t)i;
     }
   }
   __syncthreads();
@@ -1056,6 +1060,7 @@ __device__ __forceinline__ void cls_scatter_body(
     if (idx < tile_n) {
       const uint64_t v = stage[idx];
       const unsigned d = cls_digit(v);
+      if (big_src != nullptr && d != 0) continue;
       const unsigned dst = goff[d] + idx;
       const int32_t key = comp_key(v);
       out_keys[dst] = key;
@@ -1569,6 +1574,84 @@ __global__ __launch_bounds__(kBlock) void flat_lookup_te_kernel(
   }
 }
 
+// ---- vocabulary order of a list that is SHARDED over the ranks of a multi-GPU fit -------------
+// Every rank owns a key range of the merged (key, count) list.  The order "count descending, key
+// ascending" of the union is: class 255 (count >= 255, sorted exactly once all ranks' few such
+// entries are gathered), then classes 254 .. 1, each in key order = owner by owner, every owner's
+// entries in the order they have.  The label of an entry of class c < 255 is therefore
+//   (entries of the classes in front of c, all owners) + (entries of class c on the owners in
+//   front of this one) + (its rank among this shard's entries of class c)
+// -- the last term is what the class scatter computes; the first two come in as class bases
+// (`cls_hist` here is the caller's difference array of those bases: the kernel's exclusive prefix
+// over the digits reproduces them modulo 2^32).  Every rank orders 1 / G of the union instead of
+// all of it.
+__global__ __launch_bounds__(kS2BS) void label_shard_kernel(
+    const int32_t *__restrict__ keys, const int64_t *__restrict__ cnts, uint64_t n,
+    const unsigned *__restrict__ cls_hist, unsigned *status, unsigned *ticket, int32_t *big_keys,
+    int64_t *big_cnts, int32_t *label_of, int32_t *big_src) {
+  cls_scatter_body(keys, cnts, n, cls_hist, status, ticket, big_keys, big_cnts, nullptr, 0, 0, nullptr,
+                   label_of, big_src);
+}
+
+// vocabulary + table from a key-sorted list whose entries carry their position in the vocabulary
+// order (labels[i], 0-based): ordered arrays by ONE scatter, absolute labels for the table build
+__global__ __launch_bounds__(kBlock) void label_scatter_kernel(
+    const int32_t *__restrict__ keys, const int64_t *__restrict__ cnts, const int32_t *__restrict__ labels,
+    uint64_t n, int64_t first_label, int32_t *__restrict__ out_keys, int64_t *__restrict__ out_cnts,
+    int32_t *__restrict__ abs_label, int64_t *sentinel_label) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int32_t k = keys[i];
+    const uint32_t l = (uint32_t)labels[i];
+    out_keys[l] = k;
+    out_cnts[l] = cnts[i];
+    abs_label[i] = (int32_t)(first_label + (int64_t)l);
+    if (k == INT32_MIN && sentinel_label != nullptr) *sentinel_label = first_label + (int64_t)l;
+  }
+}
+
+int vocab_from_labels(const int32_t *src_keys, const int64_t *src_cnts, const int32_t *labels, uint64_t n,
+                      int32_t *out_keys, int64_t *out_cnts, void *tmp, int64_t first_label, void *table,
+                      uint64_t capacity, int64_t *sentinel_label, const int32_t *range_aux,
+                      uint64_t flat_slots, hipStream_t s) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(n < (1ull << 30), "at most 2^30-1 vocabulary entries");
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  // same layout as vocab_order_from_sorted with n_big = 0: status | label_of[n] | flat-build status
+  int32_t *abs_label = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(tmp) + pad16(ntiles * 256 * 4 + 64));
+  unsigned long long *fb_status =
+      reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(abs_label) + pad16(n * 4));
+  const bool flat = table != nullptr && range_aux != nullptr && flat_slots > 0;
+  if (table != nullptr) {
+    if (flat) {
+      NVT_CHECK_ARG(flat_slots >= 64 && flat_slots < (1ull << 32), "flat table: 64 .. 2^32-1 slots");
+      NVT_CHECK_ARG(capacity >= flat_slots + n + 64, "flat table: slots + n + 64");
+    }
+    int rc = encode_clear_any(4, table, capacity, sentinel_label, s);  // (also: no sentinel key yet)
+    if (rc) return rc;
+  }
+  NVT_PROF("vocab_order", 0, s);
+  label_scatter_kernel<<<stream_grid(n, kBlock, 8), kBlock, 0, s>>>(src_keys, src_cnts, labels, n, first_label,
+                                                                    out_keys, out_cnts, abs_label,
+                                                                    table != nullptr ? sentinel_label : nullptr);
+  NVT_CHECK_LAUNCH();
+  if (flat) {
+    int32_t *aux = const_cast<int32_t *>(range_aux);
+    flat_params_kernel<<<1, 1, 0, s>>>(src_keys, n, flat_slots, aux);
+    NVT_CHECK_LAUNCH();
+    NVT_CHECK_HIP(hipMemsetAsync(fb_status, 0, ntiles * 8 + 64, s));
+    flat_build_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(src_keys, abs_label, n, aux, fb_status,
+                                                        reinterpret_cast<unsigned *>(fb_status + ntiles),
+                                                        (unsigned long long *)table, capacity);
+    NVT_CHECK_LAUNCH();
+  } else if (table != nullptr) {
+    // an ordinary hashed table: the ordered keys carry the labels first_label + position
+    int rc = encode_insert_any(4, out_keys, n, first_label, table, capacity, sentinel_label, s);
+    if (rc) return rc;
+  }
+  return NVT_OK;
+}
+
 uint64_t vocab_order_tmp_bytes(uint64_t n, uint64_t n_big) {
   const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
   uint64_t sort_bytes = 0;
@@ -1833,6 +1916,25 @@ int nvt_class_hist(const int64_t *counts, uint64_t n, uint32_t *hist, void *stre
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
+int nvt_vocab_label_shard(const int32_t *keys, const int64_t *counts, uint64_t n, const uint32_t *class_base_diff,
+                          void *tmp, int32_t *label_of, int32_t *big_keys, int64_t *big_counts,
+                          int32_t *big_src, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(keys && counts && class_base_diff && tmp && label_of && big_keys && big_counts && big_src,
+                "null pointer");
+  NVT_CHECK_ARG(n < (1ull << 30), "at most 2^30-1 entries");
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
+  unsigned *status = reinterpret_cast<unsigned *>(tmp);
+  NVT_PROF("vocab_order", 0, s);
+  NVT_CHECK_HIP(hipMemsetAsync(status, 0, ntiles * 256 * 4 + 64, s));
+  label_shard_kernel<<<(unsigned)ntiles, kS2BS, 0, s>>>(keys, counts, n, class_base_diff, status,
+                                                       status + ntiles * 256, big_keys, big_counts, label_of,
+                                                       big_src);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
 int nvt_vocab_order_tmp_bytes(uint64_t n, uint64_t n_big, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes, "null out pointer");
   *bytes = vocab_order_tmp_bytes(n, n_big);

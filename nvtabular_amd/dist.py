@@ -346,6 +346,14 @@ HIP_EXCHANGE = True  # batched nvt_exchange_* launches around the collectives (i
 # (nvt_merge_sorted_many) instead of sorting everything it received; lists that are not sorted
 # (the LDS-resident counting paths: a few thousand keys) are sorted on the sender first.
 ORDERED_EXCHANGE = True
+# ... and the owners also ORDER their shards: with the class histograms of every owner each rank
+# computes the vocabulary positions ("count descending, key ascending") of its own entries
+# (nvt_vocab_label_shard; the few entries with count >= 255 are gathered and sorted exactly by
+# everyone) and the labels travel with the merged rows.  Every rank then lays its tables out from
+# (key, label) without ordering the union -- the part of a fit that every rank used to repeat for
+# ALL G shards (~6 ms of kernels for the 8-rank union of the Criteo vocabularies).
+DISTRIBUTED_ORDER = True
+STATS["distributed_orders"] = 0
 SMALL_SORT_MAX = 1 << 18   # entries of unsorted lists one tagged sort may take on the sender
 STATS["ordered_exchanges"] = 0
 
@@ -527,10 +535,10 @@ def merge_counts_many(tables, sorted_by_key=None, rows_bound=None):
     off = torch.zeros(G * ncol + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
     off = off.tolist()
-    sorted_merge, results, packed_all, own_hist = None, {}, None, None
+    sorted_merge, results, packed_all, own_hist, own_labels = None, {}, None, None, None
     if ordered:
         # G key-ordered runs per column: merge tree (one launch pair per level for all columns)
-        sorted_merge, packed_all, packed_len, own_hist = _merge_sorted_runs(recv, off, G, ncol)
+        sorted_merge, packed_all, packed_len, own_hist, own_labels = _merge_sorted_runs(recv, off, G, ncol)
         STATS["ordered_exchanges"] += 1
     elif packed and recv.is_cuda and _merge_counts_many_fn is _hip_merge_counts_many and MERGE_BY_SORTING:
         from . import kernels as K
@@ -542,7 +550,7 @@ def merge_counts_many(tables, sorted_by_key=None, rows_bound=None):
             STATS["sorted_merges"] += 1
     return _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted_merge,
                                 packed_all, packed_len if sorted_merge is not None else None,
-                                xb is not None, own_hist)
+                                xb is not None, own_hist, own_labels)
 
 
 SMALL_MERGE_MAX = 1 << 16  # received entries of a column up to which its runs are merged by sorting
@@ -603,14 +611,78 @@ def _merge_sorted_runs(recv, off, G, ncol):
         if lens[j]:
             K.class_hist(c, out=hist32[j])
     hist = hist32.to(torch.int64) & 0xFFFFFFFF
+    labels = _label_own_shards(merged, lens, hist32, G, ncol, dev) if DISTRIBUTED_ORDER else None
     if sum(lens) == 0:
-        return True, torch.empty(0, dtype=torch.int64, device=dev), lens, hist
+        return True, torch.empty(0, dtype=torch.int64, device=dev), lens, hist, labels
     xm = K.ExchangeBatch([(k, c) for k, c in merged])
     starts = torch.zeros(1, ncol, dtype=torch.int64)
     starts[0, 1:] = torch.cumsum(torch.tensor(lens[:-1], dtype=torch.int64), 0)
     packed_all = xm.pack_ordered([0] * ncol, [1] * ncol, 1, starts.to(dev),
                                  torch.zeros(1, ncol, dtype=torch.int64, device=dev))
-    return True, packed_all, lens, hist
+    return True, packed_all, lens, hist, labels
+
+
+def _label_own_shards(merged, lens, hist32, G, ncol, dev):
+    """Vocabulary positions (0-based, "count descending, key ascending" over the UNION of all
+    owners' shards) of this owner's entries: int32, column after column like the packed rows.
+    Collectives: one all-gather of the class histograms [ncol, 256], one all-gather(v) of the
+    entries with count >= 255 (sizes known from the histograms)."""
+    from . import kernels as K
+
+    r = rank()
+    hists = torch.stack([h.cpu() for h in _all_gather_same(hist32.to(torch.int64))]) & 0xFFFFFFFF  # [G, ncol, 256]
+    H, P = hists.sum(0), hists[:r].sum(0)
+    # base(c), c = 1 .. 254: entries of the union in classes 255 .. c + 1, + class c on the owners in front
+    Hc = H[:, 1:255]
+    above = torch.flip(torch.cumsum(torch.flip(Hc, [1]), 1), [1]) - Hc
+    base = H[:, 255:256] + above + P[:, 1:255]                      # [ncol, 254], column c - 1
+    diff = torch.zeros(ncol, 256, dtype=torch.int64)
+    diff[:, 255] = base[:, 253]
+    diff[:, 2:255] = base[:, 0:253] - base[:, 1:254]                # base(c - 1) - base(c)
+    diff &= 0xFFFFFFFF
+    diff = torch.where(diff >= (1 << 31), diff - (1 << 32), diff).to(torch.int32).to(dev)
+    nb = hists[:, :, 255]                                           # [G, ncol] entries with count >= 255
+    lab = torch.empty(sum(lens), dtype=torch.int32, device=dev)
+    at, big, lab_off = 0, [], []
+    for j, (k, c) in enumerate(merged):
+        lab_off.append(at)
+        big.append(K.label_shard(k, c, diff[j], int(nb[r, j]), lab[at:at + lens[j]]) if lens[j] else None)
+        at += lens[j]
+    STATS["distributed_orders"] += 1
+    tot_big = int(nb.sum())
+    if tot_big == 0:
+        return lab
+    mine = [(b[1] << 32) | (b[0].to(torch.int64) & 0xFFFFFFFF) for b in big if b is not None and b[0].numel()]
+    mine = torch.cat(mine) if mine else torch.empty(0, dtype=torch.int64, device=dev)
+    everything = _all_gather_v(mine, sizes=[int(v) for v in nb.sum(1).tolist()])
+    # rank-major, column-minor segments -> column-major (owners in rank order = key order)
+    seg = nb.reshape(-1)
+    goff = torch.zeros(G * ncol + 1, dtype=torch.int64)
+    goff[1:] = torch.cumsum(seg, 0)
+    col_tot = nb.sum(0)
+    col_start = torch.zeros(ncol + 1, dtype=torch.int64)
+    col_start[1:] = torch.cumsum(col_tot, 0)
+    dst = (col_start[:-1].unsqueeze(0) + (torch.cumsum(nb, 0) - nb)).reshape(-1)   # [G, ncol] -> flat
+    bkeys, bcnts = K.exchange_unpack(everything, goff.tolist(), dst.tolist(), tot_big)
+    del bkeys
+    tags = torch.repeat_interleave(torch.arange(ncol, dtype=torch.int64, device=dev), col_tot.to(dev))
+    comp = (tags << 31) | ((1 << 31) - 1 - bcnts)    # (column, count descending); stable: key ascending
+    _, order = torch.sort(comp, stable=True)
+    pos = torch.arange(tot_big, dtype=torch.int64, device=dev) - col_start[:-1].to(dev)[tags]
+    lab_cm = torch.empty(tot_big, dtype=torch.int32, device=dev)
+    lab_cm[order] = pos.to(torch.int32)              # tags are non-decreasing: tags[order] == tags
+    # this owner's entries of column j sit at dst[r, j] .. + nb[r, j] of the column-major array
+    idx, val = [], []
+    for j, b in enumerate(big):
+        n_own = int(nb[r, j])
+        if b is None or n_own == 0:
+            continue
+        d0 = int(dst[r * ncol + j])
+        idx.append(b[2].to(torch.int64) + lab_off[j])
+        val.append(lab_cm[d0:d0 + n_own])
+    if idx:
+        lab[torch.cat(idx)] = torch.cat(val)
+    return lab
 
 
 def _exchange_rows_hip(xb, rng_h, G, ncol, ordered=False):
@@ -685,7 +757,7 @@ def _exchange_rows_torch(tables, k64s, lens, rng_h, G, ncol, dev, packed):
 
 
 def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted_merge, packed_all,
-                         packed_len, device_path, own_hist=None):
+                         packed_len, device_path, own_hist=None, own_labels=None):
     """Owner-side merge (when the sorted merge did not already do it), all-gather of the merged
     shards, the per-column lists every rank ends with."""
     results = {}
@@ -720,6 +792,9 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
         mlen = torch.tensor([m.shape[0] for m in merged], dtype=torch.int64, device=dev)
     all_len = torch.stack(_all_gather_same(mlen)).cpu()  # [G, ncol]
     everything = _all_gather_v(mine, sizes=all_len.sum(1).tolist())
+    labels_everything = None
+    if own_labels is not None:   # the vocabulary positions travel with the rows (4 bytes per entry)
+        labels_everything = _all_gather_v(own_labels, sizes=all_len.sum(1).tolist())
     _mark("all_gather")
     goff = torch.zeros(G * ncol + 1, dtype=torch.int64)
     goff[1:] = torch.cumsum(all_len.reshape(-1), 0)
@@ -737,7 +812,7 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
         hist_all = scal[:, nsc:].to(torch.int32).contiguous()
     scal = scal.cpu().tolist()
     out = []
-    unpacked = None
+    unpacked = label_of = None
     if device_path and packed and everything.is_cuda and everything.numel():
         # column-major in ONE launch: segment (r, j) lands behind the shares of the ranks < r of
         # column j, so every column is one contiguous key-ordered list
@@ -753,9 +828,16 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
             for r in range(G):
                 dst[r * ncol + j] = at
                 at += int(all_len[r, j])
-        keys_all, cnts_all = K.exchange_unpack(everything, goff, dst, col_start[-1])
+        labs_all = None
+        if labels_everything is not None:
+            keys_all, cnts_all, labs_all = K.exchange_unpack(everything, goff, dst, col_start[-1],
+                                                             extra=labels_everything)
+        else:
+            keys_all, cnts_all = K.exchange_unpack(everything, goff, dst, col_start[-1])
         unpacked = [(keys_all[col_start[j]:col_start[j] + col_tot[j]],
                      cnts_all[col_start[j]:col_start[j] + col_tot[j]]) for j in range(ncol)]
+        if labs_all is not None:
+            label_of = [labs_all[col_start[j]:col_start[j] + col_tot[j]] for j in range(ncol)]
     for j in range(ncol):
         if unpacked is not None:
             keys, counts = unpacked[j]
@@ -770,6 +852,8 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
             if hist_all is not None:
                 info = dict(sorted_by_key=True, cls_hist=hist_all[j], n_big=int(scal[j][nsc + 255]) & 0xFFFFFFFF,
                             merged=True)
+                if label_of is not None:
+                    info["label_of"] = label_of[j]
             else:
                 info = dict(sorted_by_key=True, cls_hist=_class_hist_fn(counts), n_big=None, merged=True)
         out.append((keys, counts, scal[j][: len(tables[j][2])], info))

@@ -1015,6 +1015,30 @@ def class_hist(counts: torch.Tensor, out: Optional[torch.Tensor] = None) -> torc
     return hist
 
 
+def label_shard(keys: torch.Tensor, counts: torch.Tensor, class_base_diff: torch.Tensor, n_big: int,
+                label_of: torch.Tensor):
+    """nvt_vocab_label_shard: positions in the vocabulary order of the UNION for this rank's shard
+    of a key-sorted (key, count) list (entries with count < 255; the others -1), written into
+    ``label_of`` (int32[n]); returns (big_keys, big_counts, big_src) of the n_big entries with
+    count >= 255, compacted in key order (big_src: their positions in the shard)."""
+    n = int(keys.numel())
+    dev = keys.device
+    bk = torch.empty(max(n_big, 1), dtype=torch.int32, device=dev)
+    bc = torch.empty(max(n_big, 1), dtype=torch.int64, device=dev)
+    bs = torch.empty(max(n_big, 1), dtype=torch.int32, device=dev)
+    if n == 0:
+        return bk[:0], bc[:0], bs[:0]
+    lib = _lib.load()
+    out = C.c_uint64()
+    check(lib.nvt_vocab_order_tmp_bytes(n, 0, C.byref(out)), "nvt_vocab_order_tmp_bytes")
+    tmp = torch.empty(out.value + 16, dtype=torch.uint8, device=dev)
+    check(lib.nvt_vocab_label_shard(keys.contiguous().data_ptr(), counts.contiguous().data_ptr(), n,
+                                    class_base_diff.data_ptr(), tmp.data_ptr(), label_of.data_ptr(),
+                                    bk.data_ptr(), bc.data_ptr(), bs.data_ptr(), stream_ptr()),
+          "nvt_vocab_label_shard")
+    return bk[:n_big], bc[:n_big], bs[:n_big]
+
+
 def sort_by_key(keys: torch.Tensor, counts: torch.Tensor):
     """(keys, counts) ordered by key ascending (radix sort of nvt_order_rows)."""
     n = int(keys.numel())
@@ -1178,11 +1202,18 @@ class EncodeTable:
             d.ready_event = None
 
     def _fill_vocab_desc_sorted(self, d, counts, max_count, src):
-        src_keys, src_counts, cls_hist, n_big = src
+        src_keys, src_counts, cls_hist, n_big = src[:4]
+        # (a fifth element: int32 positions of the source entries in the vocabulary order -- a
+        # multi-GPU fit whose owners labelled their shards; no ordering pass is run then)
+        labels = src[4] if len(src) > 4 else None
+        if labels is not None:
+            assert labels.dtype == torch.int32 and labels.numel() == src_keys.numel()
+            labels, n_big = labels.contiguous(), 0
+            STATS["labelled_vocabularies"] = STATS.get("labelled_vocabularies", 0) + 1
         n = self.n_vocab
         assert self.key_bytes == 4 and src_keys.numel() == n and counts.numel() == n
         self._counts = counts
-        self._src = (src_keys, src_counts, cls_hist)  # read on an internal stream until `ready`
+        self._src = (src_keys, src_counts, cls_hist, labels)  # read on an internal stream until `ready`
         d.keys = self._vk.data_ptr()
         d.counts = counts.data_ptr()
         d.n = n
@@ -1191,7 +1222,8 @@ class EncodeTable:
         d.unique_keys = 1
         d.src_keys = src_keys.data_ptr()
         d.src_counts = src_counts.data_ptr()
-        d.cls_hist = cls_hist.data_ptr()
+        d.cls_hist = ptr(cls_hist)
+        d.src_labels = ptr(labels)
         d.n_big = int(n_big)
         d.range_aux = ptr(self.range_aux)
         d.range_nb_log2 = int(self.range_bits)
@@ -1939,9 +1971,10 @@ class ExchangeBatch:
         return rows
 
 
-def exchange_unpack(words: torch.Tensor, seg_off: List[int], dst_off: List[int], out_n: int):
+def exchange_unpack(words: torch.Tensor, seg_off: List[int], dst_off: List[int], out_n: int, extra=None):
     """Gathered (count << 32 | key) words in segments -> (keys int32[out_n], counts int64[out_n]),
-    segment s copied to position dst_off[s] (column-major: every column one contiguous list)."""
+    segment s copied to position dst_off[s] (column-major: every column one contiguous list).
+    extra: one int32 per word that travels along -> a third result (int32[out_n])."""
     _lib.require_gpu()
     n = int(words.numel())
     dev = words.device
@@ -1949,6 +1982,14 @@ def exchange_unpack(words: torch.Tensor, seg_off: List[int], dst_off: List[int],
     cnts = torch.empty(out_n, dtype=torch.int64, device=dev)
     so = torch.tensor(seg_off, dtype=torch.int64, device=dev)
     do = torch.tensor(dst_off, dtype=torch.int64, device=dev)
+    if extra is not None:
+        assert extra.dtype == torch.int32 and int(extra.numel()) == n
+        xo = torch.empty(out_n, dtype=torch.int32, device=dev)
+        check(_lib.load().nvt_exchange_unpack2(words.contiguous().data_ptr(), extra.contiguous().data_ptr(), n,
+                                               so.data_ptr(), do.data_ptr(), len(seg_off) - 1, keys.data_ptr(),
+                                               cnts.data_ptr(), xo.data_ptr(), stream_ptr()),
+              "nvt_exchange_unpack2")
+        return keys, cnts, xo
     check(_lib.load().nvt_exchange_unpack(words.contiguous().data_ptr(), n, so.data_ptr(), do.data_ptr(),
                                           len(seg_off) - 1, keys.data_ptr(), cnts.data_ptr(),
                                           stream_ptr()), "nvt_exchange_unpack")

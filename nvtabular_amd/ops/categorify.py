@@ -557,7 +557,7 @@ class Categorify(StatOperator):
                 # key-sorted list of the range path: ordered out of place in ONE counting pass
                 # (write_uniques' two sort_values, categorify.py:1300,1316)
                 info = g.sorted[1]
-                src = (keys, counts, info["cls_hist"], info["n_big"])
+                src = (keys, counts, info["cls_hist"], info["n_big"], info.get("label_of"))
                 keys, counts = torch.empty_like(keys), torch.empty_like(counts)
                 if info.get("range_table") is not None:
                     rtab = (info["range_table"], info["range_aux"], info["range_bits"])

@@ -56,14 +56,32 @@ def int32_frame(r, n=300_000):
 
 from nvtabular_amd import dist as _dist
 
+from nvtabular_amd import kernels as _K
+
 before = dict(_dist.STATS)
-wf32 = nvt.Workflow(["p", "q", "s", "t"] >> ops.Categorify(out_path=os.path.join(tmp, f"i{rank}")))
+labelled0 = _K.STATS.get("labelled_vocabularies", 0)
+cat32 = ops.Categorify(out_path=os.path.join(tmp, f"i{rank}"))
+wf32 = nvt.Workflow(["p", "q", "s", "t"] >> cat32)
 got32 = wf32.fit_transform(nvt.Dataset(int32_frame(rank))).to_ddf().compute()
+# all four vocabularies were laid out from the labels the owners computed (no ordering pass)
+assert _K.STATS.get("labelled_vocabularies", 0) == labelled0 + 4, _K.STATS
 # key-sorted lists (range / sort path) + short unsorted ones: groups travel in key order and the
 # owners merge sorted runs (no sort of the received rows)
 assert _dist.STATS["ordered_exchanges"] == before["ordered_exchanges"] + 1, _dist.STATS
 assert _dist.STATS["sorted_merges"] == before["sorted_merges"], _dist.STATS
 assert _dist.STATS["packed_exchanges"] == before["packed_exchanges"] + 1, _dist.STATS
+assert _dist.STATS["distributed_orders"] == before["distributed_orders"] + 1, _dist.STATS
+# the owners ordered their shards (labels travelled with the rows); every rank ordering the whole
+# union itself must give the same labels
+_dist.DISTRIBUTED_ORDER = False
+before = dict(_dist.STATS)
+wf32r = nvt.Workflow(["p", "q", "s", "t"] >> ops.Categorify(out_path=os.path.join(tmp, f"ir{rank}")))
+got32r = wf32r.fit_transform(nvt.Dataset(int32_frame(rank))).to_ddf().compute()
+assert _dist.STATS["distributed_orders"] == before["distributed_orders"], _dist.STATS
+assert _dist.STATS["ordered_exchanges"] == before["ordered_exchanges"] + 1, _dist.STATS
+_dist.DISTRIBUTED_ORDER = True
+for c in ("p", "q", "s", "t"):
+    np.testing.assert_array_equal(got32r[c].to_numpy(), got32[c].to_numpy(), err_msg="replicated order " + c)
 # the unordered exchange (cursor scatter, owner merge by sorting) stays the fallback: same labels
 _dist.ORDERED_EXCHANGE = False
 before = dict(_dist.STATS)
@@ -116,8 +134,18 @@ for c in got_s.columns:
         np.testing.assert_allclose(got_s[c].to_numpy().astype("float64"), exp_s[c].to_numpy().astype("float64"),
                                    rtol=1e-6, atol=1e-7, err_msg=c)
 full32 = pd.concat([int32_frame(r) for r in range(world)], ignore_index=True)
-ref32 = nvt.Workflow(["p", "q", "s", "t"] >> ops.Categorify(out_path=os.path.join(tmp, f"refi{rank}")))
+refcat32 = ops.Categorify(out_path=os.path.join(tmp, f"refi{rank}"))
+ref32 = nvt.Workflow(["p", "q", "s", "t"] >> refcat32)
 exp32 = ref32.fit_transform(nvt.Dataset(full32)).to_ddf().compute()
+# the vocabulary files (values in label order with their sizes): laid out from the owners' labels
+# on the multi-rank side, ordered by the single process on the other
+cat32.flush_artifacts(force=True)
+refcat32.flush_artifacts(force=True)
+for c in ("p", "q", "s", "t"):
+    va = pd.read_parquet(os.path.join(tmp, f"i{rank}", "categories", f"unique.{c}.parquet"))
+    vb = pd.read_parquet(os.path.join(tmp, f"refi{rank}", "categories", f"unique.{c}.parquet"))
+    np.testing.assert_array_equal(va[c].to_numpy(), vb[c].to_numpy(), err_msg="vocabulary " + c)
+    np.testing.assert_array_equal(va[f"{c}_size"].to_numpy(), vb[f"{c}_size"].to_numpy(), err_msg="sizes " + c)
 lo32 = sum(len(int32_frame(r)) for r in range(rank))
 exp32 = exp32.iloc[lo32: lo32 + len(got32)].reset_index(drop=True)
 for c in ("p", "q", "s", "t"):

@@ -85,9 +85,58 @@ for src in range(G):
         pieces.append((c[src::G] << 32) | (k[src::G].to(torch.int64) & 0xFFFFFFFF))
         roff.append(roff[-1] + int(pieces[-1].numel()))
 recv_o = torch.cat(pieces)
+D.DISTRIBUTED_ORDER = False   # (its collectives need a process group; the labelling is timed below)
 T("_merge_sorted_runs (unpack + merge tree + class hist + pack)", lambda: D._merge_sorted_runs(recv_o, roff, G, ncol))
 T("  of which exchange_unpack", lambda: K.exchange_unpack(recv_o, roff, [roff[s] for s in range(G * ncol)], roff[-1]))
 ka, ca = K.exchange_unpack(recv_o, roff, [roff[s] for s in range(G * ncol)], roff[-1])
 lists = [[(ka[roff[src * ncol + j]:roff[src * ncol + j + 1]], ca[roff[src * ncol + j]:roff[src * ncol + j + 1]])
           for src in range(G)] for j in range(ncol)]
 T("  of which merge_sorted_tree", lambda: K.merge_sorted_tree(lists))
+
+# the owner's labelling of its merged shards (nvt_vocab_label_shard per column; ~1 / G of the union)
+shard = K.merge_sorted_tree(lists)
+diffs = torch.zeros(ncol, 256, dtype=torch.int32, device=dev)
+labs = [torch.empty(int(k.numel()), dtype=torch.int32, device=dev) for k, _ in shard]
+nbig = [int((c >= 255).sum()) for _, c in shard]
+T("label_shard x26 (owner's shards)", lambda: [K.label_shard(k, c, diffs[j], nbig[j], labs[j])
+                                               for j, (k, c) in enumerate(shard) if k.numel()])
+
+print("---- what every rank does with the gathered union (8 ranks: ~2.7 x the per-rank lists) ----")
+from nvtabular_amd import _lib
+ulens = [min(int(n * 2.7), 40_000_000) if n > 100_000 else n for n in lens]
+g2 = torch.Generator(device=dev).manual_seed(2)
+ucols = []
+for n in ulens:
+    k = torch.randint(-2**31, 2**31 - 1, (int(n * 1.05) + 8,), device=dev, dtype=torch.int64, generator=g2).to(torch.int32)
+    k = torch.unique(k)[:n]                                      # key-sorted, duplicate-free
+    c = torch.randint(1, 400, (int(k.numel()),), device=dev, dtype=torch.int64, generator=g2)
+    ucols.append((k, c))
+torch.cuda.synchronize()
+print("union entries", sum(int(k.numel()) for k, _ in ucols))
+
+
+def finalize(with_labels):
+    descs = (_lib.VocabCol * len(ucols))()
+    keep = []
+    for d, (k, c) in zip(descs, ucols):
+        n = int(k.numel())
+        hist = K.class_hist(c)
+        labels = None
+        if with_labels:
+            labels = torch.arange(n, dtype=torch.int32, device=dev)   # (any permutation: timing only)
+        ok, oc = torch.empty_like(k), torch.empty_like(c)
+        tab = K.EncodeTable(ok, 3, unique=True, defer_build=True, range_table=None, flat=True)
+        tab.fill_vocab_desc(d, oc, 400, src=(k, c, hist, int((c >= 255).sum()), labels))
+        keep.append((tab, ok, oc, hist, labels))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K.check(_lib.load().nvt_vocab_finalize_many(descs, len(ucols), K.stream_ptr()), "finalize")
+    for tab, *_ in keep:
+        tab.wait_ready()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0)
+
+
+for mode in (False, True, False, True):
+    print(f"nvt_vocab_finalize_many, {'labels from the owners' if mode else 'ordering pass on every rank'}: "
+          f"{finalize(mode):8.3f} ms", flush=True)
