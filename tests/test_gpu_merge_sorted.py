@@ -170,3 +170,92 @@ def test_categorify_multi_partition_keeps_the_sorted_paths(tmp_path, nparts, mon
         b = pd.read_parquet(paths[c])
         np.testing.assert_array_equal(a[c].to_numpy(), b[c].to_numpy())
         np.testing.assert_array_equal(a[f"{c}_size"].to_numpy(), b[f"{c}_size"].to_numpy())
+
+
+def test_label_shard_orders_the_union_shard_by_shard():
+    """nvt_vocab_label_shard: three key-range shards of one key-sorted (key, count) list are
+    labelled independently (class bases of the union + the entries of each class on the shards in
+    front); together with an exact sort of the entries with count >= 255 the labels equal the
+    positions of numpy's "count descending, key ascending" order of the whole list."""
+    from nvtabular_amd import kernels as K
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    n = 700_000
+    keys = np.sort(rng.choice(2**31 - 1, n, replace=False).astype(np.int64) - 2**30).astype(np.int32)
+    keys[0] = np.iinfo(np.int32).min    # the sentinel key is an entry like any other here
+    counts = np.minimum(rng.zipf(1.3, n), 5_000_000).astype(np.int64)   # most 1 .. 3, some >= 255
+    order = np.lexsort((keys, -counts))
+    expect = np.empty(n, dtype=np.int64)
+    expect[order] = np.arange(n)
+    cuts = [0, 250_000, 250_001, n]     # (a one-entry shard in the middle)
+    cls = np.minimum(counts, 255)
+    hists = np.stack([np.bincount(cls[a:b], minlength=256) for a, b in zip(cuts[:-1], cuts[1:])])
+    H = hists.sum(0)
+    labels = np.full(n, -2, dtype=np.int64)
+    big_rows = []
+    for r, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        P = hists[:r].sum(0)
+        base = np.zeros(256, dtype=np.int64)      # base(c), c = 1 .. 254
+        for c in range(1, 255):
+            base[c] = H[255] + H[c + 1:255].sum() + P[c]
+        diff = np.zeros(256, dtype=np.int64)
+        diff[255] = base[254]
+        diff[2:255] = base[1:254] - base[2:255]
+        diff = (diff & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        k = torch.tensor(keys[a:b], device=dev)
+        c = torch.tensor(counts[a:b], device=dev)
+        lab = torch.empty(b - a, dtype=torch.int32, device=dev)
+        bk, bc, bs = K.label_shard(k, c, torch.tensor(diff, device=dev), int(hists[r, 255]), lab)
+        lab = lab.cpu().numpy().astype(np.int64)
+        small = counts[a:b] < 255
+        np.testing.assert_array_equal(lab[small], expect[a:b][small])
+        assert (lab[~small] == -1).all()
+        src = bs.cpu().numpy()
+        np.testing.assert_array_equal(src, np.nonzero(~small)[0])           # compacted in key order
+        np.testing.assert_array_equal(bk.cpu().numpy(), keys[a:b][src])
+        np.testing.assert_array_equal(bc.cpu().numpy(), counts[a:b][src])
+        labels[a:b] = lab
+        big_rows.append(a + src)
+    big = np.concatenate(big_rows)                                          # key order (shards in rank order)
+    pos = np.argsort(-counts[big], kind="stable")                            # count descending, key ascending
+    labels[big[pos]] = np.arange(len(big))
+    np.testing.assert_array_equal(labels, expect)
+
+
+def test_vocabulary_and_table_from_labels(tmp_path):
+    """nvt_vocab_col.src_labels: vocabulary + flat table of a key-sorted list whose entries carry
+    their position in the vocabulary order == the ordering pass on the same list (ordered keys,
+    counts, and the labels the table answers with)."""
+    from nvtabular_amd import _lib
+    from nvtabular_amd import kernels as K
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(9)
+    n = 300_000
+    keys = np.sort(rng.choice(2**31 - 1, n, replace=False).astype(np.int64) - 2**30).astype(np.int32)
+    keys[0] = np.iinfo(np.int32).min
+    counts = np.minimum(rng.zipf(1.4, n), 10**7).astype(np.int64)
+    order = np.lexsort((keys, -counts))
+    pos = np.empty(n, dtype=np.int32)
+    pos[order] = np.arange(n, dtype=np.int32)
+    k, c = torch.tensor(keys, device=dev), torch.tensor(counts, device=dev)
+    res = []
+    for labels in (None, torch.tensor(pos, device=dev)):
+        descs = (_lib.VocabCol * 1)()
+        ok, oc = torch.empty_like(k), torch.empty_like(c)
+        tab = K.EncodeTable(ok, 3, unique=True, defer_build=True, range_table=None, flat=True)
+        tab.fill_vocab_desc(descs[0], oc, int(counts.max()), src=(k, c, K.class_hist(c), int((counts >= 255).sum()), labels))
+        K.check(_lib.load().nvt_vocab_finalize_many(descs, 1, K.stream_ptr()), "nvt_vocab_finalize_many")
+        tab.wait_ready()
+        probe = torch.tensor(np.concatenate([keys[::7], np.array([5, -7, 2**31 - 1], dtype=np.int32)]), device=dev)
+        lab = tab.encode(probe, None, 1, 2)      # null label 1, out-of-vocabulary label 2
+        res.append((ok.cpu().numpy(), oc.cpu().numpy(), lab.cpu().numpy()))
+    np.testing.assert_array_equal(res[0][0], keys[order])
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    np.testing.assert_array_equal(res[1][1], res[0][1])
+    np.testing.assert_array_equal(res[1][2], res[0][2])
+    exp_lab = np.concatenate([3 + pos[::7].astype(np.int64), np.array([2, 2, 2])])
+    hit = np.isin(np.array([5, -7, 2**31 - 1], dtype=np.int32), keys)
+    exp_lab[-3:][hit] = res[0][2][-3:][hit]
+    np.testing.assert_array_equal(res[1][2], exp_lab)
