@@ -630,7 +630,7 @@ def _label_own_shards(merged, lens, hist32, G, ncol, dev):
     from . import kernels as K
 
     r = rank()
-    hists = torch.stack([h.cpu() for h in _all_gather_same(hist32.to(torch.int64))]) & 0xFFFFFFFF  # [G, ncol, 256]
+    hists = torch.stack(_all_gather_same(hist32.to(torch.int64))).cpu() & 0xFFFFFFFF   # [G, ncol, 256]
     H, P = hists.sum(0), hists[:r].sum(0)
     # base(c), c = 1 .. 254: entries of the union in classes 255 .. c + 1, + class c on the owners in front
     Hc = H[:, 1:255]
