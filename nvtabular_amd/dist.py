@@ -438,7 +438,10 @@ def merge_counts_many(tables, sorted_by_key=None, rows_bound=None):
         all-gather(v) of the merged rows          (1)
         all-reduce of the scalars                 (1)
 
-    -- 6 collectives per fit however many columns there are.  Because owners hold key RANGES
+    -- 6 collectives per fit however many columns there are.  (Ordered exchange + distributed
+    ordering, the default for key-sorted int32 lists on the GPU: the lengths and the scalars ride
+    on ONE all-gather of the owners' class histograms, then an all-gather(v) of the entries with
+    count >= 255, of the merged rows and of their labels: 7 collectives.)  Because owners hold key RANGES
     and order their shards by key, the gathered list of a column is key-sorted on every rank:
     the vocabulary order (count desc, key asc) is then ONE stable counting pass per rank
     (nvt_vocab_col.src_keys) instead of a 7-pass radix sort of the union on every rank -- the
@@ -535,10 +538,11 @@ def merge_counts_many(tables, sorted_by_key=None, rows_bound=None):
     off = torch.zeros(G * ncol + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(recv_h.reshape(-1), 0)  # received layout: source-major, column-minor
     off = off.tolist()
-    sorted_merge, results, packed_all, own_hist, own_labels = None, {}, None, None, None
+    sorted_merge, results, packed_all, own_hist, own_labels, pre = None, {}, None, None, None, None
     if ordered:
         # G key-ordered runs per column: merge tree (one launch pair per level for all columns)
-        sorted_merge, packed_all, packed_len, own_hist, own_labels = _merge_sorted_runs(recv, off, G, ncol)
+        sorted_merge, packed_all, packed_len, own_hist, own_labels, pre = _merge_sorted_runs(
+            recv, off, G, ncol, [sc for _, _, sc in tables])
         STATS["ordered_exchanges"] += 1
     elif packed and recv.is_cuda and _merge_counts_many_fn is _hip_merge_counts_many and MERGE_BY_SORTING:
         from . import kernels as K
@@ -550,13 +554,13 @@ def merge_counts_many(tables, sorted_by_key=None, rows_bound=None):
             STATS["sorted_merges"] += 1
     return _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted_merge,
                                 packed_all, packed_len if sorted_merge is not None else None,
-                                xb is not None, own_hist, own_labels)
+                                xb is not None, own_hist, own_labels, pre)
 
 
 SMALL_MERGE_MAX = 1 << 16  # received entries of a column up to which its runs are merged by sorting
 
 
-def _merge_sorted_runs(recv, off, G, ncol):
+def _merge_sorted_runs(recv, off, G, ncol, scalars=None):
     """Owner side of the ordered exchange: the received words lie in (source, column) segments,
     every segment in key order.  -> (True, the merged rows of all columns as one array of words,
     column after column, their lengths, int64[ncol, 256] class histogram of this owner's share).
@@ -611,26 +615,40 @@ def _merge_sorted_runs(recv, off, G, ncol):
         if lens[j]:
             K.class_hist(c, out=hist32[j])
     hist = hist32.to(torch.int64) & 0xFFFFFFFF
-    labels = _label_own_shards(merged, lens, hist32, G, ncol, dev) if DISTRIBUTED_ORDER else None
+    labels, pre = (_label_own_shards(merged, lens, hist32, G, ncol, dev, scalars)
+                   if DISTRIBUTED_ORDER else (None, None))
     if sum(lens) == 0:
-        return True, torch.empty(0, dtype=torch.int64, device=dev), lens, hist, labels
+        return True, torch.empty(0, dtype=torch.int64, device=dev), lens, hist, labels, pre
     xm = K.ExchangeBatch([(k, c) for k, c in merged])
     starts = torch.zeros(1, ncol, dtype=torch.int64)
     starts[0, 1:] = torch.cumsum(torch.tensor(lens[:-1], dtype=torch.int64), 0)
     packed_all = xm.pack_ordered([0] * ncol, [1] * ncol, 1, starts.to(dev),
                                  torch.zeros(1, ncol, dtype=torch.int64, device=dev))
-    return True, packed_all, lens, hist, labels
+    return True, packed_all, lens, hist, labels, pre
 
 
-def _label_own_shards(merged, lens, hist32, G, ncol, dev):
+def _label_own_shards(merged, lens, hist32, G, ncol, dev, scalars=None):
     """Vocabulary positions (0-based, "count descending, key ascending" over the UNION of all
     owners' shards) of this owner's entries: int32, column after column like the packed rows.
-    Collectives: one all-gather of the class histograms [ncol, 256], one all-gather(v) of the
-    entries with count >= 255 (sizes known from the histograms)."""
+    Collectives: one all-gather of the class histograms [ncol, 256] -- the merged lengths and
+    the caller's scalars ride on it, so the replicate step needs neither its own length all-gather
+    nor the scalar all-reduce --, one all-gather(v) of the entries with count >= 255 (sizes known
+    from the histograms).  Returns (labels, dict(all_len [G, ncol], scal [ncol][nsc] summed over
+    the ranks, hist [ncol, 256] of the union))."""
     from . import kernels as K
 
     r = rank()
-    hists = torch.stack(_all_gather_same(hist32.to(torch.int64))).cpu() & 0xFFFFFFFF   # [G, ncol, 256]
+    nsc = max([len(sc) for sc in scalars] + [0]) if scalars is not None else 0
+    meta = torch.zeros(ncol, 257 + nsc, dtype=torch.int64)
+    meta[:, 256] = torch.tensor(lens, dtype=torch.int64)
+    if nsc:
+        meta[:, 257:] = torch.tensor([list(sc) + [0] * (nsc - len(sc)) for sc in scalars], dtype=torch.int64)
+    meta = meta.to(dev)
+    meta[:, :256] = hist32.to(torch.int64) & 0xFFFFFFFF
+    gathered = torch.stack(_all_gather_same(meta)).cpu()          # [G, ncol, 257 + nsc]
+    hists = gathered[:, :, :256]
+    pre = dict(all_len=gathered[:, :, 256].contiguous(), scal=gathered[:, :, 257:].sum(0).tolist(),
+               hist=hists.sum(0), nsc=nsc)
     H, P = hists.sum(0), hists[:r].sum(0)
     # base(c), c = 1 .. 254: entries of the union in classes 255 .. c + 1, + class c on the owners in front
     Hc = H[:, 1:255]
@@ -651,7 +669,7 @@ def _label_own_shards(merged, lens, hist32, G, ncol, dev):
     STATS["distributed_orders"] += 1
     tot_big = int(nb.sum())
     if tot_big == 0:
-        return lab
+        return lab, pre
     mine = [(b[1] << 32) | (b[0].to(torch.int64) & 0xFFFFFFFF) for b in big if b is not None and b[0].numel()]
     mine = torch.cat(mine) if mine else torch.empty(0, dtype=torch.int64, device=dev)
     everything = _all_gather_v(mine, sizes=[int(v) for v in nb.sum(1).tolist()])
@@ -682,7 +700,7 @@ def _label_own_shards(merged, lens, hist32, G, ncol, dev):
         val.append(lab_cm[d0:d0 + n_own])
     if idx:
         lab[torch.cat(idx)] = torch.cat(val)
-    return lab
+    return lab, pre
 
 
 def _exchange_rows_hip(xb, rng_h, G, ncol, ordered=False):
@@ -757,7 +775,7 @@ def _exchange_rows_torch(tables, k64s, lens, rng_h, G, ncol, dev, packed):
 
 
 def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted_merge, packed_all,
-                         packed_len, device_path, own_hist=None, own_labels=None):
+                         packed_len, device_path, own_hist=None, own_labels=None, pre=None):
     """Owner-side merge (when the sorted merge did not already do it), all-gather of the merged
     shards, the per-column lists every rank ends with."""
     results = {}
@@ -790,7 +808,9 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
     else:
         mine = torch.cat(merged)
         mlen = torch.tensor([m.shape[0] for m in merged], dtype=torch.int64, device=dev)
-    all_len = torch.stack(_all_gather_same(mlen)).cpu()  # [G, ncol]
+    # (pre: the lengths, the summed scalars and the histogram of the union came with the owners'
+    # histograms already, _label_own_shards)
+    all_len = pre["all_len"] if pre is not None else torch.stack(_all_gather_same(mlen)).cpu()  # [G, ncol]
     everything = _all_gather_v(mine, sizes=all_len.sum(1).tolist())
     labels_everything = None
     if own_labels is not None:   # the vocabulary positions travel with the rows (4 bytes per entry)
@@ -803,14 +823,19 @@ def _merge_and_replicate(tables, dtypes, G, ncol, dev, packed, recv, off, sorted
     scal = torch.tensor([list(sc) + [0] * (nsc - len(sc)) for _, _, sc in tables],
                         dtype=torch.int64, device=dev)
     hist_all = None
-    if own_hist is not None:
-        # the class histogram of a merged list = the sum of the owners' (every key has ONE owner):
-        # each rank histograms 1 / G of the union and the sums ride on this all-reduce
-        scal = torch.cat([scal, own_hist], dim=1)
-    _all_reduce(scal)
-    if own_hist is not None:
-        hist_all = scal[:, nsc:].to(torch.int32).contiguous()
-    scal = scal.cpu().tolist()
+    if pre is not None:
+        hist_all = pre["hist"].to(torch.int32).to(dev)
+        hh = pre["hist"].tolist()
+        scal = [list(a) + [0] * (nsc - pre["nsc"]) + list(b) for a, b in zip(pre["scal"], hh)]
+    else:
+        if own_hist is not None:
+            # the class histogram of a merged list = the sum of the owners' (every key has ONE
+            # owner): each rank histograms 1 / G of the union and the sums ride on this all-reduce
+            scal = torch.cat([scal, own_hist], dim=1)
+        _all_reduce(scal)
+        if own_hist is not None:
+            hist_all = scal[:, nsc:].to(torch.int32).contiguous()
+        scal = scal.cpu().tolist()
     out = []
     unpacked = label_of = None
     if device_path and packed and everything.is_cuda and everything.numel():
