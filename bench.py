@@ -1388,6 +1388,7 @@ def main():
 
         if _d.TIMING:  # NVT_DIST_TIMING=1 (diagnostic, device-synchronised sections of the merge)
             result["dist_timing_ms_total"] = {k: round(1e3 * v, 2) for k, v in _d.TIMING.items()}
+        if world > 1:  # which exchange / ordering paths the fits of this run took (rank 0's counters)
             result["dist_stats"] = dict(_d.STATS)
         print(json.dumps(result))
     if world > 1:
