@@ -39,8 +39,12 @@
 #include "nvt_range.hpp"
 #include "nvt_scan.hpp"
 
+// key vectors per lane and batch of lds_stage_kernel.  4 was best while the misses of a batch were
+// walked key position by key position; with every lane walking its own misses a batch costs as
+// many probe chains as its unluckiest lane has misses, and 8 keys per lane beat 16 (p0 0.774 ->
+// 0.738 ms, p6 0.505 -> 0.465 for the 13 LDS-resident Criteo columns; 1 vector: 0.765 / 0.464)
 #ifndef NVT_STAGE_U
-#define NVT_STAGE_U 4
+#define NVT_STAGE_U 2
 #endif
 #ifndef NVT_SMALL_DIV
 #define NVT_SMALL_DIV 4
