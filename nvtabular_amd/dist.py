@@ -627,6 +627,25 @@ def _merge_sorted_runs(recv, off, G, ncol, scalars=None):
     return True, packed_all, lens, hist, labels, pre
 
 
+def _class_base_diff(hists: torch.Tensor, r: int) -> torch.Tensor:
+    """The class bases owner r hands to nvt_vocab_label_shard, as the difference array the kernel
+    integrates.  hists int64[G, ncol, 256] = every owner's histogram of min(count, 255).
+    base(c), c = 1 .. 254 = entries of the union in the classes 255 .. c + 1 (they come first in
+    "count descending") + entries of class c on the owners in front of r (key order = owner
+    order).  The kernel takes an exclusive prefix over the classes 255, 254, ...: the value at
+    255 is base(254), at c (2 <= c <= 254) it is base(c - 1) - base(c) modulo 2^32.  -> int32[ncol, 256]"""
+    ncol = hists.shape[1]
+    H, P = hists.sum(0), hists[:r].sum(0)
+    Hc = H[:, 1:255]
+    above = torch.flip(torch.cumsum(torch.flip(Hc, [1]), 1), [1]) - Hc
+    base = H[:, 255:256] + above + P[:, 1:255]                      # [ncol, 254], column c - 1
+    diff = torch.zeros(ncol, 256, dtype=torch.int64)
+    diff[:, 255] = base[:, 253]
+    diff[:, 2:255] = base[:, 0:253] - base[:, 1:254]                # base(c - 1) - base(c)
+    diff &= 0xFFFFFFFF
+    return torch.where(diff >= (1 << 31), diff - (1 << 32), diff).to(torch.int32)
+
+
 def _label_own_shards(merged, lens, hist32, G, ncol, dev, scalars=None):
     """Vocabulary positions (0-based, "count descending, key ascending" over the UNION of all
     owners' shards) of this owner's entries: int32, column after column like the packed rows.
@@ -649,16 +668,7 @@ def _label_own_shards(merged, lens, hist32, G, ncol, dev, scalars=None):
     hists = gathered[:, :, :256]
     pre = dict(all_len=gathered[:, :, 256].contiguous(), scal=gathered[:, :, 257:].sum(0).tolist(),
                hist=hists.sum(0), nsc=nsc)
-    H, P = hists.sum(0), hists[:r].sum(0)
-    # base(c), c = 1 .. 254: entries of the union in classes 255 .. c + 1, + class c on the owners in front
-    Hc = H[:, 1:255]
-    above = torch.flip(torch.cumsum(torch.flip(Hc, [1]), 1), [1]) - Hc
-    base = H[:, 255:256] + above + P[:, 1:255]                      # [ncol, 254], column c - 1
-    diff = torch.zeros(ncol, 256, dtype=torch.int64)
-    diff[:, 255] = base[:, 253]
-    diff[:, 2:255] = base[:, 0:253] - base[:, 1:254]                # base(c - 1) - base(c)
-    diff &= 0xFFFFFFFF
-    diff = torch.where(diff >= (1 << 31), diff - (1 << 32), diff).to(torch.int32).to(dev)
+    diff = _class_base_diff(hists, r).to(dev)
     nb = hists[:, :, 255]                                           # [G, ncol] entries with count >= 255
     lab = torch.empty(sum(lens), dtype=torch.int32, device=dev)
     at, big, lab_off = 0, [], []

@@ -205,3 +205,30 @@ def test_sort_unsorted_lists_orders_only_the_flagged_lists():
         assert dist._sort_unsorted_lists(tabs, [True, False, False, True]) is None
     finally:
         dist.SMALL_SORT_MAX = old
+
+
+def test_class_base_diff_integrates_to_the_label_bases():
+    """dist._class_base_diff: the kernel's exclusive prefix over the classes 255, 254, ... of the
+    difference array (modulo 2^32) must give, for every owner and class c < 255, the number of
+    entries of the union that precede the owner's entries of class c in "count descending, key
+    ascending" order."""
+    from nvtabular_amd import dist
+
+    rng = np.random.default_rng(12)
+    G, ncol = 5, 3
+    hists = rng.integers(0, 50_000, (G, ncol, 256)).astype(np.int64)
+    hists[:, 1, 200:] = 0                       # a column without large counts
+    hists[2] = 0                                # an owner without entries
+    hists[:, :, 0] = 0                          # (no entry has count 0)
+    H = hists.sum(0)
+    for r in range(G):
+        diff = dist._class_base_diff(torch.tensor(hists), r).numpy().view(np.uint32).astype(np.uint64)
+        P = hists[:r].sum(0)
+        for j in range(ncol):
+            # what cls_scatter_body computes: digit d = 255 - class, exclusive prefix over d
+            v = diff[j][::-1]                   # v[d] = diff[255 - d]
+            cbase = (np.cumsum(v) - v) % (1 << 32)
+            for c in (1, 2, 3, 100, 199, 253, 254):
+                want = H[j, 255] + H[j, c + 1:255].sum() + P[j, c]
+                assert int(cbase[255 - c]) == int(want) % (1 << 32), (r, j, c)
+            assert int(cbase[0]) == 0           # class 255 is compacted from position 0
