@@ -405,6 +405,7 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
         hs[u] = map.slot(kk[u]);
         cur[u] = lkeys[hs[u]];
       }
+#ifdef NVT_RP_SEQ_INSERT
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         if (kk[u] == kEmpty) continue;
@@ -413,6 +414,60 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
         else
           insert_from(kk[u], 1u, hs[u]);
       }
+#else
+      // Keys that are not at home yet walk their probe chains.  Key position by key position the
+      // wave paid the LONGEST chain of its 64 lanes at each of the GB positions (a chain is a
+      // loop of dependent LDS round trips); every lane walks ITS keys one after the other
+      // instead, one probe per lane and step: as many steps as the unluckiest lane needs in all.
+      unsigned todo = 0;
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        if (kk[u] == kEmpty) continue;
+        if (cur[u] == kk[u])
+          atomicAdd(&lcnt[hs[u]], 1u);  // already at home: fire and forget
+        else
+          todo |= 1u << u;
+      }
+      int32_t wkey = 0;
+      uint32_t ws = 0;
+      int wp = 0;
+      bool walking = false;
+      while (true) {
+        if (!walking && todo) {
+          const int u = (int)__ffs((int)todo) - 1;
+          wkey = kk[0];
+          ws = hs[0];
+#pragma unroll
+          for (int q = 1; q < GB; ++q) {
+            wkey = u == q ? kk[q] : wkey;
+            ws = u == q ? hs[q] : ws;
+          }
+          todo &= todo - 1u;
+          wp = 0;
+          walking = true;
+        }
+        if (!__any(walking)) break;
+        if (walking) {
+          if (ws >= (uint32_t)NSL || wp >= kRpProbe) {
+            failed = true;
+            walking = false;
+          } else {
+            int32_t c = lkeys[ws];
+            if (c == kEmpty) {
+              c = atomicCAS(&lkeys[ws], kEmpty, wkey);
+              if (c == kEmpty) c = wkey;
+            }
+            if (c == wkey) {
+              atomicAdd(&lcnt[ws], 1u);
+              walking = false;
+            } else {
+              ++ws;
+              ++wp;
+            }
+          }
+        }
+      }
+#endif
     }
   }
   NVT_TM();
