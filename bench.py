@@ -975,18 +975,27 @@ def collective_selfcheck(device, backend):
             td.all_to_all_single(out, send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
         return out
 
-    def gather_v(dev, group):
-        mine = torch.arange(3 + 2 * r, dtype=torch.int64, device=dev) + 100 * r
+    def gather_v(dev, group, dtype=torch.int64):
+        mine = torch.arange(3 + 2 * r, dtype=dtype, device=dev) + 100 * r
         sizes = [3 + 2 * p for p in range(G)]
         if dev.type == "cpu":
-            pad = torch.zeros(max(sizes), dtype=torch.int64)
+            pad = torch.zeros(max(sizes), dtype=dtype)
             pad[: mine.numel()] = mine
             bufs = [torch.empty_like(pad) for _ in range(G)]
             td.all_gather(bufs, pad, group=group)
             return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
-        out = torch.empty(sum(sizes), dtype=torch.int64, device=dev)
+        out = torch.empty(sum(sizes), dtype=dtype, device=dev)
         td.all_to_all_single(out, mine.repeat(G), output_split_sizes=sizes, input_split_sizes=[mine.numel()] * G)
         return out
+
+    def gather_v_i32(dev, group):   # (the labels of the distributed ordering travel as int32)
+        return gather_v(dev, group, torch.int32)
+
+    def gather_equal(dev, group):   # (class histograms + lengths + scalars: one int64 matrix per rank)
+        mine = (torch.arange(15, dtype=torch.int64).reshape(3, 5) * (r + 1)).to(dev)
+        bufs = [torch.empty_like(mine) for _ in range(G)]
+        td.all_gather(bufs, mine, group=group)
+        return torch.stack(bufs)
 
     def reduce_max(dev, group):
         t = torch.tensor([r, -r, 7], dtype=torch.int64, device=dev)
@@ -1000,6 +1009,7 @@ def collective_selfcheck(device, backend):
 
     try:
         for name, fn in (("all_to_all_single(uneven)", a2a_uneven), ("all_gather_v", gather_v),
+                         ("all_gather_v(int32)", gather_v_i32), ("all_gather(equal shapes)", gather_equal),
                          ("all_reduce(MAX)", reduce_max), ("all_reduce(SUM)", reduce_sum)):
             a, b = both(fn)
             same = a.shape == b.shape and bool(torch.equal(a, b))

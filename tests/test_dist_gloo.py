@@ -232,3 +232,39 @@ def test_class_base_diff_integrates_to_the_label_bases():
                 want = H[j, 255] + H[j, c + 1:255].sum() + P[j, c]
                 assert int(cbase[255 - c]) == int(want) % (1 << 32), (r, j, c)
             assert int(cbase[0]) == 0           # class 255 is compacted from position 0
+
+
+def _selfcheck_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as td
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    rep = bench.collective_selfcheck(torch.device("cpu"), "gloo")
+    q.put((rank, rep))
+    td.destroy_process_group()
+
+
+def test_bench_collective_selfcheck_runs_every_form_over_gloo():
+    """bench.collective_selfcheck (the guard in front of a multi-rank run): every collective form
+    dist.py uses -- uneven all_to_all_single, all-gather(v) in int64 and int32, all_gather of equal
+    matrices, MAX / SUM all-reduce -- runs and agrees with its gloo reference on 3 ranks."""
+    world, port = 3, 29731
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_selfcheck_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    reps = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        rep = reps[r]
+        assert rep.get("error") is None, rep
+        assert rep["ok"] and rep["ok_on_every_rank"], rep
+        names = [c["collective"] for c in rep["checks"]]
+        assert "all_gather_v(int32)" in names and "all_gather(equal shapes)" in names
