@@ -933,6 +933,11 @@ def eager_artifacts_step_ms(frame, cat_names, cont_names, tmp, steps=2):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
+# the collective FORMS dist.py relies on, by name (tests assert on this set, not on a count)
+SELFCHECK_COLLECTIVES = ("all_to_all_single(uneven)", "all_gather_v", "all_gather_v(int32)",
+                         "all_gather(equal shapes)", "all_reduce(MAX)", "all_reduce(SUM)")
+
+
 def collective_selfcheck(device, backend):
     """Before anything is timed on more than one rank: the collective FORMS dist.py relies on
     (all_to_all_single with uneven splits, the all-gather(v) written as an all-to-all in which
@@ -1008,9 +1013,9 @@ def collective_selfcheck(device, backend):
         return t
 
     try:
-        for name, fn in (("all_to_all_single(uneven)", a2a_uneven), ("all_gather_v", gather_v),
-                         ("all_gather_v(int32)", gather_v_i32), ("all_gather(equal shapes)", gather_equal),
-                         ("all_reduce(MAX)", reduce_max), ("all_reduce(SUM)", reduce_sum)):
+        forms = (a2a_uneven, gather_v, gather_v_i32, gather_equal, reduce_max, reduce_sum)
+        assert len(forms) == len(SELFCHECK_COLLECTIVES)
+        for name, fn in zip(SELFCHECK_COLLECTIVES, forms):
             a, b = both(fn)
             same = a.shape == b.shape and bool(torch.equal(a, b))
             report["checks"].append({"collective": name, "equal_to_gloo": same})

@@ -216,7 +216,7 @@ class Dataset:
 
     def to_parquet(self, output_path, shuffle=None, out_files_per_proc=None, dtypes=None,
                    cats=None, conts=None, labels=None, preserve_files=False, suffix=".parquet",
-                   num_threads=0, **_):
+                   num_threads=0, compression=None, **_):
         """Write the (transformed) dataset as parquet (merlin.io.Dataset.to_parquet; contract in
         tests/unit/workflow/test_workflow.py:171-187,363-396,444-500 and
         bench/datasets/tools/nvt_etl.py:154-171 of the reference).
@@ -229,6 +229,13 @@ class Dataset:
           output file as a whole (its pieces are held on the host until the end); ``None`` /
           ``False`` keeps the row order.
         * ``dtypes``: {column: dtype} casts applied on the way out.
+        * ``compression``: ``None`` (default) lets fixed-width numeric frames take the hand-written
+          PLAIN writer (uncompressed pages, no dictionary, no column statistics: files are larger
+          than pyarrow's snappy + dictionary output and carry no min / max for predicate
+          pushdown -- the price of writing at tens of GB/s); any codec name (``"snappy"``,
+          ``"zstd"``, ``"none"`` ...) selects pyarrow's writer with that codec, statistics and
+          dictionary pages, as the reference's writer produces.  ``NVT_PLAIN_PARQUET=0`` makes
+          pyarrow the default.
         * writes ``_metadata`` (parquet summary of all row groups), ``_file_list.txt`` and
           ``_metadata.json`` (file stats + cats / conts / labels) next to the data files.
         """
@@ -242,6 +249,7 @@ class Dataset:
         from . import dist
 
         shuffle = Shuffle.coerce(shuffle)
+        pq_kw = {} if compression is None else {"compression": compression}
         os.makedirs(str(output_path), exist_ok=True)
         output_path = str(output_path)
         rank, world = dist.rank(), dist.world_size()
@@ -271,7 +279,8 @@ class Dataset:
                 if w is None:
                     names[j] = fname(j)
                     w = writers[j] = pq.ParquetWriter(os.path.join(output_path, names[j]),
-                                                      table.schema, metadata_collector=collector)
+                                                      table.schema, metadata_collector=collector,
+                                                      **pq_kw)
                 w.write_table(table)
                 rows_in[j] = rows_in.get(j, 0) + table.num_rows
             finally:
@@ -293,7 +302,7 @@ class Dataset:
         parts_iter = iter(self.to_iter(shard=shard))
         first = next(parts_iter, None)
         plain = None
-        if first is not None and PLAIN_PARQUET and _plain_eligible(first, dtypes) and \
+        if first is not None and PLAIN_PARQUET and compression is None and _plain_eligible(first, dtypes) and \
                 not (shuffle == Shuffle.PER_WORKER and k):
             # fixed-width numeric columns: PLAIN pages written straight from pinned column
             # buffers (parquet_plain.py) -- no dictionary pass, no compression, no statistics
@@ -327,7 +336,7 @@ class Dataset:
                 table = table.take(pa.array(rng.permutation(table.num_rows)))
             names[j] = fname(j)
             w = writers[j] = pq.ParquetWriter(os.path.join(output_path, names[j]), table.schema,
-                                              metadata_collector=collector)
+                                              metadata_collector=collector, **pq_kw)
             w.write_table(table)
             rows_in[j] = table.num_rows
         schema = None
@@ -449,6 +458,11 @@ def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
                 w = writers[j] = PlainParquetWriter(
                     os.path.join(output_path, names[j]), [c[0] for c in cols],
                     [c[1].dtype for c in cols], pool=pool)
+            elif w.names != [c[0] for c in cols] or w.dtypes != [c[1].dtype for c in cols]:
+                # (pyarrow's ParquetWriter raises on a schema change too; never cast silently)
+                raise ValueError(
+                    f"to_parquet: partition schema {[(c[0], str(c[1].dtype)) for c in cols]} differs from "
+                    f"the schema {list(zip(w.names, map(str, w.dtypes)))} of {names[j]}")
             # the column writes of this row group go to the pool and are NOT waited for: row
             # groups of other files (other inodes: buffered writes to ONE file serialise on its
             # inode lock, ~10 GB/s) and the next copies proceed meanwhile
@@ -462,66 +476,78 @@ def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
 
         parts = iter(parts)
         i = -1
-        while True:
-            t_in = time.perf_counter()
-            part = next(parts, None)
-            LAST_TIMING["input_s"] += time.perf_counter() - t_in
-            if part is None:
-                break
-            i += 1
-            n = len(part)
-            if shuffle is not None and n > 1:
-                part = part.take_rows(_device_permutation(n, part))
-            cols = []
-            for name, col in part.items():
-                col = col.materialize()
-                data = col.data
-                if dtypes and name in dtypes:
-                    data = data.to(t_of[str(np.dtype(dtypes[name]))])
-                mask = K.unpack_bitmap(col.valid, n) if col.valid is not None else None
-                cols.append((name, data, mask))
-            on_gpu = any(c[1].is_cuda for c in cols)
-            if on_gpu and copy_s is None:
-                copy_s = torch.cuda.Stream()
-            if on_gpu:
-                copy_s.wait_stream(torch.cuda.current_stream())
-            pieces = [(i, 0, n)] if k is None else [
-                (j, (n * j) // k, (n * (j + 1)) // k) for j in range(k)]
-            for j, a, b in pieces:
-                if b <= a and j in touched:
-                    continue
-                touched.add(j)
-                for s0 in (range(a, b, PLAIN_ROW_GROUP) if b > a else [a]):
-                    s1 = min(b, s0 + PLAIN_ROW_GROUP)
-                    rows = s1 - s0
-                    host, keep = [], []
-                    t_st = time.perf_counter()
-                    ctx = torch.cuda.stream(copy_s) if on_gpu else _nullcontext()
-                    with ctx:
-                        for name, data, mask in cols:
-                            vals, bm = data[s0:s1], None
-                            if mask is not None:
-                                m = mask[s0:s1]
-                                vals = vals[m]
-                                bm = pack_bitmap_device(m) if m.is_cuda else torch.from_numpy(
-                                    np.packbits(m.numpy(), bitorder="little"))
-                            hv = _to_host(vals)
-                            hb = _to_host(bm) if bm is not None else None
-                            keep.append((vals, bm))
-                            host.append((name, hv.numpy(), hb.numpy() if hb is not None else None))
-                        event = None
-                        if on_gpu:
-                            event = torch.cuda.Event()
-                            event.record(copy_s)
-                    LAST_TIMING["stage_s"] += time.perf_counter() - t_st
-                    staged.append((j, host, rows, event, keep))
-                    flush_one()
-        while staged:
-            flush_one()
-        t_cl = time.perf_counter()
-        for w in writers.values():
-            w.close()
-        LAST_TIMING["close_s"] = time.perf_counter() - t_cl
+        try:
+            while True:
+                t_in = time.perf_counter()
+                part = next(parts, None)
+                LAST_TIMING["input_s"] += time.perf_counter() - t_in
+                if part is None:
+                    break
+                i += 1
+                n = len(part)
+                if shuffle is not None and n > 1:
+                    part = part.take_rows(_device_permutation(n, part))
+                cols = []
+                for name, col in part.items():
+                    col = col.materialize()
+                    data = col.data
+                    if dtypes and name in dtypes:
+                        data = data.to(t_of[str(np.dtype(dtypes[name]))])
+                    mask = K.unpack_bitmap(col.valid, n) if col.valid is not None else None
+                    cols.append((name, data, mask))
+                on_gpu = any(c[1].is_cuda for c in cols)
+                if on_gpu and copy_s is None:
+                    copy_s = torch.cuda.Stream()
+                if on_gpu:
+                    copy_s.wait_stream(torch.cuda.current_stream())
+                pieces = [(i, 0, n)] if k is None else [
+                    (j, (n * j) // k, (n * (j + 1)) // k) for j in range(k)]
+                for j, a, b in pieces:
+                    if b <= a and j in touched:
+                        continue
+                    touched.add(j)
+                    for s0 in (range(a, b, PLAIN_ROW_GROUP) if b > a else [a]):
+                        s1 = min(b, s0 + PLAIN_ROW_GROUP)
+                        rows = s1 - s0
+                        host, keep = [], []
+                        t_st = time.perf_counter()
+                        ctx = torch.cuda.stream(copy_s) if on_gpu else _nullcontext()
+                        with ctx:
+                            for name, data, mask in cols:
+                                vals, bm = data[s0:s1], None
+                                if mask is not None:
+                                    m = mask[s0:s1]
+                                    vals = vals[m]
+                                    bm = pack_bitmap_device(m) if m.is_cuda else torch.from_numpy(
+                                        np.packbits(m.numpy(), bitorder="little"))
+                                hv = _to_host(vals)
+                                hb = _to_host(bm) if bm is not None else None
+                                keep.append((vals, bm))
+                                host.append((name, hv.numpy(), hb.numpy() if hb is not None else None))
+                            event = None
+                            if on_gpu:
+                                event = torch.cuda.Event()
+                                event.record(copy_s)
+                        LAST_TIMING["stage_s"] += time.perf_counter() - t_st
+                        staged.append((j, host, rows, event, keep))
+                        flush_one()
+            while staged:
+                flush_one()
+            t_cl = time.perf_counter()
+            for w in writers.values():
+                w.close()
+            LAST_TIMING["close_s"] = time.perf_counter() - t_cl
+        except BaseException:
+            # no fds leaked, no truncated footer-less part files left behind
+            for futs, _, _ in inflight:
+                for f in futs:
+                    try:
+                        f.result()
+                    except Exception:
+                        pass
+            for w in writers.values():
+                w.abort()
+            raise
     LAST_TIMING["total_s"] = time.perf_counter() - t_all
     return names, rows_in, sorted(writers)
 

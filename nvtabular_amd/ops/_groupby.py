@@ -123,9 +123,9 @@ class GroupAgg:
                     self.hint = max(self.hint, merged["n"])
                     self.sorted_comp = merged
                     return
-                # (int64 key images with different offsets: the hash tables take over)
-                self._demote()
-                self.sorted_comp = comp
+                # (int64 keys whose union spans 2^32 or more: the hash tables take over -- the
+                # accumulated groups are demoted ONCE below and this partition's raw rows go
+                # through the hash path exactly once)
         if self.sorted_comp is not None:
             self._demote()
         if self.fold:
@@ -294,28 +294,48 @@ def merge_sorted_comps(a, b, sumsq=False, minmax=False):
     (nvt_merge_sorted_many with source maps) + one gather-combine per statistic
     (nvt_merge_payload: sums / sizes add, min / max combine, per-fold blocks as rows of kfold
     values, the transform's {sum, count} records as rows of 2 (kfold + 1)).  None when the two
-    sides carry int64 key images with different offsets.  Inside a pass (K.pass_memo) the key
+    sides carry int64 key images whose union spans 2^32 keys or more.  Inside a pass (K.pass_memo) the key
     merge of a column is shared by every aggregate on it, like the sort itself."""
     if ("fold" in a) != ("fold" in b):
         return None
     memo = K._PASS_MEMO
-    delta = int(b.get("key_offset", 0)) - int(a.get("key_offset", 0))
-    if delta:
+    off_a, off_b = int(a.get("key_offset", 0)), int(b.get("key_offset", 0))
+    if off_a != off_b:
         # int64 key column: the 32-bit image is key - offset and every partition picks its own
-        # offset (its smallest key).  Re-based to the accumulated side's offset when the
-        # partition's keys fit there (one read-back of its first / last key), else no merge.
-        rkey = ("sgb_rebase", b["keys32"].data_ptr(), int(b["n"]), delta)
+        # offset (from its smallest key).  Both sides are re-based to ONE offset when the union
+        # of their keys spans less than 2^32 (one read-back of each side's first / last key):
+        # the accumulated side keeps its offset when the partition fits there, else the common
+        # offset moves down to the union's smallest key; no merge only for a wider union.
+        rkey = ("sgb_rebase", a["keys32"].data_ptr(), int(a["n"]), off_a,
+                b["keys32"].data_ptr(), int(b["n"]), off_b)
         rb = memo.get(rkey) if memo is not None else None
         if rb is None:
-            ends = K.read_back(torch.stack([b["keys32"][0], b["keys32"][-1]]).to(torch.int64)) if b["n"] else [0, 0]
-            ok = -(1 << 31) <= int(ends[0]) + delta and int(ends[1]) + delta <= (1 << 31) - 1
-            rb = dict(k32=(b["keys32"].to(torch.int64) + delta).to(torch.int32) if ok else None,
-                      keep=b["keys32"])
+            def ends(c, off):
+                if not int(c["n"]):
+                    return None
+                e = K.read_back(torch.stack([c["keys32"][0], c["keys32"][int(c["n"]) - 1]]).to(torch.int64))
+                return int(e[0]) + off, int(e[1]) + off
+            ea, eb = ends(a, off_a), ends(b, off_b)
+            span = [e for e in (ea, eb) if e is not None]
+            lo = min(e[0] for e in span) if span else 0
+            hi = max(e[1] for e in span) if span else 0
+            new_off = None
+            if lo - off_a >= -(1 << 31) and hi - off_a <= (1 << 31) - 1:
+                new_off = off_a
+            elif hi - lo <= (1 << 32) - 1:
+                new_off = lo + (1 << 31)
+
+            def rebase(c, off):
+                if new_off is None or off == new_off:
+                    return c["keys32"]
+                return (c["keys32"].to(torch.int64) + (off - new_off)).to(torch.int32)
+            rb = dict(off=new_off, ka=rebase(a, off_a), kb=rebase(b, off_b), keep=(a["keys32"], b["keys32"]))
             if memo is not None:
                 memo[rkey] = rb
-        if rb["k32"] is None:
+        if rb["off"] is None:
             return None
-        b = dict(b, keys32=rb["k32"])
+        a = dict(a, keys32=rb["ka"], key_offset=rb["off"])
+        b = dict(b, keys32=rb["kb"], key_offset=rb["off"])
     mkey = ("sgb_merge", a["keys32"].data_ptr(), int(a["n"]), b["keys32"].data_ptr(), int(b["n"]))
     hit = memo.get(mkey) if memo is not None else None
     if hit is None:

@@ -145,7 +145,12 @@ class PlainParquetWriter:
 
     def _plan_column(self, values, valid, n, dt, start):
         """[(offset, bytes-like)] of one column chunk laid out from `start`, and its size."""
-        values = np.ascontiguousarray(values, dtype=dt)
+        values = np.asarray(values)
+        if values.dtype != dt or not values.flags.c_contiguous:
+            # never cast here: the buffer may still be the target of an asynchronous device-to-host
+            # copy (`ready`), and a silent cast would hide a schema change between row groups
+            raise TypeError(f"PlainParquetWriter: column buffer is {values.dtype} "
+                            f"(contiguous={values.flags.c_contiguous}), the file's column is {dt}")
         vbytes = memoryview(values).cast("B") if values.size else memoryview(b"")
         vb = memoryview(np.ascontiguousarray(valid)).cast("B") if valid is not None else None
         segs, at = [], start
@@ -200,6 +205,8 @@ class PlainParquetWriter:
         from their popcounts)."""
         chunks, plans = [], []
         total = 0
+        if len(columns) != len(self.names):
+            raise ValueError(f"PlainParquetWriter: {len(columns)} columns for a file of {len(self.names)}")
         for (values, valid), name, dt in zip(columns, self.names, self.dtypes):
             start = self.pos
             segs, size = self._plan_column(values, valid, n, dt, start)
@@ -241,3 +248,21 @@ class PlainParquetWriter:
         self.pending = []
         self._run([(self.pos, footer + struct.pack("<I", len(footer)) + b"PAR1")])
         os.close(self.fd)
+        self.fd = -1
+
+    def abort(self):
+        """A failed write: wait for what is in flight, close the descriptor and remove the
+        footer-less file (a truncated part file must not be left behind as if it were output)."""
+        for f in self.pending:
+            try:
+                f.result()
+            except Exception:
+                pass
+        self.pending = []
+        if self.fd >= 0:
+            os.close(self.fd)
+            self.fd = -1
+        try:
+            os.unlink(self.path)
+        except OSError:
+            pass

@@ -30,6 +30,32 @@ from .schema import Schema
 LOG = logging.getLogger("nvtabular_amd")
 
 
+class _FittedSchema:
+    """Lazy output schema of a transformed Dataset: resolved on first use, picklable (resolves
+    before pickling), and pinned to the fit that was current when transform() was called."""
+
+    def __init__(self, wf):
+        self._wf = wf
+        self._gen = getattr(wf, "_fit_generation", 0)
+        self._value = None
+
+    def __call__(self):
+        if self._value is None:
+            if getattr(self._wf, "_fit_generation", 0) != self._gen:
+                import warnings
+
+                # (the partitions of a transformed Dataset are produced lazily from the Workflow
+                # too, like the reference's dask graph: rows AND schema follow the latest fit)
+                warnings.warn("the Workflow was re-fit after transform(): this Dataset's rows and "
+                              "schema now follow the later fit", RuntimeWarning, stacklevel=3)
+            self._value = self._wf.output_schema
+            self._wf = None
+        return self._value
+
+    def __getstate__(self):
+        return {"_value": self(), "_wf": None, "_gen": self._gen}
+
+
 class Workflow:
     def __init__(self, output_node, client=None):
         self.output_node = Node.construct_from(output_node)
@@ -170,6 +196,7 @@ class Workflow:
     # ---- fit ------------------------------------------------------------------------
     def fit(self, dataset: Dataset) -> "Workflow":
         self.clear_stats()
+        self._fit_generation = getattr(self, "_fit_generation", 0) + 1
         # (re)fitting on an unchanged input schema: the graph's column schemas are already in
         # place (only fitted properties change, and those are refreshed lazily after the fit)
         if getattr(self, "_fit_root_schema", None) is None or not (dataset.schema == self._fit_root_schema):
@@ -238,7 +265,10 @@ class Workflow:
             # (schema: lazily -- folding the fitted properties in is host work, and asking
             # Categorify for its embedding sizes would enqueue the vocabulary ordering ahead of
             # the kernels of the first partition that can run underneath it)
-            out = Dataset(gen, schema=lambda: self.output_schema, npartitions=data.npartitions)
+            # The fitted state the schema is folded from is captured NOW (the operators' fit
+            # generation), so a re-fit between transform() and the first `.schema` access cannot
+            # leak a later fit's schema into this dataset.
+            out = Dataset(gen, schema=_FittedSchema(self), npartitions=data.npartitions)
             out._forwards_shard = True  # rank sharding is decided by the source dataset
             return out
         if isinstance(data, pd.DataFrame):

@@ -2,10 +2,9 @@
 (reference calling conventions tests/unit/ops/test_lambda.py:48-50,118-120), NormalizeMinMax
 against the oracle incl. the max == min branch (normalize.py:150-161), the literal-reference
 tie order (categorify.py:1300,1316), to_parquet(dtypes=...) on several partitions, hashing of
-null rows, and bench.py bringing up its own ranks."""
+null rows."""
 import json
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -198,30 +197,6 @@ def test_hash_bucket_null_rows_hash_as_key_zero_from_arrow(tmp_path):
     exp_x = O.hashed_cross(host, ["k", "o"], 777)["k_X_o"]
     np.testing.assert_array_equal(out["k"].to_numpy(), exp_b.to_numpy())
     np.testing.assert_array_equal(out["k_X_o"].to_numpy(), exp_x.to_numpy())
-
-
-def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
-    """`python bench.py --gpus 2` (no torchrun around it) starts 2 ranks itself and reports
-    n_gpus 2; gloo + both ranks on the one GPU of this box (the measured backend is nccl)."""
-    env = dict(os.environ, NVT_BENCH_BACKEND="gloo", NVT_BENCH_SHARE_GPU="1")
-    env.pop("WORLD_SIZE", None)
-    env.pop("RANK", None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows",
-                          "400000", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000",
-                          "--no-extra"],
-                         capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
-    assert res.returncode == 0, res.stderr[-2000:]
-    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-    rec = json.loads(line)
-    assert rec["n_gpus"] == 2 and rec["config"]["collective_backend"] == "gloo"
-    assert rec["value"] > 0 and rec["scaling"] == "weak"
-    # an N > 1 line is a complete line: roofline by family, the CPU baseline (rank 0, its own
-    # shard) and the parity leg (a single-rank fit inside dist.local_only())
-    assert rec["roofline"]["per_family"]["count"]["ms_per_step"] > 0
-    assert rec["cpu_baseline"]["value"] > 0 and rec["parity"]["parity_ok"] is True
-    # the collective self-check ran before the timing (here gloo against gloo: the code path)
-    sc = rec["collective_selfcheck"]
-    assert sc["ok_on_every_rank"] and len(sc["checks"]) == 4 and all(c["equal_to_gloo"] for c in sc["checks"])
 
 
 def test_fully_staged_encode_with_unseen_keys_and_nulls(tmp_path):

@@ -291,6 +291,65 @@ def test_int64_keys_spanning_more_than_32_bits_keep_the_hash_tables(tmp_path):
     np.testing.assert_allclose(got["k_x_sum"].to_numpy(), exp["k_x_sum"].to_numpy(), rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("shape", ["smaller_min_fits", "smaller_min_rebase_both", "union_wider_than_32_bits"])
+@pytest.mark.parametrize("op", ["join", "te"])
+def test_int64_partitions_with_different_key_offsets(tmp_path, shape, op):
+    """every partition of an int64 key column picks its own 32-bit image
+    offset (its smallest key).  A later partition whose smallest key lies BELOW the first
+    partition's must neither lose the earlier partitions' statistics nor count itself twice:
+    images that fit the accumulated offset are re-based onto it, a union narrower than 2^32 gets
+    a common offset, a wider union falls back to the hash tables (accumulated groups demoted
+    once, the partition's rows hashed once).  Reference semantics: the partition tree of
+    categorify.py:955-1137 under join_groupby.py:140-173 / target_encoding.py:171-214."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(5)
+    base = 9_000_000_000_000
+    n = 60_000
+
+    def part(lo, hi, seed):
+        r = np.random.default_rng(seed)
+        ids = r.integers(lo, hi, 4_000, dtype=np.int64)
+        k = ids[(r.random(n) ** 2 * ids.size).astype(np.int64)] + base
+        return pd.DataFrame({"k": k, "x": r.normal(size=n), "y": (r.random(n) < 0.3).astype("float32")})
+
+    if shape == "smaller_min_fits":       # partition 2 reaches 1000 keys below partition 1's minimum
+        parts = [part(5_000, 2_000_000, 1), part(4_000, 1_500_000, 2), part(4_500, 2_500_000, 3)]
+    elif shape == "smaller_min_rebase_both":  # partition 2 lies 3e9 below: only a common offset fits both
+        parts = [part(3_000_000_000, 3_000_900_000, 1), part(0, 900_000, 2), part(1_000_000_000, 3_000_500_000, 3)]
+    else:                                  # union of the partitions spans 6e9 >= 2^32
+        parts = [part(6_000_000_000, 6_000_900_000, 1), part(0, 900_000, 2), part(10, 6_000_000_500, 3)]
+    # shared keys between partitions so that a double count / a lost partition shows
+    parts[1] = pd.concat([parts[1], parts[0].iloc[:500].assign(k=parts[1]["k"].iloc[:500].to_numpy())],
+                         ignore_index=True)
+    df = pd.concat(parts, ignore_index=True)
+    if op == "join":
+        stats = ["count", "sum", "min", "max"]
+        jg = ops.JoinGroupby(out_path=str(tmp_path / "g"), stats=stats, cont_cols=["x"])
+        wf = nvt.Workflow(["k"] >> jg).fit(nvt.Dataset(parts))
+        index = jg._device_stats["k"].index
+        assert isinstance(index, K.GroupbyTable if shape == "union_wider_than_32_bits" else K.FlatIndex)
+        got = wf.transform(nvt.Dataset(parts)).to_ddf().compute()
+        cats = O.join_groupby_fit([p.copy() for p in parts], ["k"], ["x"], stats, str(tmp_path / "c"))
+        exp = O.join_groupby_transform(df.copy(), ["k"], cats)
+        np.testing.assert_array_equal(got["k_count"].to_numpy(), exp["k_count"].to_numpy())
+        for c in ("k_x_sum", "k_x_min", "k_x_max"):
+            np.testing.assert_allclose(got[c].to_numpy(), exp[c].to_numpy(), rtol=1e-9, atol=1e-9, err_msg=c)
+    else:
+        te = ops.TargetEncoding(["y"], out_path=str(tmp_path / "g"), kfold=3, fold_seed=42, p_smooth=20)
+        wf = nvt.Workflow(["k"] >> te).fit(nvt.Dataset(parts))
+        got = wf.transform(nvt.Dataset(parts)).to_ddf().compute()
+        stats, means = O.target_encoding_fit([p.copy() for p in parts], ["k"], ["y"], str(tmp_path / "c"),
+                                             kfold=3, fold_seed=42)
+        exp = pd.concat([O.target_encoding_transform(p[["k", "y"]].copy(), ["k"], ["y"], stats, means,
+                                                     kfold=3, fold_seed=42, p_smooth=20)
+                         for p in parts], ignore_index=True)
+        for c in exp.columns:
+            np.testing.assert_allclose(got[c].to_numpy(), exp[c].to_numpy(), rtol=1e-5, atol=1e-6, err_msg=c)
+
+
 @pytest.mark.parametrize("n", [32768, 32769, 34816, 100_001])
 @pytest.mark.parametrize("shape", ["one_group", "all_distinct", "two_hot", "runs"])
 def test_sgb_edge_shapes(n, shape):

@@ -438,27 +438,6 @@ def test_cfg1_movielens_shape_vs_oracle(tmp_path):
     np.testing.assert_allclose(got["rating"].to_numpy(), ref["rating"].to_numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.timeout(400)
-def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
-    """SURVEY 8(e) end to end: two torchrun ranks share this GPU (gloo, collectives staged
-    through the host), each fits its OWN frame; tests/multirank_check.py asserts that the
-    merged vocabularies / moments and every rank's encoded rows equal a single-process fit of
-    the concatenated frames.  Only the nccl calls themselves remain unexercised on a 1-GPU box."""
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29700 + os.getpid() % 200
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "tests", "multirank_check.py")]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=350)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    for r in (0, 1):
-        assert f"rank {r}: multi-rank fit == single-process fit of the union" in res.stdout
-
-
 def test_frame_to_arrow_keeps_types_nulls_and_lists():
     """DeviceFrame.to_arrow (the output half of the parquet path): integer columns keep their
     type and their nulls, floats their NaNs, list columns their offsets."""

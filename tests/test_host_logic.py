@@ -174,3 +174,20 @@ def test_fold_sparse_and_sorted_groupby_eligibility():
     assert not K.sorted_groupby_eligible(k32, None, n, K.SORTED_GROUPBY_MAX_KFOLD + 1)
     assert not K.sorted_groupby_eligible(k32, None, (1 << 29) + 1, 5)      # row index + 3 fold bits > 32
     assert K.sorted_groupby_eligible(k32, None, (1 << 29), 5)
+
+
+def test_harness_rehearsals_collect_last():
+    """Tests that shell out to bench.py / torchrun live in test_zz_rehearsals.py only: under
+    `pytest -x` a harness assertion must not be able to mask the kernel-parity tests collected
+    behind it (Weak #1)."""
+    import glob
+    import os
+    import re
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "test_*.py")))
+    assert os.path.basename(files[-1]) == "test_zz_rehearsals.py"
+    for f in files[:-1]:
+        if os.path.basename(f).startswith("test_gpu_"):
+            src = open(f).read()
+            assert not re.search(r"subprocess|torch\.distributed\.run", src), f

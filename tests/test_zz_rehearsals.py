@@ -1,0 +1,63 @@
+"""Harness rehearsals: tests that shell out to `bench.py` / `torch.distributed.run`.
+
+They live in a file that collects LAST (`test_zz_*`) so that under `pytest -x` an assertion about
+the bench harness cannot mask the kernel-parity tests (round 4 ended red that way: VERDICT r04
+"What's weak" #1).  Reference shape of the multi-worker checks: SURVEY 8(e),
+tests/unit/ops/test_categorify.py:509-540 (dask cluster fixtures)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
+    """`python bench.py --gpus 2` (no torchrun around it) starts 2 ranks itself and reports
+    n_gpus 2; gloo + both ranks on the one GPU of this box (the measured backend is nccl)."""
+    env = dict(os.environ, NVT_BENCH_BACKEND="gloo", NVT_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows",
+                          "400000", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000",
+                          "--no-extra"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["collective_backend"] == "gloo"
+    assert rec["value"] > 0 and rec["scaling"] == "weak"
+    # an N > 1 line is a complete line: roofline by family, the CPU baseline (rank 0, its own
+    # shard) and the parity leg (a single-rank fit inside dist.local_only())
+    assert rec["roofline"]["per_family"]["count"]["ms_per_step"] > 0
+    assert rec["cpu_baseline"]["value"] > 0 and rec["parity"]["parity_ok"] is True
+    # the collective self-check ran before the timing (here gloo against gloo: the code path)
+    sc = rec["collective_selfcheck"]
+    import bench
+    assert sc["ok_on_every_rank"] and all(c["equal_to_gloo"] for c in sc["checks"])
+    assert {c["collective"] for c in sc["checks"]} == set(bench.SELFCHECK_COLLECTIVES)
+
+
+@pytest.mark.timeout(400)
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
+    """SURVEY 8(e) end to end: two torchrun ranks share this GPU (gloo, collectives staged
+    through the host), each fits its OWN frame; tests/multirank_check.py asserts that the
+    merged vocabularies / moments and every rank's encoded rows equal a single-process fit of
+    the concatenated frames.  Only the nccl calls themselves remain unexercised on a 1-GPU box."""
+    root = ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "multirank_check.py")]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=350)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    for r in (0, 1):
+        assert f"rank {r}: multi-rank fit == single-process fit of the union" in res.stdout
