@@ -382,7 +382,10 @@ int nvt_te_apply_folds(const int64_t *group_all, const uint8_t *fold, int kfold,
  * kfold = 1 with words_kfold > 1: per-group entries from words regrouped for ANOTHER
  * aggregate's folds (JoinGroupby after TargetEncoding on the same column: one sort, one
  * regroup).  state: the block nvt_sgb_regroup filled (device, read by the kernels only).
- * No host synchronisation anywhere. */
+ * sorted_out[j] (array may be NULL, entries may be NULL): value column j in the order of the
+ * words, in its own dtype [n] -- written while the column is gathered by row; sorted_in[j]: such
+ * an array from an earlier aggregate on the same words, read streaming INSTEAD of the gather by
+ * row (columns without validity bitmap, not int64).  No host synchronisation anywhere. */
 int nvt_sgb_sort_ws_bytes(uint64_t n, uint64_t *bytes);
 int nvt_key_minmax(const void *keys, int key_dtype, uint64_t n, int64_t *out2, void *stream);
 int nvt_sgb_sort(const void *keys, int key_dtype, int64_t key_bias, const uint8_t *fold, int kfold,
@@ -395,7 +398,8 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
                    const int *vdtypes, const uint8_t *const *val_valid, int nvals, int flags,
                    uint64_t n, uint64_t cap, uint64_t *out_size, double *out_sum, double *out_sumsq,
                    double *out_min, double *out_max, uint64_t *tot_size, double *tot_sum,
-                   double *te_records, const uint64_t *state, void *stream);
+                   double *te_records, const uint64_t *state, const void *const *sorted_in,
+                   void *const *sorted_out, void *stream);
 /* Owner-side merge of the (key, count) rows of the multi-GPU exchange by sorting
  * (categorify.py:1054-1070 _mid_level_groupby, done on the owner rank): rows = n words
  * (count << 32 | int32 key), 0 <= count < 2^31, in nseg segments [seg_off[s], seg_off[s + 1])
@@ -529,6 +533,34 @@ int nvt_flat_lookup_te(const void *keys, int dtype, const uint8_t *valid, uint64
                        const void *table, uint64_t capacity, int64_t key_offset, const uint8_t *fold,
                        int kfold, const double *records, double p_smooth, double y_mean, void *out,
                        int out_dtype, void *stream);
+
+/* Lookup images: ONE probe and ONE packed record per row for every operator on a key column
+ * (JoinGroupby.transform join_groupby.py:198-217 + TargetEncoding.transform
+ * target_encoding.py:341-371 on the same key are two left merges on that key in the reference).
+ * image = bytes[groups][stride_bytes] (stride a multiple of 8): every operator owns a byte range
+ * of the record and stores there what a row receives, already in the OUTPUT dtype.
+ * nvt_flat_lookup_image: g = gid_in[i] when gid_in != NULL, else the flat-index probe of keys[i];
+ * gid_out (may be NULL) receives g as int32 (-1: no group).  Output c copies `sizes[c]` (4 / 8)
+ * bytes from image[g][offs[c] + (folds[c] ? (1 + folds[c][i]) * sizes[c] : 0)] to outs[c][i];
+ * rows without group receive miss_bits[c].  *unseen (may be NULL) is OR-ed with 1 when any row had
+ * no group.  ncols <= 24.
+ * nvt_image_pack: image[g][offs[c]] = (dst dtype) src[c][g], src float64 / int64 arrays [groups].
+ * nvt_te_image: (kfold + 1) values per group at image[g][off + slot * size]: slot 0 =
+ * (sum + p*mean) / (count + p), slot 1 + f = the out-of-fold value of fold f (mean when the
+ * (group, fold) pair has no rows) from records double[groups][2 * (kfold + 1)] (te_records of
+ * nvt_sgb_reduce; kfold = 0: records {sum, count}) -- the expression nvt_te_apply evaluates per
+ * row, evaluated once per (group, fold): identical bits. */
+int nvt_flat_lookup_image(const void *keys, int dtype, const uint8_t *valid, uint64_t n,
+                          const int32_t *aux, const void *table, uint64_t capacity, int64_t key_offset,
+                          const int32_t *gid_in, int32_t *gid_out, const void *image,
+                          uint32_t stride_bytes, int ncols, void *const *outs,
+                          const uint8_t *const *folds, const uint32_t *offs, const uint32_t *sizes,
+                          const uint64_t *miss_bits, uint64_t *unseen, void *stream);
+int nvt_image_pack(const void *const *src, const int *src_dtypes, const int *dst_dtypes,
+                   const uint32_t *offs, int ncols, uint64_t groups, void *image,
+                   uint32_t stride_bytes, void *stream);
+int nvt_te_image(const double *records, int kfold, uint64_t groups, double p_smooth, double y_mean,
+                 int out_dtype, void *image, uint32_t stride_bytes, uint32_t off, void *stream);
 
 /* ---- batched entry points: ONE call per operator per partition -----------------------
  * The reference hands a whole dataframe to the backend per operator call

@@ -100,11 +100,16 @@ SIGNATURES = {
     "nvt_sgb_regroup_ws_bytes": [_u64, C.POINTER(_u64)],
     "nvt_sgb_regroup": [_vp, _i32, _i32, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp],
     "nvt_sgb_reduce": [_vp, _i32, _i32, _pp, C.POINTER(C.c_int), _pp, _i32, _i32, _u64, _u64,
-                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _vp],
     "nvt_flat_lookup_gather": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _i32, _pp,
                                C.POINTER(C.c_int), C.POINTER(_dbl), _vp, _vp],
     "nvt_flat_lookup_te": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _i32, _vp, _dbl, _dbl, _vp,
                            _i32, _vp],
+    "nvt_flat_lookup_image": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _i64, _vp, _vp, _vp, _u32, _i32, _pp,
+                              _pp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u64), _vp, _vp],
+    "nvt_image_pack": [_pp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_u32), _i32, _u64, _vp,
+                       _u32, _vp],
+    "nvt_te_image": [_vp, _i32, _u64, _dbl, _dbl, _i32, _vp, _u32, _u32, _vp],
     "nvt_exchange_ranges": [_vp, _i32, _vp, _vp],
     "nvt_exchange_ranges_sorted": [_vp, _i32, _vp, _vp],
     "nvt_exchange_hist": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp],

@@ -74,6 +74,11 @@ struct GbRowArgs {
   const void *vals[kMaxVals];
   const uint8_t *val_valid[kMaxVals];
   int vdtype[kMaxVals];
+  // sort path (gb_segreduce_kernel): a value column in the order of the words -- written by the
+  // first aggregate of a pass that gathers it by row (sorted_out), read back streaming by the
+  // next aggregate on the same words (sorted_in) instead of a second random gather
+  const void *sorted_in[kMaxVals];
+  void *sorted_out[kMaxVals];
 };
 
 struct GbMergeArgs {
@@ -185,6 +190,17 @@ __device__ __forceinline__ bool load_val(const void *p, int dtype, uint64_t i, d
       return true;
   }
   return false;
+}
+
+// the value as load_val read it, back in its own dtype (exact: v came from that dtype; NaN stays NaN)
+__device__ __forceinline__ void store_val(void *p, int dtype, uint64_t i, double v) {
+  switch (dtype) {
+    case NVT_F32: reinterpret_cast<float *>(p)[i] = (float)v; break;
+    case NVT_F64: reinterpret_cast<double *>(p)[i] = v; break;
+    case NVT_I32: reinterpret_cast<int32_t *>(p)[i] = (int32_t)v; break;
+    case NVT_I64: reinterpret_cast<int64_t *>(p)[i] = (int64_t)v; break;
+    case NVT_U8: reinterpret_cast<uint8_t *>(p)[i] = (uint8_t)v; break;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void gb_clear_kernel(GbView t) {
@@ -345,8 +361,13 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
     }
     for (int j = 0; j < t.nvals; ++j) {
       double v = 0;
-      const bool ok = live && load_val(a.vals[j], a.vdtype[j], row, &v) &&
-                      bit_valid(a.val_valid[j], row);
+      bool ok;
+      if (a.sorted_in[j]) {  // (no validity bitmap on this path: the caller checked)
+        ok = act && load_val(a.sorted_in[j], a.vdtype[j], i, &v) && live;
+      } else {
+        ok = live && load_val(a.vals[j], a.vdtype[j], row, &v) && bit_valid(a.val_valid[j], row);
+        if (a.sorted_out[j] && act) store_val(a.sorted_out[j], a.vdtype[j], i, live ? v : 0.0);
+      }
       double sum = ok ? v : 0.0, sq = ok ? v * v : 0.0, mn = ok ? v : inf, mx = ok ? v : -inf;
       double any = ok ? 1.0 : 0.0;
       // inclusive segmented scan in row order: equal slots are contiguous, so "same slot as the
@@ -1271,7 +1292,8 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
                    const int *vdtypes, const uint8_t *const *val_valid, int nvals, int flags,
                    uint64_t n, uint64_t cap, uint64_t *out_size, double *out_sum, double *out_sumsq,
                    double *out_min, double *out_max, uint64_t *tot_size, double *tot_sum,
-                   double *te_records, const uint64_t *state, void *stream) {
+                   double *te_records, const uint64_t *state, const void *const *sorted_in,
+                   void *const *sorted_out, void *stream) {
   NVT_CHECK_ARG(regrouped && out_size && state, "null pointer");
   NVT_CHECK_ARG(nvals >= 0 && nvals <= kMaxVals, "nvals must be 0..8");
   NVT_CHECK_ARG(nvals == 0 || (vals && vdtypes && out_sum), "null vals / out_sum");
@@ -1314,6 +1336,11 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
     a.vals[j] = vals[j];
     a.vdtype[j] = vdtypes[j];
     a.val_valid[j] = val_valid ? val_valid[j] : nullptr;
+    a.sorted_in[j] = sorted_in ? sorted_in[j] : nullptr;
+    a.sorted_out[j] = sorted_out ? sorted_out[j] : nullptr;
+    NVT_CHECK_ARG(!(a.sorted_in[j] && a.val_valid[j]), "sorted values come without a validity bitmap");
+    NVT_CHECK_ARG(vdtypes[j] != NVT_I64 || (!a.sorted_in[j] && !a.sorted_out[j]),
+                  "int64 values are not carried in sorted order (not exact in a double)");
   }
   const uint32_t div = kfold == words_kfold ? 1u : (uint32_t)words_kfold;
   gb_segreduce_kernel<true><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, regrouped, div);

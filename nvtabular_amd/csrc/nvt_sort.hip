@@ -1574,6 +1574,122 @@ __global__ __launch_bounds__(kBlock) void flat_lookup_te_kernel(
   }
 }
 
+// ---- lookup images: ONE probe and ONE record per row for every operator on a key column ----
+// JoinGroupby.transform and TargetEncoding.transform on the same key column are two left merges
+// on the same key in the reference (join_groupby.py:198-217, target_encoding.py:341-371).  Here
+// every such operator ("consumer") owns a byte range of ONE packed per-group record whose values
+// are already what a row receives, in the OUTPUT dtype: JoinGroupby's statistics cast to
+// float32 / int32, TargetEncoding's smoothed value for every fold ((kfold + 1) values: slot 0 =
+// no fold, slot 1 + f = rows of fold f) -- the formula depends on (group, fold) only, so
+// evaluating it per group at the end of the fit gives the row's value bit for bit.  A row then
+// costs one random sector for the probe and one for its record (<= 64 bytes), whatever the
+// number of operators and statistics; the kernel moves 4- or 8-byte words, it does not convert.
+constexpr int kImageMaxCols = 24;
+struct ImageOuts {
+  void *out[kImageMaxCols];
+  const uint8_t *fold[kImageMaxCols];  // fold id column of this output (nullptr: fixed offset)
+  uint64_t miss[kImageMaxCols];        // value bits of a row without group
+  uint32_t off[kImageMaxCols];         // byte offset inside the record (slot 0)
+  uint32_t fstride[kImageMaxCols];     // bytes per fold slot (= the value size)
+  uint32_t size[kImageMaxCols];        // 4 or 8
+};
+
+template <typename K, int MAXC>
+__global__ __launch_bounds__(kBlock) void flat_lookup_image_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const int32_t *__restrict__ aux, const unsigned long long *__restrict__ table, uint64_t slots,
+    int64_t offset, const int32_t *__restrict__ gid_in, int32_t *__restrict__ gid_out,
+    const uint8_t *__restrict__ image, uint32_t stride_bytes, int ncols, ImageOuts o,
+    unsigned long long *unseen) {
+  const FlatIndexView v = flat_view(aux, table, slots, offset);
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  bool any_unseen = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t g = gid_in ? (int64_t)gid_in[i] : flat_probe(v, keys, valid, i);
+    if (gid_out) gid_out[i] = (int32_t)g;
+    any_unseen |= g < 0;
+    const uint8_t *rec = image + (uint64_t)(g < 0 ? 0 : g) * stride_bytes;
+    uint64_t x[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {  // all loads first: they hit the one sector of the record
+      if (c < ncols) {
+        uint32_t at = o.off[c];
+        if (o.fold[c]) at += (1u + (uint32_t)o.fold[c][i]) * o.fstride[c];
+        x[c] = o.size[c] == 8 ? *reinterpret_cast<const uint64_t *>(rec + at)
+                              : (uint64_t)*reinterpret_cast<const uint32_t *>(rec + at);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < ncols) {
+        const uint64_t y = g < 0 ? o.miss[c] : x[c];
+        if (o.size[c] == 8) __builtin_nontemporal_store(y, reinterpret_cast<uint64_t *>(o.out[c]) + i);
+        else __builtin_nontemporal_store((uint32_t)y, reinterpret_cast<uint32_t *>(o.out[c]) + i);
+      }
+    }
+  }
+  if (unseen && __ballot(any_unseen) != 0ull && lane_id() == 0) atomicOr(unseen, 1ull);
+}
+
+// image[g * stride + off + 4|8 * c] = (dst dtype) src[c][g]: a consumer's statistics (float64 /
+// int64 arrays of one value per group) written into its byte range of the records
+struct ImagePackArgs {
+  const void *src[kImageMaxCols];
+  int src_dtype[kImageMaxCols];  // NVT_F64 / NVT_I64
+  int dst_dtype[kImageMaxCols];  // NVT_F32 / NVT_F64 / NVT_I32 / NVT_I64
+  uint32_t off[kImageMaxCols];
+};
+
+__device__ __forceinline__ void image_store(uint8_t *at, int dtype, double x, int64_t xi, bool is_int) {
+  switch (dtype) {
+    case NVT_F32: *reinterpret_cast<float *>(at) = is_int ? (float)xi : (float)x; break;
+    case NVT_F64: *reinterpret_cast<double *>(at) = is_int ? (double)xi : x; break;
+    case NVT_I32: *reinterpret_cast<int32_t *>(at) = is_int ? (int32_t)xi : (int32_t)x; break;
+    default: *reinterpret_cast<int64_t *>(at) = is_int ? xi : (int64_t)x; break;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void image_pack_kernel(ImagePackArgs a, int ncols, uint64_t groups,
+                                                            uint8_t *__restrict__ image,
+                                                            uint32_t stride_bytes) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    uint8_t *rec = image + g * stride_bytes;
+    for (int c = 0; c < ncols; ++c) {
+      const bool is_int = a.src_dtype[c] == NVT_I64;
+      const double x = is_int ? 0.0 : reinterpret_cast<const double *>(a.src[c])[g];
+      const int64_t xi = is_int ? reinterpret_cast<const int64_t *>(a.src[c])[g] : 0;
+      image_store(rec + a.off[c], a.dst_dtype[c], x, xi, is_int);
+    }
+  }
+}
+
+// TargetEncoding's byte range: (kfold + 1) values per group from the fit's {sum, count, (sum_f,
+// count_f) ...} records -- exactly the expression flat_lookup_te_kernel / nvt_te_apply evaluate
+// per row (target_encoding.py:350-371), once per (group, fold)
+template <typename OUT>
+__global__ __launch_bounds__(kBlock) void te_image_kernel(const double *__restrict__ records,
+                                                          unsigned kfold, uint64_t groups, double p,
+                                                          double y_mean, uint8_t *__restrict__ image,
+                                                          uint32_t stride_bytes, uint32_t off) {
+  const unsigned per = kfold + 1, rs = 2 * (kfold + 1);
+  const uint64_t total = groups * per, stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+    const uint64_t g = e / per;
+    const unsigned slot = (unsigned)(e - g * per);
+    const double *rec = records + g * rs;
+    const double2 tot = *reinterpret_cast<const double2 *>(rec);
+    double r;
+    if (slot == 0) {
+      r = (tot.x + p * y_mean) / (tot.y + p);
+    } else {
+      const double2 f = *reinterpret_cast<const double2 *>(rec + 2 * slot);
+      r = f.y > 0.0 ? (tot.x - f.x + p * y_mean) / (tot.y - f.y + p) : y_mean;
+    }
+    *reinterpret_cast<OUT *>(image + g * stride_bytes + off + slot * sizeof(OUT)) = (OUT)r;
+  }
+}
+
 // ---- vocabulary order of a list that is SHARDED over the ranks of a multi-GPU fit -------------
 // Every rank owns a key range of the merged (key, count) list.  The order "count descending, key
 // ascending" of the union is: class 255 (count >= 255, sorted exactly once all ranks' few such
@@ -2070,6 +2186,110 @@ int nvt_flat_lookup_te(const void *keys, int dtype, const uint8_t *valid, uint64
   else if (out_dtype == NVT_F32) NVT_TE_LAUNCH(int64_t, float);
   else NVT_TE_LAUNCH(int64_t, double);
 #undef NVT_TE_LAUNCH
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_flat_lookup_image(const void *keys, int dtype, const uint8_t *valid, uint64_t n,
+                          const int32_t *aux, const void *table, uint64_t capacity, int64_t key_offset,
+                          const int32_t *gid_in, int32_t *gid_out, const void *image,
+                          uint32_t stride_bytes, int ncols, void *const *outs,
+                          const uint8_t *const *folds, const uint32_t *offs, const uint32_t *sizes,
+                          const uint64_t *miss_bits, uint64_t *unseen, void *stream) {
+  if (n == 0) return NVT_OK;
+  NVT_CHECK_ARG(aux && table && image && outs && offs && sizes && miss_bits, "null pointer");
+  NVT_CHECK_ARG(keys || gid_in, "keys or group ids");
+  NVT_CHECK_ARG(ncols >= 1 && ncols <= kImageMaxCols, "1..24 outputs");
+  NVT_CHECK_ARG(stride_bytes >= 8 && stride_bytes % 8 == 0, "record stride: a multiple of 8 bytes");
+  NVT_CHECK_ARG(dtype == NVT_I32 || dtype == NVT_I64, "key dtype must be int32 / int64");
+  ImageOuts o;
+  memset(&o, 0, sizeof(o));
+  for (int c = 0; c < ncols; ++c) {
+    NVT_CHECK_ARG(outs[c], "null output");
+    NVT_CHECK_ARG(sizes[c] == 4 || sizes[c] == 8, "values are 4 or 8 bytes");
+    NVT_CHECK_ARG(offs[c] % sizes[c] == 0, "value offsets are aligned to the value size");
+    o.out[c] = outs[c];
+    o.fold[c] = folds ? folds[c] : nullptr;
+    o.miss[c] = miss_bits[c];
+    o.off[c] = offs[c];
+    o.fstride[c] = sizes[c];
+    o.size[c] = sizes[c];
+    // (with a fold column the caller guarantees off + (kfold + 1) * size <= stride)
+    NVT_CHECK_ARG((uint64_t)offs[c] + sizes[c] <= stride_bytes, "value outside the record");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_lookup", n * (dtype == NVT_I64 ? 8ull : 4ull), s);
+  const unsigned grid = stream_grid(n, kBlock * 2);
+  const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(table);
+  unsigned long long *flag = reinterpret_cast<unsigned long long *>(unseen);
+  const uint8_t *img = reinterpret_cast<const uint8_t *>(image);
+#define NVT_IMG(K, MAXC)                                                                          \
+  flat_lookup_image_kernel<K, MAXC><<<grid, kBlock, 0, s>>>((const K *)keys, valid, n, aux, tab,  \
+                                                            capacity, key_offset, gid_in, gid_out, \
+                                                            img, stride_bytes, ncols, o, flag)
+#define NVT_IMG_K(K)                    \
+  do {                                  \
+    if (ncols <= 2) NVT_IMG(K, 2);      \
+    else if (ncols <= 4) NVT_IMG(K, 4); \
+    else if (ncols <= 8) NVT_IMG(K, 8); \
+    else if (ncols <= 16) NVT_IMG(K, 16); \
+    else NVT_IMG(K, 24);                \
+  } while (0)
+  if (dtype == NVT_I32) NVT_IMG_K(int32_t);
+  else NVT_IMG_K(int64_t);
+#undef NVT_IMG_K
+#undef NVT_IMG
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_image_pack(const void *const *src, const int *src_dtypes, const int *dst_dtypes,
+                   const uint32_t *offs, int ncols, uint64_t groups, void *image,
+                   uint32_t stride_bytes, void *stream) {
+  if (groups == 0 || ncols == 0) return NVT_OK;
+  NVT_CHECK_ARG(src && src_dtypes && dst_dtypes && offs && image, "null pointer");
+  NVT_CHECK_ARG(ncols >= 1 && ncols <= kImageMaxCols, "1..24 columns");
+  ImagePackArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int c = 0; c < ncols; ++c) {
+    NVT_CHECK_ARG(src[c], "null source column");
+    NVT_CHECK_ARG(src_dtypes[c] == NVT_F64 || src_dtypes[c] == NVT_I64, "sources are float64 / int64");
+    const int d = dst_dtypes[c];
+    NVT_CHECK_ARG(d == NVT_F32 || d == NVT_F64 || d == NVT_I32 || d == NVT_I64, "values are f32 / f64 / i32 / i64");
+    const uint32_t sz = (d == NVT_F32 || d == NVT_I32) ? 4u : 8u;
+    NVT_CHECK_ARG(offs[c] % sz == 0 && (uint64_t)offs[c] + sz <= stride_bytes, "value outside the record");
+    a.src[c] = src[c];
+    a.src_dtype[c] = src_dtypes[c];
+    a.dst_dtype[c] = d;
+    a.off[c] = offs[c];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_index", groups * 8ull * ncols, s);
+  image_pack_kernel<<<stream_grid(groups, kBlock, 8), kBlock, 0, s>>>(
+      a, ncols, groups, reinterpret_cast<uint8_t *>(image), stride_bytes);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_te_image(const double *records, int kfold, uint64_t groups, double p_smooth, double y_mean,
+                 int out_dtype, void *image, uint32_t stride_bytes, uint32_t off, void *stream) {
+  if (groups == 0) return NVT_OK;
+  NVT_CHECK_ARG(records && image, "null pointer");
+  NVT_CHECK_ARG(kfold >= 0 && kfold <= 256, "kfold must be 0 (records of {sum, count}) .. 256");
+  NVT_CHECK_ARG(out_dtype == NVT_F32 || out_dtype == NVT_F64, "out dtype must be f32 / f64");
+  const uint32_t sz = out_dtype == NVT_F32 ? 4u : 8u;
+  NVT_CHECK_ARG(off % sz == 0 && (uint64_t)off + (uint64_t)(kfold + 1) * sz <= stride_bytes,
+                "values outside the record");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_index", groups * 16ull * (kfold + 1), s);
+  const unsigned grid = stream_grid(groups * (uint64_t)(kfold + 1), kBlock, 8);
+  uint8_t *img = reinterpret_cast<uint8_t *>(image);
+  if (out_dtype == NVT_F32)
+    te_image_kernel<float><<<grid, kBlock, 0, s>>>(records, (unsigned)kfold, groups, p_smooth, y_mean, img,
+                                                   stride_bytes, off);
+  else
+    te_image_kernel<double><<<grid, kBlock, 0, s>>>(records, (unsigned)kfold, groups, p_smooth, y_mean, img,
+                                                    stride_bytes, off);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

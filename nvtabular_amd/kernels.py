@@ -1766,6 +1766,9 @@ def sorted_groupby_eligible(keys: torch.Tensor, key_valid, n: int, kfold: int = 
             and 1 <= kfold <= SORTED_GROUPBY_MAX_KFOLD)
 
 
+SHARE_SORTED_VALUES = os.environ.get("NVT_SHARE_SORTED_VALUES", "1") != "0"
+
+
 def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int, vals, val_valid,
                    sumsq=False, minmax=False, cap_hint: int = 0, te_records=False):
     """nvt_sgb_sort + nvt_sgb_regroup + nvt_sgb_reduce: groups of ONE int32 key column, dense
@@ -1860,10 +1863,27 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
     vp = _lib.ptr_array([v.data_ptr() for v in vals])
     vv = _lib.ptr_array([ptr(v) for v in val_valid])
     vd = (C.c_int * max(1, nvals))(*[dtype_code(v.dtype) for v in vals])
+    # value columns in the order of the words: the first aggregate of a pass gathers a column by
+    # row (one random sector per row) and leaves it behind in sorted order, the next aggregate
+    # on the same words (JoinGroupby after TargetEncoding on the same target) reads that copy
+    # streaming
+    sv = grp.setdefault("sorted_vals", {})
+    s_in, s_out = [None] * nvals, [None] * nvals
+    for j, v in enumerate(vals):
+        if val_valid[j] is not None or v.dtype == torch.int64 or not SHARE_SORTED_VALUES:
+            continue
+        skey = (v.data_ptr(), v.dtype, v._version)
+        have = sv.get(skey)
+        if have is not None:
+            s_in[j] = have[0]
+        elif _PASS_MEMO is not None:
+            s_out[j] = torch.empty(n, dtype=v.dtype, device=dev)
+            sv[skey] = (s_out[j], v)   # (v held: its address cannot be recycled in this pass)
     check(lib.nvt_sgb_reduce(
         grp["words"].data_ptr(), wk, kfold, vp, vd, vv, nvals, flags, n, cap, size.data_ptr(),
         ptr(fsum), ptr(fsq), ptr(fmin), ptr(fmax), ptr(tsize), ptr(tsum), ptr(rec),
-        grp["state"].data_ptr(), stream_ptr()), "nvt_sgb_reduce")
+        grp["state"].data_ptr(), _lib.ptr_array([ptr(t) for t in s_in]),
+        _lib.ptr_array([ptr(t) for t in s_out]), stream_ptr()), "nvt_sgb_reduce")
     nan = float("nan")
 
     def rows(mat, m):
@@ -2140,6 +2160,139 @@ class FlatIndex:
             int(kfold) if fold is not None else 1, records.data_ptr(), float(p_smooth), float(y_mean),
             out.data_ptr(), dtype_code(out_dtype), stream_ptr()), "nvt_flat_lookup_te")
         return out
+
+
+    # ---- lookup images: one probe + one packed record per row for ALL operators on this key ----
+    def attach(self, consumer: "LookupConsumer"):
+        """An operator fitted on these groups registers the values its transform hands a row
+        (include/nvt_hip.h, "Lookup images").  Replaces an earlier consumer of the same owner /
+        tag (a re-registration after fit_finalize)."""
+        cons = getattr(self, "consumers", None)
+        if cons is None:
+            cons = self.consumers = []
+        cons[:] = [c for c in cons if not (c.owner is consumer.owner and c.tag == consumer.tag)]
+        cons.append(consumer)
+        self._image = None
+
+    def _build_image(self):
+        at, place = 0, {}
+        for c in self.consumers:
+            at = (at + 7) & ~7
+            place[id(c)] = at
+            at += c.width
+        total = max(8, (at + 7) & ~7)
+        # records of <= 64 bytes never straddle a 64-byte sector; larger ones are sector-aligned
+        stride = next_pow2(total) if total <= 64 else (total + 63) & ~63
+        image = torch.empty(max(self.n, 1) * stride, dtype=torch.uint8, device=self.keys32.device)
+        for c in self.consumers:
+            c.fill(image, stride, place[id(c)], self.n)
+        self._image = (image, stride, place)
+        return self._image
+
+    def image_lookup(self, consumer: "LookupConsumer", keys, key_valid, fold=None):
+        """{output name: tensor[n]} of `consumer` for the rows of keys[0], and the device word
+        that is non-zero when a row had no group.  Inside a pass (pass_memo) the ONE launch
+        serves every attached consumer: the others find their columns in the memo."""
+        k = self._key(keys)
+        n = int(k.numel())
+        valid = key_valid[0]
+        memo = _PASS_MEMO
+        mkey = ("image", id(self), k.data_ptr(), n, k._version, ptr(valid))
+        hit = memo.get(mkey) if memo is not None else None
+        if hit is not None and id(consumer) in hit["outs"]:
+            return hit["outs"][id(consumer)], hit["unseen"]
+        img = getattr(self, "_image", None) or self._build_image()
+        image, stride, place = img
+        todo = list(self.consumers) if (memo is not None and hit is None) else [consumer]
+        dev = k.device
+        outs, ptrs, folds, offs, sizes, miss, keep = {}, [], [], [], [], [], []
+        for c in todo:
+            f = None
+            if c.fold_fn is not None:
+                f = fold if (c is consumer and fold is not None) else c.fold_fn(n, dev)
+                f = f.contiguous()
+                assert f.dtype == torch.uint8 and int(f.numel()) == n
+                keep.append(f)
+            mine = outs.setdefault(id(c), {})
+            for name, dt, rel, per_fold, mv in c.outputs:
+                t = torch.empty(n, dtype=dt, device=dev)
+                mine[name] = t
+                ptrs.append(t.data_ptr())
+                folds.append(ptr(f) if per_fold else None)
+                offs.append(place[id(c)] + rel)
+                sizes.append(t.element_size())
+                miss.append(_value_bits(mv, dt))
+        nc = len(ptrs)
+        if nc > 24:
+            raise _lib.NvtHipError("image_lookup: more than 24 output columns on one key column")
+        unseen = torch.zeros(1, dtype=torch.int64, device=dev)
+        STATS["image_lookups"] = STATS.get("image_lookups", 0) + 1
+        if n:
+            check(_lib.load().nvt_flat_lookup_image(
+                k.data_ptr(), dtype_code(k.dtype), ptr(valid), n, self.aux.data_ptr(),
+                self.table.data_ptr(), self.capacity, self.key_offset, None, None, image.data_ptr(),
+                stride, nc, _lib.ptr_array(ptrs), _lib.ptr_array(folds), (C.c_uint32 * nc)(*offs),
+                (C.c_uint32 * nc)(*sizes), (C.c_uint64 * nc)(*miss), unseen.data_ptr(), stream_ptr()),
+                "nvt_flat_lookup_image")
+        if memo is not None and hit is None:
+            memo[mkey] = dict(outs=outs, unseen=unseen, keep=(k, valid, keep))
+        elif hit is not None:
+            hit["outs"].update(outs)   # (a consumer attached after the pass's first launch)
+        return outs[id(consumer)], unseen
+
+
+def _value_bits(value, dt) -> int:
+    import struct
+
+    if dt == torch.float32:
+        return struct.unpack("<I", struct.pack("<f", float(value)))[0]
+    if dt == torch.float64:
+        return struct.unpack("<Q", struct.pack("<d", float(value)))[0]
+    if dt == torch.int32:
+        return int(value) & 0xFFFFFFFF
+    return int(value) & 0xFFFFFFFFFFFFFFFF
+
+
+class LookupConsumer:
+    """What one operator's transform hands a row of a key column, as a byte range of the packed
+    per-group record of FlatIndex.image_lookup.
+
+    outputs: [(name, torch dtype, byte offset inside the range, per_fold, value of a row without
+    group)]; per_fold outputs hold (kfold + 1) consecutive values (slot 0: no fold) and need
+    fold_fn(n, device) -> uint8 fold ids.  fill(image, stride, offset, groups) writes the range."""
+
+    def __init__(self, owner, tag, width, outputs, fill, fold_fn=None):
+        self.owner, self.tag, self.width = owner, tag, int(width)
+        self.outputs, self.fill, self.fold_fn = list(outputs), fill, fold_fn
+
+
+def image_pack(image, stride, columns, groups):
+    """columns: [(float64 / int64 tensor [groups], output torch dtype, absolute byte offset)]."""
+    if not columns or not groups:
+        return
+    nc = len(columns)
+    srcs = [c[0].contiguous() for c in columns]
+    for t in srcs:
+        assert t.dtype in (torch.float64, torch.int64) and int(t.numel()) >= groups
+    check(_lib.load().nvt_image_pack(
+        _lib.ptr_array([t.data_ptr() for t in srcs]), (C.c_int * nc)(*[dtype_code(t.dtype) for t in srcs]),
+        (C.c_int * nc)(*[dtype_code(c[1]) for c in columns]), (C.c_uint32 * nc)(*[int(c[2]) for c in columns]),
+        nc, int(groups), image.data_ptr(), int(stride), stream_ptr()), "nvt_image_pack")
+
+
+def te_image(image, stride, offset, records, kfold, groups, p_smooth, y_mean, out_dtype):
+    """records [groups, 2 * (kfold + 1)] float64 (kfold 0: {sum, count}) -> (kfold + 1) smoothed
+    values per group at `offset` of the records of `image`."""
+    if not groups:
+        return
+    assert records.dtype == torch.float64 and records.is_contiguous()
+    assert int(records.shape[1]) == 2 * (int(kfold) + 1)
+    check(_lib.load().nvt_te_image(records.data_ptr(), int(kfold), int(groups), float(p_smooth),
+                                   float(y_mean), dtype_code(out_dtype), image.data_ptr(), int(stride),
+                                   int(offset), stream_ptr()), "nvt_te_image")
+
+
+LOOKUP_IMAGES = os.environ.get("NVT_LOOKUP_IMAGES", "1") != "0"
 
 
 def te_apply_folds(group_all, fold, kfold, sum_all, cnt_all, sum_fold, cnt_fold, p_smooth, y_mean,

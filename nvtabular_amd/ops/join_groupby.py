@@ -148,9 +148,49 @@ class JoinGroupby(StatOperator):
                         cols[f"{name}{self.name_sep}{cont}{self.name_sep}{stat}"] = derived[(j, stat)]
             f32 = [f"{name}{self.name_sep}{cont}{self.name_sep}{stat}" for cont in agg.val_cols
                    for stat in ("sum", "min", "max") if agg.val_dtypes.get(cont) == torch.float32]
-            self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols,
-                                              f32_columns=f32, index_table=comp.get("index_table"))
+            st = self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols,
+                                                   f32_columns=f32, index_table=comp.get("index_table"))
+            self._attach_image(name, st)
         return out
+
+    def _plan(self, st):
+        """(column, output dtype, value of a row without group) per statistic (join_groupby.py:
+        29-34 AGG_DTYPES, :214 astype)."""
+        plan = []
+        for cname in st.columns:
+            out_dt, miss = torch.float64, float("nan")
+            if cname in st.f32_columns:
+                out_dt = torch.float32
+            for agg, npdt in AGG_DTYPES.items():
+                if cname.endswith(f"{self.name_sep}{agg}"):
+                    out_dt = torch.int32 if npdt == np.int32 else torch.float32
+            plan.append((cname, out_dt, 0.0 if out_dt == torch.int32 else miss))
+        return plan
+
+    def _attach_image(self, name, st):
+        """Sort-path groups: this operator's statistics, cast to their output dtypes, as a byte
+        range of the key column's lookup image (K.FlatIndex.image_lookup)."""
+        self._consumers = getattr(self, "_consumers", {})
+        self._consumers.pop(name, None)
+        plan = self._plan(st)
+        if not (K.LOOKUP_IMAGES and isinstance(st.index, K.FlatIndex) and len(st.key_cols) == 1
+                and 1 <= len(plan) <= 16):
+            return
+        # 8-byte values first: every value stays aligned to its size
+        order = sorted(range(len(plan)), key=lambda i: 0 if plan[i][1] in (torch.float64, torch.int64) else 1)
+        rel, at = {}, 0
+        for i in order:
+            rel[i] = at
+            at += 8 if plan[i][1] in (torch.float64, torch.int64) else 4
+        outputs = [(plan[i][0], plan[i][1], rel[i], False, plan[i][2]) for i in range(len(plan))]
+
+        def fill(image, stride, offset, groups, st=st, plan=plan, rel=rel):
+            K.image_pack(image, stride, [(st.columns[plan[i][0]], plan[i][1], offset + rel[i])
+                                         for i in range(len(plan))], groups)
+
+        cons = K.LookupConsumer(self, name, at, outputs, fill)
+        st.index.attach(cons)
+        self._consumers[name] = cons
 
     def flush_artifacts(self):
         """Write any deferred cat_stats.<group>.parquet directories."""
@@ -185,19 +225,18 @@ class JoinGroupby(StatOperator):
                 k, v = key_view(frame[c].materialize())
                 keys.append(k)
                 valids.append(v)
-            plan = []  # (column, output dtype, value of a row without group)
-            for cname in st.columns:
-                out_dt, miss = torch.float64, float("nan")
-                if cname in st.f32_columns:
-                    out_dt = torch.float32
-                for agg, npdt in AGG_DTYPES.items():
-                    if cname.endswith(f"{self.name_sep}{agg}"):
-                        out_dt = torch.int32 if npdt == np.int32 else torch.float32
-                plan.append((cname, out_dt, 0.0 if out_dt == torch.int32 else miss))
+            plan = self._plan(st)  # (column, output dtype, value of a row without group)
             if isinstance(st.index, K.FlatIndex) and 1 <= len(plan) <= 16:
-                # sort-path groups: probe + every statistic of the group's record in ONE launch
-                outs, unseen = st.index.gather(keys, valids, st.records(), [p[1] for p in plan],
-                                               [p[2] for p in plan])
+                cons = getattr(self, "_consumers", {}).get(name)
+                if cons is not None and cons in (getattr(st.index, "consumers", None) or []):
+                    # ONE probe + ONE packed record per row for every operator fitted on this
+                    # key column in the same pass (TargetEncoding's values ride in the same launch)
+                    got, unseen = st.index.image_lookup(cons, keys, valids)
+                    outs = [got[p[0]] for p in plan]
+                else:
+                    # sort-path groups: probe + every statistic of the group's record in ONE launch
+                    outs, unseen = st.index.gather(keys, valids, st.records(), [p[1] for p in plan],
+                                                   [p[2] for p in plan])
                 any_unseen = None  # read back once, and only when an integer column needs it
                 for (cname, out_dt, _), o in zip(plan, outs):
                     if cname in new:
@@ -284,6 +323,7 @@ class JoinGroupby(StatOperator):
         self.categories = {}
         self.storage_name = {}
         self._device_stats = {}
+        self._consumers = {}
         self._pending = {}
 
 

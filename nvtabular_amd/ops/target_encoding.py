@@ -210,6 +210,55 @@ class TargetEncoding(StatOperator):
         if dask_stats[1] is not None:
             for col, m in dask_stats[1].items():
                 self.means[col] = float(m["mean"])
+        self._attach_images()
+
+    def _out_torch_dtype(self):
+        return torch.float64 if np.dtype(self.output_dtype) == np.dtype("float64") else torch.float32
+
+    def _attach_images(self):
+        """Sort-path groups (one int32 / narrow int64 key column): this operator's byte range of
+        the key column's lookup image (K.FlatIndex.image_lookup) -- (kfold + 1) smoothed values
+        per target and group, target_encoding.py:350-371 evaluated once per (group, fold)."""
+        self._consumers = {}
+        if not K.LOOKUP_IMAGES:
+            return
+        fit_folds = self.kfold > 1
+        y_mean = self.target_mean or self.means
+        out_dt = self._out_torch_dtype()
+        size = 8 if out_dt == torch.float64 else 4
+        slots = (self.kfold + 1) if fit_folds else 1
+        for name, st_all in list(self._device_stats.items()):
+            if not isinstance(st_all, _Stats) or not isinstance(st_all.index, K.FlatIndex):
+                continue
+            if len(st_all.key_cols) != 1:
+                continue
+            st_fold = None
+            if fit_folds:
+                fname = _make_name(self.fold_name, *st_all.key_cols, sep=self.name_sep)
+                st_fold = self._device_stats.get(fname)
+                if not isinstance(st_fold, _FoldDense) or st_fold.records is None:
+                    continue
+            targets = [c[len("sum:"):] for c in st_all.columns if c.startswith("sum:")]
+            try:
+                means = {t: float(y_mean[t] if isinstance(y_mean, dict) else y_mean) for t in targets}
+            except (KeyError, TypeError):
+                continue
+            outputs = [(("te", t), out_dt, j * slots * size, fit_folds, means[t])
+                       for j, t in enumerate(targets)]
+
+            def fill(image, stride, offset, groups, st_all=st_all, st_fold=st_fold, targets=targets,
+                     means=means):
+                for j, t in enumerate(targets):
+                    rec = st_fold.records[t] if fit_folds else st_all.te_records(t)
+                    K.te_image(image, stride, offset + j * slots * size, rec.contiguous(),
+                               self.kfold if fit_folds else 0, groups, self.p_smooth, means[t], out_dt)
+
+            fold_fn = None
+            if fit_folds:
+                fold_fn = lambda n, dev: _fold_column(n, self.kfold, self.fold_seed, dev).data  # noqa: E731
+            cons = K.LookupConsumer(self, name, len(targets) * slots * size, outputs, fill, fold_fn)
+            st_all.index.attach(cons)
+            self._consumers[name] = cons
 
     # ------------------------------------------------------------ transform --
     def _stats_for(self, name, key_cols):
@@ -269,6 +318,17 @@ class TargetEncoding(StatOperator):
             # target (no group-id columns in HBM)
             fused = isinstance(st_all.index, K.FlatIndex) and (
                 (not fit_folds) or (isinstance(st_fold, _FoldDense) and st_fold.records is not None))
+            cons = getattr(self, "_consumers", {}).get(name_all) if fused else None
+            if cons is not None and getattr(st_all.index, "consumers", None) and cons in st_all.index.consumers \
+                    and [o[0][1] for o in cons.outputs] == targets and cons.outputs[0][1] == out_dt:
+                # ONE probe + ONE packed record per row for every operator fitted on this key
+                # column in the same pass (JoinGroupby's statistics ride in the same launch)
+                k, v = key_view(work[cat_group[0]].materialize())
+                fold_t = work[self.fold_name].data if fit_folds else None
+                got, _ = st_all.index.image_lookup(cons, [k], [v], fold=fold_t)
+                for i, t in enumerate(targets):
+                    new[out_col[i]] = DeviceColumn(got[("te", t)])
+                continue
             if fused:
                 k, v = key_view(work[cat_group[0]].materialize())
                 for i, t in enumerate(targets):
@@ -371,4 +431,5 @@ class TargetEncoding(StatOperator):
         self.stats = {}
         self.means = {}
         self._device_stats = {}
+        self._consumers = {}
         self._pending = {}

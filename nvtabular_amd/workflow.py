@@ -260,7 +260,9 @@ class Workflow:
 
             def gen(columns=None, shard=None):
                 for part in data.to_iter(columns=roots, shard=shard):
-                    yield self._run(self.output_node, part, {})
+                    with pass_memo():  # operators on the same key column share one lookup
+                        out_part = self._run(self.output_node, part, {})
+                    yield out_part
 
             # (schema: lazily -- folding the fitted properties in is host work, and asking
             # Categorify for its embedding sizes would enqueue the vocabulary ordering ahead of
@@ -275,11 +277,13 @@ class Workflow:
             if self._output_schema is None:
                 self.fit_schema(Schema.from_frame(data))
             frame, _ = as_device_frame(data[self._root_columns()])
-            return self._run(self.output_node, frame, {}).to_pandas()
+            with pass_memo():
+                return self._run(self.output_node, frame, {}).to_pandas()
         if isinstance(data, DeviceFrame):
             if self._output_schema is None:
                 self.fit_schema(Schema.from_frame(data))
-            return self._run(self.output_node, data, {})
+            with pass_memo():
+                return self._run(self.output_node, data, {})
         raise TypeError(f"Workflow.transform: unsupported input {type(data)}")
 
     def fit_transform(self, dataset: Dataset) -> Dataset:
