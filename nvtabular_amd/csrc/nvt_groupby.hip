@@ -308,7 +308,12 @@ struct SegAcc {
 // last word (they may continue in the neighbouring rows) need atomics.  With ~4 rows per group
 // that is 14 of 16 runs.  slot_div: the words' slots are g * slot_div + fold and this
 // aggregate wants g (words regrouped for another aggregate's folds).
-template <bool EXCL>
+// Shuffles are what this kernel issues most (ds_bpermute: one LDS crossbar trip per 32-bit word):
+// run lengths, the count of valid rows / values and the "exclusive run" test come from BALLOTS of
+// the run heads (scalar bit arithmetic, no shuffle), and only the statistics the table carries
+// are scanned -- SQ / MM are compile-time.  TargetEncoding's reduction (sum only) shuffles 13
+// words per 64 rows where the first version shuffled 96.
+template <bool EXCL, bool SQ, bool MM>
 __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArgs a, uint64_t n,
                                                               const uint64_t *__restrict__ words,
                                                               uint32_t slot_div) {
@@ -323,6 +328,7 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
   // window of the dense arrays at any time: 596 us instead of 443 for 20 M rows)
   const uint64_t per_wave = ((n + nwaves - 1) / nwaves + kWave - 1) / kWave * kWave;
   const uint64_t chunk_end = (wave0 + 1) * per_wave < n ? (wave0 + 1) * per_wave : n;
+  const unsigned long long below = (2ull << lane) - 1ull;  // lanes 0 .. lane
   for (uint64_t base = wave0 * per_wave; base < chunk_end; base += kWave) {
     const uint64_t i = base + lane;
     const bool act = i < n;
@@ -331,31 +337,26 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
     const uint32_t slot = (slot_div > 1 && raw != 0xFFFFFFFFu) ? raw / slot_div : raw;
     const uint32_t row = (uint32_t)w;
     const bool live = act && raw != 0xFFFFFFFFu && slot < t.cap;
-    const uint32_t next = __shfl_down(slot, 1, 64);
-    const bool tail = lane == 63 || next != slot;
-    bool excl = false;
+    const uint32_t prev = __shfl_up(slot, 1, 64);
+    // run heads of this row of 64 words (lane 0 starts a run as far as the row is concerned)
+    const unsigned long long heads = __ballot(lane == 0 || prev != slot);
+    const unsigned start = 63u - (unsigned)__clzll(heads & below);   // first lane of this lane's run
+    const unsigned long long run = below & ~((1ull << start) - 1ull);  // lanes start .. lane
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    // a run that begins behind lane 0 and ends in front of lane 63 belongs to this row alone
+    const bool excl = EXCL && lane < 63 && start > 0;
     // size / count (rows whose FIRST key component is non-null, categorify.py:995-999)
     {
-      double sz = live ? 1.0 : 0.0;
-      double ct = (live && bit_valid(a.key_valid[0], row)) ? 1.0 : 0.0;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const double osz = __shfl_up(sz, off, 64), oct = __shfl_up(ct, off, 64);
-        const uint32_t os = __shfl_up(slot, off, 64);
-        if (lane >= (unsigned)off && os == slot) {
-          sz += osz;
-          ct += oct;
-        }
-      }
-      // the run's first word sits at lane + 1 - sz: inside the row when that is > 0
-      excl = EXCL && lane < 63 && (double)(lane + 1) > sz;
+      const unsigned long long sz = (unsigned long long)(lane - start + 1);
+      unsigned long long ct = sz;
+      if (a.key_valid[0]) ct = (unsigned long long)__popcll(__ballot(live && bit_valid(a.key_valid[0], row)) & run);
       if (live && tail) {
         if (excl) {
-          if (t.size) t.size[slot] = (unsigned long long)sz;
-          if (t.count && ct > 0) t.count[slot] = (unsigned long long)ct;
+          if (t.size) t.size[slot] = sz;
+          if (t.count && ct > 0) t.count[slot] = ct;
         } else {
-          if (t.size) atomicAdd(&t.size[slot], (unsigned long long)sz);
-          if (t.count && ct > 0) atomicAdd(&t.count[slot], (unsigned long long)ct);
+          if (t.size) atomicAdd(&t.size[slot], sz);
+          if (t.count && ct > 0) atomicAdd(&t.count[slot], ct);
         }
       }
     }
@@ -369,38 +370,41 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
         if (a.sorted_out[j] && act) store_val(a.sorted_out[j], a.vdtype[j], i, live ? v : 0.0);
       }
       double sum = ok ? v : 0.0, sq = ok ? v * v : 0.0, mn = ok ? v : inf, mx = ok ? v : -inf;
-      double any = ok ? 1.0 : 0.0;
-      // inclusive segmented scan in row order: equal slots are contiguous, so "same slot as the
-      // lane `off` below" means that lane belongs to this run
+      const unsigned long long any = (unsigned long long)__popcll(__ballot(ok) & run);
+      // inclusive segmented scan in row order: the lane `off` below belongs to this run when it
+      // is not in front of the run's first lane
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
-        const double osum = __shfl_up(sum, off, 64), osq = __shfl_up(sq, off, 64);
-        const double omn = __shfl_up(mn, off, 64), omx = __shfl_up(mx, off, 64);
-        const double oany = __shfl_up(any, off, 64);
-        const uint32_t os = __shfl_up(slot, off, 64);
-        if (lane >= (unsigned)off && os == slot) {
-          sum = osum + sum;  // earlier rows first
-          sq = osq + sq;
-          mn = omn < mn ? omn : mn;
-          mx = omx > mx ? omx : mx;
-          any += oany;
+        const bool take = lane >= start + (unsigned)off;
+        const double osum = __shfl_up(sum, off, 64);
+        if (take) sum = osum + sum;  // earlier rows first
+        if constexpr (SQ) {
+          const double osq = __shfl_up(sq, off, 64);
+          if (take) sq = osq + sq;
+        }
+        if constexpr (MM) {
+          const double omn = __shfl_up(mn, off, 64), omx = __shfl_up(mx, off, 64);
+          if (take) {
+            mn = omn < mn ? omn : mn;
+            mx = omx > mx ? omx : mx;
+          }
         }
       }
       if (live && tail && any > 0) {
         const uint64_t o = (uint64_t)j * t.cap + slot;
         if (excl) {
           t.sum[o] = sum;
-          if (t.vcount) t.vcount[o] = (unsigned long long)any;
-          if (t.sumsq) t.sumsq[o] = sq;
-          if (t.vmin) {
+          if (t.vcount) t.vcount[o] = any;
+          if constexpr (SQ) t.sumsq[o] = sq;
+          if constexpr (MM) {
             t.vmin[o] = mn;
             t.vmax[o] = mx;
           }
         } else {
           atomicAdd(&t.sum[o], sum);
-          if (t.vcount) atomicAdd(&t.vcount[o], (unsigned long long)any);
-          if (t.sumsq) atomicAdd(&t.sumsq[o], sq);
-          if (t.vmin) {
+          if (t.vcount) atomicAdd(&t.vcount[o], any);
+          if constexpr (SQ) atomicAdd(&t.sumsq[o], sq);
+          if constexpr (MM) {
             atomic_min_f64(&t.vmin[o], mn);
             atomic_max_f64(&t.vmax[o], mx);
           }
@@ -408,6 +412,17 @@ __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArg
       }
     }
   }
+}
+
+template <bool EXCL>
+static void launch_segreduce(const GbView &t, const GbRowArgs &a, uint64_t n, const uint64_t *words,
+                             uint32_t slot_div, hipStream_t s) {
+  const unsigned grid = stream_grid(n, kBlock * 4, 8);
+  const bool sq = t.nvals > 0 && t.sumsq != nullptr, mm = t.nvals > 0 && t.vmin != nullptr;
+  if (sq && mm) gb_segreduce_kernel<EXCL, true, true><<<grid, kBlock, 0, s>>>(t, a, n, words, slot_div);
+  else if (sq) gb_segreduce_kernel<EXCL, true, false><<<grid, kBlock, 0, s>>>(t, a, n, words, slot_div);
+  else if (mm) gb_segreduce_kernel<EXCL, false, true><<<grid, kBlock, 0, s>>>(t, a, n, words, slot_div);
+  else gb_segreduce_kernel<EXCL, false, false><<<grid, kBlock, 0, s>>>(t, a, n, words, slot_div);
 }
 
 // ---- Groupby operator (groupby.py:236-263): row order + per-group aggregates ----------------
@@ -1061,7 +1076,7 @@ int nvt_gb_update(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *co
   uint64_t *sorted = nullptr;
   int rc = sort_words_bits(words, n, 32, 32 + cap_bits, sort_tmp, &sorted, s);
   if (rc) return rc;
-  gb_segreduce_kernel<false><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(view_of(t), a, n, sorted, 1u);
+  launch_segreduce<false>(view_of(t), a, n, sorted, 1u, s);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
@@ -1199,7 +1214,7 @@ int nvt_seg_aggregate(const uint64_t *words, uint64_t n, uint64_t ngroups, const
   NVT_CHECK_ARG(nvals == 0 || out_sum, "null out_sum");
   hipStream_t s = (hipStream_t)stream;
   NVT_PROF("groupby_aggregate", 0, s);
-  gb_segreduce_kernel<false><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, words, 1u);
+  launch_segreduce<false>(t, a, n, words, 1u, s);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }
@@ -1343,7 +1358,7 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
                   "int64 values are not carried in sorted order (not exact in a double)");
   }
   const uint32_t div = kfold == words_kfold ? 1u : (uint32_t)words_kfold;
-  gb_segreduce_kernel<true><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, regrouped, div);
+  launch_segreduce<true>(t, a, n, regrouped, div, s);
   NVT_CHECK_LAUNCH();
   if (kfold > 1) {
     sgb_fold_total_kernel<<<stream_grid(cap, kBlock, 8), kBlock, 0, s>>>(
@@ -1408,7 +1423,7 @@ int nvt_count_merge_sorted(const int64_t *rows, uint64_t n, const uint64_t *seg_
   memset(&a, 0, sizeof(a));
   a.vals[0] = cnt32;
   a.vdtype[0] = NVT_I32;
-  gb_segreduce_kernel<true><<<stream_grid(n, kBlock * 4, 8), kBlock, 0, s>>>(t, a, n, regrouped, 1u);
+  launch_segreduce<true>(t, a, n, regrouped, 1u, s);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

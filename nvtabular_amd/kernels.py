@@ -1816,8 +1816,11 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
         sp, rbc = C.c_void_p(), C.c_int()
         check(lib.nvt_sgb_sort(keys.data_ptr(), kdt, bias, ptr(fold), kfold, n, sort_ws.data_ptr(),
                                C.byref(sp), C.byref(rbc), stream_ptr()), "nvt_sgb_sort")
+        # (a re-sort WITH folds after an aggregate without: the groups are the same keys -- their
+        # key lists and what hangs off them, the lookup index, are taken over below)
         hit = dict(sorted=sp.value, rb=rbc.value, kfold=kfold, fold=ptr(fold), ws=sort_ws,
-                   keys=keys, fold_t=fold, groups=None, bias=bias)
+                   keys=keys, fold_t=fold, groups=None, bias=bias,
+                   prev_groups=hit["groups"] if hit is not None else None)
         if _PASS_MEMO is not None:
             _PASS_MEMO[memo_key] = hit
     grp = hit["groups"]
@@ -1849,6 +1852,12 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
         # ("shared": what outlives the pass -- the lookup index of these groups, built once)
         grp = hit["groups"] = dict(words=words, kfold=wk, k64=k64[:g], k32=k32[:g], g=g, state=state,
                                    shared={})
+        pg = hit.get("prev_groups")
+        if pg is not None and pg["g"] == g:
+            # same key column, same rows: the same ascending key list.  ONE list (and one lookup
+            # index, one merge across partitions) for every aggregate on the column, whatever the
+            # order of the operators
+            grp["k64"], grp["k32"], grp["shared"] = pg["k64"], pg["k32"], pg["shared"]
     g, wk = grp["g"], grp["kfold"]
     cap = max(g, 1)
     slots = cap * kfold

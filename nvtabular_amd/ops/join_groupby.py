@@ -227,7 +227,7 @@ class JoinGroupby(StatOperator):
                 valids.append(v)
             plan = self._plan(st)  # (column, output dtype, value of a row without group)
             if isinstance(st.index, K.FlatIndex) and 1 <= len(plan) <= 16:
-                cons = getattr(self, "_consumers", {}).get(name)
+                cons = getattr(self, "_consumers", {}).get(name) if K.LOOKUP_IMAGES else None
                 if cons is not None and cons in (getattr(st.index, "consumers", None) or []):
                     # ONE probe + ONE packed record per row for every operator fitted on this
                     # key column in the same pass (TargetEncoding's values ride in the same launch)
