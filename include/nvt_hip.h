@@ -547,9 +547,10 @@ int nvt_flat_lookup_te(const void *keys, int dtype, const uint8_t *valid, uint64
  * nvt_image_pack: image[g][offs[c]] = (dst dtype) src[c][g], src float64 / int64 arrays [groups].
  * nvt_te_image: (kfold + 1) values per group at image[g][off + slot * size]: slot 0 =
  * (sum + p*mean) / (count + p), slot 1 + f = the out-of-fold value of fold f (mean when the
- * (group, fold) pair has no rows) from records double[groups][2 * (kfold + 1)] (te_records of
- * nvt_sgb_reduce; kfold = 0: records {sum, count}) -- the expression nvt_te_apply evaluates per
- * row, evaluated once per (group, fold): identical bits. */
+ * (group, fold) pair has no rows), from the totals tot_count / tot_sum [groups] and the dense fold
+ * statistics fold_count / fold_sum [groups * kfold] of nvt_sgb_reduce (kfold = 0: totals only)
+ * -- the expression nvt_te_apply_folds evaluates per row, evaluated once per (group, fold):
+ * identical bits. */
 int nvt_flat_lookup_image(const void *keys, int dtype, const uint8_t *valid, uint64_t n,
                           const int32_t *aux, const void *table, uint64_t capacity, int64_t key_offset,
                           const int32_t *gid_in, int32_t *gid_out, const void *image,
@@ -559,7 +560,8 @@ int nvt_flat_lookup_image(const void *keys, int dtype, const uint8_t *valid, uin
 int nvt_image_pack(const void *const *src, const int *src_dtypes, const int *dst_dtypes,
                    const uint32_t *offs, int ncols, uint64_t groups, void *image,
                    uint32_t stride_bytes, void *stream);
-int nvt_te_image(const double *records, int kfold, uint64_t groups, double p_smooth, double y_mean,
+int nvt_te_image(const int64_t *tot_count, const double *tot_sum, const int64_t *fold_count,
+                 const double *fold_sum, int kfold, uint64_t groups, double p_smooth, double y_mean,
                  int out_dtype, void *image, uint32_t stride_bytes, uint32_t off, void *stream);
 
 /* ---- batched entry points: ONE call per operator per partition -----------------------

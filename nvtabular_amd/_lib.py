@@ -109,7 +109,7 @@ SIGNATURES = {
                               _pp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u64), _vp, _vp],
     "nvt_image_pack": [_pp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_u32), _i32, _u64, _vp,
                        _u32, _vp],
-    "nvt_te_image": [_vp, _i32, _u64, _dbl, _dbl, _i32, _vp, _u32, _u32, _vp],
+    "nvt_te_image": [_vp, _vp, _vp, _vp, _i32, _u64, _dbl, _dbl, _i32, _vp, _u32, _u32, _vp],
     "nvt_exchange_ranges": [_vp, _i32, _vp, _vp],
     "nvt_exchange_ranges_sorted": [_vp, _i32, _vp, _vp],
     "nvt_exchange_hist": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp],

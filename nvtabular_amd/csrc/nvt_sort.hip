@@ -364,7 +364,7 @@ inline uint64_t pad16(uint64_t x) { return (x + 15) & ~15ull; }
 //                     the data IS the flag (one relaxed agent-scope 4-byte store / load, the
 //                     "R2 granule" form of cdna_hip_programming.md G16), so no fences are needed.
 constexpr int kOsMaxPass = 8;
-constexpr int kOsHistBlocks = 256;
+constexpr int kOsHistBlocks = 1024;  // 4 per CU: 256 left 4 waves per CU waiting for their loads
 constexpr unsigned kOsAgg = 1u << 30, kOsPrefix = 2u << 30, kOsMask = (1u << 30) - 1u;
 
 __global__ __launch_bounds__(kS2BS) void os_hist_kernel(const int32_t *__restrict__ keys,
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kS2BS) void os_hist_words_kernel(const uint64_t *__
   const unsigned l = lane_id();
   const uint64_t stride = (uint64_t)gridDim.x * kS2BS;
   const uint64_t iters = (n + stride - 1) / stride;
-  constexpr int U = 4;  // loads in flight per thread (256 workgroups stream the whole array)
+  constexpr int U = 4;  // loads in flight per thread
   for (uint64_t it = 0; it < iters; it += U) {
     uint64_t cw[U];
     bool av[U];
@@ -1664,27 +1664,30 @@ __global__ __launch_bounds__(kBlock) void image_pack_kernel(ImagePackArgs a, int
   }
 }
 
-// TargetEncoding's byte range: (kfold + 1) values per group from the fit's {sum, count, (sum_f,
-// count_f) ...} records -- exactly the expression flat_lookup_te_kernel / nvt_te_apply evaluate
-// per row (target_encoding.py:350-371), once per (group, fold)
+// TargetEncoding's byte range: (kfold + 1) values per group from the fit's statistics -- totals
+// {count, sum}[g] and the dense per-(group, fold) {count, sum}[g * kfold + f] of the sort path
+// (nvt_sgb_reduce) -- exactly the expression nvt_te_apply_folds evaluates per row
+// (target_encoding.py:350-371), once per (group, fold).  A thread per value: the fold arrays are
+// read in memory order, a record's values leave as one contiguous run.
 template <typename OUT>
-__global__ __launch_bounds__(kBlock) void te_image_kernel(const double *__restrict__ records,
-                                                          unsigned kfold, uint64_t groups, double p,
-                                                          double y_mean, uint8_t *__restrict__ image,
-                                                          uint32_t stride_bytes, uint32_t off) {
-  const unsigned per = kfold + 1, rs = 2 * (kfold + 1);
+__global__ __launch_bounds__(kBlock) void te_image_kernel(
+    const int64_t *__restrict__ tot_count, const double *__restrict__ tot_sum,
+    const int64_t *__restrict__ fold_count, const double *__restrict__ fold_sum, unsigned kfold,
+    uint64_t groups, double p, double y_mean, uint8_t *__restrict__ image, uint32_t stride_bytes,
+    uint32_t off) {
+  const unsigned per = kfold + 1;
   const uint64_t total = groups * per, stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
     const uint64_t g = e / per;
     const unsigned slot = (unsigned)(e - g * per);
-    const double *rec = records + g * rs;
-    const double2 tot = *reinterpret_cast<const double2 *>(rec);
+    const double c = (double)tot_count[g], d = tot_sum[g];
     double r;
     if (slot == 0) {
-      r = (tot.x + p * y_mean) / (tot.y + p);
+      r = (d + p * y_mean) / (c + p);
     } else {
-      const double2 f = *reinterpret_cast<const double2 *>(rec + 2 * slot);
-      r = f.y > 0.0 ? (tot.x - f.x + p * y_mean) / (tot.y - f.y + p) : y_mean;
+      const uint64_t f = g * kfold + (slot - 1);
+      const double fc = (double)fold_count[f], fs = fold_sum[f];
+      r = fc > 0.0 ? (d - fs + p * y_mean) / (c - fc + p) : y_mean;
     }
     *reinterpret_cast<OUT *>(image + g * stride_bytes + off + slot * sizeof(OUT)) = (OUT)r;
   }
@@ -2271,25 +2274,27 @@ int nvt_image_pack(const void *const *src, const int *src_dtypes, const int *dst
   return NVT_OK;
 }
 
-int nvt_te_image(const double *records, int kfold, uint64_t groups, double p_smooth, double y_mean,
+int nvt_te_image(const int64_t *tot_count, const double *tot_sum, const int64_t *fold_count,
+                 const double *fold_sum, int kfold, uint64_t groups, double p_smooth, double y_mean,
                  int out_dtype, void *image, uint32_t stride_bytes, uint32_t off, void *stream) {
   if (groups == 0) return NVT_OK;
-  NVT_CHECK_ARG(records && image, "null pointer");
-  NVT_CHECK_ARG(kfold >= 0 && kfold <= 256, "kfold must be 0 (records of {sum, count}) .. 256");
+  NVT_CHECK_ARG(tot_count && tot_sum && image, "null pointer");
+  NVT_CHECK_ARG(kfold >= 0 && kfold <= 256, "kfold must be 0 (no folds) .. 256");
+  NVT_CHECK_ARG(kfold == 0 || (fold_count && fold_sum), "fold statistics come with kfold > 0");
   NVT_CHECK_ARG(out_dtype == NVT_F32 || out_dtype == NVT_F64, "out dtype must be f32 / f64");
   const uint32_t sz = out_dtype == NVT_F32 ? 4u : 8u;
   NVT_CHECK_ARG(off % sz == 0 && (uint64_t)off + (uint64_t)(kfold + 1) * sz <= stride_bytes,
                 "values outside the record");
   hipStream_t s = (hipStream_t)stream;
   NVT_PROF("groupby_index", groups * 16ull * (kfold + 1), s);
-  const unsigned grid = stream_grid(groups * (uint64_t)(kfold + 1), kBlock, 8);
+  const unsigned grid = stream_grid(groups * (uint64_t)(kfold + 1), kBlock * 2, 8);
   uint8_t *img = reinterpret_cast<uint8_t *>(image);
   if (out_dtype == NVT_F32)
-    te_image_kernel<float><<<grid, kBlock, 0, s>>>(records, (unsigned)kfold, groups, p_smooth, y_mean, img,
-                                                   stride_bytes, off);
+    te_image_kernel<float><<<grid, kBlock, 0, s>>>(tot_count, tot_sum, fold_count, fold_sum, (unsigned)kfold,
+                                                   groups, p_smooth, y_mean, img, stride_bytes, off);
   else
-    te_image_kernel<double><<<grid, kBlock, 0, s>>>(records, (unsigned)kfold, groups, p_smooth, y_mean, img,
-                                                    stride_bytes, off);
+    te_image_kernel<double><<<grid, kBlock, 0, s>>>(tot_count, tot_sum, fold_count, fold_sum, (unsigned)kfold,
+                                                    groups, p_smooth, y_mean, img, stride_bytes, off);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

@@ -2192,9 +2192,11 @@ class FlatIndex:
         total = max(8, (at + 7) & ~7)
         # records of <= 64 bytes never straddle a 64-byte sector; larger ones are sector-aligned
         stride = next_pow2(total) if total <= 64 else (total + 63) & ~63
-        image = torch.empty(max(self.n, 1) * stride, dtype=torch.uint8, device=self.keys32.device)
+        # (a consumer's statistics may hold one group more than the key list: the null-key group)
+        rows = max([self.n + 1] + [c.groups for c in self.consumers])
+        image = torch.empty(rows * stride, dtype=torch.uint8, device=self.keys32.device)
         for c in self.consumers:
-            c.fill(image, stride, place[id(c)], self.n)
+            c.fill(image, stride, place[id(c)], c.groups)
         self._image = (image, stride, place)
         return self._image
 
@@ -2268,11 +2270,13 @@ class LookupConsumer:
 
     outputs: [(name, torch dtype, byte offset inside the range, per_fold, value of a row without
     group)]; per_fold outputs hold (kfold + 1) consecutive values (slot 0: no fold) and need
-    fold_fn(n, device) -> uint8 fold ids.  fill(image, stride, offset, groups) writes the range."""
+    fold_fn(n, device) -> uint8 fold ids.  fill(image, stride, offset, groups) writes the range
+    of the first `groups` records."""
 
-    def __init__(self, owner, tag, width, outputs, fill, fold_fn=None):
+    def __init__(self, owner, tag, width, outputs, fill, fold_fn=None, groups=0):
         self.owner, self.tag, self.width = owner, tag, int(width)
         self.outputs, self.fill, self.fold_fn = list(outputs), fill, fold_fn
+        self.groups = int(groups)   # records this consumer fills (the groups of its statistics)
 
 
 def image_pack(image, stride, columns, groups):
@@ -2289,16 +2293,23 @@ def image_pack(image, stride, columns, groups):
         nc, int(groups), image.data_ptr(), int(stride), stream_ptr()), "nvt_image_pack")
 
 
-def te_image(image, stride, offset, records, kfold, groups, p_smooth, y_mean, out_dtype):
-    """records [groups, 2 * (kfold + 1)] float64 (kfold 0: {sum, count}) -> (kfold + 1) smoothed
-    values per group at `offset` of the records of `image`."""
+def te_image(image, stride, offset, tot_count, tot_sum, fold_count, fold_sum, kfold, groups, p_smooth,
+             y_mean, out_dtype):
+    """(kfold + 1) smoothed values per group at `offset` of the records of `image`, from the
+    totals [groups] and the dense per-(group, fold) statistics [groups * kfold] (kfold 0: totals
+    only)."""
     if not groups:
         return
-    assert records.dtype == torch.float64 and records.is_contiguous()
-    assert int(records.shape[1]) == 2 * (int(kfold) + 1)
-    check(_lib.load().nvt_te_image(records.data_ptr(), int(kfold), int(groups), float(p_smooth),
-                                   float(y_mean), dtype_code(out_dtype), image.data_ptr(), int(stride),
-                                   int(offset), stream_ptr()), "nvt_te_image")
+    tc, ts = tot_count.contiguous(), tot_sum.contiguous()
+    assert tc.dtype == torch.int64 and ts.dtype == torch.float64
+    fc = fs = None
+    if kfold:
+        fc, fs = fold_count.contiguous(), fold_sum.contiguous()
+        assert fc.dtype == torch.int64 and fs.dtype == torch.float64
+        assert int(fc.numel()) >= groups * kfold and int(fs.numel()) >= groups * kfold
+    check(_lib.load().nvt_te_image(tc.data_ptr(), ts.data_ptr(), ptr(fc), ptr(fs), int(kfold), int(groups),
+                                   float(p_smooth), float(y_mean), dtype_code(out_dtype), image.data_ptr(),
+                                   int(stride), int(offset), stream_ptr()), "nvt_te_image")
 
 
 LOOKUP_IMAGES = os.environ.get("NVT_LOOKUP_IMAGES", "1") != "0"

@@ -105,7 +105,7 @@ class GroupAgg:
         if sort_ok and K.sorted_groupby_eligible(s_keys[0], s_kvalid[0], s_n, kfold):
             comp = K.sorted_groupby(s_keys[0], s_fold, kfold, s_vals, s_vvalid, sumsq=self.sumsq,
                                     minmax=self.minmax, cap_hint=self.part_hint or self.hint,
-                                    te_records=True)
+                                    te_records=not K.LOOKUP_IMAGES)
             if comp is not None and nullgrp is not None:
                 comp["nullgrp"] = nullgrp
             if comp is not None:  # (None: int64 keys spanning 2^32 or more)

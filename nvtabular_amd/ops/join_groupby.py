@@ -188,7 +188,7 @@ class JoinGroupby(StatOperator):
             K.image_pack(image, stride, [(st.columns[plan[i][0]], plan[i][1], offset + rel[i])
                                          for i in range(len(plan))], groups)
 
-        cons = K.LookupConsumer(self, name, at, outputs, fill)
+        cons = K.LookupConsumer(self, name, at, outputs, fill, groups=st.n)
         st.index.attach(cons)
         self._consumers[name] = cons
 

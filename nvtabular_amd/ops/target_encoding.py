@@ -236,7 +236,7 @@ class TargetEncoding(StatOperator):
             if fit_folds:
                 fname = _make_name(self.fold_name, *st_all.key_cols, sep=self.name_sep)
                 st_fold = self._device_stats.get(fname)
-                if not isinstance(st_fold, _FoldDense) or st_fold.records is None:
+                if not isinstance(st_fold, _FoldDense):
                     continue
             targets = [c[len("sum:"):] for c in st_all.columns if c.startswith("sum:")]
             try:
@@ -248,15 +248,19 @@ class TargetEncoding(StatOperator):
 
             def fill(image, stride, offset, groups, st_all=st_all, st_fold=st_fold, targets=targets,
                      means=means):
+                cnt = st_all.columns["count"].to(torch.int64)
                 for j, t in enumerate(targets):
-                    rec = st_fold.records[t] if fit_folds else st_all.te_records(t)
-                    K.te_image(image, stride, offset + j * slots * size, rec.contiguous(),
+                    K.te_image(image, stride, offset + j * slots * size, cnt,
+                               st_all.columns[f"sum:{t}"].to(torch.float64),
+                               st_fold.count if fit_folds else None,
+                               st_fold.sums[t] if fit_folds else None,
                                self.kfold if fit_folds else 0, groups, self.p_smooth, means[t], out_dt)
 
             fold_fn = None
             if fit_folds:
                 fold_fn = lambda n, dev: _fold_column(n, self.kfold, self.fold_seed, dev).data  # noqa: E731
-            cons = K.LookupConsumer(self, name, len(targets) * slots * size, outputs, fill, fold_fn)
+            cons = K.LookupConsumer(self, name, len(targets) * slots * size, outputs, fill, fold_fn,
+                                    groups=st_all.n)
             st_all.index.attach(cons)
             self._consumers[name] = cons
 

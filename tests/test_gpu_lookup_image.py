@@ -57,6 +57,11 @@ def test_image_kernels_equal_the_per_operator_kernels(kfold, out_dt):
     else:
         rec = np.concatenate([fsum.sum(1, keepdims=True), fcnt.sum(1, keepdims=True) + 1], axis=1)
     rec_t = torch.from_numpy(np.ascontiguousarray(rec)).to(dev)
+    # the same numbers as the fit keeps them: totals [g] + dense fold statistics [g * kfold]
+    tot_c = torch.from_numpy(rec[:, 1].astype(np.int64)).to(dev)
+    tot_s = torch.from_numpy(np.ascontiguousarray(rec[:, 0])).to(dev)
+    fold_c = torch.from_numpy(fcnt.astype(np.int64).reshape(-1)).to(dev) if kfold else None
+    fold_s = torch.from_numpy(np.ascontiguousarray(fsum.reshape(-1))).to(dev) if kfold else None
     fold = torch.from_numpy(rng.integers(0, kf, n).astype(np.uint8)).to(dev) if kfold else None
     p, ym = 20.0, 0.37
 
@@ -64,8 +69,9 @@ def test_image_kernels_equal_the_per_operator_kernels(kfold, out_dt):
     te_size = 8 if out_dt == torch.float64 else 4
     te_cons = K.LookupConsumer(
         owner, "te", (kfold + 1) * te_size, [("te", out_dt, 0, bool(kfold), ym)],
-        lambda image, stride, off, groups: K.te_image(image, stride, off, rec_t, kfold, groups, p, ym, out_dt),
-        (lambda m, d: fold) if kfold else None)
+        lambda image, stride, off, groups: K.te_image(image, stride, off, tot_c, tot_s, fold_c, fold_s, kfold,
+                                                     groups, p, ym, out_dt),
+        (lambda m, d: fold) if kfold else None, groups=g)
     order = sorted(range(4), key=lambda i: 0 if plan[i][2] in (torch.float64, torch.int64) else 1)
     rel, at = {}, 0
     for i in order:
@@ -74,7 +80,7 @@ def test_image_kernels_equal_the_per_operator_kernels(kfold, out_dt):
     jg_cons = K.LookupConsumer(
         owner, "jg", at, [(plan[i][0], plan[i][2], rel[i], False, plan[i][3]) for i in range(4)],
         lambda image, stride, off, groups: K.image_pack(
-            image, stride, [(plan[i][1], plan[i][2], off + rel[i]) for i in range(4)], groups))
+            image, stride, [(plan[i][1], plan[i][2], off + rel[i]) for i in range(4)], groups), groups=g)
     index.attach(te_cons)
     index.attach(jg_cons)
     before = K.STATS.get("image_lookups", 0)
