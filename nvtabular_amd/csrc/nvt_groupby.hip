@@ -308,141 +308,203 @@ struct SegAcc {
 // last word (they may continue in the neighbouring rows) need atomics.  With ~4 rows per group
 // that is 14 of 16 runs.  slot_div: the words' slots are g * slot_div + fold and this
 // aggregate wants g (words regrouped for another aggregate's folds).
-// Shuffles are what this kernel issues most (ds_bpermute: one LDS crossbar trip per 32-bit word):
-// run lengths, the count of valid rows / values and the "exclusive run" test come from BALLOTS of
-// the run heads (scalar bit arithmetic, no shuffle), and only the statistics the table carries
-// are scanned -- SQ / MM are compile-time.  TargetEncoding's reduction (sum only) shuffles 13
-// words per 64 rows where the first version shuffled 96.
+// What this kernel waits for (experiment modes, 20 M rows / 5 M groups, profiles/r05_notes.md):
+// the scan itself is ~100 us; gathering a value by row ~300 us (random sectors); and the
+// accumulator writes were ~250 us as long as every row of 64 words sent its first and last run to
+// the dense arrays with ATOMICS next to the plain stores of the runs in between (an atomic on a
+// line with pending partial writes is slow, whatever the key skew).  So a wave now CARRIES the
+// run that reaches the end of a row into the next row of its chunk: only the first and the last
+// run of a wave's whole chunk (~2400 words) can continue in another wave's chunk and use
+// atomics; everything else is a plain store by the lane that ends the run.
+//   * run lengths, valid counts and run ownership come from BALLOTS of the run heads (scalar bit
+//     arithmetic), only the statistics the table carries are scanned (SQ / MM compile-time):
+//     13 crossbar trips per 64 rows for TargetEncoding's reduction where the first version had 96;
+//   * U rows per trip: their loads are issued together; the carry is wave-uniform and touches a
+//     row only after its scan, so the scan chains of the U rows still interleave;
+//   * one walk over the chunk per value column (the carry of several columns would have to be
+//     indexed dynamically, i.e. live in scratch); sizes / counts ride on the first walk.
+__device__ __forceinline__ double bcast_lane_f64(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ unsigned long long bcast_lane_u64(unsigned long long x, int src) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 template <bool EXCL, bool SQ, bool MM>
 __global__ __launch_bounds__(kBlock) void gb_segreduce_kernel(GbView t, GbRowArgs a, uint64_t n,
                                                               const uint64_t *__restrict__ words,
                                                               uint32_t slot_div) {
   const double inf = std::numeric_limits<double>::infinity();
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
   const unsigned lane = lane_id();
   const uint64_t nwaves = (uint64_t)gridDim.x * (kBlock / kWave);
   const uint64_t wave0 = (uint64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
-  // every wave walks ONE contiguous chunk of the sorted words in 64-element steps (fixed trip
-  // count: every lane takes part in the shuffles).  The slots of a chunk are a contiguous range
-  // when the words are ordered by slot: the accumulators a wave writes are its own region, far
-  // from the other waves' (a grid-stride walk put the whole GPU's stores into the same ~1 MB
-  // window of the dense arrays at any time: 596 us instead of 443 for 20 M rows)
+  // every wave walks ONE contiguous chunk of the sorted words in rows of 64.  The slots of a chunk
+  // are a contiguous range when the words are ordered by slot: the accumulators a wave writes
+  // are its own region, far from the other waves' (a grid-stride walk put the whole GPU's stores
+  // into the same ~1 MB window of the dense arrays at any time: 596 us instead of 443)
   const uint64_t per_wave = ((n + nwaves - 1) / nwaves + kWave - 1) / kWave * kWave;
+  const uint64_t chunk_begin = wave0 * per_wave;
   const uint64_t chunk_end = (wave0 + 1) * per_wave < n ? (wave0 + 1) * per_wave : n;
   const unsigned long long below = (2ull << lane) - 1ull;  // lanes 0 .. lane
-  // U rows of 64 words per trip, each its own segment space: their loads (words, gathered or
-  // sorted values) are issued together and their scan chains interleave -- one row per trip
-  // left a wave waiting for one load, then 13 dependent crossbar trips, then its stores
-  // (vmcnt counts stores too on gfx9): 430-620 us for 20 M rows whatever the data
   constexpr int U = 4;
-  for (uint64_t base = wave0 * per_wave; base < chunk_end; base += (uint64_t)kWave * U) {
-    uint64_t idx[U];
-    uint32_t slot[U], row[U];
-    unsigned start[U];
-    unsigned long long run[U];
-    bool act[U], live[U], tail[U], excl[U];
-    uint64_t w[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      idx[u] = base + (uint64_t)u * kWave + lane;
-      act[u] = idx[u] < chunk_end;
-      w[u] = act[u] ? words[idx[u]] : ~0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t raw = (uint32_t)(w[u] >> 32);
-      slot[u] = (slot_div > 1 && raw != 0xFFFFFFFFu) ? raw / slot_div : raw;
-      row[u] = (uint32_t)w[u];
-      live[u] = act[u] && raw != 0xFFFFFFFFu && slot[u] < t.cap;
-      const uint32_t prev = __shfl_up(slot[u], 1, 64);
-      // run heads of this row of 64 words (lane 0 starts a run as far as the row is concerned)
-      const unsigned long long heads = __ballot(lane == 0 || prev != slot[u]);
-      start[u] = 63u - (unsigned)__clzll(heads & below);            // first lane of this lane's run
-      run[u] = below & ~((1ull << start[u]) - 1ull);                // lanes start .. lane
-      tail[u] = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-      // a run that begins behind lane 0 and ends in front of lane 63 belongs to this row alone
-      excl[u] = EXCL && lane < 63 && start[u] > 0;
-    }
-    // size / count (rows whose FIRST key component is non-null, categorify.py:995-999)
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned long long sz = (unsigned long long)(lane - start[u] + 1);
-      unsigned long long ct = sz;
-      if (a.key_valid[0])
-        ct = (unsigned long long)__popcll(__ballot(live[u] && bit_valid(a.key_valid[0], row[u])) & run[u]);
-      if (live[u] && tail[u]) {
-        if (excl[u]) {
-          if (t.size) t.size[slot[u]] = sz;
-          if (t.count && ct > 0) t.count[slot[u]] = ct;
+  const int npass = t.nvals > 0 ? t.nvals : 1;
+  for (int j = 0; j < npass; ++j) {
+    const bool with_val = t.nvals > 0, with_size = j == 0;
+    // the carried run (wave-uniform): its slot, whether it began at the chunk's first word (then
+    // it may continue a run of the previous wave's chunk), and its partial statistics
+    uint32_t c_slot = kNone;
+    bool c_first = false;
+    unsigned long long c_sz = 0, c_ct = 0, c_any = 0;
+    double c_sum = 0.0, c_sq = 0.0, c_mn = inf, c_mx = -inf;
+    // writes one finished run (called by ONE lane): own = nobody else adds to this slot
+    auto emit = [&](uint32_t sl, bool own, unsigned long long sz, unsigned long long ct,
+                    unsigned long long any, double sum, double sq, double mn, double mx) {
+      if (with_size) {
+        if (own) {
+          if (t.size) t.size[sl] = sz;
+          if (t.count && ct > 0) t.count[sl] = ct;
         } else {
-          if (t.size) atomicAdd(&t.size[slot[u]], sz);
-          if (t.count && ct > 0) atomicAdd(&t.count[slot[u]], ct);
+          if (t.size) atomicAdd(&t.size[sl], sz);
+          if (t.count && ct > 0) atomicAdd(&t.count[sl], ct);
         }
       }
-    }
-    for (int j = 0; j < t.nvals; ++j) {
+      if (with_val && any > 0) {
+        const uint64_t o = (uint64_t)j * t.cap + sl;
+        if (own) {
+          t.sum[o] = sum;
+          if (t.vcount) t.vcount[o] = any;
+          if constexpr (SQ) t.sumsq[o] = sq;
+          if constexpr (MM) {
+            t.vmin[o] = mn;
+            t.vmax[o] = mx;
+          }
+        } else {
+          atomicAdd(&t.sum[o], sum);
+          if (t.vcount) atomicAdd(&t.vcount[o], any);
+          if constexpr (SQ) atomicAdd(&t.sumsq[o], sq);
+          if constexpr (MM) {
+            atomic_min_f64(&t.vmin[o], mn);
+            atomic_max_f64(&t.vmax[o], mx);
+          }
+        }
+      }
+    };
+    for (uint64_t base = chunk_begin; base < chunk_end; base += (uint64_t)kWave * U) {
+      uint64_t idx[U], w[U];
+      bool act[U];
       double v[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        idx[u] = base + (uint64_t)u * kWave + lane;
+        act[u] = idx[u] < chunk_end;
+        w[u] = act[u] ? words[idx[u]] : ~0ull;
+      }
+      uint32_t slot[U], row[U];
+      bool live[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t raw = (uint32_t)(w[u] >> 32);
+        slot[u] = (slot_div > 1 && raw != kNone) ? raw / slot_div : raw;
+        if (!(act[u] && raw != kNone && slot[u] < t.cap)) slot[u] = kNone;  // rows nobody counts
+        live[u] = slot[u] != kNone;
+        row[u] = (uint32_t)w[u];
         v[u] = 0;
-        if (a.sorted_in[j]) {  // (no validity bitmap on this path: the caller checked)
-          ok[u] = act[u] && load_val(a.sorted_in[j], a.vdtype[j], idx[u], &v[u]) && live[u];
-        } else {
-          ok[u] = live[u] && load_val(a.vals[j], a.vdtype[j], row[u], &v[u]) &&
-                  bit_valid(a.val_valid[j], row[u]);
+        ok[u] = false;
+        if (with_val) {
+          if (a.sorted_in[j]) {  // (no validity bitmap on this path: the caller checked)
+            ok[u] = act[u] && load_val(a.sorted_in[j], a.vdtype[j], idx[u], &v[u]) && live[u];
+          } else {
+            ok[u] = live[u] && load_val(a.vals[j], a.vdtype[j], row[u], &v[u]) &&
+                    bit_valid(a.val_valid[j], row[u]);
+          }
         }
       }
-      if (a.sorted_out[j] && !a.sorted_in[j]) {
+      if (with_val && a.sorted_out[j] && !a.sorted_in[j]) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
           if (act[u]) store_val(a.sorted_out[j], a.vdtype[j], idx[u], live[u] ? v[u] : 0.0);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        if (base + (uint64_t)u * kWave >= chunk_end) break;  // (uniform)
+        const uint32_t prev = __shfl_up(slot[u], 1, 64);
+        // run heads of this row (lane 0 starts a run as far as the row is concerned)
+        const unsigned long long heads = __ballot(lane == 0 || prev != slot[u]);
+        const unsigned start = 63u - (unsigned)__clzll(heads & below);   // first lane of this lane's run
+        const unsigned long long run = below & ~((1ull << start) - 1ull);  // lanes start .. lane
+        const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+        unsigned long long sz = (unsigned long long)(lane - start + 1), ct = sz;
+        if (with_size && a.key_valid[0])
+          ct = (unsigned long long)__popcll(__ballot(live[u] && bit_valid(a.key_valid[0], row[u])) & run);
         double sum = ok[u] ? v[u] : 0.0, sq = ok[u] ? v[u] * v[u] : 0.0;
         double mn = ok[u] ? v[u] : inf, mx = ok[u] ? v[u] : -inf;
-        const unsigned long long any = (unsigned long long)__popcll(__ballot(ok[u]) & run[u]);
-        // inclusive segmented scan in row order: the lane `off` below belongs to this run when
-        // it is not in front of the run's first lane
+        unsigned long long any = (unsigned long long)__popcll(__ballot(ok[u]) & run);
+        if (with_val) {
+          // inclusive segmented scan in row order: the lane `off` below belongs to this run when
+          // it is not in front of the run's first lane
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const bool take = lane >= start[u] + (unsigned)off;
-          const double osum = __shfl_up(sum, off, 64);
-          if (take) sum = osum + sum;  // earlier rows first
-          if constexpr (SQ) {
-            const double osq = __shfl_up(sq, off, 64);
-            if (take) sq = osq + sq;
-          }
-          if constexpr (MM) {
-            const double omn = __shfl_up(mn, off, 64), omx = __shfl_up(mx, off, 64);
-            if (take) {
-              mn = omn < mn ? omn : mn;
-              mx = omx > mx ? omx : mx;
+          for (int off = 1; off < 64; off <<= 1) {
+            const bool take = lane >= start + (unsigned)off;
+            const double osum = __shfl_up(sum, off, 64);
+            if (take) sum = osum + sum;  // earlier rows first
+            if constexpr (SQ) {
+              const double osq = __shfl_up(sq, off, 64);
+              if (take) sq = osq + sq;
+            }
+            if constexpr (MM) {
+              const double omn = __shfl_up(mn, off, 64), omx = __shfl_up(mx, off, 64);
+              if (take) {
+                mn = omn < mn ? omn : mn;
+                mx = omx > mx ? omx : mx;
+              }
             }
           }
         }
-        if (live[u] && tail[u] && any > 0) {
-          const uint64_t o = (uint64_t)j * t.cap + slot[u];
-          if (excl[u]) {
-            t.sum[o] = sum;
-            if (t.vcount) t.vcount[o] = any;
-            if constexpr (SQ) t.sumsq[o] = sq;
-            if constexpr (MM) {
-              t.vmin[o] = mn;
-              t.vmax[o] = mx;
-            }
-          } else {
-            atomicAdd(&t.sum[o], sum);
-            if (t.vcount) atomicAdd(&t.vcount[o], any);
-            if constexpr (SQ) atomicAdd(&t.sumsq[o], sq);
-            if constexpr (MM) {
-              atomic_min_f64(&t.vmin[o], mn);
-              atomic_max_f64(&t.vmax[o], mx);
-            }
+        // the carried run continues in this row's first run, or is finished
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot[u]);
+        const bool cont = c_slot != kNone && c_slot == s0;
+        if (c_slot != kNone && !cont && lane == 0)
+          emit(c_slot, EXCL && !c_first, c_sz, c_ct, c_any, c_sum, c_sq, c_mn, c_mx);
+        // does this row's first run begin at the chunk's first word?
+        const bool row_first = base + (uint64_t)u * kWave == chunk_begin;
+        const bool first_run_first = cont ? c_first : row_first;
+        if (cont && start == 0) {
+          sz += c_sz;
+          ct += c_ct;
+          any += c_any;
+          sum = c_sum + sum;
+          if constexpr (SQ) sq = c_sq + sq;
+          if constexpr (MM) {
+            mn = c_mn < mn ? c_mn : mn;
+            mx = c_mx > mx ? c_mx : mx;
           }
+        }
+        // runs that end inside the row: written by their last lane
+        if (live[u] && tail && lane < 63)
+          emit(slot[u], EXCL && (start > 0 || !first_run_first), sz, ct, any, sum, sq, mn, mx);
+        // the run that reaches lane 63 is carried on
+        const unsigned start63 = (unsigned)__builtin_amdgcn_readlane((int)start, 63);
+        c_slot = (uint32_t)__builtin_amdgcn_readlane((int)slot[u], 63);
+        c_first = start63 == 0 ? first_run_first : false;
+        c_sz = bcast_lane_u64(sz, 63);
+        c_ct = bcast_lane_u64(ct, 63);
+        c_any = bcast_lane_u64(any, 63);
+        c_sum = bcast_lane_f64(sum, 63);
+        if constexpr (SQ) c_sq = bcast_lane_f64(sq, 63);
+        if constexpr (MM) {
+          c_mn = bcast_lane_f64(mn, 63);
+          c_mx = bcast_lane_f64(mx, 63);
         }
       }
     }
+    // the chunk's last run may continue in the next wave's chunk
+    if (c_slot != kNone && lane == 0) emit(c_slot, false, c_sz, c_ct, c_any, c_sum, c_sq, c_mn, c_mx);
   }
 }
 

@@ -2123,6 +2123,7 @@ class FlatIndex:
         k = k.contiguous()
         n = k.numel()
         out = torch.empty(n, dtype=torch.int64, device=k.device)
+        STATS["flat_lookups"] = STATS.get("flat_lookups", 0) + 1
         check(_lib.load().nvt_flat_lookup(k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n,
                                           self.aux.data_ptr(), self.table.data_ptr(), self.capacity,
                                           self.key_offset, out.data_ptr(), stream_ptr()),
@@ -2145,6 +2146,7 @@ class FlatIndex:
         assert records.dtype == torch.float64 and records.is_contiguous() and ncols == len(out_dtypes)
         outs = [torch.empty(n, dtype=dt, device=k.device) for dt in out_dtypes]
         unseen = torch.zeros(1, dtype=torch.int64, device=k.device)
+        STATS["flat_lookups"] = STATS.get("flat_lookups", 0) + 1
         check(_lib.load().nvt_flat_lookup_gather(
             k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
             self.table.data_ptr(), self.capacity, self.key_offset, records.data_ptr(), ncols,
@@ -2162,6 +2164,7 @@ class FlatIndex:
         assert records.dtype == torch.float64 and records.is_contiguous()
         assert int(records.shape[1]) == (2 * (kfold + 1) if fold is not None else 2)
         out = torch.empty(n, dtype=out_dtype, device=k.device)
+        STATS["flat_lookups"] = STATS.get("flat_lookups", 0) + 1
         check(_lib.load().nvt_flat_lookup_te(
             k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
             self.table.data_ptr(), self.capacity, self.key_offset,

@@ -322,7 +322,9 @@ class TargetEncoding(StatOperator):
             # target (no group-id columns in HBM)
             fused = isinstance(st_all.index, K.FlatIndex) and (
                 (not fit_folds) or (isinstance(st_fold, _FoldDense) and st_fold.records is not None))
-            cons = getattr(self, "_consumers", {}).get(name_all) if (fused and K.LOOKUP_IMAGES) else None
+            cons = None
+            if K.LOOKUP_IMAGES and isinstance(st_all.index, K.FlatIndex):
+                cons = getattr(self, "_consumers", {}).get(name_all)
             if cons is not None and getattr(st_all.index, "consumers", None) and cons in st_all.index.consumers \
                     and [o[0][1] for o in cons.outputs] == targets and cons.outputs[0][1] == out_dt:
                 # ONE probe + ONE packed record per row for every operator fitted on this key

@@ -162,9 +162,10 @@ def test_workflow_serves_both_operators_from_one_launch_per_partition(tmp_path, 
         return nvt.Workflow(te + jg if order == "te_jg" else jg + te)
 
     wf = build("a").fit(nvt.Dataset(parts))
-    before = K.STATS.get("image_lookups", 0)
+    before, other = K.STATS.get("image_lookups", 0), K.STATS.get("flat_lookups", 0)
     got = wf.transform(nvt.Dataset(parts)).to_ddf().compute()
     assert K.STATS["image_lookups"] == before + nparts
+    assert K.STATS.get("flat_lookups", 0) == other   # and no per-operator probe next to it
     K.LOOKUP_IMAGES = False   # the SAME fitted statistics through the per-operator kernels
     try:
         before = K.STATS.get("image_lookups", 0)

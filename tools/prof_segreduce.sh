@@ -1,7 +1,7 @@
 #!/bin/bash
-# kernel trace of tools/segreduce_probe.py for SKEW=3 and SKEW=1 -> per-kernel averages
+# kernel trace of tools/segreduce_probe.py (sort-path reductions alone) -> per-kernel averages
 cd /tmp && export TMPDIR=/tmp
-for sk in 3 1; do
+for sk in ${SKEWS:-3}; do
   out=$GRAFT_REPO_ROOT/gpurun_out/segr_$sk
   rm -rf $out; mkdir -p $out
   SKEW=$sk timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- \
