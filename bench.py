@@ -238,17 +238,17 @@ def family_of(scope):
 
 
 def pmc_traffic():
-    """HBM bytes from the committed PMC passes (profiles/r04_pmc_traffic.json: FETCH_SIZE /
+    """HBM bytes from the committed PMC passes (profiles/r05_pmc_traffic.json: FETCH_SIZE /
     WRITE_SIZE collected in separate `rocprofv3 --pmc` passes over this command and corrected
-    per MI355X_MICROARCH.md; made by tools/prof_r04.sh + tools/pmc_summarize.py).  PMC cannot be
+    per MI355X_MICROARCH.md; made by tools/prof_r05.sh + tools/pmc_summarize.py).  PMC cannot be
     sampled from inside the timed run, so these are the figures of the same command at the same
     size.  -> {"families": {family: bytes per step}, "step": bytes per step} or None."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        d["source"] = ("committed profile profiles/r04_pmc_traffic.json (rocprofv3 --pmc passes of "
-                       "this command at this size, tools/prof_r04.sh; NOT collected in this run)")
+        d["source"] = ("committed profile profiles/r05_pmc_traffic.json (rocprofv3 --pmc passes of "
+                       "this command at this size, tools/prof_r05.sh; NOT collected in this run)")
         return d
     except Exception:
         return None
@@ -267,6 +267,68 @@ def _host_timeline(marks):
     period = [marks[i + 1][0] - marks[i][0] for i in range(len(marks) - 1)]
     return {"step_period": stats(period), "fit": stats([b - a for a, b, _ in marks]),
             "transform_enqueue": stats([c - b for _, b, c in marks])}
+
+
+def cfg4_roofline(per_kernel_ms, rows, traffic_file="r05_cfg4_pmc_traffic.json"):
+    """`roofline` block of the TargetEncoding + JoinGroupby entries: kernel families = the
+    library's launch scopes (HIP events on the launch stream, K.profile_report), algorithmic
+    bytes per row from SURVEY 8(d): fit = JoinGroupby.fit (4 key + 4 value) + TargetEncoding.fit
+    (4 + 4 + 1 fold byte) = 17 B/row over sort + reduce + index build; transform = (4 key + 12
+    float32 statistics + 4 count) + (4 key + 1 fold byte + 4) = 29 B/row over the lookup."""
+    fam = {
+        "fit_sort": (("groupby_sort",), 17),          # the word sort (keys + fold bits + row ids)
+        "fit_reduce": (("groupby_sorted", "merge_sorted", "merge_payload"), 17),
+        "fit_index": (("groupby_index", "encode_build"), 0),
+        "transform_lookup": (("groupby_lookup", "te_apply"), 29),
+    }
+    per_family = {}
+    for name, (scopes, bpr) in fam.items():
+        ms = sum(v for k, v in per_kernel_ms.items() if k in scopes)
+        b = bpr * rows
+        per_family[name] = {"ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": b,
+                            "GBps": round(b / ms / 1e6, 1) if ms > 0 and b else None,
+                            "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4) if ms > 0 and b else None}
+    fit_ms = sum(per_family[k]["ms_per_step"] for k in ("fit_sort", "fit_reduce", "fit_index"))
+    tr_ms = per_family["transform_lookup"]["ms_per_step"]
+    whole = fit_ms + tr_ms
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", traffic_file)) as f:
+            t = json.load(f)
+        if int(t.get("rows", 0)) == int(rows):
+            traffic = t.get("hbm_bytes_per_step")
+    except Exception:
+        pass
+    dom = max(("fit_sort", "fit_reduce", "transform_lookup"), key=lambda k: per_family[k]["ms_per_step"])
+    return {
+        "bound": "hbm", "kernel": dom, "achieved": per_family[dom]["GBps"], "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": per_family[dom]["frac"],
+        "fit_GBps": round(17 * rows / fit_ms / 1e6, 1) if fit_ms > 0 else None,
+        "transform_GBps": round(29 * rows / tr_ms / 1e6, 1) if tr_ms > 0 else None,
+        "whole_step_frac_kernel_time": round(46 * rows / whole / 1e6 / HBM_PEAK_GBS, 4) if whole > 0 else None,
+        "traffic": traffic,
+        "traffic_source": (f"committed profile profiles/{traffic_file} (rocprofv3 --pmc passes of "
+                           "tools/cfg4_probe.py at this size; NOT collected in this run)") if traffic else None,
+        "per_family": per_family,
+    }
+
+
+def fold_generation_ms(device, rows, kfold=5, seed=42):
+    """The seeded fold column of TargetEncoding (numpy's MT19937 stream regenerated on the
+    device, once per (kfold, seed, device) and process: ops/target_encoding.py::_FOLD_CACHE) --
+    what the FIRST fit of a process pays and the timed steps do not."""
+    from nvtabular_amd.ops import target_encoding as T
+
+    key = (int(kfold), int(seed), str(device))
+    saved = T._FOLD_CACHE.pop(key, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    T._fold_column(rows, kfold, seed, device)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    if saved is not None and saved.numel() >= T._FOLD_CACHE[key].numel():
+        T._FOLD_CACHE[key] = saved
+    return round(ms, 3)
 
 
 def extra_cfg4(device, tmp, rows, sample_rows, steps=5):
@@ -328,6 +390,11 @@ def extra_cfg4(device, tmp, rows, sample_rows, steps=5):
         "algorithmic_GBps": rows * steps / dt * bytes_per_row / 1e9,
         "gpu_busy_ms": round(rep["busy_ms"], 3),
         "per_kernel_ms": {k: round(v[0], 3) for k, v in rep["kernels"].items()},
+        "roofline": cfg4_roofline({k: v[0] for k, v in rep["kernels"].items()}, rows),
+        # the seeded folds are a deterministic sequence cached per process: generated once,
+        # OUTSIDE the timed steps (the warm-up step pays it)
+        "fold_generation_ms": fold_generation_ms(device, rows),
+        "fold_generation_inside_ms_per_step": False,
     }
     # ---- CPU restatement + parity on a sample ----
     m = min(sample_rows, rows)
@@ -451,6 +518,10 @@ def extra_cfg4_multipart(device, tmp, rows_per_part=1 << 28, nparts=4, card=100_
         "ratio_to_single_partition_rows_per_s": (rows / dt / single) if single else None,
         "gpu_busy_ms": round(rep["busy_ms"], 3),
         "per_kernel_ms": {k: round(v[0], 3) for k, v in rep["kernels"].items()},
+        "roofline": cfg4_roofline({k: v[0] for k, v in rep["kernels"].items()}, rows,
+                                  traffic_file="r05_cfg4mp_pmc_traffic.json"),
+        "fold_generation_ms": fold_generation_ms(device, rows_per_part),
+        "fold_generation_inside_ms_per_step": False,
     }
     del frames, ds, wf
     torch.cuda.empty_cache()

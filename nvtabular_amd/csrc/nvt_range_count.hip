@@ -65,14 +65,19 @@ __device__ __forceinline__ uint32_t hot_bucket_r(int32_t key) { return hot_image
 // ---------------------------------------------------------------------------------------------
 // pass 1: hot counters + range partition of the cold rows
 // ---------------------------------------------------------------------------------------------
-template <int U>
+// NBL: nb_log2 at compile time (8 / 9 / 10: what the host picks for real columns) so that NB, CAP,
+// BPW and the lane-role masks of the flush are constants -- the kernel sits at 100+ scalar
+// registers and spent scalar and vector instructions on them every round (SQ counters,
+// profiles/r05_sq_counters.json: 28 SALU + 70 VALU per key); 0 = the run-time value.
+template <int U, int NBL>
 __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
     const int32_t *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
-    const int32_t *__restrict__ aux, int nb_log2, uint32_t region_cap, int32_t *__restrict__ regions,
+    const int32_t *__restrict__ aux, int nb_log2_rt, uint32_t region_cap, int32_t *__restrict__ regions,
     uint32_t *__restrict__ fills, unsigned *__restrict__ hot_cnt, uint64_t *state,
     unsigned long long *__restrict__ clr_status, unsigned *__restrict__ clr_hist) {
   // what pass 2 expects cleared (two memset launches per column otherwise): the look-back status
   // words with the ticket behind them, and the class histogram
+  const int nb_log2 = NBL ? NBL : nb_log2_rt;
   {
     const unsigned nst = (1u << nb_log2) + 8u;  // + 64 bytes: the ticket
     for (unsigned i = blockIdx.x * kRpBS + threadIdx.x; i < nst; i += kRpG * kRpBS) clr_status[i] = 0ull;
@@ -776,16 +781,17 @@ int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int n
   NVT_CHECK_HIP(hipMemsetAsync(w.status, 0, (uint64_t)NB * 8 + 64, s));
   NVT_CHECK_HIP(hipMemsetAsync(aux + NVT_RANGE_AUX_HIST, 0, 256 * 4, s));
 #endif
-  static const int upr = getenv("NVT_RANGE_U") ? atoi(getenv("NVT_RANGE_U")) : NVT_RANGE_U;
-  if (upr == 4)
-    rp_partition_kernel<4><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
-                                                  w.fills, w.hot_cnt, state, w.status, hist);
-  else if (upr == 1)
-    rp_partition_kernel<1><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
-                                                  w.fills, w.hot_cnt, state, w.status, hist);
-  else
-    rp_partition_kernel<2><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, w.regions,
-                                                  w.fills, w.hot_cnt, state, w.status, hist);
+#define NVT_RP_PART(NBL)                                                                         \
+  rp_partition_kernel<NVT_RANGE_U, NBL><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, \
+                                                               w.regions, w.fills, w.hot_cnt,    \
+                                                               state, w.status, hist)
+  static const bool rt_nb = getenv("NVT_RANGE_RT_NB") != nullptr;  // (A/B: the run-time variant)
+  if (rt_nb) NVT_RP_PART(0);
+  else if (nb_log2 == 8) NVT_RP_PART(8);
+  else if (nb_log2 == 9) NVT_RP_PART(9);
+  else if (nb_log2 == 10) NVT_RP_PART(10);
+  else NVT_RP_PART(0);
+#undef NVT_RP_PART
   NVT_CHECK_LAUNCH();
   mark("partition");
   hot_totals_kernel<<<kHotSlotsR / 64, 64 * kTotGroups, 0, s>>>(w.hot_cnt, kRpG, w.hot_tot);

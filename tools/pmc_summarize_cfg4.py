@@ -20,8 +20,9 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(f"{src}/fetch_counter_collection.csv", "FETCH_SIZE")
 write = per_kernel(f"{src}/write_counter_collection.csv", "WRITE_SIZE")
-steps = max(1, sum(v[1] for k, v in fetch.items() if "flat_lookup_te_kernel" in k))
-out = {"steps": steps, "kernels": {}}
+steps = max(1, sum(v[1] for k, v in fetch.items() if "sgb_pack_kernel" in k) - 1)   # (one fit more: the parity leg)
+rows = 20_000_000
+out = {"steps": steps, "rows": rows, "kernels": {}}
 tot = 0.0
 for name in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(name, [0.0, 0])
@@ -32,6 +33,8 @@ for name in sorted(set(fetch) | set(write)):
                             "hbm_bytes_per_step": int((2.0 * f + w) / steps)}
     tot += (2.0 * f + w) / steps
 out["step_hbm_bytes"] = int(tot)
+out["hbm_bytes_per_step"] = int(tot)
+out["traffic_over_algorithmic"] = round(tot / (46.0 * rows), 2)
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/cfg4_probe.py "
                 "(20 M rows, 5 M keys: TargetEncoding kfold 5 + JoinGroupby, sort path); "
                 "algorithmic bytes per step: 46 B x 20 M rows = 0.92 GB")
