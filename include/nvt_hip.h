@@ -47,6 +47,7 @@ extern "C" {
 #define NVT_EINVAL (-1)   /* bad argument */
 #define NVT_EHIP (-2)     /* a HIP runtime call failed */
 #define NVT_ENOMEM (-3)
+#define NVT_EUNSUPPORTED (-4) /* valid input this library does not handle (the caller falls back) */
 
 /* element types of continuous columns */
 #define NVT_F32 0
@@ -563,6 +564,29 @@ int nvt_image_pack(const void *const *src, const int *src_dtypes, const int *dst
 int nvt_te_image(const int64_t *tot_count, const double *tot_sum, const int64_t *fold_count,
                  const double *fold_sum, int kfold, uint64_t groups, double p_smooth, double y_mean,
                  int out_dtype, void *image, uint32_t stride_bytes, uint32_t off, void *stream);
+
+/* ---- parquet in: PLAIN / uncompressed column chunks of flat numeric columns -------------
+ * (merlin.io.Dataset(engine="parquet") under Workflow.fit / transform:
+ * tests/unit/workflow/test_cpu_workflow.py:67-81, bench/examples/dask-nvtabular-criteo-benchmark.py
+ * :216-237; the reference's dataframe backend decodes the pages.)
+ * nvt_pq_decode_chunk (HOST function, no GPU, thread-safe): chunk = the bytes of one column chunk
+ * from its first data page on (DataPage v1 / v2, PLAIN values, definition levels in the RLE /
+ * bit-packed hybrid, max_def_level 0 = REQUIRED or 1 = OPTIONAL).  Writes the rows' Arrow validity
+ * bitmap (LSB first, row i = bit valid_bit_offset + i: consecutive row groups of a partition go
+ * into ONE bitmap, by one thread; valid_out needs ceil((offset + rows) / 8) + 8 bytes) and the
+ * pages' values -- non-null ones only -- behind each other into values_out.  *rows_out must come
+ * out as expect_rows; *values_count = non-null rows.  NVT_EUNSUPPORTED: dictionary / compressed /
+ * other encodings / nested columns (the caller reads the file another way).
+ * nvt_expand_valid: out[i] = bit i of bitmap ? packed[valid rows in front of i] : 0 for n rows
+ * of 4- or 8-byte values (bitmap 8-byte aligned, ceil(n / 64) * 8 bytes readable); ws:
+ * nvt_expand_valid_ws_bytes(n). */
+int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_size, int max_def_level,
+                        uint64_t expect_rows, uint8_t *valid_out, uint64_t valid_bit_offset,
+                        uint8_t *values_out, uint64_t values_cap_bytes, uint64_t *rows_out,
+                        uint64_t *values_count);
+int nvt_expand_valid_ws_bytes(uint64_t n, uint64_t *bytes);
+int nvt_expand_valid(const void *packed, int type_size, const uint8_t *bitmap, uint64_t n, void *out,
+                     void *ws, void *stream);
 
 /* ---- batched entry points: ONE call per operator per partition -----------------------
  * The reference hands a whole dataframe to the backend per operator call

@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("NVT_HIP_LIB") or os.path.join(_HERE, "libnvt_hip.so")
 # dtype codes (include/nvt_hip.h)
 NVT_F32, NVT_F64, NVT_I32, NVT_I64, NVT_U8 = 0, 1, 2, 3, 4
 NVT_GB_SUMSQ, NVT_GB_MINMAX = 1, 2
+NVT_EINVAL, NVT_EHIP, NVT_ENOMEM, NVT_EUNSUPPORTED = -1, -2, -3, -4   # include/nvt_hip.h
 ST_NULLS, ST_SENTINEL, ST_OCCUPIED, ST_OVERFLOW, ST_ROWS = 0, 1, 2, 3, 4
 ST_MAXCOUNT = 8
 ST_BIG = 9
@@ -110,6 +111,9 @@ SIGNATURES = {
     "nvt_image_pack": [_pp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_u32), _i32, _u64, _vp,
                        _u32, _vp],
     "nvt_te_image": [_vp, _vp, _vp, _vp, _i32, _u64, _dbl, _dbl, _i32, _vp, _u32, _u32, _vp],
+    "nvt_pq_decode_chunk": [_vp, _u64, _i32, _i32, _u64, _vp, _u64, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)],
+    "nvt_expand_valid_ws_bytes": [_u64, C.POINTER(_u64)],
+    "nvt_expand_valid": [_vp, _i32, _vp, _u64, _vp, _vp, _vp],
     "nvt_exchange_ranges": [_vp, _i32, _vp, _vp],
     "nvt_exchange_ranges_sorted": [_vp, _i32, _vp, _vp],
     "nvt_exchange_hist": [_vp, _i32, C.POINTER(_i64), C.POINTER(_u64), _i32, _vp, _vp],

@@ -443,6 +443,8 @@ def as_device_frame(df, device=None):
         return df, False
     if isinstance(df, pd.DataFrame):
         return DeviceFrame.from_pandas(df, device), True
+    if hasattr(df, "to_device") and type(df).__name__ == "StagedPartition":
+        return df.to_device(device), False   # (io.StagedPartition: the hand-written parquet reader)
     try:
         import pyarrow as pa
 

@@ -98,34 +98,65 @@ class Dataset:
         if self._schema is None:
             self._schema = Schema.from_frame(pq.ParquetFile(files[0]).schema_arrow)
 
+        # files the hand-written reader takes (flat numeric columns, PLAIN, uncompressed:
+        # parquet_plain.PlainParquetFile); everything else is decoded by pyarrow
+        plain_files = {}
+
+        def plain_file(f):
+            if f not in plain_files:
+                pf = None
+                if PLAIN_PARQUET_READ:
+                    try:
+                        from .parquet_plain import PlainParquetFile
+
+                        pf = PlainParquetFile(f)
+                        if not pf.eligible:
+                            pf = None
+                    except Exception:
+                        pf = None
+                plain_files[f] = pf
+            return plain_files[f]
+
+        def read(piece, columns):
+            f, groups = piece
+            pf = plain_file(f)
+            if pf is not None:
+                from .parquet_plain import read_row_groups_staged
+
+                try:
+                    return StagedPartition(read_row_groups_staged(pf, groups, columns, pool=_plain_read_pool()))
+                except Exception as e:  # (a page kind the footer did not announce: pyarrow reads it)
+                    from . import _lib
+
+                    if not isinstance(e, _lib.NvtHipError):
+                        raise
+                    plain_files[f] = None
+            return pq.ParquetFile(f).read_row_groups(groups, columns=columns)
+
         def gen(columns=None, only=None):
-            # decode a few partitions ahead on host threads (pyarrow parallelises over the
-            # columns of ONE read; several reads in flight keep more of the host cores busy)
+            # decode a few partitions ahead on host threads (one read spreads over the columns of
+            # its row groups; several reads in flight keep more of the host cores busy)
             from collections import deque
             from concurrent.futures import ThreadPoolExecutor
 
             todo = [p for i, p in enumerate(pieces) if only is None or only(i)]
             if len(todo) <= 1:
-                for f, groups in todo:
-                    yield pq.ParquetFile(f).read_row_groups(groups, columns=columns)
+                for piece in todo:
+                    yield read(piece, columns)
                 return
-
-            def read(piece):
-                f, groups = piece
-                return pq.ParquetFile(f).read_row_groups(groups, columns=columns)
 
             with ThreadPoolExecutor(max_workers=DECODE_AHEAD) as pool:
                 window = deque()
                 it = iter(todo)
                 for piece in it:
-                    window.append(pool.submit(read, piece))
+                    window.append(pool.submit(read, piece, columns))
                     if len(window) >= DECODE_AHEAD:
                         break
                 while window:
                     table = window.popleft().result()
                     nxt = next(it, None)
                     if nxt is not None:
-                        window.append(pool.submit(read, nxt))
+                        window.append(pool.submit(read, nxt, columns))
                     yield table
 
         self._parts_fn = gen
@@ -387,6 +418,66 @@ class Dataset:
 
 
 PLAIN_PARQUET = os.environ.get("NVT_PLAIN_PARQUET", "1") != "0"
+PLAIN_PARQUET_READ = os.environ.get("NVT_PLAIN_PARQUET_READ", "1") != "0"
+PLAIN_READ_THREADS = int(os.environ.get("NVT_PARQUET_READ_THREADS", "32"))
+_PLAIN_READ_POOL = None
+
+
+def _plain_read_pool():
+    global _PLAIN_READ_POOL
+    if _PLAIN_READ_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _PLAIN_READ_POOL = ThreadPoolExecutor(max_workers=PLAIN_READ_THREADS, thread_name_prefix="nvt-pqread")
+    return _PLAIN_READ_POOL
+
+
+class StagedPartition:
+    """A partition as the hand-written parquet reader leaves it on the host: per column the
+    packed non-null values and the validity bitmap in pinned memory
+    (parquet_plain.read_row_groups_staged).  ``to_device`` enqueues the copies on the CURRENT
+    stream (the prefetcher's side stream) and expands columns with nulls to one slot per row on
+    the device (nvt_expand_valid)."""
+
+    def __init__(self, columns):
+        self.columns = columns
+
+    @property
+    def num_rows(self):
+        return next(iter(self.columns.values())).rows if self.columns else 0
+
+    def to_device(self, device=None):
+        import ctypes as C
+
+        import torch
+
+        from . import kernels as K
+        from .device import DeviceColumn, DeviceFrame, default_device
+
+        device = device or default_device()
+        out = {}
+        for name, sc in self.columns.items():
+            tdt = sc.values.dtype
+            if device.type != "cuda":   # (host-only use: tests of the reader itself)
+                raise K._lib.NvtHipError("StagedPartition.to_device needs a GPU")
+            packed = sc.values[:sc.nvalid].to(device, non_blocking=True)
+            if sc.valid is None:
+                out[name] = DeviceColumn(packed)
+                continue
+            nb = ((sc.rows + 63) // 64) * 8
+            bitmap = sc.valid[:nb].to(device, non_blocking=True)
+            if sc.nvalid == 0:
+                data = torch.zeros(sc.rows, dtype=tdt, device=device)
+            else:
+                data = torch.empty(sc.rows, dtype=tdt, device=device)
+                need = C.c_uint64()
+                lib = K._lib.load()
+                K.check(lib.nvt_expand_valid_ws_bytes(sc.rows, C.byref(need)), "nvt_expand_valid_ws_bytes")
+                ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+                K.check(lib.nvt_expand_valid(packed.data_ptr(), sc.dtype.itemsize, bitmap.data_ptr(), sc.rows,
+                                             data.data_ptr(), ws.data_ptr(), K.stream_ptr()), "nvt_expand_valid")
+            out[name] = DeviceColumn(data, bitmap)
+        return DeviceFrame(out)
 PLAIN_WRITE_THREADS = int(os.environ.get("NVT_PARQUET_THREADS", "16"))
 PLAIN_ROW_GROUP = int(os.environ.get("NVT_PARQUET_ROW_GROUP", str(1 << 22)))
 PLAIN_INFLIGHT = int(os.environ.get("NVT_PARQUET_INFLIGHT", "8"))   # row groups being written at once

@@ -266,3 +266,221 @@ class PlainParquetWriter:
             os.unlink(self.path)
         except OSError:
             pass
+
+
+# ================================================================================================
+# reading side: footer (thrift compact FileMetaData) + column chunks of PLAIN / uncompressed pages
+# ================================================================================================
+class _TReader:
+    """Minimal thrift compact-protocol reader: a struct comes back as {field id: value}, nested
+    structs as dicts, lists as Python lists, binaries as bytes."""
+
+    def __init__(self, buf, pos=0):
+        self.b, self.p = buf, pos
+
+    def varint(self) -> int:
+        v = sh = 0
+        while True:
+            c = self.b[self.p]
+            self.p += 1
+            v |= (c & 0x7F) << sh
+            if not c & 0x80:
+                return v
+            sh += 7
+
+    def zigzag(self) -> int:
+        v = self.varint()
+        return (v >> 1) ^ -(v & 1)
+
+    def value(self, t):
+        if t == 1:
+            return True
+        if t == 2:
+            return False
+        if t == 3:
+            self.p += 1
+            return self.b[self.p - 1]
+        if t in (4, 5, 6):
+            return self.zigzag()
+        if t == 7:
+            self.p += 8
+            return struct.unpack("<d", bytes(self.b[self.p - 8:self.p]))[0]
+        if t == 8:
+            n = self.varint()
+            self.p += n
+            return bytes(self.b[self.p - n:self.p])
+        if t in (9, 10):
+            h = self.b[self.p]
+            self.p += 1
+            n = h >> 4
+            if n == 15:
+                n = self.varint()
+            et = h & 0x0F
+            if et in (1, 2):   # list<bool>: one byte per element
+                out = [self.b[self.p + i] == 1 for i in range(n)]
+                self.p += n
+                return out
+            return [self.value(et) for _ in range(n)]
+        if t == 11:
+            n = self.varint()
+            if n == 0:
+                return {}
+            kv = self.b[self.p]
+            self.p += 1
+            return {self.value(kv >> 4): self.value(kv & 0x0F) for _ in range(n)}
+        if t == 12:
+            return self.struct()
+        raise ValueError(f"thrift compact: unknown type {t}")
+
+    def struct(self) -> dict:
+        out, fid = {}, 0
+        while True:
+            h = self.b[self.p]
+            self.p += 1
+            if h == 0:
+                return out
+            d, t = h >> 4, h & 0x0F
+            fid = fid + d if d else self.zigzag()
+            out[fid] = self.value(t)
+
+
+_PQ_NP = {1: np.dtype("int32"), 2: np.dtype("int64"), 4: np.dtype("float32"), 5: np.dtype("float64")}
+
+
+class PlainParquetFile:
+    """Footer of one parquet file and, per row group, the column chunks the hand-written reader
+    can take: flat columns (no nesting), physical type INT32 / INT64 / FLOAT / DOUBLE without a
+    converted / logical type that changes the meaning of the bits (dates, decimals, unsigned),
+    codec UNCOMPRESSED, no dictionary page, encodings within {PLAIN, RLE, BIT_PACKED}.
+    ``eligible`` says whether EVERY column of every row group qualifies; otherwise the caller
+    reads the file with pyarrow."""
+
+    def __init__(self, path: str):
+        self.path = path
+        size = os.path.getsize(path)
+        with open(path, "rb") as f:
+            if size < 12:
+                raise ValueError(f"{path}: not a parquet file")
+            f.seek(size - 8)
+            tail = f.read(8)
+            if tail[4:] != b"PAR1":
+                raise ValueError(f"{path}: no parquet magic")
+            flen = struct.unpack("<I", tail[:4])[0]
+            f.seek(size - 8 - flen)
+            meta = _TReader(f.read(flen)).struct()
+        schema = meta.get(2, [])
+        self.num_rows = int(meta.get(3, 0))
+        self.eligible, self.why = True, ""
+        root_children = int(schema[0].get(5, 0)) if schema else 0
+        leaves = schema[1:]
+        if len(leaves) != root_children or any(e.get(5) for e in leaves):
+            self.eligible, self.why = False, "nested schema"
+        self.names = [e.get(4, b"").decode() for e in leaves]
+        self.dtypes, self.max_def = [], []
+        for e in leaves:
+            ptype, rep = e.get(1), e.get(3, 0)
+            conv, logical = e.get(6), e.get(10)
+            dt = _PQ_NP.get(ptype)
+            if dt is None or rep == 2:
+                self.eligible, self.why = False, f"column {e.get(4)!r}: physical type {ptype} / repetition {rep}"
+            # converted types that reinterpret the integer: DATE 6, TIME 7-8, TIMESTAMP 9-10,
+            # UINT 11-14 (INT_8..INT_64 = 15-18 keep the bits), DECIMAL 5
+            if conv is not None and conv not in (15, 16, 17, 18):
+                self.eligible, self.why = False, f"column {e.get(4)!r}: converted type {conv}"
+            if logical is not None:
+                # LogicalType union: 10 = INTEGER {1: bitWidth, 2: isSigned}
+                integer = logical.get(10) if isinstance(logical, dict) else None
+                if not (integer is not None and integer.get(2, True) and
+                        integer.get(1, 0) == (32 if ptype == 1 else 64) and len(logical) == 1):
+                    self.eligible, self.why = False, f"column {e.get(4)!r}: logical type {logical}"
+            self.dtypes.append(dt)
+            self.max_def.append(0 if rep == 0 else 1)
+        self.row_groups = []
+        for rg in meta.get(4, []):
+            cols = []
+            for cc in rg.get(1, []):
+                md = cc.get(3) or {}
+                enc = set(md.get(2, []))
+                ok = (md.get(4) == 0 and 11 not in md and enc <= {0, 3, 4} and cc.get(1) in (None, b""))
+                if not ok:
+                    self.eligible, self.why = False, (f"chunk of {md.get(3)}: codec {md.get(4)}, encodings "
+                                                      f"{sorted(enc)}, dictionary page {md.get(11)}")
+                cols.append(dict(offset=int(md.get(9, 0)), size=int(md.get(7, 0)), num_values=int(md.get(5, 0)),
+                                 path=[x.decode() for x in md.get(3, [])]))
+            if [c["path"] for c in cols] != [[n] for n in self.names]:
+                self.eligible, self.why = False, "column chunks do not follow the schema order"
+            self.row_groups.append(dict(num_rows=int(rg.get(3, 0)), columns=cols))
+
+    @property
+    def num_row_groups(self):
+        return len(self.row_groups)
+
+
+class StagedColumn:
+    """One column of a partition in pinned host memory: packed (non-null) values + validity
+    bitmap, as nvt_pq_decode_chunk leaves them."""
+
+    __slots__ = ("values", "valid", "rows", "nvalid", "dtype")
+
+    def __init__(self, values, valid, rows, nvalid, dtype):
+        self.values, self.valid, self.rows, self.nvalid, self.dtype = values, valid, rows, nvalid, dtype
+
+
+def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None, pin=True):
+    """{column: StagedColumn} for the concatenation of `groups` (row-group indices) of an eligible
+    file.  One task per column: pread of a chunk into a scratch buffer, then nvt_pq_decode_chunk
+    (ctypes: GIL released) moves its values and validity bits to their place in the partition's
+    (pinned) staging buffers."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    lib = _lib.load()
+    names = [n for n in pf.names if columns is None or n in columns]
+    total = sum(pf.row_groups[g]["num_rows"] for g in groups)
+    fd = os.open(pf.path, os.O_RDONLY)
+
+    def task(n):
+        """One column: its chunks of the row groups one after the other -- packed values behind
+        each other, validity bits at the partition's row positions (a thread per COLUMN: two row
+        groups may share a bitmap byte)."""
+        j = pf.names.index(n)
+        dt = pf.dtypes[j]
+        vals = torch.empty(total, dtype=getattr(torch, dt.name), pin_memory=pin)
+        valid = None
+        if pf.max_def[j]:
+            valid = torch.zeros(((total + 63) // 64) * 8 + 8, dtype=torch.uint8, pin_memory=pin)
+        row_at = val_at = 0
+        for g in groups:
+            cc = pf.row_groups[g]["columns"][j]
+            rows = pf.row_groups[g]["num_rows"]
+            buf = bytearray(cc["size"])
+            got, mv = 0, memoryview(buf)
+            while got < cc["size"]:
+                k = os.preadv(fd, [mv[got:]], cc["offset"] + got)
+                if k <= 0:
+                    raise IOError(f"{pf.path}: short read of column chunk {n}")
+                got += k
+            cbuf = (C.c_uint8 * len(buf)).from_buffer(buf)
+            r, v = C.c_uint64(), C.c_uint64()
+            rc = lib.nvt_pq_decode_chunk(cbuf, len(buf), dt.itemsize, pf.max_def[j], rows,
+                                         valid.data_ptr() if valid is not None else None, row_at,
+                                         vals.data_ptr() + val_at * dt.itemsize, (total - val_at) * dt.itemsize,
+                                         C.byref(r), C.byref(v))
+            if rc != 0:
+                raise _lib.NvtHipError(f"nvt_pq_decode_chunk({pf.path}, {n}, row group {g}): "
+                                       f"{lib.nvt_last_error().decode()} (rc {rc})")
+            row_at += rows
+            val_at += int(v.value)
+        return StagedColumn(vals, valid if (valid is not None and val_at < total) else None, total, val_at, dt)
+
+    try:
+        if pool is not None and len(names) > 1:
+            cols = [f.result() for f in [pool.submit(task, n) for n in names]]
+        else:
+            cols = [task(n) for n in names]
+    finally:
+        os.close(fd)
+    return dict(zip(names, cols))

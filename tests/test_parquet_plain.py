@@ -85,3 +85,131 @@ def test_several_row_groups_and_metadata_collection(tmp_path):
 def test_unsupported_dtype_is_refused(tmp_path):
     with pytest.raises(TypeError):
         PP.PlainParquetWriter(str(tmp_path / "h.parquet"), ["s"], ["uint8"])
+
+
+# ---- reading side: footer + nvt_pq_decode_chunk (host C, no GPU) ------------------------------
+def _staged_equals_arrow(staged, table):
+    for name in table.column_names:
+        s, col = staged[name], table.column(name).combine_chunks()
+        valid = np.asarray(col.is_valid())
+        assert s.rows == len(col) and s.nvalid == int(valid.sum()), name
+        if s.valid is None:
+            assert valid.all() or s.nvalid == s.rows, name
+        else:
+            bits = np.unpackbits(s.valid.numpy(), bitorder="little")[:s.rows].astype(bool)
+            np.testing.assert_array_equal(bits, valid, err_msg=name)
+        got = s.values.numpy()[:s.nvalid]
+        exp = col.drop_null().to_numpy()
+        assert got.dtype == exp.dtype, name
+        np.testing.assert_array_equal(got.view(np.uint8), exp.view(np.uint8), err_msg=name)   # NaN bits too
+
+
+def _mixed_table(n, seed=0):
+    rng = np.random.default_rng(seed)
+    return pa.table({
+        "a": pa.array(rng.integers(-5, 1000, n).astype("int32"), mask=rng.random(n) < 0.2),
+        "b": pa.array(np.where(rng.random(n) < 0.01, np.nan, rng.normal(size=n))),          # NaN != null
+        "c": pa.array(rng.integers(0, 2**40, n), mask=rng.random(n) < 0.5),
+        "d": pa.array(rng.normal(size=n).astype("float32"), mask=np.ones(n, bool)),           # all null
+        "e": pa.array(rng.integers(0, 9, n).astype("int64")),                                 # no nulls
+        "f": pa.array(np.repeat(rng.integers(0, 3, (n + 99) // 100), 100)[:n].astype("int32"),
+                      mask=np.repeat(rng.random((n + 999) // 1000) < 0.5, 1000)[:n]),         # long RLE runs
+    })
+
+
+@pytest.mark.parametrize("page_version", ["1.0", "2.0"])
+@pytest.mark.parametrize("row_group_size", [100_000, 77_777, 1 << 30])
+def test_plain_reader_equals_pyarrow_on_pyarrow_files(tmp_path, page_version, row_group_size):
+    """PLAIN / uncompressed files as pyarrow writes them (DataPage v1 and v2, small pages, row
+    groups that do not end on byte boundaries of the bitmap): values, nulls and dtypes of the
+    hand-written reader equal pyarrow's own reader, row groups concatenated."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    t = _mixed_table(300_001)
+    path = str(tmp_path / "p.parquet")
+    pq.write_table(t, path, use_dictionary=False, compression=None, row_group_size=row_group_size,
+                   data_page_version=page_version, data_page_size=32 * 1024)
+    pf = PP.PlainParquetFile(path)
+    assert pf.eligible, pf.why
+    assert pf.names == t.column_names and pf.num_rows == t.num_rows
+    groups = list(range(pf.num_row_groups))
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        staged = PP.read_row_groups_staged(pf, groups, pin=False, pool=pool)
+    _staged_equals_arrow(staged, pq.ParquetFile(path).read_row_groups(groups))
+    # a column subset, one row group in the middle
+    if len(groups) > 2:
+        staged = PP.read_row_groups_staged(pf, [1], columns=["c", "a"], pin=False)
+        assert set(staged) == {"a", "c"}
+        _staged_equals_arrow(staged, pq.ParquetFile(path).read_row_groups([1], columns=["a", "c"]))
+
+
+def test_plain_reader_reads_the_plain_writers_files(tmp_path):
+    rng = np.random.default_rng(5)
+    n = PP.PAGE_VALUES + 4099
+    specs = [("a", "int64", 0.0), ("b", "float64", 0.3), ("c", "int32", 0.05), ("e", "int64", 1.0)]
+    path = str(tmp_path / "w.parquet")
+    w = PP.PlainParquetWriter(path, [s[0] for s in specs], [s[1] for s in specs])
+    for _ in range(2):
+        cols = []
+        for name, dt, nf in specs:
+            vals, mask, packed, bitmap = _col(rng, n, dt, nf)
+            cols.append((packed, bitmap))
+        w.write_row_group(cols, n)
+    w.close()
+    pf = PP.PlainParquetFile(path)
+    assert pf.eligible, pf.why
+    staged = PP.read_row_groups_staged(pf, [0, 1], pin=False)
+    _staged_equals_arrow(staged, pq.read_table(path))
+
+
+@pytest.mark.parametrize("kind", ["dictionary", "snappy", "string", "list", "date", "uint"])
+def test_files_the_plain_reader_leaves_to_pyarrow(tmp_path, kind):
+    n = 1000
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 5, n).astype("int32")
+    kw = dict(use_dictionary=False, compression=None)
+    t = pa.table({"x": x})
+    if kind == "dictionary":
+        kw["use_dictionary"] = True
+    elif kind == "snappy":
+        kw["compression"] = "snappy"
+    elif kind == "string":
+        t = pa.table({"x": x, "s": pa.array([str(v) for v in x])})
+    elif kind == "list":
+        t = pa.table({"x": x, "l": pa.array([[int(v)] for v in x])})
+    elif kind == "date":
+        t = pa.table({"x": pa.array(x, type=pa.date32())})
+    elif kind == "uint":
+        t = pa.table({"x": pa.array(x.astype("uint32"))})
+    path = str(tmp_path / "q.parquet")
+    pq.write_table(t, path, **kw)
+    pf = PP.PlainParquetFile(path)
+    assert not pf.eligible and pf.why
+
+
+def test_decode_chunk_rejects_what_it_does_not_handle(tmp_path):
+    """The C decoder's own checks (a footer can lie): truncated chunk, wrong row count."""
+    import ctypes as C
+
+    from nvtabular_amd import _lib
+
+    t = pa.table({"a": pa.array(np.arange(5000, dtype="int32"), mask=np.arange(5000) % 7 == 0)})
+    path = str(tmp_path / "r.parquet")
+    pq.write_table(t, path, use_dictionary=False, compression=None)
+    pf = PP.PlainParquetFile(path)
+    cc = pf.row_groups[0]["columns"][0]
+    raw = open(path, "rb").read()[cc["offset"]: cc["offset"] + cc["size"]]
+    lib = _lib.load()
+    vals = np.zeros(5000, dtype="int32")
+    bm = np.zeros(5000 // 8 + 16, dtype="uint8")
+    r, v = C.c_uint64(), C.c_uint64()
+
+    def call(buf, rows):
+        b = (C.c_uint8 * len(buf)).from_buffer_copy(buf)
+        return lib.nvt_pq_decode_chunk(b, len(buf), 4, 1, rows, bm.ctypes.data, 0, vals.ctypes.data, vals.nbytes,
+                                       C.byref(r), C.byref(v))
+
+    assert call(raw, 5000) == 0 and r.value == 5000 and v.value == 5000 - 715
+    assert call(raw[: len(raw) // 2], 5000) == _lib.NVT_EINVAL
+    assert call(raw, 4000) == _lib.NVT_EINVAL      # more rows in the pages than announced
+    assert call(raw, 6000) == _lib.NVT_EINVAL      # fewer
