@@ -182,6 +182,10 @@ int nvt_vocab_sort_i64(int64_t *keys, int64_t *counts, uint64_t n, int64_t max_c
  * encode table slot: i32 = {int32 key, int32 label}; i64 = {int64 key, int64 label}.
  * Build assigns label first_label + i to vocab_keys[i]. */
 int nvt_encode_table_bytes(int key_bytes, uint64_t capacity, uint64_t *bytes);
+/* Diagnostic of the cache-mode encode (int32 keys whose vocabulary exceeds the LDS head): with
+ * NVT_ENC_STATS=1 in the environment the kernels count out2[0] = rows that went on to the table in
+ * HBM and out2[1] = rows looked up, since the last reset (synchronises the stream). */
+int nvt_encode_stats(uint64_t *out2, int reset, void *stream);
 /* unique_keys != 0 promises vocab_keys holds no duplicates (true for fitted vocabularies):
  * int32 slots are then claimed and filled with one 64-bit CAS.  With duplicates (user
  * vocabs) the lowest label wins. */

@@ -267,6 +267,26 @@ __device__ __forceinline__ void two_buckets(K key, uint32_t &b1, uint32_t &b2) {
   b2 = (((h ^ (h >> 15)) * 0x2C1B3C6Du) >> 17) & (NB - 1);
   b2 = b2 == b1 ? b1 ^ 1u : b2;
 }
+// HEAD16 (int32 keys, cache mode): the head's labels are frequency ranks -- first_label + the
+// position of the key among the n_hot most frequent ones -- so a slot needs the key and a 16-bit
+// rank, 6 bytes instead of 8: {key0, key1} int2 per bucket + one word of two 16-bit ranks, and
+// 12288 buckets (144 KiB of the CU's 160) instead of 8192 (128 KiB): 21504 hot keys at 7/8 load
+// instead of 14336.  Fewer rows miss the head, and a miss is what the cache mode pays for (one
+// random 64-byte sector each).  Bucket index: 15 hash bits h, (3 h) >> 3.
+constexpr int kHead16Buckets = 12288;
+constexpr int kHead16Keys = kHead16Buckets * 2 / 8 * 7;   // 21504 < 65536
+__device__ __forceinline__ void two_buckets16(int32_t key, uint32_t &b1, uint32_t &b2) {
+  const uint32_t k = (uint32_t)key, lo = k ^ (k >> 7), hi = k >> 8;
+  const uint32_t h1 = ((__umul24(hi, 0x5BD1E9u) + __umul24(lo, 0x9E3779u)) >> 17) & 0x7FFFu;
+  const uint32_t h2 = ((__umul24(hi, 0x7FEB35u) + __umul24(lo, 0x846CA7u)) >> 17) & 0x7FFFu;
+  b1 = (h1 + 2u * h1) >> 3;
+  b2 = (h2 + 2u * h2) >> 3;
+  b2 = b2 == b1 ? (b1 ^ 1u) : b2;   // (12288 is even: b ^ 1 stays in range)
+}
+// rows that went on to the table in HBM / rows looked up, when the host asks for them
+// (NVT_ENC_STATS=1, nvt_encode_stats): a diagnostic, two atomics per wave at the kernel's end
+__device__ unsigned long long g_enc_stats[2];
+
 // first slot of the linear-probing LDS table
 template <int SLOTS, typename K>
 __device__ __forceinline__ uint32_t lds_home(K key) {
@@ -286,13 +306,15 @@ __device__ __forceinline__ uint32_t lds_home(K key) {
 // dumped; nvt_range.hpp): first slot from the monotone map, probing runs forward without
 // wrapping (an empty slot ends every chain).
 template <typename K, typename OUT, bool TWO = false, bool GLOBAL = true, int UU = 2,
-          int RANGE = 0>  // 0: hashed table, 1: bucket regions dumped by the counting pass, 2: flat
+          int RANGE = 0,  // 0: hashed table, 1: bucket regions dumped by the counting pass, 2: flat
+          bool HEAD16 = false>
 __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
     int64_t null_label, int64_t oov_label, uint32_t num_buckets, OUT *__restrict__ out,
     const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label,
-    const int32_t *__restrict__ range_aux = nullptr) {
+    const int32_t *__restrict__ range_aux = nullptr, int count_stats = 0) {
+  static_assert(!HEAD16 || (TWO && sizeof(K) == 4), "HEAD16: the 2-choice head of int32 keys");
   constexpr bool global_needed = GLOBAL;
   RangeMap rmap = {0u, 0u, 0u, 0, 0};
   __shared__ uint32_t s_pieces[RANGE == 1 ? kRpPwWords : 1];
@@ -311,11 +333,22 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
   constexpr int SLOTS = HotCfg<K>::slots;
   using L = decltype(EncSlot<K>::label);
   using C = typename EncTraits<K>::cas_t;
-  __shared__ EncSlot<K> lt[SLOTS];
+  constexpr int kLdsBytes = HEAD16 ? kHead16Buckets * 12 : SLOTS * (int)sizeof(EncSlot<K>);
+  __shared__ __align__(16) unsigned char lraw[kLdsBytes];
+  EncSlot<K> *lt = reinterpret_cast<EncSlot<K> *>(lraw);
+  int2 *tkeys = reinterpret_cast<int2 *>(lraw);                                     // HEAD16: {key0, key1}
+  uint32_t *tlab = reinterpret_cast<uint32_t *>(lraw + (HEAD16 ? kHead16Buckets * 8 : 0));  // two 16-bit ranks
   __shared__ long long s_sent;  // label of the sentinel key when it is among the staged keys
-  for (int i = threadIdx.x; i < SLOTS; i += kEncBS) {
-    lt[i].key = EMPTY;
-    lt[i].label = 0;
+  if constexpr (HEAD16) {
+    for (int i = threadIdx.x; i < kHead16Buckets; i += kEncBS) {
+      tkeys[i] = make_int2((int)EMPTY, (int)EMPTY);
+      tlab[i] = 0u;
+    }
+  } else {
+    for (int i = threadIdx.x; i < SLOTS; i += kEncBS) {
+      lt[i].key = EMPTY;
+      lt[i].label = 0;
+    }
   }
   if (threadIdx.x == 0) s_sent = -1;
   __syncthreads();
@@ -324,6 +357,22 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     if (key == EMPTY) {
       s_sent = first_label + (long long)i;
       continue;
+    }
+    if constexpr (HEAD16) {
+      uint32_t b1, b2;
+      two_buckets16((int32_t)key, b1, b2);
+      const uint32_t cand[4] = {2 * b1, 2 * b1 + 1, 2 * b2, 2 * b2 + 1};   // key words of the int2 array
+      int *kw = reinterpret_cast<int *>(tkeys);
+      unsigned short *lw = reinterpret_cast<unsigned short *>(tlab);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int prev = atomicCAS(&kw[cand[c]], (int)EMPTY, (int)key);
+        if (prev == (int)EMPTY) {
+          lw[cand[c]] = (unsigned short)i;   // rank: i < n_hot <= kHead16Keys < 2^16
+          break;
+        }
+      }
+      continue;  // all four slots taken: not cached
     }
     if constexpr (TWO) {
       uint32_t b1, b2;
@@ -355,6 +404,18 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
 
   // LDS lookup: label, or -1 when the key is not in the staged head of the vocabulary
   auto hot_lookup = [&](K key) -> int64_t {
+    if constexpr (HEAD16) {
+      uint32_t b1, b2;
+      two_buckets16((int32_t)key, b1, b2);
+      const int2 a = tkeys[b1], c = tkeys[b2];
+      const uint32_t la = tlab[b1], lc = tlab[b2];
+      int lab = -1;
+      lab = a.x == (int)key ? (int)(la & 0xFFFFu) : lab;
+      lab = a.y == (int)key ? (int)(la >> 16) : lab;
+      lab = c.x == (int)key ? (int)(lc & 0xFFFFu) : lab;
+      lab = c.y == (int)key ? (int)(lc >> 16) : lab;
+      return lab < 0 ? (int64_t)-1 : first_label + (int64_t)lab;
+    }
     if constexpr (TWO) {
       uint32_t b1, b2;
       two_buckets<SLOTS / 2>(key, b1, b2);
@@ -394,6 +455,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
   // latency is otherwise exposed once per iteration (~20 iterations per column)
   VecT nxt_pack[U];
   unsigned nxt_vb[U];
+  unsigned st_miss = 0, st_rows = 0;   // (count_stats)
   auto issue_loads = [&](uint64_t v0, VecT (&pk)[U], unsigned (&bits)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -447,6 +509,10 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
         } else {
           lab[q] = hot_lookup(k[q]);
           need[q] = lab[q] < 0 && global_needed;
+          if (count_stats) {
+            st_rows += 1u;
+            st_miss += need[q] ? 1u : 0u;
+          }
         }
       } else {
         lab[q] = null_label;
@@ -561,6 +627,17 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
       r = finish(key, lab);
     }
     out[i] = r;
+  }
+  if (count_stats) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      st_miss += __shfl_down(st_miss, off, 64);
+      st_rows += __shfl_down(st_rows, off, 64);
+    }
+    if (lane_id() == 0) {
+      atomicAdd(&g_enc_stats[0], (unsigned long long)st_miss);
+      atomicAdd(&g_enc_stats[1], (unsigned long long)st_rows);
+    }
   }
 }
 
@@ -693,32 +770,33 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
       // (range tables: `mask` = capacity - 1 bounds the search of a FLAT table -- capacity slots --
       // and is unused for the dumped bucket tables, capacity 0)
       if (global_needed && (two || range_aux != nullptr)) {  // cache mode: 2-choice table filled to 7/8
-        const uint64_t cap2 = (uint64_t)HotCfg<K>::slots / 8 * 7;
+        static const bool head16 = getenv("NVT_ENC_HEAD16") == nullptr || atoi(getenv("NVT_ENC_HEAD16")) != 0;
+        static const int stats = getenv("NVT_ENC_STATS") ? atoi(getenv("NVT_ENC_STATS")) : 0;
+        const uint64_t cap2 = head16 ? (uint64_t)kHead16Keys : (uint64_t)HotCfg<K>::slots / 8 * 7;
         n_hot = (uint32_t)(n_vocab < cap2 ? n_vocab : cap2);
-        if (range_aux != nullptr) {
-          // capacity > 0: a FLAT range table of `capacity` slots (bounded search); 0: the bucket
-          // regions dumped by the counting pass
-#define NVT_ENC_RANGE(OUTT, KIND)                                                                  \
-  encode_hot_kernel<K, OUTT, true, true, 2, KIND><<<hgrid, kEncBS, 0, s>>>(                         \
+#define NVT_ENC_CACHE(OUTT, KIND, H16)                                                            \
+  encode_hot_kernel<K, OUTT, true, true, 2, KIND, H16><<<hgrid, kEncBS, 0, s>>>(                   \
       keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,          \
-      reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux)
-          if (capacity > 0) {
-            if (out_bytes == 8) NVT_ENC_RANGE(int64_t, 2); else NVT_ENC_RANGE(int32_t, 2);
-          } else {
-            if (out_bytes == 8) NVT_ENC_RANGE(int64_t, 1); else NVT_ENC_RANGE(int32_t, 1);
-          }
-#undef NVT_ENC_RANGE
-          NVT_CHECK_LAUNCH();
-          return NVT_OK;
+      reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux, stats)
+#define NVT_ENC_CACHE_K(KIND)                                                \
+  do {                                                                       \
+    if (head16) {                                                            \
+      if (out_bytes == 8) NVT_ENC_CACHE(int64_t, KIND, true);                \
+      else NVT_ENC_CACHE(int32_t, KIND, true);                               \
+    } else {                                                                 \
+      if (out_bytes == 8) NVT_ENC_CACHE(int64_t, KIND, false);               \
+      else NVT_ENC_CACHE(int32_t, KIND, false);                              \
+    }                                                                        \
+  } while (0)
+        // range tables -- capacity > 0: a FLAT range table of `capacity` slots (bounded search);
+        // 0: the bucket regions dumped by the counting pass; no range_aux: the hashed table
+        if (range_aux != nullptr) {
+          if (capacity > 0) NVT_ENC_CACHE_K(2); else NVT_ENC_CACHE_K(1);
+        } else {
+          NVT_ENC_CACHE_K(0);
         }
-        if (out_bytes == 8)
-          encode_hot_kernel<K, int64_t, true><<<hgrid, kEncBS, 0, s>>>(
-              keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
-              reinterpret_cast<int64_t *>(out), hot_keys, n_hot, first_label);
-        else
-          encode_hot_kernel<K, int32_t, true><<<hgrid, kEncBS, 0, s>>>(
-              keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,
-              reinterpret_cast<int32_t *>(out), hot_keys, n_hot, first_label);
+#undef NVT_ENC_CACHE_K
+#undef NVT_ENC_CACHE
         NVT_CHECK_LAUNCH();
         return NVT_OK;
       }
@@ -813,6 +891,21 @@ int encode_insert_any(int key_bytes, const void *vocab, uint64_t n, int64_t firs
 using namespace nvt;
 
 extern "C" {
+
+int nvt_encode_stats(uint64_t *out2, int reset, void *stream) {
+  NVT_CHECK_ARG(out2, "null out");
+  hipStream_t s = (hipStream_t)stream;
+  NVT_CHECK_HIP(hipStreamSynchronize(s));
+  unsigned long long v[2] = {0, 0};
+  NVT_CHECK_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_enc_stats), sizeof(v)));
+  out2[0] = v[0];
+  out2[1] = v[1];
+  if (reset) {
+    const unsigned long long z[2] = {0, 0};
+    NVT_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_enc_stats), z, sizeof(z)));
+  }
+  return NVT_OK;
+}
 
 int nvt_encode_table_bytes(int key_bytes, uint64_t capacity, uint64_t *bytes) {
   NVT_CHECK_ARG(bytes && (key_bytes == 4 || key_bytes == 8), "key_bytes must be 4 or 8");

@@ -426,6 +426,25 @@ class StagedColumn:
         self.values, self.valid, self.rows, self.nvalid, self.dtype = values, valid, rows, nvalid, dtype
 
 
+_TLS = None
+
+
+def _scratch(nbytes: int) -> bytearray:
+    """This thread's read buffer, grown in powers of two."""
+    global _TLS
+    if _TLS is None:
+        import threading
+
+        _TLS = threading.local()
+    buf = getattr(_TLS, "buf", None)
+    if buf is None or len(buf) < nbytes:
+        cap = 1 << 20
+        while cap < nbytes:
+            cap <<= 1
+        buf = _TLS.buf = bytearray(cap)
+    return buf
+
+
 def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None, pin=True):
     """{column: StagedColumn} for the concatenation of `groups` (row-group indices) of an eligible
     file.  One task per column: pread of a chunk into a scratch buffer, then nvt_pq_decode_chunk
@@ -456,16 +475,16 @@ def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None
         for g in groups:
             cc = pf.row_groups[g]["columns"][j]
             rows = pf.row_groups[g]["num_rows"]
-            buf = bytearray(cc["size"])
-            got, mv = 0, memoryview(buf)
+            buf = _scratch(cc["size"])   # (per thread, reused: a fresh 30 MB bytearray is zero-filled
+            got, mv = 0, memoryview(buf)  #  and page-faulted in for every chunk)
             while got < cc["size"]:
-                k = os.preadv(fd, [mv[got:]], cc["offset"] + got)
+                k = os.preadv(fd, [mv[got:cc["size"]]], cc["offset"] + got)
                 if k <= 0:
                     raise IOError(f"{pf.path}: short read of column chunk {n}")
                 got += k
             cbuf = (C.c_uint8 * len(buf)).from_buffer(buf)
             r, v = C.c_uint64(), C.c_uint64()
-            rc = lib.nvt_pq_decode_chunk(cbuf, len(buf), dt.itemsize, pf.max_def[j], rows,
+            rc = lib.nvt_pq_decode_chunk(cbuf, cc["size"], dt.itemsize, pf.max_def[j], rows,
                                          valid.data_ptr() if valid is not None else None, row_at,
                                          vals.data_ptr() + val_at * dt.itemsize, (total - val_at) * dt.itemsize,
                                          C.byref(r), C.byref(v))
