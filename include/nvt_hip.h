@@ -565,6 +565,14 @@ int nvt_flat_lookup_image(const void *keys, int dtype, const uint8_t *valid, uin
 int nvt_image_pack(const void *const *src, const int *src_dtypes, const int *dst_dtypes,
                    const uint32_t *offs, int ncols, uint64_t groups, void *image,
                    uint32_t stride_bytes, void *stream);
+/* JoinGroupby's values from the fit's accumulators (count int64 [groups]; sum / sumsq / mn / mx:
+ * arrays of nvals float64 [groups] pointers, NULL arrays / entries when no requested statistic
+ * needs them): output c = statistic kinds[c] (0 count, 1 sum, 2 mean, 3 min, 4 max, 5 var, 6 std;
+ * categorify.py:1087-1131) of value column vals[c], stored as dst_dtypes[c] at image[g][offs[c]]. */
+int nvt_jg_image(const int64_t *count, const double *const *sum, const double *const *sumsq,
+                 const double *const *mn, const double *const *mx, int nvals, const int *kinds,
+                 const int *vals, const int *dst_dtypes, const uint32_t *offs, int ncols, uint64_t groups,
+                 void *image, uint32_t stride_bytes, void *stream);
 int nvt_te_image(const int64_t *tot_count, const double *tot_sum, const int64_t *fold_count,
                  const double *fold_sum, int kfold, uint64_t groups, double p_smooth, double y_mean,
                  int out_dtype, void *image, uint32_t stride_bytes, uint32_t off, void *stream);

@@ -1664,6 +1664,51 @@ __global__ __launch_bounds__(kBlock) void image_pack_kernel(ImagePackArgs a, int
   }
 }
 
+// JoinGroupby's byte range straight from the fit's accumulators (join_groupby.py:175-217 over
+// categorify.py:1087-1131 _bottom_level_groupby): count, sum, mean = sum / n, var = (sumsq -
+// sum * sum / n) / max(n - 1, 1) (NaN for n = 1), std = sqrt(var), min, max -- evaluated per group
+// in float64 like the column-wise path (ops/_groupby.py derive_stats), stored in the output dtype.
+constexpr int kJgMaxVals = 8;
+struct JgImageArgs {
+  const int64_t *count;
+  const double *sum[kJgMaxVals], *sumsq[kJgMaxVals], *mn[kJgMaxVals], *mx[kJgMaxVals];
+  int kind[kImageMaxCols];   // 0 count, 1 sum, 2 mean, 3 min, 4 max, 5 var, 6 std
+  int val[kImageMaxCols];    // value column of the statistic
+  int dst_dtype[kImageMaxCols];
+  uint32_t off[kImageMaxCols];
+};
+__global__ __launch_bounds__(kBlock) void jg_image_kernel(JgImageArgs a, int ncols, uint64_t groups,
+                                                          uint8_t *__restrict__ image, uint32_t stride_bytes) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
+    uint8_t *rec = image + g * stride_bytes;
+    const int64_t ni = a.count[g];
+    const double n = (double)ni;
+    for (int c = 0; c < ncols; ++c) {
+      const int j = a.val[c];
+      double x = 0.0;
+      bool is_int = false;
+      switch (a.kind[c]) {
+        case 0: is_int = true; break;
+        case 1: x = a.sum[j][g]; break;
+        case 2: x = a.sum[j][g] / n; break;
+        case 3: x = a.mn[j][g]; break;
+        case 4: x = a.mx[j][g]; break;
+        default: {
+          const double s1 = a.sum[j][g], s2 = a.sumsq[j][g];
+          const double sq = __dmul_rn(s1, s1);            // (no contraction with the division / subtraction)
+          const double num = __dsub_rn(s2, __ddiv_rn(sq, n));
+          const double dn = n - 1.0;
+          double var = __ddiv_rn(num, dn < 1.0 ? 1.0 : dn);
+          if (dn == 0.0) var = __longlong_as_double(0x7FF8000000000000ll);
+          x = a.kind[c] == 5 ? var : sqrt(var);
+        }
+      }
+      image_store(rec + a.off[c], a.dst_dtype[c], x, ni, is_int);
+    }
+  }
+}
+
 // TargetEncoding's byte range: (kfold + 1) values per group from the fit's statistics -- totals
 // {count, sum}[g] and the dense per-(group, fold) {count, sum}[g * kfold + f] of the sort path
 // (nvt_sgb_reduce) -- exactly the expression nvt_te_apply_folds evaluates per row
@@ -2270,6 +2315,46 @@ int nvt_image_pack(const void *const *src, const int *src_dtypes, const int *dst
   NVT_PROF("groupby_index", groups * 8ull * ncols, s);
   image_pack_kernel<<<stream_grid(groups, kBlock, 8), kBlock, 0, s>>>(
       a, ncols, groups, reinterpret_cast<uint8_t *>(image), stride_bytes);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+
+int nvt_jg_image(const int64_t *count, const double *const *sum, const double *const *sumsq,
+                 const double *const *mn, const double *const *mx, int nvals, const int *kinds,
+                 const int *vals, const int *dst_dtypes, const uint32_t *offs, int ncols, uint64_t groups,
+                 void *image, uint32_t stride_bytes, void *stream) {
+  if (groups == 0 || ncols == 0) return NVT_OK;
+  NVT_CHECK_ARG(count && kinds && vals && dst_dtypes && offs && image, "null pointer");
+  NVT_CHECK_ARG(ncols >= 1 && ncols <= kImageMaxCols, "1..24 columns");
+  NVT_CHECK_ARG(nvals >= 0 && nvals <= kJgMaxVals, "0..8 value columns");
+  JgImageArgs a;
+  memset(&a, 0, sizeof(a));
+  a.count = count;
+  for (int j = 0; j < nvals; ++j) {
+    a.sum[j] = sum ? sum[j] : nullptr;
+    a.sumsq[j] = sumsq ? sumsq[j] : nullptr;
+    a.mn[j] = mn ? mn[j] : nullptr;
+    a.mx[j] = mx ? mx[j] : nullptr;
+  }
+  for (int c = 0; c < ncols; ++c) {
+    const int k = kinds[c], j = vals[c], d = dst_dtypes[c];
+    NVT_CHECK_ARG(k >= 0 && k <= 6, "statistic kind 0..6");
+    NVT_CHECK_ARG(k == 0 || (j >= 0 && j < nvals), "value column out of range");
+    NVT_CHECK_ARG(k == 0 || a.sum[j] || k == 3 || k == 4, "null sum array");
+    NVT_CHECK_ARG((k != 3 || a.mn[j]) && (k != 4 || a.mx[j]) && (k < 5 || (a.sum[j] && a.sumsq[j])),
+                  "null accumulator array for a requested statistic");
+    NVT_CHECK_ARG(d == NVT_F32 || d == NVT_F64 || d == NVT_I32 || d == NVT_I64, "values are f32 / f64 / i32 / i64");
+    const uint32_t sz = (d == NVT_F32 || d == NVT_I32) ? 4u : 8u;
+    NVT_CHECK_ARG(offs[c] % sz == 0 && (uint64_t)offs[c] + sz <= stride_bytes, "value outside the record");
+    a.kind[c] = k;
+    a.val[c] = k == 0 ? 0 : j;
+    a.dst_dtype[c] = d;
+    a.off[c] = offs[c];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  NVT_PROF("groupby_index", groups * 8ull * ncols, s);
+  jg_image_kernel<<<stream_grid(groups, kBlock, 8), kBlock, 0, s>>>(a, ncols, groups,
+                                                                    reinterpret_cast<uint8_t *>(image), stride_bytes);
   NVT_CHECK_LAUNCH();
   return NVT_OK;
 }

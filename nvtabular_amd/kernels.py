@@ -2296,6 +2296,37 @@ def image_pack(image, stride, columns, groups):
         nc, int(groups), image.data_ptr(), int(stride), stream_ptr()), "nvt_image_pack")
 
 
+JG_KINDS = {"count": 0, "sum": 1, "mean": 2, "min": 3, "max": 4, "var": 5, "std": 6}
+
+
+def jg_image(image, stride, comp, outputs, groups):
+    """outputs: [(statistic name, value column index, output torch dtype, absolute byte offset)]
+    evaluated per group from the accumulators of `comp` (count / sum / sumsq / min / max)."""
+    if not outputs or not groups:
+        return
+    nvals = len(comp["sum"])
+    count = comp["count"].to(torch.int64).contiguous()
+
+    def arr(name):
+        lst = comp.get(name) or []
+        if len(lst) != nvals:
+            return None, []
+        keep = [t.to(torch.float64).contiguous() for t in lst]
+        return _lib.ptr_array([t.data_ptr() for t in keep]), keep
+
+    ps, ks = arr("sum")
+    pq, kq = arr("sumsq")
+    pmn, kmn = arr("min")
+    pmx, kmx = arr("max")
+    nc = len(outputs)
+    check(_lib.load().nvt_jg_image(
+        count.data_ptr(), ps, pq, pmn, pmx, nvals, (C.c_int * nc)(*[JG_KINDS[o[0]] for o in outputs]),
+        (C.c_int * nc)(*[int(o[1]) for o in outputs]), (C.c_int * nc)(*[dtype_code(o[2]) for o in outputs]),
+        (C.c_uint32 * nc)(*[int(o[3]) for o in outputs]), nc, int(groups), image.data_ptr(), int(stride),
+        stream_ptr()), "nvt_jg_image")
+    del ks, kq, kmn, kmx
+
+
 def te_image(image, stride, offset, tot_count, tot_sum, fold_count, fold_sum, kfold, groups, p_smooth,
              y_mean, out_dtype):
     """(kfold + 1) smoothed values per group at `offset` of the records of `image`, from the

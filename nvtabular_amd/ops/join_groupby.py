@@ -18,6 +18,40 @@ from .categorify import _make_name
 AGG_DTYPES = {"count": np.int32, "std": np.float32, "var": np.float32, "mean": np.float32}
 
 
+class _LazyColumns:
+    """{column name: float64 tensor [groups]} whose values are computed on first access (the names
+    -- what schemas and the lookup plan need -- are known up front)."""
+
+    def __init__(self, names, compute):
+        self._names, self._compute, self._vals = list(names), compute, None
+
+    def _get(self):
+        if self._vals is None:
+            self._vals = self._compute()
+        return self._vals
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def __contains__(self, k):
+        return k in self._names
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def keys(self):
+        return list(self._names)
+
+    def values(self):
+        return [self._get()[k] for k in self._names]
+
+    def items(self):
+        return [(k, self._get()[k]) for k in self._names]
+
+
 class _Stats:
     """Device-resident stat table of one group: lookup index + stat columns."""
 
@@ -136,16 +170,25 @@ class JoinGroupby(StatOperator):
             if not self.defer_artifacts:
                 self.flush_artifacts()
             out[name] = d
-            # device cache for transform
-            derived = derive_stats(comp, self.stats)
-            cols = {}
+            # device cache for transform: the statistics as float64 columns, evaluated lazily --
+            # the lookup image (K.jg_image) takes them straight from the accumulators; only the
+            # column-wise paths (hashed index, NVT_LOOKUP_IMAGES=0) read these arrays
+            spec = []   # (column name, statistic, value column index) in _bottom_level_groupby's order
             if "count" in self.stats:
-                cols[f"{name}{self.name_sep}count"] = comp["count"].to(torch.float64)
+                spec.append((f"{name}{self.name_sep}count", "count", 0))
             for j, cont in enumerate(agg.val_cols):
                 # column order of _bottom_level_groupby's `required` list (categorify.py:1087-1131)
                 for stat in ("sum", "mean", "min", "max", "var", "std"):
                     if stat in self.stats:
-                        cols[f"{name}{self.name_sep}{cont}{self.name_sep}{stat}"] = derived[(j, stat)]
+                        spec.append((f"{name}{self.name_sep}{cont}{self.name_sep}{stat}", stat, j))
+
+            def compute(comp=comp, spec=spec):
+                derived = derive_stats(comp, self.stats)
+                return {cn: (comp["count"].to(torch.float64) if stat == "count" else derived[(j, stat)])
+                        for cn, stat, j in spec}
+
+            cols = _LazyColumns([c[0] for c in spec], compute)
+            cols.spec, cols.comp = spec, comp
             f32 = [f"{name}{self.name_sep}{cont}{self.name_sep}{stat}" for cont in agg.val_cols
                    for stat in ("sum", "min", "max") if agg.val_dtypes.get(cont) == torch.float32]
             st = self._device_stats[name] = _Stats(agg.key_cols, comp["keys"], comp["null_mask"], cols,
@@ -185,6 +228,12 @@ class JoinGroupby(StatOperator):
         outputs = [(plan[i][0], plan[i][1], rel[i], False, plan[i][2]) for i in range(len(plan))]
 
         def fill(image, stride, offset, groups, st=st, plan=plan, rel=rel):
+            spec = getattr(st.columns, "spec", None)
+            if spec is not None:   # straight from the accumulators: one launch, no float64 columns
+                K.jg_image(image, stride, st.columns.comp,
+                           [(spec[i][1], spec[i][2], plan[i][1], offset + rel[i]) for i in range(len(plan))],
+                           groups)
+                return
             K.image_pack(image, stride, [(st.columns[plan[i][0]], plan[i][1], offset + rel[i])
                                          for i in range(len(plan))], groups)
 
