@@ -422,6 +422,14 @@ int nvt_count_merge_sorted(const int64_t *rows, uint64_t n, const uint64_t *seg_
  * value, bit for bit numpy's sequence.  One workgroup walks the generator (it is sequential);
  * kfold <= 128. */
 int nvt_fold_mt19937(uint32_t seed, int kfold, uint64_t n, uint8_t *out, void *stream);
+/* The same values from chunks of 2^18 draws generated in parallel (jump-ahead polynomials of the
+ * generator's characteristic polynomial, tools/mt_jump_polys.py): ws = nvt_fold_mt19937_par_ws_bytes
+ * bytes of device scratch; *total_out (device word) receives the accepted values the chunks held --
+ * the caller checks total >= n (the chunk count carries an 8-sigma margin) and falls back to
+ * nvt_fold_mt19937 otherwise. */
+int nvt_fold_mt19937_par_ws_bytes(uint64_t n, int kfold, uint64_t *bytes);
+int nvt_fold_mt19937_par(uint32_t seed, int kfold, uint64_t n, uint8_t *out, void *ws, uint64_t ws_bytes,
+                         uint64_t *total_out, void *stream);
 /* Distinct keys of the first n rows of every column, ESTIMATED (HyperLogLog, 4096 registers: 1.6 %
  * standard error, small counts by linear counting), and the valid rows among them: what steers
  * the first counting path of a fit that has no cardinality hints (the role of the reference's

@@ -113,6 +113,8 @@ SIGNATURES = {
     "nvt_jg_image": [_vp, _pp, _pp, _pp, _pp, _i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                      C.POINTER(_u32), _i32, _u64, _vp, _u32, _vp],
     "nvt_te_image": [_vp, _vp, _vp, _vp, _i32, _u64, _dbl, _dbl, _i32, _vp, _u32, _u32, _vp],
+    "nvt_fold_mt19937_par_ws_bytes": [_u64, _i32, C.POINTER(_u64)],
+    "nvt_fold_mt19937_par": [_u32, _i32, _u64, _vp, _vp, _u64, _vp, _vp],
     "nvt_encode_stats": [C.POINTER(_u64), _i32, _vp],
     "nvt_pq_decode_chunk": [_vp, _u64, _i32, _i32, _u64, _vp, _u64, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)],
     "nvt_expand_valid_ws_bytes": [_u64, C.POINTER(_u64)],

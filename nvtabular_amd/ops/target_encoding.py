@@ -33,6 +33,8 @@ def _add_fold(n, kfold, fold_seed=None) -> np.ndarray:
 
 _FOLD_CACHE = {}  # (kfold, fold_seed, device) -> uint8 tensor of the longest partition seen
 DEVICE_FOLDS = os.environ.get("NVT_DEVICE_FOLDS", "1") != "0"
+PARALLEL_FOLDS = os.environ.get("NVT_PARALLEL_FOLDS", "1") != "0"
+PARALLEL_FOLDS_MIN = 1 << 19   # below: one workgroup walks the generator (a few ms)
 
 
 def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
@@ -62,8 +64,24 @@ def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
             # and no copy; (a little head room: a longer partition later extends, not restarts)
             m = int(n) + int(n) // 16
             cached = torch.empty(m, dtype=torch.uint8, device=device)
-            K.check(K._lib.load().nvt_fold_mt19937(seed, int(kfold), m, cached.data_ptr(), K.stream_ptr()),
-                    "nvt_fold_mt19937")
+            lib = K._lib.load()
+            done = False
+            if PARALLEL_FOLDS and m >= PARALLEL_FOLDS_MIN:
+                # chunks of 2^18 draws generated in parallel (jump-ahead), then put behind each
+                # other; the chunk count carries an 8-sigma margin -- the total is checked
+                import ctypes as C
+
+                need = C.c_uint64()
+                K.check(lib.nvt_fold_mt19937_par_ws_bytes(m, int(kfold), C.byref(need)), "nvt_fold_mt19937_par_ws_bytes")
+                ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+                total = torch.zeros(1, dtype=torch.int64, device=device)
+                K.check(lib.nvt_fold_mt19937_par(seed, int(kfold), m, cached.data_ptr(), ws.data_ptr(), need.value,
+                                                 total.data_ptr(), K.stream_ptr()), "nvt_fold_mt19937_par")
+                done = int(K.read_back(total)[0]) >= m
+                del ws
+            if not done:
+                K.check(lib.nvt_fold_mt19937(seed, int(kfold), m, cached.data_ptr(), K.stream_ptr()),
+                        "nvt_fold_mt19937")
         else:
             f = _add_fold(n, kfold, fold_seed).astype(np.uint8)
             cached = torch.from_numpy(f).to(device)

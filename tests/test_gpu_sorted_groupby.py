@@ -542,6 +542,45 @@ def test_device_folds_are_numpys_mt19937_stream(kfold, seed):
         np.testing.assert_array_equal(out.cpu().numpy(), exp.astype(np.uint8))
 
 
+@pytest.mark.parametrize("kfold,seed,n", [(5, 42, 3_000_001), (3, 7, 1 << 20), (2, 0, 700_000), (100, 5, 2_500_000),
+                                          (8, 1, 9_000_000)])
+def test_parallel_folds_are_the_same_mt19937_stream(kfold, seed, n):
+    """nvt_fold_mt19937_par (chunks of 2^18 draws reached by jump-ahead polynomials,
+    tools/mt_jump_polys.py) == numpy.random.RandomState(seed).choice(arange(kfold), n), bit for
+    bit (target_encoding.py:427-439): 5-70 chunks, i.e. jumps through up to 7 polynomials, rejection
+    rates 0 .. 37.5 %, a length that ends inside a chunk."""
+    import ctypes as C
+
+    from nvtabular_amd import kernels as K
+
+    lib = K._lib.load()
+    need = C.c_uint64()
+    K.check(lib.nvt_fold_mt19937_par_ws_bytes(n, kfold, C.byref(need)))
+    ws = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    K.check(lib.nvt_fold_mt19937_par(seed, kfold, n, out.data_ptr(), ws.data_ptr(), need.value, total.data_ptr(),
+                                     K.stream_ptr()))
+    assert int(total.item()) >= n
+    typ = np.min_scalar_type(kfold * 2)
+    exp = np.random.RandomState(seed).choice(np.arange(kfold, dtype=typ), n)
+    np.testing.assert_array_equal(out.cpu().numpy(), exp.astype(np.uint8))
+
+
+def test_fold_column_takes_the_parallel_generator_and_matches_numpy():
+    from nvtabular_amd.ops import target_encoding as T
+
+    key = (5, 4242, "cuda:0")
+    T._FOLD_CACHE.pop(key, None)
+    n = 2_000_000
+    col = T._fold_column(n, 5, 4242, torch.device("cuda:0"))
+    exp = np.random.RandomState(4242).choice(np.arange(5, dtype=np.uint8), n)
+    np.testing.assert_array_equal(col.data.cpu().numpy(), exp)
+    # a longer partition later: regenerated (longer prefix of the same stream)
+    col2 = T._fold_column(3 * n, 5, 4242, torch.device("cuda:0"))
+    np.testing.assert_array_equal(col2.data[:n].cpu().numpy(), exp)
+
+
 @pytest.mark.parametrize("nparts", [1, 3])
 def test_null_keys_are_one_group_on_the_sort_path(tmp_path, nparts):
     """A nullable int32 key column: the rows without a key form one group (the reference groups
