@@ -1307,6 +1307,28 @@ def main():
         except Exception as e:  # never break the line
             full_frame = {"full_frame_ok": False, "error": repr(e)}
     del out, wf_cold
+    dist_diag = None
+    if world > 1:
+        # ONE more fit + transform, outside every timed region, with the exchange's sections timed
+        # (device-synchronised marks) and the bytes of every collective form counted: the first
+        # RCCL run explains itself -- where the ranks wait, what crosses the links
+        from nvtabular_amd import dist as _dd
+
+        barrier()
+        _dd.reset_traffic()
+        _dd.enable_timing(True)
+        t4 = time.perf_counter()
+        step()
+        barrier()
+        diag_ms = 1e3 * (time.perf_counter() - t4)
+        dist_diag = {"step_ms_with_synchronised_marks": round(diag_ms, 3),
+                     "sections_ms": {k: round(1e3 * v, 3) for k, v in (_dd.TIMING or {}).items()},
+                     "collectives": {k: dict(v) for k, v in _dd.TRAFFIC.items()},
+                     "bytes_sent_per_rank": sum(v["bytes_sent"] for v in _dd.TRAFFIC.values()),
+                     "bytes_received_per_rank": sum(v["bytes_received"] for v in _dd.TRAFFIC.values()),
+                     "collective_calls_per_fit": sum(v["calls"] for v in _dd.TRAFFIC.values()),
+                     "note": "rank 0's view of one fit + transform outside the timed steps"}
+        _dd.enable_timing(False)
     if world > 1:
         import torch.distributed as td
 
@@ -1469,6 +1491,7 @@ def main():
         result["extra_configs"] = extras
     if world > 1:
         result["collective_selfcheck"] = selfcheck
+        result["dist_breakdown"] = dist_diag
     if rank == 0:
         from nvtabular_amd import dist as _d
 

@@ -77,7 +77,28 @@ def _staged() -> bool:
     return _backend() == "gloo"
 
 
+# bytes this rank hands to / receives from every collective form since the last reset_traffic():
+# host arithmetic on shapes only (always on; the bench puts it into every N > 1 line)
+TRAFFIC = {}
+
+
+def _count_traffic(name: str, sent: int, received: int):
+    rec = TRAFFIC.setdefault(name, {"calls": 0, "bytes_sent": 0, "bytes_received": 0})
+    rec["calls"] += 1
+    rec["bytes_sent"] += int(sent)
+    rec["bytes_received"] += int(received)
+
+
+def reset_traffic():
+    TRAFFIC.clear()
+
+
+def _nbytes(t: torch.Tensor) -> int:
+    return int(t.numel()) * t.element_size()
+
+
 def _all_reduce(t: torch.Tensor, op=td.ReduceOp.SUM) -> torch.Tensor:
+    _count_traffic("all_reduce", _nbytes(t), _nbytes(t))
     if _staged() and t.is_cuda:
         h = t.cpu()
         td.all_reduce(h, op=op)
@@ -90,6 +111,7 @@ def _all_reduce(t: torch.Tensor, op=td.ReduceOp.SUM) -> torch.Tensor:
 def _all_gather_same(t: torch.Tensor) -> List[torch.Tensor]:
     """Every rank's tensor of identical shape, rank order."""
     G = world_size()
+    _count_traffic("all_gather(equal shapes)", _nbytes(t), _nbytes(t) * G)
     if _staged() and t.is_cuda:
         h = t.cpu()
         bufs = [torch.empty_like(h) for _ in range(G)]
@@ -128,6 +150,7 @@ def _all_to_all_counts(send_counts: torch.Tensor) -> torch.Tensor:
     G = world_size()
     recv = torch.empty_like(send_counts)
     if _backend() == "nccl":
+        _count_traffic("all_to_all_single(counts)", _nbytes(send_counts), _nbytes(send_counts))
         td.all_to_all_single(recv, send_counts)
     else:
         r = rank()
@@ -140,6 +163,7 @@ def _all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[
     G = world_size()
     out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype,
                       device=send.device)
+    _count_traffic("all_to_all_single(uneven)", _nbytes(send), _nbytes(out))
     if _backend() == "nccl":
         td.all_to_all_single(out, send.contiguous(), output_split_sizes=recv_counts,
                              input_split_sizes=send_counts)
@@ -181,6 +205,8 @@ def _all_gather_v(t: torch.Tensor, sizes: Optional[List[int]] = None) -> torch.T
     if sizes is None:
         n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
         sizes = [int(s.item()) for s in _all_gather_same(n)]
+    row = (int(t[0].numel()) if t.dim() > 1 and t.shape[0] else 1) * t.element_size()
+    _count_traffic("all_gather_v", _nbytes(t) * (G - 1), sum(sizes) * row)
     if _backend() == "nccl":
         # exact sizes, no padding to the longest shard (key-range owners are not balanced):
         # an all-to-all(v) in which every rank sends its whole tensor to every peer moves
@@ -323,8 +349,16 @@ if __import__("os").environ.get("NVT_DIST_TIMING"):
 _last_mark = [0.0]
 
 
+def enable_timing(on: bool = True):
+    """Section timing for ONE diagnostic fit (device-synchronised at every mark, so never inside a
+    timed region): `dist.TIMING` = {section: seconds}.  bench.py runs one such fit per N > 1 line."""
+    global TIMING
+    TIMING = {} if on else None
+
+
 def _mark(name=None):
-    """Diagnostic timing (NVT_DIST_TIMING=1): seconds since the previous mark go to TIMING[name]."""
+    """Diagnostic timing (NVT_DIST_TIMING=1 / enable_timing): seconds since the previous mark go to
+    TIMING[name]."""
     if TIMING is None:
         return
     import time
@@ -358,6 +392,18 @@ SMALL_SORT_MAX = 1 << 18   # entries of unsorted lists one tagged sort may take 
 STATS["ordered_exchanges"] = 0
 
 
+def _stable_order(words: torch.Tensor) -> torch.Tensor:
+    """Indices that sort non-negative int64 `words` ascending, stable.  On the GPU: the library's
+    radix order (nvt_sort_key_u64 + nvt_order_rows, two 32-bit passes -- the sort of the Groupby
+    operator), not torch.sort; the host stand-in serves the gloo tests on CPU tensors."""
+    if words.is_cuda:
+        from . import kernels as K
+
+        perm = K.order_rows(int(words.numel()), words.device, [(words.contiguous(), None, True)])
+        return perm & 0xFFFFFFFF
+    return torch.argsort(words, stable=True)
+
+
 def _sort_unsorted_lists(tables, sorted_by_key):
     """The lists flagged unsorted ordered by key with ONE sort of (column << 32 | biased key)
     words; None when they hold more than SMALL_SORT_MAX entries (the caller keeps the unordered
@@ -370,8 +416,8 @@ def _sort_unsorted_lists(tables, sorted_by_key):
         return None
     words = torch.cat([(tables[j][0].to(torch.int64) + (1 << 31)) | (i << 32) for i, j in enumerate(todo)])
     cnts = torch.cat([tables[j][1].to(torch.int64) for j in todo])
-    words, order = torch.sort(words)
-    cnts = cnts[order]
+    order = _stable_order(words)
+    words, cnts = words[order], cnts[order]
     keys = ((words & 0xFFFFFFFF) - (1 << 31)).to(torch.int32)
     out, at = list(tables), 0
     for j, n in zip(todo, lens):
@@ -598,17 +644,14 @@ def _merge_sorted_runs(recv, off, G, ncol, scalars=None):
                                                   for j in big])):
             merged[j] = m
     if small:
-        tags = torch.repeat_interleave(torch.arange(len(small), dtype=torch.int64, device=dev),
-                                       torch.tensor([tot[j] for j in small], dtype=torch.int64, device=dev))
-        words = (keys_all[:n_small].to(torch.int64) + (1 << 31)) | (tags << 32)
-        words, order = torch.sort(words)
-        uniq, inv = torch.unique_consecutive(words, return_inverse=True)
-        sums = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).index_add_(0, inv, cnts_all[:n_small][order])
-        bounds = torch.searchsorted(uniq, torch.arange(len(small) + 1, dtype=torch.int64, device=dev) << 32)
-        bounds = bounds.cpu().tolist()
-        mkeys = ((uniq & 0xFFFFFFFF) - (1 << 31)).to(torch.int32)
-        for i, j in enumerate(small):
-            merged[j] = (mkeys[bounds[i]:bounds[i + 1]], sums[bounds[i]:bounds[i + 1]])
+        # (column, key) groups of all the small columns by ONE tagged sort + segmented sum of the
+        # library (nvt_count_merge_sorted: the owner-side merge of the unordered exchange)
+        seg = [0]
+        for j in small:
+            seg.append(seg[-1] + tot[j])
+        rows = (cnts_all[:n_small] << 32) | (keys_all[:n_small].to(torch.int64) & 0xFFFFFFFF)
+        for j, m in zip(small, K.merge_counts_sorted(rows, seg, len(small))):
+            merged[j] = m
     lens = [int(k.numel()) for k, _ in merged]
     hist32 = torch.zeros(ncol, 256, dtype=torch.int32, device=dev)
     for j, (_, c) in enumerate(merged):
@@ -695,7 +738,7 @@ def _label_own_shards(merged, lens, hist32, G, ncol, dev, scalars=None):
     del bkeys
     tags = torch.repeat_interleave(torch.arange(ncol, dtype=torch.int64, device=dev), col_tot.to(dev))
     comp = (tags << 31) | ((1 << 31) - 1 - bcnts)    # (column, count descending); stable: key ascending
-    _, order = torch.sort(comp, stable=True)
+    order = _stable_order(comp)
     pos = torch.arange(tot_big, dtype=torch.int64, device=dev) - col_start[:-1].to(dev)[tags]
     lab_cm = torch.empty(tot_big, dtype=torch.int32, device=dev)
     lab_cm[order] = pos.to(torch.int32)              # tags are non-decreasing: tags[order] == tags
@@ -730,6 +773,7 @@ def _exchange_rows_hip(xb, rng_h, G, ncol, ordered=False):
     _mark("group_rows")
     if _backend() == "nccl":
         recv_mat = torch.empty_like(send_mat)
+        _count_traffic("all_to_all_single(count matrix)", _nbytes(send_mat), _nbytes(send_mat))
         td.all_to_all_single(recv_mat, send_mat.contiguous())
     else:
         recv_mat = torch.stack([m[rank()] for m in _all_gather_same(send_mat.contiguous())])
@@ -776,6 +820,7 @@ def _exchange_rows_torch(tables, k64s, lens, rng_h, G, ncol, dev, packed):
     # ---- count matrix: row g of mine goes to rank g ------------------------------------
     if _backend() == "nccl":
         recv_mat = torch.empty_like(send_mat)
+        _count_traffic("all_to_all_single(count matrix)", _nbytes(send_mat), _nbytes(send_mat))
         td.all_to_all_single(recv_mat, send_mat.contiguous())
     else:
         recv_mat = torch.stack([m[rank()] for m in _all_gather_same(send_mat.contiguous())])

@@ -43,6 +43,10 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
     import bench
     assert sc["ok_on_every_rank"] and all(c["equal_to_gloo"] for c in sc["checks"])
     assert {c["collective"] for c in sc["checks"]} == set(bench.SELFCHECK_COLLECTIVES)
+    # every N > 1 line explains its exchange: sections of one diagnostic fit + bytes per collective
+    bd = rec["dist_breakdown"]
+    assert bd["sections_ms"] and bd["bytes_sent_per_rank"] > 0 and bd["collective_calls_per_fit"] >= 4
+    assert "all_to_all_single(uneven)" in bd["collectives"]
 
 
 @pytest.mark.timeout(400)
