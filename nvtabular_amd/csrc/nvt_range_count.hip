@@ -383,25 +383,46 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
   // (One run after the other was a chain of 16 dependent global loads per wave.)
   {
     constexpr int RPW = kRpG / NW;  // runs per wave
-    unsigned pre[RPW + 1];
-    pre[0] = 0;
+    // prefix of this wave's run lengths in LDS: lane q <= RPW holds pre[q].  Which run a flat
+    // index f falls in is followed by a per-lane cursor -- f only grows for a lane, so the cursor
+    // moves RPW times in the whole walk (one LDS compare per key).  The first version counted
+    // `f >= pre[q]` over all 16 runs and then selected pre[r] out of registers: ~60 vector
+    // instructions per gathered key for one address (SQ counters, profiles/r05_notes.md).
+    __shared__ unsigned s_pre[NW][RPW + 2];
+    {
+      unsigned acc = 0;
 #pragma unroll
-    for (int q = 0; q < RPW; ++q) pre[q + 1] = pre[q] + run_len[w * RPW + q];
-    const unsigned total = pre[RPW];
+      for (int q = 0; q < RPW; ++q) {
+        if (lane == (unsigned)q) s_pre[w][q] = acc;
+        acc += run_len[w * RPW + q];
+      }
+      if (lane == (unsigned)RPW) s_pre[w][RPW] = acc;
+    }
+    __syncthreads();                  // (lanes read the words other lanes of their wave wrote)
+    const unsigned *pre = s_pre[w];
+    unsigned total = 0;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) total += run_len[w * RPW + q];
     const int32_t *rbase = regions + ((uint64_t)b * kRpG + w * RPW) * region_cap;
 #ifndef NVT_RP_GB
 #define NVT_RP_GB 8
 #endif
     constexpr int GB = NVT_RP_GB;
+    unsigned r = 0, r_lo = 0, r_hi = pre[1];   // cursor: run r covers flat indices [r_lo, r_hi)
     for (unsigned f0 = 0; f0 < total && !failed; f0 += GB * kWave) {
       int32_t kk[GB];
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const unsigned f = f0 + u * kWave + lane;
-        unsigned r = 0;
-#pragma unroll
-        for (int q = 1; q < RPW; ++q) r += f >= pre[q] ? 1u : 0u;
-        kk[u] = f < total ? rbase[(uint64_t)r * region_cap + (f - pre[r])] : kEmpty;
+        kk[u] = kEmpty;
+        if (f < total) {
+          while (f >= r_hi) {   // (f < total = pre[RPW]: the cursor stops at the last run at the latest)
+            ++r;
+            r_lo = r_hi;
+            r_hi = pre[r + 1];
+          }
+          kk[u] = rbase[(uint64_t)r * region_cap + (f - r_lo)];
+        }
       }
       uint32_t hs[GB];
       int32_t cur[GB];
