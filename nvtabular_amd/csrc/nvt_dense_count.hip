@@ -1176,6 +1176,7 @@ __global__ __launch_bounds__(1024) void hot_sample_kernel(const HotSampleBatch b
       pm.ulo = 0; pm.span = 0; pm.mul = 0; pm.sh = 0; pm.flat = 0;
       pm.piece_slots = (uint32_t)s_map[4];
       pm.pw = s_pw;
+      pm.lpw = (const __attribute__((address_space(3))) uint32_t *)s_pw;
       unsigned *bcnt = seen;
       for (int i = threadIdx.x; i < 1025; i += 1024) bcnt[i] = 0;
       __syncthreads();

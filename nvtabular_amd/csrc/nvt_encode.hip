@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
     const int32_t *__restrict__ range_aux = nullptr, int count_stats = 0) {
   static_assert(!HEAD16 || (TWO && sizeof(K) == 4), "HEAD16: the 2-choice head of int32 keys");
   constexpr bool global_needed = GLOBAL;
-  RangeMap rmap = {0u, 0u, 0u, 0, 0};
+  RangeMap rmap = {0u, 0u, 0u, 0, 0, 0u, nullptr, nullptr};
   __shared__ uint32_t s_pieces[RANGE == 1 ? kRpPwWords : 1];
   if constexpr (RANGE) rmap = load_map(range_aux);
   if constexpr (RANGE == 1) stage_pieces(rmap, s_pieces, threadIdx.x, kEncBS);  // (barrier below)

@@ -66,26 +66,33 @@ struct RangeMap {
   int flat;  // 1: the table is ONE run of F slots (+ tail), slot = f (vocabulary tables built from a
              //    key-sorted list: flat_build_kernel); 0: bucket regions dumped by the counting pass
   uint32_t piece_slots;      // 0: linear map; else fine slots per piece (the piecewise form)
-  const uint32_t *pw;        // piecewise parameters (global or LDS)
+  const uint32_t *pw;        // piecewise parameters in global memory
+  // ... and staged in LDS (stage_pieces): an LDS-address-space pointer, so that the six dependent
+  // reads of the splitter search are ds_read, not flat loads that wait for vmcnt(0) each (a
+  // generic pointer that may point either way compiled to flat_load_dword + s_waitcnt vmcnt(0)
+  // per step: the piecewise map of the dense-id columns)
+  const __attribute__((address_space(3))) uint32_t *lpw;
+  template <typename P>
+  __device__ __forceinline__ uint32_t fine_pieces(P q, uint32_t u) const {
+    // piece p: splitters[p] <= u < splitters[p + 1] (keys outside the sampled range clamp)
+    unsigned p = 0;
+#pragma unroll
+    for (unsigned step = kRpPieces / 2; step > 0; step >>= 1)
+      p += (u >= q[p + step]) ? step : 0u;
+    const uint32_t s0 = q[p], s1 = q[p + 1];
+    uint32_t d = u > s0 ? u - s0 : 0u;
+    d = d < s1 - s0 - 1u ? d : s1 - s0 - 1u;
+    const uint32_t m = q[kRpPwMul + p];
+    const bool hi = (q[kRpPwSh + (p >> 5)] >> (p & 31)) & 1u;
+    // wide piece (more keys than slots): high half of d * (S << 32) / width; narrow piece
+    // (dense ids: fewer keys than slots): 16-bit fixed point, (d * ((S << 16) / width)) >> 16
+    uint32_t f = hi ? __umulhi(d, m) : (uint32_t)(((uint64_t)d * m) >> 16);
+    f = f < piece_slots - 1u ? f : piece_slots - 1u;
+    return p * piece_slots + f;
+  }
   __device__ __forceinline__ uint32_t fine(int32_t key) const {
     const uint32_t u = ukey(key);
-    if (piece_slots) {
-      // piece p: splitters[p] <= u < splitters[p + 1] (keys outside the sampled range clamp)
-      unsigned p = 0;
-#pragma unroll
-      for (unsigned step = kRpPieces / 2; step > 0; step >>= 1)
-        p += (u >= pw[p + step]) ? step : 0u;
-      const uint32_t s0 = pw[p], s1 = pw[p + 1];
-      uint32_t d = u > s0 ? u - s0 : 0u;
-      d = d < s1 - s0 - 1u ? d : s1 - s0 - 1u;
-      const uint32_t m = pw[kRpPwMul + p];
-      const bool hi = (pw[kRpPwSh + (p >> 5)] >> (p & 31)) & 1u;
-      // wide piece (more keys than slots): high half of d * (S << 32) / width; narrow piece
-      // (dense ids: fewer keys than slots): 16-bit fixed point, (d * ((S << 16) / width)) >> 16
-      uint32_t f = hi ? __umulhi(d, m) : (uint32_t)(((uint64_t)d * m) >> 16);
-      f = f < piece_slots - 1u ? f : piece_slots - 1u;
-      return p * piece_slots + f;
-    }
+    if (piece_slots) return lpw ? fine_pieces(lpw, u) : fine_pieces(pw, u);
     uint32_t d = u > ulo ? u - ulo : 0u;
     d = d < span ? d : span;
     return __umulhi(d << sh, mul);
@@ -167,7 +174,7 @@ constexpr int kRpPwWords = 2 * kRpPieces + 3;
 __device__ __forceinline__ void stage_pieces(RangeMap &m, uint32_t *lds, unsigned tid, unsigned nthreads) {
   if (!m.piece_slots) return;
   for (unsigned i = tid; i < (unsigned)kRpPwWords; i += nthreads) lds[i] = m.pw[i];
-  m.pw = lds;
+  m.lpw = (const __attribute__((address_space(3))) uint32_t *)lds;
 }
 
 __device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {
@@ -181,6 +188,7 @@ __device__ __forceinline__ RangeMap load_map(const int32_t *__restrict__ aux) {
   // never use pieces: their aux blocks end before the piecewise parameters)
   m.piece_slots = m.flat ? 0u : (uint32_t)aux[NVT_RANGE_AUX_LO + 7];
   m.pw = reinterpret_cast<const uint32_t *>(aux + NVT_RANGE_AUX_PW);
+  m.lpw = nullptr;
   return m;
 }
 
