@@ -21,7 +21,7 @@ python tools/pmc_summarize_cfg4.py $out/pmc4 $out/r05_cfg4_pmc_traffic.json > $o
 f=$(find $out -name "stats_kernel_stats.csv" | head -1); cp $f $out/r05_kernel_stats.csv
 f=$(find $out -name "mp_kernel_stats.csv" | head -1); cp $f $out/r05_multipart_kernel_stats.csv
 f=$(find $out -name "cfg4_kernel_stats.csv" | head -1); cp $f $out/r05_cfg4_kernel_stats.csv
-fc=$(find $out -name "fetch_counter_collection.csv" | head -1); wc=$(find $out -name "write_counter_collection.csv" | head -1)
+fc=$(find $out -name "fetch_counter_collection.csv" -not -path "*/pmc4/*" | head -1); wc=$(find $out -name "write_counter_collection.csv" -not -path "*/pmc4/*" | head -1)
 mkdir -p $out/pmc; cp $fc $out/pmc/fetch_counter_collection.csv; cp $wc $out/pmc/write_counter_collection.csv
 python tools/pmc_summarize_r05.py $out/pmc $out/r05_pmc_traffic.json > $out/pmc_summary.txt 2>&1
 find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*.db" -delete
