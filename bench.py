@@ -483,6 +483,10 @@ def extra_cfg4_multipart(device, tmp, rows_per_part=1 << 28, nparts=4, card=100_
                                       out_path=os.path.join(path, "jg"))
         return nvt.Workflow(te + jg)
 
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
     frames = [make(700 + i, rows_per_part) for i in range(nparts)]
     wf = build(os.path.join(tmp, "cfg4mp"))
     ds = nvt.Dataset(frames)
@@ -492,13 +496,20 @@ def extra_cfg4_multipart(device, tmp, rows_per_part=1 << 28, nparts=4, card=100_
         for out in wf.transform(ds).to_iter():
             del out
 
+    # two warm-up steps: the first sizes the tables (no hints yet), the second lets the caching
+    # allocator settle on the multi-GB blocks of a hinted step (a hipMalloc of several GB inside a
+    # timed step is a 50-100 ms host stall: `allocator.device_allocs_in_timed_steps` says whether
+    # that happened)
+    step()
     step()
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ms1 = torch.cuda.memory_stats()
     K.profile_begin()
     step()
     rep = K.profile_report()
@@ -517,11 +528,19 @@ def extra_cfg4_multipart(device, tmp, rows_per_part=1 << 28, nparts=4, card=100_
         "single_partition_rows_per_s": single,
         "ratio_to_single_partition_rows_per_s": (rows / dt / single) if single else None,
         "gpu_busy_ms": round(rep["busy_ms"], 3),
+        "rows_per_s_of_gpu_busy_time": rows / (rep["busy_ms"] / 1e3) if rep["busy_ms"] else None,
         "per_kernel_ms": {k: round(v[0], 3) for k, v in rep["kernels"].items()},
         "roofline": cfg4_roofline({k: v[0] for k, v in rep["kernels"].items()}, rows,
                                   traffic_file="r05_cfg4mp_pmc_traffic.json"),
         "fold_generation_ms": fold_generation_ms(device, rows_per_part),
         "fold_generation_inside_ms_per_step": False,
+        # device allocations inside the timed steps: a step that has to hipMalloc / hipFree (the
+        # caching allocator out of fitting blocks) stalls on the host, not on the GPU
+        "allocator": {"reserved_GB": round(ms1["reserved_bytes.all.current"] / 1e9, 2),
+                      "allocated_peak_GB": round(ms1["allocated_bytes.all.peak"] / 1e9, 2),
+                      "device_allocs_in_timed_steps": ms1["num_device_alloc"] - ms0["num_device_alloc"],
+                      "device_frees_in_timed_steps": ms1["num_device_free"] - ms0["num_device_free"],
+                      "alloc_retries_in_timed_steps": ms1["num_alloc_retries"] - ms0["num_alloc_retries"]},
     }
     del frames, ds, wf
     torch.cuda.empty_cache()
