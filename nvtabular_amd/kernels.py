@@ -2184,6 +2184,7 @@ class FlatIndex:
             cons = self.consumers = []
         cons[:] = [c for c in cons if not (c.owner is consumer.owner and c.tag == consumer.tag)]
         cons.append(consumer)
+        consumer.index = self
         self._image = None
 
     def _build_image(self):
@@ -2280,6 +2281,20 @@ class LookupConsumer:
         self.owner, self.tag, self.width = owner, tag, int(width)
         self.outputs, self.fill, self.fold_fn = list(outputs), fill, fold_fn
         self.groups = int(groups)   # records this consumer fills (the groups of its statistics)
+        self.index = None
+
+    def release(self):
+        """The owner clears its fit: leave the index and drop what this consumer holds NOW.  The
+        closures reference the operator, the operator references the consumer: without this the
+        multi-GB image and statistics of a fit wait for Python's cycle collector, and the next
+        fit's allocations miss the cached blocks (hipMalloc of several GB inside a step)."""
+        idx, self.index = self.index, None
+        if idx is not None:
+            cons = getattr(idx, "consumers", None)
+            if cons is not None and self in cons:
+                cons.remove(self)
+            idx._image = None
+        self.fill = self.fold_fn = self.owner = None
 
 
 def image_pack(image, stride, columns, groups):

@@ -214,7 +214,9 @@ class JoinGroupby(StatOperator):
         """Sort-path groups: this operator's statistics, cast to their output dtypes, as a byte
         range of the key column's lookup image (K.FlatIndex.image_lookup)."""
         self._consumers = getattr(self, "_consumers", {})
-        self._consumers.pop(name, None)
+        old = self._consumers.pop(name, None)
+        if old is not None:
+            old.release()
         plan = self._plan(st)
         if not (K.LOOKUP_IMAGES and isinstance(st.index, K.FlatIndex) and len(st.key_cols) == 1
                 and 1 <= len(plan) <= 16):
@@ -372,6 +374,8 @@ class JoinGroupby(StatOperator):
         self.categories = {}
         self.storage_name = {}
         self._device_stats = {}
+        for cons in getattr(self, "_consumers", {}).values():
+            cons.release()
         self._consumers = {}
         self._pending = {}
 

@@ -237,6 +237,8 @@ class TargetEncoding(StatOperator):
         """Sort-path groups (one int32 / narrow int64 key column): this operator's byte range of
         the key column's lookup image (K.FlatIndex.image_lookup) -- (kfold + 1) smoothed values
         per target and group, target_encoding.py:350-371 evaluated once per (group, fold)."""
+        for old in getattr(self, "_consumers", {}).values():
+            old.release()
         self._consumers = {}
         if not K.LOOKUP_IMAGES:
             return
@@ -455,5 +457,7 @@ class TargetEncoding(StatOperator):
         self.stats = {}
         self.means = {}
         self._device_stats = {}
+        for cons in getattr(self, "_consumers", {}).values():
+            cons.release()
         self._consumers = {}
         self._pending = {}
