@@ -475,6 +475,8 @@ def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None
         for g in groups:
             cc = pf.row_groups[g]["columns"][j]
             rows = pf.row_groups[g]["num_rows"]
+            if rows == 0:
+                continue
             buf = _scratch(cc["size"])   # (per thread, reused: a fresh 30 MB bytearray is zero-filled
             got, mv = 0, memoryview(buf)  #  and page-faulted in for every chunk)
             while got < cc["size"]:

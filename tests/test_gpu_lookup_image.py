@@ -199,3 +199,34 @@ def test_workflow_serves_both_operators_from_one_launch_per_partition(tmp_path, 
                           "y": np.zeros(2, dtype="float32")})
     with pytest.raises(ValueError, match="unseen categories"):
         wf.transform(nvt.Dataset(other)).to_ddf().compute()
+
+
+def test_per_operator_kernels_still_serve_a_fit_without_images(tmp_path, monkeypatch):
+    """NVT_LOOKUP_IMAGES=0 (the per-operator path: transform records in the fit, nvt_flat_lookup_te /
+    nvt_flat_lookup_gather in the transform) stays a complete, oracle-equal path."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+
+    monkeypatch.setattr(K, "LOOKUP_IMAGES", False)
+    rng = np.random.default_rng(4)
+    n = 90_000
+    ids, rows = _keys(rng, n, 6_000)
+    df = pd.DataFrame({"k": rows, "x": rng.normal(size=n), "y": (rng.random(n) < 0.3).astype("float32")})
+    stats = ["count", "sum", "mean", "std"]
+    te = ["k"] >> ops.TargetEncoding("y", out_path=str(tmp_path / "te"), kfold=5, fold_seed=42, p_smooth=20)
+    jg = ["k"] >> ops.JoinGroupby(out_path=str(tmp_path / "jg"), stats=stats, cont_cols=["x"])
+    wf = nvt.Workflow(te + jg).fit(nvt.Dataset(df))
+    before, flat = K.STATS.get("image_lookups", 0), K.STATS.get("flat_lookups", 0)
+    got = wf.transform(nvt.Dataset(df)).to_ddf().compute()
+    assert K.STATS.get("image_lookups", 0) == before and K.STATS.get("flat_lookups", 0) == flat + 2
+    cats = O.join_groupby_fit([df.copy()], ["k"], ["x"], stats, str(tmp_path / "c"))
+    exp_j = O.join_groupby_transform(df.copy(), ["k"], cats)
+    st, means = O.target_encoding_fit([df.copy()], ["k"], ["y"], str(tmp_path / "c2"), kfold=5, fold_seed=42)
+    exp_t = O.target_encoding_transform(df[["k", "y"]].copy(), ["k"], ["y"], st, means, kfold=5, fold_seed=42,
+                                        p_smooth=20)
+    np.testing.assert_array_equal(got["k_count"].to_numpy(), exp_j["k_count"].to_numpy())
+    for c in ("k_x_sum", "k_x_mean", "k_x_std"):
+        np.testing.assert_allclose(got[c].to_numpy().astype("float64"), exp_j[c].to_numpy().astype("float64"),
+                                   rtol=2e-5, atol=1e-6, err_msg=c)
+    np.testing.assert_allclose(got["TE_k_y"].to_numpy(), exp_t["TE_k_y"].to_numpy(), rtol=1e-5, atol=1e-6)

@@ -213,3 +213,29 @@ def test_decode_chunk_rejects_what_it_does_not_handle(tmp_path):
     assert call(raw[: len(raw) // 2], 5000) == _lib.NVT_EINVAL
     assert call(raw, 4000) == _lib.NVT_EINVAL      # more rows in the pages than announced
     assert call(raw, 6000) == _lib.NVT_EINVAL      # fewer
+
+
+def test_plain_reader_required_columns_and_empty_files(tmp_path):
+    """REQUIRED columns (max definition level 0: no levels in the pages), a file without rows, a
+    file of many tiny row groups."""
+    n = 10_007
+    rng = np.random.default_rng(2)
+    schema = pa.schema([pa.field("r", pa.int64(), nullable=False), pa.field("o", pa.float32(), nullable=True)])
+    t = pa.table({"r": rng.integers(0, 10**12, n), "o": pa.array(rng.normal(size=n).astype("float32"),
+                                                               mask=rng.random(n) < 0.4)}, schema=schema)
+    path = str(tmp_path / "req.parquet")
+    pq.write_table(t, path, use_dictionary=False, compression=None, row_group_size=1001, data_page_size=2048)
+    pf = PP.PlainParquetFile(path)
+    assert pf.eligible, pf.why
+    assert pf.max_def == [0, 1] and pf.num_row_groups == 10
+    staged = PP.read_row_groups_staged(pf, list(range(pf.num_row_groups)), pin=False)
+    assert staged["r"].valid is None
+    _staged_equals_arrow(staged, pq.read_table(path))
+    # no rows at all
+    path0 = str(tmp_path / "empty.parquet")
+    pq.write_table(t.slice(0, 0), path0, use_dictionary=False, compression=None)
+    pf0 = PP.PlainParquetFile(path0)
+    assert pf0.num_rows == 0
+    if pf0.eligible and pf0.num_row_groups:
+        st0 = PP.read_row_groups_staged(pf0, list(range(pf0.num_row_groups)), pin=False)
+        assert all(c.rows == 0 for c in st0.values())
