@@ -307,14 +307,16 @@ __device__ __forceinline__ uint32_t lds_home(K key) {
 // wrapping (an empty slot ends every chain).
 template <typename K, typename OUT, bool TWO = false, bool GLOBAL = true, int UU = 2,
           int RANGE = 0,  // 0: hashed table, 1: bucket regions dumped by the counting pass, 2: flat
-          bool HEAD16 = false>
-__global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
+          bool HEAD16 = false,
+          bool HALF = false>  // half the head (64 KiB), <= 64 VGPRs: TWO workgroups per CU
+__global__ __launch_bounds__(kEncBS, HALF ? 2 : 1) void encode_hot_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
     int64_t null_label, int64_t oov_label, uint32_t num_buckets, OUT *__restrict__ out,
     const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label,
     const int32_t *__restrict__ range_aux = nullptr, int count_stats = 0) {
   static_assert(!HEAD16 || (TWO && sizeof(K) == 4), "HEAD16: the 2-choice head of int32 keys");
+  static_assert(!HALF || (TWO && !HEAD16), "HALF: the 2-choice head with 8-byte slots");
   constexpr bool global_needed = GLOBAL;
   RangeMap rmap = {0u, 0u, 0u, 0, 0, 0u, nullptr, nullptr};
   __shared__ uint32_t s_pieces[RANGE == 1 ? kRpPwWords : 1];
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(kEncBS) void encode_hot_kernel(
   };
   constexpr K EMPTY = EncTraits<K>::empty;
   constexpr int VEC = EncTraits<K>::vec;
-  constexpr int SLOTS = HotCfg<K>::slots;
+  constexpr int SLOTS = HALF ? HotCfg<K>::slots / 2 : HotCfg<K>::slots;
   using L = decltype(EncSlot<K>::label);
   using C = typename EncTraits<K>::cas_t;
   constexpr int kLdsBytes = HEAD16 ? kHead16Buckets * 12 : SLOTS * (int)sizeof(EncSlot<K>);
@@ -772,15 +774,28 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
       if (global_needed && (two || range_aux != nullptr)) {  // cache mode: 2-choice table filled to 7/8
         static const bool head16 = getenv("NVT_ENC_HEAD16") == nullptr || atoi(getenv("NVT_ENC_HEAD16")) != 0;
         static const int stats = getenv("NVT_ENC_STATS") ? atoi(getenv("NVT_ENC_STATS")) : 0;
-        const uint64_t cap2 = head16 ? (uint64_t)kHead16Keys : (uint64_t)HotCfg<K>::slots / 8 * 7;
+        // NVT_ENC_HALF=1 (experiment): half the head, one key vector per lane and <= 64 VGPRs, so
+        // that TWO workgroups share a CU -- the waves of a cache-mode launch are parked 77 % of
+        // their cycles (SQ_WAIT_ANY), and one workgroup per CU is 4 waves per SIMD
+        static const bool half = getenv("NVT_ENC_HALF") != nullptr && atoi(getenv("NVT_ENC_HALF")) != 0;
+        const uint64_t cap2 = half ? (uint64_t)HotCfg<K>::slots / 16 * 7
+                                   : head16 ? (uint64_t)kHead16Keys : (uint64_t)HotCfg<K>::slots / 8 * 7;
         n_hot = (uint32_t)(n_vocab < cap2 ? n_vocab : cap2);
+        if (half) hgrid = stream_grid(n / VEC + 1, kEncBS, 2);
 #define NVT_ENC_CACHE(OUTT, KIND, H16)                                                            \
   encode_hot_kernel<K, OUTT, true, true, 2, KIND, H16><<<hgrid, kEncBS, 0, s>>>(                   \
       keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,          \
       reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux, stats)
+#define NVT_ENC_CACHE_HALF(OUTT, KIND)                                                            \
+  encode_hot_kernel<K, OUTT, true, true, 1, KIND, false, true><<<hgrid, kEncBS, 0, s>>>(           \
+      keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,          \
+      reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux, stats)
 #define NVT_ENC_CACHE_K(KIND)                                                \
   do {                                                                       \
-    if (head16) {                                                            \
+    if (half) {                                                              \
+      if (out_bytes == 8) NVT_ENC_CACHE_HALF(int64_t, KIND);                 \
+      else NVT_ENC_CACHE_HALF(int32_t, KIND);                                \
+    } else if (head16) {                                                     \
       if (out_bytes == 8) NVT_ENC_CACHE(int64_t, KIND, true);                \
       else NVT_ENC_CACHE(int32_t, KIND, true);                               \
     } else {                                                                 \
@@ -795,6 +810,7 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
         } else {
           NVT_ENC_CACHE_K(0);
         }
+#undef NVT_ENC_CACHE_HALF
 #undef NVT_ENC_CACHE_K
 #undef NVT_ENC_CACHE
         NVT_CHECK_LAUNCH();
