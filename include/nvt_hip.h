@@ -720,7 +720,13 @@ typedef struct nvt_vocab_col {
    * hashed when flat_slots == 0) is built from the labels -- no ordering pass.  sort_tmp:
    * nvt_vocab_order_tmp_bytes(n, 0) bytes. */
   const int32_t *src_labels;
+  /* optional (int32 keys, n > NVT_ENCODE_RESIDENT_I32, unique keys): NVT_ENCODE_HEAD_BYTES bytes that
+   * receive the LDS head of the cache-mode encode -- the first keys of the ORDERED vocabulary laid
+   * out as the launch's workgroups hold them -- built once here, on the stream that orders the
+   * vocabulary, instead of by every workgroup of every encode launch (nvt_encode_col.head_image). */
+  void *head_image;
 } nvt_vocab_col;
+#define NVT_ENCODE_HEAD_BYTES (12288 * 12 + 64)
 #define NVT_FLAT_AUX_WORDS (NVT_RANGE_AUX_LO + 16)
 #define NVT_FLAT_AUX_MAXDISP (NVT_RANGE_AUX_LO + 8)
 #define NVT_FLAT_AUX_NULLGROUP (NVT_RANGE_AUX_LO + 10)  /* nvt_flat_lookup*: 1 + the group of rows whose
@@ -764,6 +770,8 @@ typedef struct nvt_encode_col {
   void *wait_event;         /* optional nvt_event the launch waits for (stream-side)     */
   const int32_t *range_aux; /* `table` is a range table (nvt_count_col.range_table): probed by
                                the monotone map whose parameters sit in this aux block      */
+  const void *head_image;   /* optional: the head image nvt_vocab_finalize_many built for this
+                               vocabulary (valid once wait_event has fired)                 */
 } nvt_encode_col;
 int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream);
 

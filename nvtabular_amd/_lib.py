@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("NVT_HIP_LIB") or os.path.join(_HERE, "libnvt_hip.so")
 NVT_F32, NVT_F64, NVT_I32, NVT_I64, NVT_U8 = 0, 1, 2, 3, 4
 NVT_GB_SUMSQ, NVT_GB_MINMAX = 1, 2
 NVT_EINVAL, NVT_EHIP, NVT_ENOMEM, NVT_EUNSUPPORTED = -1, -2, -3, -4   # include/nvt_hip.h
+ENCODE_HEAD_BYTES = 12288 * 12 + 64   # NVT_ENCODE_HEAD_BYTES
 ST_NULLS, ST_SENTINEL, ST_OCCUPIED, ST_OVERFLOW, ST_ROWS = 0, 1, 2, 3, 4
 ST_MAXCOUNT = 8
 ST_BIG = 9
@@ -172,7 +173,8 @@ class VocabCol(C.Structure):
                 ("first_label", _i64), ("table", _vp), ("capacity", _u64),
                 ("sentinel_label", _vp), ("ready_event", _vp), ("src_keys", _vp),
                 ("src_counts", _vp), ("cls_hist", _vp), ("n_big", _u64), ("range_aux", _vp),
-                ("range_nb_log2", C.c_int32), ("flat_slots", C.c_uint64), ("src_labels", _vp)]
+                ("range_nb_log2", C.c_int32), ("flat_slots", C.c_uint64), ("src_labels", _vp),
+                ("head_image", _vp)]
 
 
 class MergeCol(C.Structure):
@@ -186,7 +188,7 @@ class EncodeCol(C.Structure):
                 ("sentinel_label", _vp), ("null_label", _i64), ("oov_label", _i64),
                 ("num_buckets", _u32), ("key_bytes", C.c_int32), ("out_bytes", C.c_int32),
                 ("out", _vp), ("vocab_keys", _vp), ("n_vocab", _u64), ("first_label", _i64),
-                ("wait_event", _vp), ("range_aux", _vp)]
+                ("wait_event", _vp), ("range_aux", _vp), ("head_image", _vp)]
 
 
 SIGNATURES.update({

@@ -299,48 +299,23 @@ __device__ __forceinline__ uint32_t lds_home(K key) {
   return (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
 }
 
-// GLOBAL = false: the whole vocabulary is staged (no table in HBM): the probe phases and their
-// registers disappear.  (UU = 3 / 4 key vectors per lane in flight, and a 2048-slot table with
-// two workgroups per CU for vocabularies <= 1024 keys, were each ~2 % slower: profiles/r02_notes.md)
-// RANGE (int32 keys): `table` is a range table (the per-bucket tables of the counting pass,
-// dumped; nvt_range.hpp): first slot from the monotone map, probing runs forward without
-// wrapping (an empty slot ends every chain).
-template <typename K, typename OUT, bool TWO = false, bool GLOBAL = true, int UU = 2,
-          int RANGE = 0,  // 0: hashed table, 1: bucket regions dumped by the counting pass, 2: flat
-          bool HEAD16 = false,
-          bool HALF = false>  // half the head (64 KiB), <= 64 VGPRs: TWO workgroups per CU
-__global__ __launch_bounds__(kEncBS, HALF ? 2 : 1) void encode_hot_kernel(
-    const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
-    const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
-    int64_t null_label, int64_t oov_label, uint32_t num_buckets, OUT *__restrict__ out,
-    const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label,
-    const int32_t *__restrict__ range_aux = nullptr, int count_stats = 0) {
-  static_assert(!HEAD16 || (TWO && sizeof(K) == 4), "HEAD16: the 2-choice head of int32 keys");
-  static_assert(!HALF || (TWO && !HEAD16), "HALF: the 2-choice head with 8-byte slots");
-  constexpr bool global_needed = GLOBAL;
-  RangeMap rmap = {0u, 0u, 0u, 0, 0, 0u, nullptr, nullptr};
-  __shared__ uint32_t s_pieces[RANGE == 1 ? kRpPwWords : 1];
-  if constexpr (RANGE) rmap = load_map(range_aux);
-  if constexpr (RANGE == 1) stage_pieces(rmap, s_pieces, threadIdx.x, kEncBS);  // (barrier below)
-  auto first_slot = [&](K key) -> uint64_t {
-    if constexpr (RANGE) return rmap.table_slot((int32_t)key);
-    return (uint64_t)slot_hash(key) & mask;
-  };
-  auto next_slot = [&](uint64_t sl) -> uint64_t {
-    if constexpr (RANGE) return sl + 1;
-    return (sl + 1) & mask;
-  };
+// The LDS head of a launch: the first n_hot keys of the frequency-ordered vocabulary.  Every
+// workgroup of an encode launch used to build it for itself (clear 128-144 KiB, read the keys,
+// CAS them in: ~22 us in front of each of the 13 cache-mode launches of a Criteo step, 0.25-0.3 ms
+// per step measured by returning right behind it); nvt_vocab_finalize_many now builds it ONCE per
+// vocabulary into a global image (enc_head_build_kernel, on the stream that orders the vocabulary:
+// off the critical path) and the launch's workgroups copy the image with coalesced loads.
+template <typename K, bool TWO, bool HEAD16, int SLOTS>
+__device__ __forceinline__ void build_head(unsigned char *lraw, long long *s_sent_p,
+                                           const K *__restrict__ hot_keys, uint32_t n_hot,
+                                           int64_t first_label) {
   constexpr K EMPTY = EncTraits<K>::empty;
-  constexpr int VEC = EncTraits<K>::vec;
-  constexpr int SLOTS = HALF ? HotCfg<K>::slots / 2 : HotCfg<K>::slots;
   using L = decltype(EncSlot<K>::label);
   using C = typename EncTraits<K>::cas_t;
-  constexpr int kLdsBytes = HEAD16 ? kHead16Buckets * 12 : SLOTS * (int)sizeof(EncSlot<K>);
-  __shared__ __align__(16) unsigned char lraw[kLdsBytes];
   EncSlot<K> *lt = reinterpret_cast<EncSlot<K> *>(lraw);
-  int2 *tkeys = reinterpret_cast<int2 *>(lraw);                                     // HEAD16: {key0, key1}
-  uint32_t *tlab = reinterpret_cast<uint32_t *>(lraw + (HEAD16 ? kHead16Buckets * 8 : 0));  // two 16-bit ranks
-  __shared__ long long s_sent;  // label of the sentinel key when it is among the staged keys
+  int2 *tkeys = reinterpret_cast<int2 *>(lraw);
+  uint32_t *tlab = reinterpret_cast<uint32_t *>(lraw + (HEAD16 ? kHead16Buckets * 8 : 0));
+  long long &s_sent = *s_sent_p;
   if constexpr (HEAD16) {
     for (int i = threadIdx.x; i < kHead16Buckets; i += kEncBS) {
       tkeys[i] = make_int2((int)EMPTY, (int)EMPTY);
@@ -401,6 +376,73 @@ __global__ __launch_bounds__(kEncBS, HALF ? 2 : 1) void encode_hot_kernel(
     }
   }
   __syncthreads();
+}
+
+template <bool HEAD16>
+__global__ __launch_bounds__(kEncBS) void enc_head_build_kernel(const int32_t *__restrict__ hot_keys,
+                                                                uint32_t n_hot, int64_t first_label,
+                                                                unsigned char *__restrict__ image) {
+  constexpr int SLOTS = HotCfg<int32_t>::slots;
+  constexpr int kLdsBytes = HEAD16 ? kHead16Buckets * 12 : SLOTS * (int)sizeof(EncSlot<int32_t>);
+  __shared__ __align__(16) unsigned char lraw[kLdsBytes];
+  __shared__ long long s_sent;
+  build_head<int32_t, true, HEAD16, SLOTS>(lraw, &s_sent, hot_keys, n_hot, first_label);
+  const int4 *src = reinterpret_cast<const int4 *>(lraw);
+  int4 *dst = reinterpret_cast<int4 *>(image);
+  for (int i = threadIdx.x; i < kLdsBytes / 16; i += kEncBS) dst[i] = src[i];
+  if (threadIdx.x == 0) *reinterpret_cast<long long *>(image + kLdsBytes) = s_sent;
+}
+
+// GLOBAL = false: the whole vocabulary is staged (no table in HBM): the probe phases and their
+// registers disappear.  (UU = 3 / 4 key vectors per lane in flight, and a 2048-slot table with
+// two workgroups per CU for vocabularies <= 1024 keys, were each ~2 % slower: profiles/r02_notes.md)
+// RANGE (int32 keys): `table` is a range table (the per-bucket tables of the counting pass,
+// dumped; nvt_range.hpp): first slot from the monotone map, probing runs forward without
+// wrapping (an empty slot ends every chain).
+template <typename K, typename OUT, bool TWO = false, bool GLOBAL = true, int UU = 2,
+          int RANGE = 0,  // 0: hashed table, 1: bucket regions dumped by the counting pass, 2: flat
+          bool HEAD16 = false,
+          bool HALF = false>  // half the head (64 KiB), <= 64 VGPRs: TWO workgroups per CU
+__global__ __launch_bounds__(kEncBS, HALF ? 2 : 1) void encode_hot_kernel(
+    const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const EncSlot<K> *__restrict__ table, uint64_t mask, const int64_t *__restrict__ sentinel_label,
+    int64_t null_label, int64_t oov_label, uint32_t num_buckets, OUT *__restrict__ out,
+    const K *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label,
+    const int32_t *__restrict__ range_aux = nullptr, int count_stats = 0,
+    const unsigned char *__restrict__ head_image = nullptr) {
+  static_assert(!HEAD16 || (TWO && sizeof(K) == 4), "HEAD16: the 2-choice head of int32 keys");
+  static_assert(!HALF || (TWO && !HEAD16), "HALF: the 2-choice head with 8-byte slots");
+  constexpr bool global_needed = GLOBAL;
+  RangeMap rmap = {0u, 0u, 0u, 0, 0, 0u, nullptr, nullptr};
+  __shared__ uint32_t s_pieces[RANGE == 1 ? kRpPwWords : 1];
+  if constexpr (RANGE) rmap = load_map(range_aux);
+  if constexpr (RANGE == 1) stage_pieces(rmap, s_pieces, threadIdx.x, kEncBS);  // (barrier below)
+  auto first_slot = [&](K key) -> uint64_t {
+    if constexpr (RANGE) return rmap.table_slot((int32_t)key);
+    return (uint64_t)slot_hash(key) & mask;
+  };
+  auto next_slot = [&](uint64_t sl) -> uint64_t {
+    if constexpr (RANGE) return sl + 1;
+    return (sl + 1) & mask;
+  };
+  constexpr K EMPTY = EncTraits<K>::empty;
+  constexpr int VEC = EncTraits<K>::vec;
+  constexpr int SLOTS = HALF ? HotCfg<K>::slots / 2 : HotCfg<K>::slots;
+  constexpr int kLdsBytes = HEAD16 ? kHead16Buckets * 12 : SLOTS * (int)sizeof(EncSlot<K>);
+  __shared__ __align__(16) unsigned char lraw[kLdsBytes];
+  EncSlot<K> *lt = reinterpret_cast<EncSlot<K> *>(lraw);
+  int2 *tkeys = reinterpret_cast<int2 *>(lraw);                                     // HEAD16: {key0, key1}
+  uint32_t *tlab = reinterpret_cast<uint32_t *>(lraw + (HEAD16 ? kHead16Buckets * 8 : 0));  // two 16-bit ranks
+  __shared__ long long s_sent;  // label of the sentinel key when it is among the staged keys
+  if (head_image != nullptr) {   // (uniform) prebuilt by nvt_vocab_finalize_many: coalesced copy
+    const int4 *src = reinterpret_cast<const int4 *>(head_image);
+    int4 *dst = reinterpret_cast<int4 *>(lraw);
+    for (int i = threadIdx.x; i < kLdsBytes / 16; i += kEncBS) dst[i] = src[i];
+    if (threadIdx.x == 0) s_sent = *reinterpret_cast<const long long *>(head_image + kLdsBytes);
+    __syncthreads();
+  } else {
+    build_head<K, TWO, HEAD16, SLOTS>(lraw, &s_sent, hot_keys, n_hot, first_label);
+  }
   // a vocabulary staged in full needs neither the global table nor its sentinel word
   const int64_t sent = global_needed ? *sentinel_label : (int64_t)s_sent;
 
@@ -730,12 +772,19 @@ int build_launch(const K *vocab, uint64_t n, int64_t first_label, void *table, u
   return NVT_OK;
 }
 
+// the head-layout switch of this process (the image nvt_vocab_finalize_many builds and the layout
+// the cache-mode launch expects are decided by the same word)
+static bool enc_head16() {
+  static const bool v = getenv("NVT_ENC_HEAD16") == nullptr || atoi(getenv("NVT_ENC_HEAD16")) != 0;
+  return v;
+}
+
 template <typename K>
 int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *table,
                   uint64_t capacity, const int64_t *sentinel_label, int64_t null_label,
                   int64_t oov_label, uint32_t num_buckets, void *out, int out_bytes,
                   const K *hot_keys, uint64_t n_vocab, int64_t first_label, hipStream_t s,
-                  const int32_t *range_aux = nullptr) {
+                  const int32_t *range_aux = nullptr, const void *head_image = nullptr) {
   // a duplicate-free vocabulary that fits the LDS table is encoded without the global table
   constexpr uint64_t kResident = sizeof(K) == 4 ? NVT_ENCODE_RESIDENT_I32 : NVT_ENCODE_RESIDENT_I64;
   const bool resident = hot_keys != nullptr && n_vocab > 0 && n_vocab <= kResident;
@@ -772,7 +821,7 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
       // (range tables: `mask` = capacity - 1 bounds the search of a FLAT table -- capacity slots --
       // and is unused for the dumped bucket tables, capacity 0)
       if (global_needed && (two || range_aux != nullptr)) {  // cache mode: 2-choice table filled to 7/8
-        static const bool head16 = getenv("NVT_ENC_HEAD16") == nullptr || atoi(getenv("NVT_ENC_HEAD16")) != 0;
+        const bool head16 = enc_head16();
         static const int stats = getenv("NVT_ENC_STATS") ? atoi(getenv("NVT_ENC_STATS")) : 0;
         // NVT_ENC_HALF=1 (experiment): half the head, one key vector per lane and <= 64 VGPRs, so
         // that TWO workgroups share a CU -- the waves of a cache-mode launch are parked 77 % of
@@ -782,10 +831,13 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
                                    : head16 ? (uint64_t)kHead16Keys : (uint64_t)HotCfg<K>::slots / 8 * 7;
         n_hot = (uint32_t)(n_vocab < cap2 ? n_vocab : cap2);
         if (half) hgrid = stream_grid(n / VEC + 1, kEncBS, 2);
+        static const bool use_image = getenv("NVT_ENC_NO_HEAD_IMAGE") == nullptr;   // (A/B switch)
+        if (half || !use_image) head_image = nullptr;
 #define NVT_ENC_CACHE(OUTT, KIND, H16)                                                            \
   encode_hot_kernel<K, OUTT, true, true, 2, KIND, H16><<<hgrid, kEncBS, 0, s>>>(                   \
       keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,          \
-      reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux, stats)
+      reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux, stats,           \
+      reinterpret_cast<const unsigned char *>(head_image))
 #define NVT_ENC_CACHE_HALF(OUTT, KIND)                                                            \
   encode_hot_kernel<K, OUTT, true, true, 1, KIND, false, true><<<hgrid, kEncBS, 0, s>>>(           \
       keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,          \
@@ -906,6 +958,27 @@ int encode_insert_any(int key_bytes, const void *vocab, uint64_t n, int64_t firs
 
 using namespace nvt;
 
+namespace nvt {
+// head image of an ORDERED int32 vocabulary of n keys (n > NVT_ENCODE_RESIDENT_I32: the launches
+// that encode with it run in cache mode), NVT_ENCODE_HEAD_BYTES bytes at `image`
+int encode_head_build(const int32_t *vocab_keys, uint64_t n, int64_t first_label, void *image,
+                      hipStream_t s) {
+  if (image == nullptr || vocab_keys == nullptr || n <= NVT_ENCODE_RESIDENT_I32) return NVT_OK;
+  static const bool half = getenv("NVT_ENC_HALF") != nullptr && atoi(getenv("NVT_ENC_HALF")) != 0;
+  if (half) return NVT_OK;   // (the experiment builds its smaller head per launch)
+  const bool h16 = enc_head16();
+  const uint64_t cap = h16 ? (uint64_t)kHead16Keys : (uint64_t)HotCfg<int32_t>::slots / 8 * 7;
+  const uint32_t n_hot = (uint32_t)(n < cap ? n : cap);
+  NVT_PROF("vocab_order", 0, s);
+  if (h16)
+    enc_head_build_kernel<true><<<1, kEncBS, 0, s>>>(vocab_keys, n_hot, first_label, (unsigned char *)image);
+  else
+    enc_head_build_kernel<false><<<1, kEncBS, 0, s>>>(vocab_keys, n_hot, first_label, (unsigned char *)image);
+  NVT_CHECK_LAUNCH();
+  return NVT_OK;
+}
+}  // namespace nvt
+
 extern "C" {
 
 int nvt_encode_stats(uint64_t *out2, int reset, void *stream) {
@@ -990,7 +1063,7 @@ int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
       rc = encode_launch<int32_t>((const int32_t *)c.keys, c.valid, c.n, c.table, c.capacity,
                                   c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,
                                   c.out_bytes, (const int32_t *)c.vocab_keys, c.n_vocab,
-                                  c.first_label, cs, c.range_aux);
+                                  c.first_label, cs, c.range_aux, c.head_image);
     else if (c.key_bytes == 8)
       rc = encode_launch<int64_t>((const int64_t *)c.keys, c.valid, c.n, c.table, c.capacity,
                                   c.sentinel_label, c.null_label, c.oov_label, c.num_buckets, c.out,

@@ -82,6 +82,10 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
                                 c.sentinel_label, c.unique_keys, s);
       if (rc) return rc;
     }
+    if (c.head_image && c.key_bytes == 4 && c.unique_keys) {
+      int rc = encode_head_build((const int32_t *)c.keys, c.n, c.first_label, c.head_image, s);
+      if (rc) return rc;
+    }
     if (c.ready_event) {
       NVT_CHECK_HIP(hipEventRecord((hipEvent_t)c.ready_event, s));
       if (s != main_s && getenv("NVT_FLUSH_QUERY")) (void)hipStreamQuery(s);
@@ -154,6 +158,10 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
                                  (int32_t *)c.keys, c.counts, c.sort_tmp, c.first_label, c.table,
                                  c.capacity, c.sentinel_label, c.range_aux, c.flat_slots, s);
       if (rc) return rc;
+      if (c.head_image && c.key_bytes == 4 && c.unique_keys) {
+        rc = encode_head_build((const int32_t *)c.keys, c.n, c.first_label, c.head_image, s);
+        if (rc) return rc;
+      }
       if (c.ready_event) {
         NVT_CHECK_HIP(hipEventRecord((hipEvent_t)c.ready_event, s));
       } else if (s != main_s)
@@ -202,8 +210,14 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
     }
     int rc = vocab_order_tail_batch(tails.data(), (int)tails.size(), ts);
     if (rc) return rc;
-    for (int i : tail_cols)
-      if (cols[i].ready_event) NVT_CHECK_HIP(hipEventRecord((hipEvent_t)cols[i].ready_event, ts));
+    for (int i : tail_cols) {
+      const nvt_vocab_col &c = cols[i];
+      if (c.head_image && c.key_bytes == 4 && c.unique_keys) {
+        rc = encode_head_build((const int32_t *)c.keys, c.n, c.first_label, c.head_image, ts);
+        if (rc) return rc;
+      }
+      if (c.ready_event) NVT_CHECK_HIP(hipEventRecord((hipEvent_t)c.ready_event, ts));
+    }
   }
   if (fork && need_join) {
     for (int i = 0; i < kSide; ++i) {

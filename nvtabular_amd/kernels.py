@@ -1078,6 +1078,9 @@ ASYNC_FINALIZE = os.environ.get("NVT_ASYNC_FINALIZE", "1") != "0"
 _SORT_BYTES = {}  # (key_bytes, n) -> nvt_vocab_sort_tmp_bytes
 
 
+ENCODE_HEAD_IMAGE = os.environ.get("NVT_ENCODE_HEAD_IMAGE", "1") != "0"
+
+
 class EncodeTable:
     """key -> label probe table built from an ordered vocabulary."""
 
@@ -1114,8 +1117,14 @@ class EncodeTable:
         self._src = None       # key-sorted source list of the one-pass ordering, same lifetime
         self.ready = None      # Event recorded behind the sort / build on an internal stream
         self.pending = False   # True until the current stream has been made to wait for it
+        # the LDS head of the cache-mode encode, built ONCE per vocabulary by
+        # nvt_vocab_finalize_many (include/nvt_hip.h nvt_vocab_col.head_image): only tables whose
+        # vocabulary is ordered there (defer_build) get one
+        self.head_image = None
         if unique and 0 < self.n_vocab <= resident:
             return
+        if ENCODE_HEAD_IMAGE and defer_build and unique and self.key_bytes == 4:
+            self.head_image = torch.empty(_lib.ENCODE_HEAD_BYTES, dtype=torch.uint8, device=dev)
         if range_table is not None:
             assert defer_build and unique and self.key_bytes == 4
             self.table, self.range_aux, self.range_bits = range_table
@@ -1190,6 +1199,7 @@ class EncodeTable:
         d.table = ptr(self.table)
         d.capacity = self.capacity
         d.sentinel_label = ptr(self.sentinel_label)
+        d.head_image = ptr(self.head_image)
         if n > 1 and not small and ASYNC_FINALIZE:
             # ordered on an internal stream: hand-off by event instead of a stream join, so the
             # caller's stream keeps working (fill + normalize, encodes of the small vocabularies)
@@ -1237,6 +1247,7 @@ class EncodeTable:
         self.sort_tmp = torch.empty(nbytes + 16, dtype=torch.uint8, device=self._vk.device)
         d.sort_tmp = self.sort_tmp.data_ptr()
         d.first_label = self.first_label
+        d.head_image = ptr(self.head_image)
         d.table = ptr(self.table)
         d.capacity = self.capacity
         d.sentinel_label = ptr(self.sentinel_label)
@@ -1289,6 +1300,7 @@ class EncodeTable:
         d.n_vocab = self.n_vocab if self.vocab_keys is not None else 0
         d.first_label = self.first_label
         d.range_aux = ptr(self.range_aux)
+        d.head_image = ptr(self.head_image)
         if self.pending:
             d.wait_event = self.ready.handle  # nvt_encode_many waits on the launch stream
             self.pending = False
