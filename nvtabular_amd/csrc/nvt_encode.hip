@@ -299,6 +299,17 @@ __device__ __forceinline__ uint32_t lds_home(K key) {
   return (uint32_t)(slot_hash(key) >> 13) & (SLOTS - 1);
 }
 
+struct HeadJob {
+  const int32_t *keys;
+  unsigned char *image;
+  int64_t first_label;
+  uint32_t n_hot;
+};
+constexpr int kHeadJobsMax = 32;
+struct HeadJobs {
+  HeadJob j[kHeadJobsMax];
+};
+
 // The LDS head of a launch: the first n_hot keys of the frequency-ordered vocabulary.  Every
 // workgroup of an encode launch used to build it for itself (clear 128-144 KiB, read the keys,
 // CAS them in: ~22 us in front of each of the 13 cache-mode launches of a Criteo step, 0.25-0.3 ms
@@ -379,18 +390,17 @@ __device__ __forceinline__ void build_head(unsigned char *lraw, long long *s_sen
 }
 
 template <bool HEAD16>
-__global__ __launch_bounds__(kEncBS) void enc_head_build_kernel(const int32_t *__restrict__ hot_keys,
-                                                                uint32_t n_hot, int64_t first_label,
-                                                                unsigned char *__restrict__ image) {
+__global__ __launch_bounds__(kEncBS) void enc_head_build_many_kernel(HeadJobs jobs) {
   constexpr int SLOTS = HotCfg<int32_t>::slots;
   constexpr int kLdsBytes = HEAD16 ? kHead16Buckets * 12 : SLOTS * (int)sizeof(EncSlot<int32_t>);
   __shared__ __align__(16) unsigned char lraw[kLdsBytes];
   __shared__ long long s_sent;
-  build_head<int32_t, true, HEAD16, SLOTS>(lraw, &s_sent, hot_keys, n_hot, first_label);
+  const HeadJob j = jobs.j[blockIdx.x];
+  build_head<int32_t, true, HEAD16, SLOTS>(lraw, &s_sent, j.keys, j.n_hot, j.first_label);
   const int4 *src = reinterpret_cast<const int4 *>(lraw);
-  int4 *dst = reinterpret_cast<int4 *>(image);
+  int4 *dst = reinterpret_cast<int4 *>(j.image);
   for (int i = threadIdx.x; i < kLdsBytes / 16; i += kEncBS) dst[i] = src[i];
-  if (threadIdx.x == 0) *reinterpret_cast<long long *>(image + kLdsBytes) = s_sent;
+  if (threadIdx.x == 0) *reinterpret_cast<long long *>(j.image + kLdsBytes) = s_sent;
 }
 
 // GLOBAL = false: the whole vocabulary is staged (no table in HBM): the probe phases and their
@@ -959,23 +969,42 @@ int encode_insert_any(int key_bytes, const void *vocab, uint64_t n, int64_t firs
 using namespace nvt;
 
 namespace nvt {
-// head image of an ORDERED int32 vocabulary of n keys (n > NVT_ENCODE_RESIDENT_I32: the launches
-// that encode with it run in cache mode), NVT_ENCODE_HEAD_BYTES bytes at `image`
-int encode_head_build(const int32_t *vocab_keys, uint64_t n, int64_t first_label, void *image,
-                      hipStream_t s) {
-  if (image == nullptr || vocab_keys == nullptr || n <= NVT_ENCODE_RESIDENT_I32) return NVT_OK;
+// head images of ORDERED int32 vocabularies (n > NVT_ENCODE_RESIDENT_I32: the launches that encode
+// with them run in cache mode), NVT_ENCODE_HEAD_BYTES bytes each: ONE launch, a workgroup per
+// vocabulary.  Entries with a null image / too few keys are skipped.
+int encode_head_build_many(const int32_t *const *vocab_keys, const uint64_t *n, const int64_t *first_label,
+                           void *const *images, int count, hipStream_t s) {
   static const bool half = getenv("NVT_ENC_HALF") != nullptr && atoi(getenv("NVT_ENC_HALF")) != 0;
   if (half) return NVT_OK;   // (the experiment builds its smaller head per launch)
   const bool h16 = enc_head16();
   const uint64_t cap = h16 ? (uint64_t)kHead16Keys : (uint64_t)HotCfg<int32_t>::slots / 8 * 7;
-  const uint32_t n_hot = (uint32_t)(n < cap ? n : cap);
-  NVT_PROF("vocab_order", 0, s);
-  if (h16)
-    enc_head_build_kernel<true><<<1, kEncBS, 0, s>>>(vocab_keys, n_hot, first_label, (unsigned char *)image);
-  else
-    enc_head_build_kernel<false><<<1, kEncBS, 0, s>>>(vocab_keys, n_hot, first_label, (unsigned char *)image);
-  NVT_CHECK_LAUNCH();
-  return NVT_OK;
+  HeadJobs jobs;
+  int m = 0;
+  auto flush = [&]() -> int {
+    if (m == 0) return NVT_OK;
+    NVT_PROF("vocab_order", 0, s);
+    if (h16) enc_head_build_many_kernel<true><<<m, kEncBS, 0, s>>>(jobs);
+    else enc_head_build_many_kernel<false><<<m, kEncBS, 0, s>>>(jobs);
+    NVT_CHECK_LAUNCH();
+    m = 0;
+    return NVT_OK;
+  };
+  for (int i = 0; i < count; ++i) {
+    if (images[i] == nullptr || vocab_keys[i] == nullptr || n[i] <= NVT_ENCODE_RESIDENT_I32) continue;
+    jobs.j[m].keys = vocab_keys[i];
+    jobs.j[m].image = (unsigned char *)images[i];
+    jobs.j[m].first_label = first_label[i];
+    jobs.j[m].n_hot = (uint32_t)(n[i] < cap ? n[i] : cap);
+    if (++m == kHeadJobsMax) {
+      int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+int encode_head_build(const int32_t *vocab_keys, uint64_t n, int64_t first_label, void *image,
+                      hipStream_t s) {
+  return encode_head_build_many(&vocab_keys, &n, &first_label, &image, 1, s);
 }
 }  // namespace nvt
 

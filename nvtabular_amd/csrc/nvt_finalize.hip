@@ -76,13 +76,30 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
   // with a ready_event the vocabulary's stream is not joined into `stream`: the event is
   // recorded behind its last kernel and the consumer waits on it
   bool need_join = false;
-  auto finish = [&](const nvt_vocab_col &c, hipStream_t s) -> int {
+  // the LDS head images of several vocabularies in ONE launch (a workgroup each)
+  auto build_heads = [&](const std::vector<int> &which, hipStream_t s) -> int {
+    std::vector<const int32_t *> k;
+    std::vector<uint64_t> nn;
+    std::vector<int64_t> fl;
+    std::vector<void *> im;
+    for (int i : which) {
+      const nvt_vocab_col &c = cols[i];
+      if (!(c.head_image && c.key_bytes == 4 && c.unique_keys)) continue;
+      k.push_back((const int32_t *)c.keys);
+      nn.push_back(c.n);
+      fl.push_back(c.first_label);
+      im.push_back(c.head_image);
+    }
+    if (k.empty()) return NVT_OK;
+    return encode_head_build_many(k.data(), nn.data(), fl.data(), im.data(), (int)k.size(), s);
+  };
+  auto finish = [&](const nvt_vocab_col &c, hipStream_t s, bool head = true) -> int {
     if (c.table != nullptr && c.src_keys == nullptr) {
       int rc = encode_build_any(c.key_bytes, c.keys, c.n, c.first_label, c.table, c.capacity,
                                 c.sentinel_label, c.unique_keys, s);
       if (rc) return rc;
     }
-    if (c.head_image && c.key_bytes == 4 && c.unique_keys) {
+    if (head && c.head_image && c.key_bytes == 4 && c.unique_keys) {
       int rc = encode_head_build((const int32_t *)c.keys, c.n, c.first_label, c.head_image, s);
       if (rc) return rc;
     }
@@ -140,8 +157,10 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
       hipStream_t s = fork ? pool->s[0] : main_s;
       int rc = vocab_order_sorted_batch(jobs.data(), (int)jobs.size(), s);
       if (rc) return rc;
+      rc = build_heads(job_cols, s);
+      if (rc) return rc;
       for (int i : job_cols) {
-        rc = finish(cols[i], s);
+        rc = finish(cols[i], s, false);
         if (rc) return rc;
       }
     }
@@ -210,14 +229,10 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
     }
     int rc = vocab_order_tail_batch(tails.data(), (int)tails.size(), ts);
     if (rc) return rc;
-    for (int i : tail_cols) {
-      const nvt_vocab_col &c = cols[i];
-      if (c.head_image && c.key_bytes == 4 && c.unique_keys) {
-        rc = encode_head_build((const int32_t *)c.keys, c.n, c.first_label, c.head_image, ts);
-        if (rc) return rc;
-      }
-      if (c.ready_event) NVT_CHECK_HIP(hipEventRecord((hipEvent_t)c.ready_event, ts));
-    }
+    rc = build_heads(tail_cols, ts);
+    if (rc) return rc;
+    for (int i : tail_cols)
+      if (cols[i].ready_event) NVT_CHECK_HIP(hipEventRecord((hipEvent_t)cols[i].ready_event, ts));
   }
   if (fork && need_join) {
     for (int i = 0; i < kSide; ++i) {

@@ -80,6 +80,8 @@ int vocab_order_sorted_batch(const OrderSortedJob *jobs, int njobs, hipStream_t 
 // LDS head image of an ordered int32 vocabulary for the cache-mode encode (nvt_encode.hip)
 int encode_head_build(const int32_t *vocab_keys, uint64_t n, int64_t first_label, void *image,
                       hipStream_t s);
+int encode_head_build_many(const int32_t *const *vocab_keys, const uint64_t *n, const int64_t *first_label,
+                           void *const *images, int count, hipStream_t s);
 // key-sorted list whose entries carry their 0-based position in the vocabulary order (multi-GPU:
 // labelled shard by shard on the owners): ordered arrays + table without any ordering pass
 int vocab_from_labels(const int32_t *src_keys, const int64_t *src_cnts, const int32_t *labels, uint64_t n,
