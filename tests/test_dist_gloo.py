@@ -58,7 +58,12 @@ def _worker(rank, world, port, q):
             (torch.from_numpy(l32.index.to_numpy()), torch.from_numpy(l32.to_numpy()), [1, 2, 3]),
             (torch.arange(7 if rank == 0 else 0, dtype=torch.int64),
              torch.ones(7 if rank == 0 else 0, dtype=torch.int64), [rank])]
+    dist.reset_traffic()
     many = dist.merge_counts_many(tabs)
+    # the byte counters every N > 1 bench line carries (dist_breakdown): host arithmetic on shapes
+    tr = dist.TRAFFIC
+    assert tr and all(v["calls"] >= 1 and v["bytes_sent"] >= 0 and v["bytes_received"] > 0 for v in tr.values())
+    assert "all_to_all_single(uneven)" in tr and "all_reduce" in tr
     assert many[1][0].dtype == torch.int32 and many[0][0].dtype == torch.int64
     tot_r = sum(range(world))
     assert many[0][2] == [3 * world + tot_r, 10 * world] and many[1][2] == [world, 2 * world, 3 * world]

@@ -239,3 +239,41 @@ def test_plain_reader_required_columns_and_empty_files(tmp_path):
     if pf0.eligible and pf0.num_row_groups:
         st0 = PP.read_row_groups_staged(pf0, list(range(pf0.num_row_groups)), pin=False)
         assert all(c.rows == 0 for c in st0.values())
+
+
+def test_plain_reader_property_random_files(tmp_path):
+    """Random row counts, null patterns (incl. long runs), page sizes, page versions and row-group
+    sizes: the hand-written reader equals pyarrow's on every file (hypothesis-style sweep with a
+    fixed seed: 40 files)."""
+    rng = np.random.default_rng(20260924)
+    for it in range(40):
+        n = int(rng.integers(1, 60_000))
+        kinds = rng.integers(0, 4, 3)
+        cols = {}
+        for j, kind in enumerate(kinds):
+            dt = ["int32", "int64", "float32", "float64"][int(rng.integers(0, 4))]
+            vals = (rng.normal(size=n) * 1e3).astype(dt)
+            if kind == 0:
+                mask = None
+            elif kind == 1:
+                mask = rng.random(n) < rng.random()
+            elif kind == 2:   # long runs of nulls / non-nulls (RLE runs in the levels)
+                run = int(rng.integers(1, 5000))
+                mask = np.repeat(rng.random((n + run - 1) // run) < 0.5, run)[:n]
+            else:
+                mask = np.ones(n, bool) if rng.random() < 0.5 else np.zeros(n, bool)
+            cols[f"c{j}"] = pa.array(vals, mask=mask)
+        t = pa.table(cols)
+        path = str(tmp_path / f"r{it}.parquet")
+        pq.write_table(t, path, use_dictionary=False, compression=None,
+                       row_group_size=int(rng.integers(1, n + 1)) if rng.random() < 0.7 else n,
+                       data_page_version=["1.0", "2.0"][int(rng.integers(0, 2))],
+                       data_page_size=int(rng.integers(64, 1 << 16)))
+        pf = PP.PlainParquetFile(path)
+        assert pf.eligible, pf.why
+        groups = list(range(pf.num_row_groups))
+        if len(groups) > 64:     # (keep the sweep fast: a window of row groups)
+            lo = int(rng.integers(0, len(groups) - 64))
+            groups = groups[lo:lo + 64]
+        staged = PP.read_row_groups_staged(pf, groups, pin=False)
+        _staged_equals_arrow(staged, pq.ParquetFile(path).read_row_groups(groups))
