@@ -247,7 +247,7 @@ class Dataset:
 
     def to_parquet(self, output_path, shuffle=None, out_files_per_proc=None, dtypes=None,
                    cats=None, conts=None, labels=None, preserve_files=False, suffix=".parquet",
-                   num_threads=0, compression=None, **_):
+                   num_threads=0, compression=None, statistics=False, **_):
         """Write the (transformed) dataset as parquet (merlin.io.Dataset.to_parquet; contract in
         tests/unit/workflow/test_workflow.py:171-187,363-396,444-500 and
         bench/datasets/tools/nvt_etl.py:154-171 of the reference).
@@ -267,6 +267,9 @@ class Dataset:
           ``"zstd"``, ``"none"`` ...) selects pyarrow's writer with that codec, statistics and
           dictionary pages, as the reference's writer produces.  ``NVT_PLAIN_PARQUET=0`` makes
           pyarrow the default.
+        * ``statistics=True``: the PLAIN writer also records min / max of every column chunk
+          (computed on the device next to the copy out); the null count of every chunk is always
+          written.  pyarrow's writer always writes statistics.
         * writes ``_metadata`` (parquet summary of all row groups), ``_file_list.txt`` and
           ``_metadata.json`` (file stats + cats / conts / labels) next to the data files.
         """
@@ -337,7 +340,8 @@ class Dataset:
                 not (shuffle == Shuffle.PER_WORKER and k):
             # fixed-width numeric columns: PLAIN pages written straight from pinned column
             # buffers (parquet_plain.py) -- no dictionary pass, no compression, no statistics
-            plain = _write_plain(itertools.chain([first], parts_iter), output_path, fname, k, shuffle, dtypes)
+            plain = _write_plain(itertools.chain([first], parts_iter), output_path, fname, k, shuffle, dtypes,
+                                 statistics=bool(statistics))
             parts_iter, first = iter(()), None
         rest = itertools.chain([first], parts_iter) if first is not None else iter(())
         for i, part in enumerate(rest):
@@ -503,7 +507,7 @@ def _plain_eligible(frame, dtypes) -> bool:
     return True
 
 
-def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
+def _write_plain(parts, output_path, fname, k, shuffle, dtypes, statistics=False):
     """Dataset.to_parquet for fixed-width numeric frames: every partition is cut into row groups
     of PLAIN_ROW_GROUP rows; a row group's columns are copied into pinned host buffers on a side
     stream (nulls: values compacted and the validity bitmap re-packed on the device first) while
@@ -533,7 +537,7 @@ def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
 
     with ThreadPoolExecutor(max_workers=PLAIN_WRITE_THREADS) as pool:
         def flush_one():
-            j, cols, rows, event, keep = staged.popleft()
+            j, cols, rows, event, keep, stats = staged.popleft()
             t0 = time.perf_counter()
             # the host does not wait for the copies: every column task synchronises with the
             # event itself before it writes.  Only validity bitmaps must be here already (the
@@ -557,7 +561,7 @@ def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
             # the column writes of this row group go to the pool and are NOT waited for: row
             # groups of other files (other inodes: buffered writes to ONE file serialise on its
             # inode lock, ~10 GB/s) and the next copies proceed meanwhile
-            futs = w.write_row_group([(c[1], c[2]) for c in cols], rows, wait=False, ready=ready)
+            futs = w.write_row_group([(c[1], c[2]) for c in cols], rows, wait=False, ready=ready, stats=stats)
             inflight.append((futs, cols, keep))
             while len(inflight) > PLAIN_INFLIGHT:
                 for f in inflight.popleft()[0]:
@@ -600,7 +604,7 @@ def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
                     for s0 in (range(a, b, PLAIN_ROW_GROUP) if b > a else [a]):
                         s1 = min(b, s0 + PLAIN_ROW_GROUP)
                         rows = s1 - s0
-                        host, keep = [], []
+                        host, keep, stats = [], [], ([] if statistics else None)
                         t_st = time.perf_counter()
                         ctx = torch.cuda.stream(copy_s) if on_gpu else _nullcontext()
                         with ctx:
@@ -613,6 +617,18 @@ def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
                                         np.packbits(m.numpy(), bitorder="little"))
                                 hv = _to_host(vals)
                                 hb = _to_host(bm) if bm is not None else None
+                                if statistics:
+                                    mm = None
+                                    if vals.numel():
+                                        if vals.dtype.is_floating_point:   # (NaN is no minimum / maximum)
+                                            nan = torch.isnan(vals)
+                                            lo = torch.where(nan, torch.full_like(vals, float("inf")), vals).amin()
+                                            hi = torch.where(nan, torch.full_like(vals, float("-inf")), vals).amax()
+                                        else:
+                                            lo, hi = torch.aminmax(vals)
+                                        mm = _to_host(torch.stack([lo, hi]))
+                                        keep.append((mm,))
+                                    stats.append(mm.numpy() if mm is not None else None)
                                 keep.append((vals, bm))
                                 host.append((name, hv.numpy(), hb.numpy() if hb is not None else None))
                             event = None
@@ -620,7 +636,7 @@ def _write_plain(parts, output_path, fname, k, shuffle, dtypes):
                                 event = torch.cuda.Event()
                                 event.record(copy_s)
                         LAST_TIMING["stage_s"] += time.perf_counter() - t_st
-                        staged.append((j, host, rows, event, keep))
+                        staged.append((j, host, rows, event, keep, stats))
                         flush_one()
             while staged:
                 flush_one()

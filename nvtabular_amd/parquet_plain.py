@@ -193,7 +193,7 @@ class PlainParquetWriter:
                 k = os.pwrite(self.fd, mv, off)
                 mv, off = mv[k:], off + k
 
-    def write_row_group(self, columns, n: int, wait: bool = True, ready=None):
+    def write_row_group(self, columns, n: int, wait: bool = True, ready=None, stats=None):
         """columns[j] = (values, valid): `values` a 1-D numpy array of the column's dtype holding
         the NON-NULL values in row order, `valid` None or the Arrow validity bitmap (uint8, LSB
         first, >= ceil(n / 8) bytes) of the n rows.  wait=False (with a pool): returns the
@@ -202,20 +202,23 @@ class PlainParquetWriter:
         buffers alive until the futures are done, close() waits for whatever is left.
         ready: called by every column task before it touches its buffers (the VALUES may still
         be in flight when this returns; validity bitmaps must be complete: pages are laid out
-        from their popcounts)."""
+        from their popcounts).
+        stats[j]: None, or a 2-element numpy array of the column's dtype that holds {min, max} of
+        the non-null values by the time close() runs (it may still be in flight now): written as
+        the chunk's min / max statistics (NaN / empty chunks: omitted).  The null count of every
+        chunk is always written."""
         chunks, plans = [], []
         total = 0
         if len(columns) != len(self.names):
             raise ValueError(f"PlainParquetWriter: {len(columns)} columns for a file of {len(self.names)}")
-        for (values, valid), name, dt in zip(columns, self.names, self.dtypes):
+        for j, ((values, valid), name, dt) in enumerate(zip(columns, self.names, self.dtypes)):
             start = self.pos
             segs, size = self._plan_column(values, valid, n, dt, start)
             plans.append(segs)
             self.pos += size
-            meta = (_Struct().i32(1, _PQ_TYPE[dt]).list(2, _CT_I32, [_zigzag(0), _zigzag(3)])
-                    .list(3, _CT_BINARY, [_varint(len(name.encode())) + name.encode()])
-                    .i32(4, 0).i64(5, n).i64(6, size).i64(7, size).i64(9, start).done())
-            chunks.append(_Struct().i64(2, start).struct(3, meta).done())
+            nvalid = int(np.asarray(values).size)
+            chunks.append(dict(name=name, dt=dt, n=n, size=size, start=start, nulls=n - nvalid,
+                               minmax=stats[j] if (stats is not None and nvalid > 0) else None))
             total += size
         futures = []
         if self.pool is not None:
@@ -232,20 +235,46 @@ class PlainParquetWriter:
         else:
             for segs in plans:
                 self._run(segs, ready)
-        self.row_groups.append(_Struct().list(1, _CT_STRUCT, chunks).i64(2, total).i64(3, n).done())
+        self.row_groups.append((chunks, total, n))   # (thrift structs are built by close(): statistics)
         self.num_rows += n
         return futures
 
+    @staticmethod
+    def _chunk_struct(c) -> bytes:
+        dt, name = c["dt"], c["name"]
+        st = _Struct()
+        mm = c["minmax"]
+        lo = hi = None
+        if mm is not None:
+            mm = np.asarray(mm)
+            if mm.dtype == dt and mm.size == 2 and not (mm.dtype.kind == "f" and not np.isfinite(mm).all()):
+                lo, hi = mm[0:1].tobytes(), mm[1:2].tobytes()
+        if hi is not None:
+            st.binary(1, hi).binary(2, lo)               # (deprecated pair: signed order, same bytes)
+        st.i64(3, c["nulls"])
+        if hi is not None:
+            st.binary(5, hi).binary(6, lo)               # max_value / min_value
+        meta = (_Struct().i32(1, _PQ_TYPE[dt]).list(2, _CT_I32, [_zigzag(0), _zigzag(3)])
+                .list(3, _CT_BINARY, [_varint(len(name.encode())) + name.encode()])
+                .i32(4, 0).i64(5, c["n"]).i64(6, c["size"]).i64(7, c["size"]).i64(9, c["start"])
+                .struct(12, st.done()).done())
+        return _Struct().i64(2, c["start"]).struct(3, meta).done()
+
     def close(self):
-        schema = [_Struct().binary(4, "schema").i32(5, len(self.names)).done()]
-        for name, dt in zip(self.names, self.dtypes):
-            schema.append(_Struct().i32(1, _PQ_TYPE[dt]).i32(3, 1).binary(4, name).done())
-        footer = (_Struct().i32(1, 1).list(2, _CT_STRUCT, schema).i64(3, self.num_rows)
-                  .list(4, _CT_STRUCT, self.row_groups)
-                  .binary(6, "nvtabular_amd plain writer").done())
         for f in self.pending:
             f.result()
         self.pending = []
+        schema = [_Struct().binary(4, "schema").i32(5, len(self.names)).done()]
+        for name, dt in zip(self.names, self.dtypes):
+            schema.append(_Struct().i32(1, _PQ_TYPE[dt]).i32(3, 1).binary(4, name).done())
+        groups = [_Struct().list(1, _CT_STRUCT, [self._chunk_struct(c) for c in chunks]).i64(2, total).i64(3, n).done()
+                  for chunks, total, n in self.row_groups]
+        # column_orders: TYPE_ORDER for every column (min_value / max_value are only defined with it)
+        type_order = _Struct().struct(1, _Struct().done()).done()
+        footer = (_Struct().i32(1, 1).list(2, _CT_STRUCT, schema).i64(3, self.num_rows)
+                  .list(4, _CT_STRUCT, groups)
+                  .binary(6, "nvtabular_amd plain writer")
+                  .list(7, _CT_STRUCT, [type_order] * len(self.names)).done())
         self._run([(self.pos, footer + struct.pack("<I", len(footer)) + b"PAR1")])
         os.close(self.fd)
         self.fd = -1

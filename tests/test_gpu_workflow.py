@@ -377,6 +377,50 @@ def test_plain_parquet_writer_equals_pyarrow_path(tmp_path, k, monkeypatch):
     assert outs["plain"][num[0]].isna().sum() == df[num[0]].isna().sum()
 
 
+def test_to_parquet_statistics_of_the_plain_writer(tmp_path, monkeypatch):
+    """to_parquet(statistics=True): min / max of every chunk computed on the device next to the
+    copy out, null counts always -- equal to what pyarrow computes for the same data."""
+    import glob
+    import os
+
+    import pyarrow.parquet as pq
+
+    import nvtabular_amd as nvt
+    from nvtabular_amd import io as nio
+
+    df = _criteo_like(20_011, seed=6)
+    num = [c for c in df.columns if df[c].dtype.kind in "if"]
+    monkeypatch.setattr(nio, "PLAIN_ROW_GROUP", 8192)
+    out = str(tmp_path / "s")
+    nio.LAST_TIMING.clear()
+    nvt.Dataset(df[num].copy()).to_parquet(out, statistics=True)
+    assert nio.LAST_TIMING   # the plain path ran
+    f = sorted(glob.glob(os.path.join(out, "*.parquet")))[0]
+    md = pq.read_metadata(f)
+    back = pd.read_parquet(f)
+    table = pq.read_table(f)
+    at = 0
+    for g in range(md.num_row_groups):
+        rows = md.row_group(g).num_rows
+        part = back.iloc[at:at + rows]
+        for j, c in enumerate(md.schema.names):
+            st = md.row_group(g).column(j).statistics
+            col = part[c]
+            # (parquet nulls: a NaN of a float column is a value, not a null)
+            assert st.null_count == table.column(c).slice(at, rows).null_count, c
+            vals = col.dropna().to_numpy()
+            vals = vals[~np.isnan(vals.astype("float64"))]
+            if vals.size:
+                assert st.has_min_max and st.min == vals.min() and st.max == vals.max(), c
+        at += rows
+    # without the switch: null counts only
+    out2 = str(tmp_path / "n")
+    nvt.Dataset(df[num].copy()).to_parquet(out2)
+    st = pq.read_metadata(sorted(glob.glob(os.path.join(out2, "*.parquet")))[0]).row_group(0).column(0).statistics
+    assert st is not None and not st.has_min_max
+    assert st.null_count == table.column(md.schema.names[0]).slice(0, md.row_group(0).num_rows).null_count
+
+
 def test_save_load_graph_json_all_ops(tmp_path):
     """graph.json round trip through every serialisable operator of the path: the loaded
     workflow (fresh operator objects, state from JSON + artifacts/) transforms identically."""

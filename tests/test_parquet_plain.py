@@ -277,3 +277,39 @@ def test_plain_reader_property_random_files(tmp_path):
             groups = groups[lo:lo + 64]
         staged = PP.read_row_groups_staged(pf, groups, pin=False)
         _staged_equals_arrow(staged, pq.ParquetFile(path).read_row_groups(groups))
+
+
+def test_plain_writer_statistics(tmp_path):
+    """Every chunk carries its null count; with {min, max} handed over (to_parquet(statistics=True))
+    also min / max, readable by pyarrow (row-group pruning of downstream readers); NaN-only /
+    all-null chunks carry none."""
+    rng = np.random.default_rng(8)
+    n = 5000
+    a = rng.integers(-1000, 1000, n).astype("int64")
+    b = rng.normal(size=n).astype("float32")
+    mask_b = rng.random(n) >= 0.25
+    path = str(tmp_path / "s.parquet")
+    w = PP.PlainParquetWriter(path, ["a", "b", "c"], ["int64", "float32", "float64"])
+    w.write_row_group([(a, None), (b[mask_b], np.packbits(mask_b, bitorder="little")),
+                       (np.zeros(0, "float64"), np.zeros((n + 7) // 8, "uint8"))], n,
+                      stats=[np.array([a.min(), a.max()], "int64"),
+                             np.array([b[mask_b].min(), b[mask_b].max()], "float32"), None])
+    w.write_row_group([(a[:10], None), (b[:10], None), (np.full(10, np.nan), None)], 10,
+                      stats=[None, None, np.array([np.nan, np.nan], "float64")])
+    w.close()
+    md = pq.read_metadata(path)
+    s = md.row_group(0).column(0).statistics
+    assert s.has_min_max and s.min == a.min() and s.max == a.max() and s.null_count == 0
+    s = md.row_group(0).column(1).statistics
+    assert s.has_min_max and s.min == b[mask_b].min() and s.max == b[mask_b].max()
+    assert s.null_count == int((~mask_b).sum())
+    s = md.row_group(0).column(2).statistics
+    assert s.null_count == n and not s.has_min_max
+    for j in range(3):
+        s = md.row_group(1).column(j).statistics
+        assert s.null_count == 0 and not s.has_min_max
+    t = pq.read_table(path, filters=[("a", ">", int(a.max()) + 5)])   # pruned by the statistics
+    assert t.num_rows == 0
+    assert pq.read_table(path).num_rows == n + 10
+    pf = PP.PlainParquetFile(path)
+    assert pf.eligible, pf.why
