@@ -339,7 +339,7 @@ int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_siz
       return NVT_EUNSUPPORTED;
     }
     const uint64_t prow = (uint64_t)h.num_values;
-    if (rows + prow > expect_rows) {
+    if (h.num_values < 0 || prow > expect_rows - rows) {
       set_error("nvt_pq_decode_chunk: more rows than the row group holds");
       return NVT_EINVAL;
     }
@@ -366,9 +366,12 @@ int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_siz
         set_error("nvt_pq_decode_chunk: repetition levels (nested column)");
         return NVT_EUNSUPPORTED;
       }
+      if (h.def_bytes < 0 || (uint64_t)(pend - q) < (uint64_t)h.def_bytes) {
+        set_error("nvt_pq_decode_chunk: definition levels run past the page");
+        return NVT_EINVAL;
+      }
       if (max_def_level == 1) {
-        if ((uint64_t)(pend - q) < (uint64_t)h.def_bytes ||
-            !decode_levels(q, (uint64_t)h.def_bytes, prow, valid_out, valid_bit_offset + rows, &pvalid)) {
+        if (!decode_levels(q, (uint64_t)h.def_bytes, prow, valid_out, valid_bit_offset + rows, &pvalid)) {
           set_error("nvt_pq_decode_chunk: malformed definition levels");
           return NVT_EINVAL;
         }

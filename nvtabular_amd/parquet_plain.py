@@ -436,6 +436,9 @@ class PlainParquetFile:
                                                       f"{sorted(enc)}, dictionary page {md.get(11)}")
                 cols.append(dict(offset=int(md.get(9, 0)), size=int(md.get(7, 0)), num_values=int(md.get(5, 0)),
                                  path=[x.decode() for x in md.get(3, [])]))
+                if not (0 <= cols[-1]["offset"] and 0 <= cols[-1]["size"] and
+                        cols[-1]["offset"] + cols[-1]["size"] <= size):
+                    self.eligible, self.why = False, f"chunk of {md.get(3)} lies outside the file"
             if [c["path"] for c in cols] != [[n] for n in self.names]:
                 self.eligible, self.why = False, "column chunks do not follow the schema order"
             self.row_groups.append(dict(num_rows=int(rg.get(3, 0)), columns=cols))
@@ -526,11 +529,20 @@ def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None
             val_at += int(v.value)
         return StagedColumn(vals, valid if (valid is not None and val_at < total) else None, total, val_at, dt)
 
+    futs = []
     try:
         if pool is not None and len(names) > 1:
-            cols = [f.result() for f in [pool.submit(task, n) for n in names]]
+            futs = [pool.submit(task, n) for n in names]
+            cols = [f.result() for f in futs]
         else:
             cols = [task(n) for n in names]
     finally:
+        # (after a failed column the others may still be reading: the descriptor is closed -- and
+        # its number free for the next open -- only when none of them uses it any more)
+        for f in futs:
+            f.cancel()
+        for f in futs:
+            if not f.cancelled():
+                f.exception()
         os.close(fd)
     return dict(zip(names, cols))

@@ -215,6 +215,95 @@ def test_decode_chunk_rejects_what_it_does_not_handle(tmp_path):
     assert call(raw, 6000) == _lib.NVT_EINVAL      # fewer
 
 
+@pytest.mark.parametrize("page_version", ["1.0", "2.0"])
+@pytest.mark.parametrize("max_def", [0, 1])
+def test_decode_chunk_survives_corrupted_pages(tmp_path, page_version, max_def):
+    """A chunk with flipped / overwritten bytes (page headers, level runs, lengths) is decoded or
+    refused -- never read or written outside its buffers: the outputs sit in guarded arrays whose
+    margins must stay untouched, and negative / huge header fields must not wrap the bounds checks."""
+    import ctypes as C
+
+    from nvtabular_amd import _lib
+
+    n = 3000
+    rng = np.random.default_rng(5 + max_def)
+    arr = pa.array(rng.integers(0, 1 << 30, n).astype("int64"), mask=(rng.random(n) < 0.3) if max_def else None)
+    t = pa.table({"a": arr}) if max_def else pa.Table.from_arrays(
+        [arr], schema=pa.schema([pa.field("a", pa.int64(), nullable=False)]))
+    path = str(tmp_path / "f.parquet")
+    pq.write_table(t, path, use_dictionary=False, compression=None, data_page_version=page_version,
+                   data_page_size=4096)
+    pf = PP.PlainParquetFile(path)
+    assert pf.eligible and pf.max_def == [max_def]
+    cc = pf.row_groups[0]["columns"][0]
+    raw = bytearray(open(path, "rb").read()[cc["offset"]: cc["offset"] + cc["size"]])
+    lib = _lib.load()
+    guard = 4096
+    vals = np.full(n * 8 + 2 * guard, 0xA5, dtype="uint8")
+    bm = np.full(n // 8 + 16 + 2 * guard, 0xA5, dtype="uint8")
+    r, v = C.c_uint64(), C.c_uint64()
+    seen = set()
+    for it in range(4000):
+        buf = bytearray(raw)
+        if it:
+            for _ in range(int(rng.integers(1, 4))):
+                # most damage goes to the first bytes of a page (its header) and to the level runs
+                at = int(rng.integers(0, len(buf))) if rng.random() < 0.5 else int(rng.integers(0, 64)) + \
+                    int(rng.integers(0, len(buf) // 4096 + 1)) * 4096 % max(1, len(buf) - 64)
+                buf[at] = int(rng.integers(0, 256)) if rng.random() < 0.7 else (0xFF if rng.random() < 0.5 else 0x80)
+        b = (C.c_uint8 * len(buf)).from_buffer(buf)
+        rc = lib.nvt_pq_decode_chunk(b, len(buf), 8, max_def, n, bm.ctypes.data + guard, 0,
+                                     vals.ctypes.data + guard, n * 8, C.byref(r), C.byref(v))
+        seen.add(rc)
+        assert rc in (0, _lib.NVT_EINVAL, _lib.NVT_EUNSUPPORTED)
+        assert (vals[:guard] == 0xA5).all() and (vals[-guard:] == 0xA5).all()
+        assert (bm[:guard] == 0xA5).all() and (bm[guard + n // 8 + 16:] == 0xA5).all()
+        if rc == 0:
+            assert r.value == n and v.value <= n
+    assert 0 in seen and _lib.NVT_EINVAL in seen
+
+
+def test_decode_chunk_header_fields_cannot_wrap_the_bounds_checks():
+    """Hand-made page headers with negative counts / lengths: a negative num_values must not pass
+    `rows + num_values <= expected` by wrapping (its level run would then fill the bitmap far past its
+    end), a negative definition_levels_byte_length must not move the value pointer in front of the
+    page."""
+    import ctypes as C
+
+    from nvtabular_amd import _lib
+    from nvtabular_amd.parquet_plain import _Struct, _varint
+
+    lib = _lib.load()
+    one = np.arange(1, dtype="int64").tobytes()
+
+    def v1_page(num_values, levels, values):
+        body = (len(levels).to_bytes(4, "little") + levels if levels is not None else b"") + values
+        dph = _Struct().i32(1, num_values).i32(2, 0).i32(3, 3).i32(4, 3).done()
+        return _Struct().i32(1, 0).i32(2, len(body)).i32(3, len(body)).struct(5, dph).done() + body
+
+    def v2_page(num_values, def_bytes, body):
+        dph = (_Struct().i32(1, num_values).i32(2, 0).i32(3, num_values).i32(4, 0).i32(5, def_bytes)
+               .i32(6, 0).done())
+        return _Struct().i32(1, 3).i32(2, len(body)).i32(3, len(body)).struct(8, dph).done() + body
+
+    def call(chunk, max_def, rows):
+        vals = np.zeros(64, dtype="int64")
+        bm = np.zeros(64, dtype="uint8")
+        r, v = C.c_uint64(), C.c_uint64()
+        b = (C.c_uint8 * len(chunk)).from_buffer_copy(chunk)
+        return lib.nvt_pq_decode_chunk(b, len(chunk), 8, max_def, rows, bm.ctypes.data, 0, vals.ctypes.data,
+                                       vals.nbytes, C.byref(r), C.byref(v))
+
+    rle_one = _varint(1 << 1) + b"\x01"                      # one row, level 1
+    assert call(v1_page(1, rle_one, one) + v1_page(1, rle_one, one), 1, 2) == 0
+    huge_run = _varint((1 << 40) << 1) + b"\x01"             # 2^40 rows "valid"
+    assert call(v1_page(1, rle_one, one) + v1_page(-1, huge_run, one), 1, 2) == _lib.NVT_EINVAL
+    assert call(v1_page(1, None, one) + v1_page(-1, None, one), 0, 2) == _lib.NVT_EINVAL
+    assert call(v2_page(2, 0, one + one), 0, 2) == 0
+    assert call(v2_page(2, -16, one + one), 0, 2) == _lib.NVT_EINVAL
+    assert call(v2_page(2, 1 << 20, one + one), 0, 2) == _lib.NVT_EINVAL
+
+
 def test_plain_reader_required_columns_and_empty_files(tmp_path):
     """REQUIRED columns (max definition level 0: no levels in the pages), a file without rows, a
     file of many tiny row groups."""
