@@ -871,9 +871,11 @@ def extra_end_to_end(device, tmp, rows, nparts=6, reps=2):
     """What the reference's benchmark actually times
     (bench/examples/dask-nvtabular-criteo-benchmark.py:216-237): parquet files in ->
     Workflow.fit + Workflow.transform -> parquet files out, cfg2 schema, `rows` rows in `nparts`
-    input files.  Input: uncompressed PLAIN parquet decoded by pyarrow on the host cores, pinned
-    staging + side-stream copies; output: the hand-written PLAIN writer (parquet_plain.py), one
-    file per input partition.  Files live under the bench's temp directory (page cache)."""
+    input files.  Input: uncompressed PLAIN parquet read by the hand-written reader (page walk +
+    definition levels in host C, nvt_pq_decode_chunk, a pool thread per column; packed values over
+    PCIe from pinned staging on a side stream; columns with nulls expanded on the device); output:
+    the hand-written PLAIN writer (parquet_plain.py), one file per input partition.  Files live
+    under the bench's temp directory (page cache)."""
     import shutil
 
     import pyarrow.parquet as pq
