@@ -2199,6 +2199,14 @@ class FlatIndex:
         consumer.index = self
         self._image = None
 
+    def prepare_image(self):
+        """End of a fit: enqueue the image the first transform would build (behind the fit's last
+        kernels, without a read-back), so that it is computed while the host walks into the
+        transform instead of in front of the first lookup."""
+        if (EAGER_IMAGES and LOOKUP_IMAGES and getattr(self, "consumers", None)
+                and getattr(self, "_image", None) is None):
+            self._build_image()
+
     def _build_image(self):
         at, place = 0, {}
         for c in self.consumers:
@@ -2374,6 +2382,9 @@ def te_image(image, stride, offset, tot_count, tot_sum, fold_count, fold_sum, kf
 
 
 LOOKUP_IMAGES = os.environ.get("NVT_LOOKUP_IMAGES", "1") != "0"
+# Workflow.fit ends by enqueueing the lookup images of its groupby operators (FlatIndex.prepare_image)
+# instead of leaving them to the first transform; "0": built lazily by the first lookup.
+EAGER_IMAGES = os.environ.get("NVT_EAGER_IMAGES", "1") != "0"
 
 
 def te_apply_folds(group_all, fold, kfold, sum_all, cnt_all, sum_fold, cnt_fold, p_smooth, y_mean,

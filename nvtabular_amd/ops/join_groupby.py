@@ -370,6 +370,13 @@ class JoinGroupby(StatOperator):
         self.categories = new
         self.out_path = new_path
 
+    def prepare_transform(self):
+        """Called by Workflow.fit once every operator is fitted: the lookup images this operator
+        shares with the other operators on its key columns are enqueued now."""
+        for cons in getattr(self, "_consumers", {}).values():
+            if cons.index is not None:
+                cons.index.prepare_image()
+
     def clear(self):
         self.categories = {}
         self.storage_name = {}

@@ -232,6 +232,13 @@ class Workflow:
                 with annotate(n.op.range_name("fit")):
                     n.op.fit_finalize(n.op.fit_end(states[id(n)], n.input_columns))
                 fitted.add(id(n))
+        # what the first transform would otherwise build in front of its first lookup (the lookup
+        # images shared by the groupby operators of a key column) is enqueued behind the fit's last
+        # kernels: it runs while the host walks into the transform
+        for n in stat_nodes:
+            prepare = getattr(n.op, "prepare_transform", None)
+            if prepare is not None:
+                prepare()
         # properties such as embedding sizes depend on the fitted state: refreshed lazily
         self._stale_schema_root = dataset.schema
         if any(getattr(n.op, "dynamic_dtypes", False) for n in nodes if n.op is not None):
