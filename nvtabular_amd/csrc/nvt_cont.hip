@@ -238,6 +238,71 @@ __global__ void minmax_final_kernel(const double *__restrict__ partials, unsigne
 }
 
 // ---------------------------------------------------------------------------
+// 4-byte values in, 8-byte values out (int32 / float32 -> float64 / int64: the Criteo continuous
+// columns through FillMissing >> Normalize, Clip, LogOp): with a 16-byte load per lane a lane
+// owns 32 output bytes and each of its two 16-byte stores writes every other 16 bytes of the
+// wave's 2 KiB -- half-written lines per store instruction, 4.7-4.9 TB/s for this 4-in / 8-out
+// stream however the grid is cut.  Here a lane takes TWO elements per run of 128 (an 8-byte load,
+// one 16-byte store): every store instruction of a wave covers 1024 contiguous bytes, 5.6-6.0
+// TB/s for the same stream (tools/micro/stream_ratio.hip: the store shape, not the grid, the
+// unroll or the load width, is what separates the two).  f(raw, valid bit, was_null&) -> OUT.
+// ---------------------------------------------------------------------------
+template <typename T, typename OUT, typename F>
+__device__ __forceinline__ void widen_stream(const T *__restrict__ x, const uint8_t *__restrict__ valid,
+                                             uint64_t n, OUT *__restrict__ out,
+                                             uint8_t *__restrict__ filled, F &&f) {
+  static_assert(sizeof(T) == 4 && sizeof(OUT) == 8, "4-byte values in, 8-byte values out");
+  constexpr int RUN = 2 * kWave, U = 4;
+  typedef int v2i_nt __attribute__((ext_vector_type(2)));
+  typedef int v4i_nt __attribute__((ext_vector_type(4)));
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  const uint64_t nruns = n / RUN;
+  // (the wave index through readfirstlane: run numbers, bounds and base addresses are scalar)
+  const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / kWave) +
+                        (uint64_t)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const uint64_t nwaves = stride / kWave;
+  for (uint64_t r0 = wave * U; r0 < nruns; r0 += nwaves * U) {
+    v2i_nt raw[U];
+    unsigned vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      raw[u] = v2i_nt{0, 0};
+      vb[u] = 3u;
+      if (r0 + u < nruns) {
+        const uint64_t e = (r0 + u) * RUN + 2 * lane;
+        raw[u] = __builtin_nontemporal_load(reinterpret_cast<const v2i_nt *>(x + e));
+        if (valid != nullptr) vb[u] = (unsigned)valid[e >> 3] >> (e & 7);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r0 + u >= nruns) break;
+      const uint64_t e = (r0 + u) * RUN + 2 * lane;
+      T v[2];
+      memcpy(v, &raw[u], 8);
+      OUT r[2];
+      uint8_t m[2];
+      r[0] = f(v[0], (bool)(vb[u] & 1), m[0]);
+      r[1] = f(v[1], (bool)((vb[u] >> 1) & 1), m[1]);
+      v4i_nt o;
+      memcpy(&o, r, 16);
+      __builtin_nontemporal_store(o, reinterpret_cast<v4i_nt *>(out + e));
+      if (filled != nullptr) {
+        uint16_t pk;
+        memcpy(&pk, m, 2);
+        *reinterpret_cast<uint16_t *>(filled + e) = pk;
+      }
+    }
+  }
+  for (uint64_t i = nruns * RUN + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    uint8_t m;
+    out[i] = f(x[i], bit_valid(valid, i), m);
+    if (filled != nullptr) filled[i] = m;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // fused FillMissing + Normalize
 // ---------------------------------------------------------------------------
 template <typename T, typename OUT>
@@ -274,8 +339,12 @@ __device__ __forceinline__ void fill_norm_body(
     if (inv_is_div != 0.0) v /= scale;
     return (OUT)v;
   };
-  const uint64_t nvec = n / VEC;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  if constexpr (sizeof(T) == 4 && sizeof(OUT) == 8) {
+    widen_stream<T, OUT>(x, valid, n, out, filled, f);
+    return;
+  }
+  const uint64_t nvec = n / VEC;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
     T v[VEC];
     load_vec<T>(x + i * VEC, v);
@@ -378,6 +447,11 @@ __global__ __launch_bounds__(kBlock) void clip_log_kernel(
     if (do_log) return (OUT)logf((float)v + 1.0f);  // the reference computes in float32
     return (OUT)v;
   };
+  if constexpr (sizeof(T) == 4 && sizeof(OUT) == 8) {
+    widen_stream<T, OUT>(x, valid, n, out, nullptr,
+                         [&](T raw, bool ok, uint8_t &m) -> OUT { m = 0; return f(raw, ok); });
+    return;
+  }
   const uint64_t nvec = n / VEC;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
