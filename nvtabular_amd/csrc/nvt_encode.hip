@@ -403,6 +403,108 @@ __global__ __launch_bounds__(kEncBS) void enc_head_build_many_kernel(HeadJobs jo
   if (threadIdx.x == 0) *reinterpret_cast<long long *>(j.image + kLdsBytes) = s_sent;
 }
 
+// Small vocabularies (<= SLOTS / 2 keys, int32 keys -> int64 labels: the reference's default dtype):
+// the 4-in / 8-out stream of widen_stream (nvt_cont.hip) with an LDS lookup in the middle.  The
+// fully staged encode_hot_kernel holds a 128 KiB table whatever the vocabulary, i.e. ONE 1024-thread
+// workgroup per CU, and a lane that loads 16 bytes of keys owns 32 bytes of labels, written as two
+// 16-byte stores 32 bytes apart: 131 us per 45 M-row column = 4.1 TB/s, of which experiment modes
+// attribute 49 us to the stores, 48 us to the bare loop over the keys (3.75 TB/s with nothing but
+// loads: 16 waves per CU) and 4 us to the lookups.  Here the table has SLOTS slots (16 / 32 KiB), a
+// workgroup is 256 threads (8 / 5 of them per CU), a lane takes two keys per run of 128 and every
+// store instruction of a wave covers 1024 contiguous bytes.
+template <int SLOTS>
+__global__ __launch_bounds__(kBlock) void encode_small_kernel(
+    const int32_t *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n, int64_t null_label,
+    int64_t oov_label, uint32_t num_buckets, int64_t *__restrict__ out,
+    const int32_t *__restrict__ hot_keys, uint32_t n_hot, int64_t first_label) {
+  constexpr int32_t EMPTY = EncTraits<int32_t>::empty;
+  __shared__ EncSlot<int32_t> lt[SLOTS];
+  __shared__ long long s_sent;
+  for (int i = threadIdx.x; i < SLOTS; i += kBlock) {
+    lt[i].key = EMPTY;
+    lt[i].label = 0;
+  }
+  if (threadIdx.x == 0) s_sent = -1;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_hot; i += kBlock) {
+    const int32_t key = hot_keys[i];
+    if (key == EMPTY) {
+      s_sent = first_label + (long long)i;
+      continue;
+    }
+    uint32_t sl = lds_home<SLOTS>(key);
+    while (true) {
+      const int32_t prev = atomicCAS(&lt[sl].key, EMPTY, key);
+      if (prev == EMPTY || prev == key) {
+        if (prev == EMPTY) lt[sl].label = (int32_t)(first_label + (int64_t)i);
+        break;
+      }
+      sl = (sl + 1) & (SLOTS - 1);
+    }
+  }
+  __syncthreads();
+  const int64_t sent = (int64_t)s_sent;
+  auto encode = [&](int32_t key, bool ok) -> int64_t {
+    if (!ok) return null_label;
+    int64_t lab = -1;
+    if (key == EMPTY) {
+      lab = sent;
+    } else {
+      uint32_t sl = lds_home<SLOTS>(key);
+      while (true) {
+        const EncSlot<int32_t> e = lt[sl];
+        if (e.key == key) {
+          lab = (int64_t)e.label;
+          break;
+        }
+        if (e.key == EMPTY) break;
+        sl = (sl + 1) & (SLOTS - 1);
+      }
+    }
+    if (lab < 0) {
+      lab = oov_label;
+      if (num_buckets > 1) lab += (int64_t)(key_hash32((int64_t)key) % num_buckets);
+    }
+    return lab;
+  };
+  constexpr int RUN = 2 * kWave, U = 4;
+  typedef int v2i_nt __attribute__((ext_vector_type(2)));
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  const uint64_t nruns = n / RUN;
+  // (the wave index through readfirstlane: run numbers, bounds and base addresses are scalar)
+  const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / kWave) +
+                        (uint64_t)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const uint64_t nwaves = stride / kWave;
+  for (uint64_t r0 = wave * U; r0 < nruns; r0 += nwaves * U) {
+    v2i_nt raw[U];
+    unsigned vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      raw[u] = v2i_nt{0, 0};
+      vb[u] = 3u;
+      if (r0 + u < nruns) {
+        const uint64_t e = (r0 + u) * RUN + 2 * lane;
+        raw[u] = __builtin_nontemporal_load(reinterpret_cast<const v2i_nt *>(keys + e));
+        if (valid != nullptr) vb[u] = (unsigned)valid[e >> 3] >> (e & 7);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r0 + u >= nruns) break;
+      const uint64_t e = (r0 + u) * RUN + 2 * lane;
+      int64_t r[2];
+      r[0] = encode(raw[u].x, (bool)(vb[u] & 1));
+      r[1] = encode(raw[u].y, (bool)((vb[u] >> 1) & 1));
+      nvt_v4i o;
+      memcpy(&o, r, 16);
+      __builtin_nontemporal_store(o, reinterpret_cast<nvt_v4i *>(out + e));
+    }
+  }
+  for (uint64_t i = nruns * RUN + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    out[i] = encode(keys[i], bit_valid(valid, i));
+}
+
 // GLOBAL = false: the whole vocabulary is staged (no table in HBM): the probe phases and their
 // registers disappear.  (UU = 3 / 4 key vectors per lane in flight, and a 2048-slot table with
 // two workgroups per CU for vocabularies <= 1024 keys, were each ~2 % slower: profiles/r02_notes.md)
@@ -883,6 +985,25 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
   encode_hot_kernel<K, OUTT, false, GL, UUU><<<hgrid, kEncBS, 0, s>>>(                            \
       keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,        \
       reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label)
+    if constexpr (sizeof(K) == 4) {
+      // small vocabularies with int64 labels: smaller tables, 256-thread workgroups, contiguous stores
+      static const bool small_on = getenv("NVT_ENC_NO_SMALL") == nullptr;   // (A/B switch)
+      if (!global_needed && out_bytes == 8 && small_on && n_vocab <= 2048) {
+        const unsigned sgrid = stream_grid(n / 2 + 1, kBlock * 8, 8);
+        if (n_vocab <= 1024)
+          encode_small_kernel<2048><<<sgrid, kBlock, 0, s>>>(
+              reinterpret_cast<const int32_t *>(keys), valid, n, null_label, oov_label, num_buckets,
+              reinterpret_cast<int64_t *>(out), reinterpret_cast<const int32_t *>(hot_keys), n_hot,
+              first_label);
+        else
+          encode_small_kernel<4096><<<sgrid, kBlock, 0, s>>>(
+              reinterpret_cast<const int32_t *>(keys), valid, n, null_label, oov_label, num_buckets,
+              reinterpret_cast<int64_t *>(out), reinterpret_cast<const int32_t *>(hot_keys), n_hot,
+              first_label);
+        NVT_CHECK_LAUNCH();
+        return NVT_OK;
+      }
+    }
     if (global_needed) {
       if (out_bytes == 8) NVT_ENC_HOT(int64_t, true, 2); else NVT_ENC_HOT(int32_t, true, 2);
     } else {
