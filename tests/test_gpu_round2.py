@@ -225,6 +225,36 @@ def test_fully_staged_encode_with_unseen_keys_and_nulls(tmp_path):
         np.testing.assert_array_equal(out[c].to_numpy(), exp[c].to_numpy(), err_msg=c)
 
 
+@pytest.mark.parametrize("vocab", [1, 3, 1000, 1024, 1025, 2048, 2049])
+@pytest.mark.parametrize("num_buckets", [None, 7])
+def test_small_vocabulary_encode_at_the_table_boundaries(tmp_path, vocab, num_buckets):
+    """Vocabularies <= 1024 / <= 2048 keys take encode_small_kernel (2048- / 4096-slot LDS tables,
+    256-thread workgroups, two keys per lane and run of 128), 2049 keys the fully staged kernel: the
+    labels on both sides of each boundary -- rows not a multiple of 128, nulls, keys the fit never
+    saw (hashed into buckets or not), INT32_MIN as an ordinary key -- must equal the oracle's."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(vocab)
+    n = 100_000 + 77
+    ids = np.arange(vocab, dtype=np.int64) * 104729 - 5_000_000
+    ids[0] = np.iinfo(np.int32).min      # the tables' empty marker is a key like any other
+    x = ids[np.minimum(rng.zipf(1.3, n) - 1, vocab - 1)] if vocab > 1 else np.full(n, ids[0])
+    x[:vocab] = ids                       # every key occurs
+    df = pd.DataFrame({"a": pd.array(x.astype("int32"), dtype="Int32")})
+    df.loc[rng.random(n) < 0.05, "a"] = pd.NA
+    kw = {} if num_buckets is None else {"num_buckets": num_buckets}
+    wf = nvt.Workflow(["a"] >> ops.Categorify(out_path=str(tmp_path / "gpu"), **kw))
+    wf.fit(nvt.Dataset(df))
+    df2 = df.copy()
+    df2.loc[::53, "a"] = 1_999_999_999    # never seen by fit
+    df2.loc[5::997, "a"] = -1_999_999_999
+    out = wf.transform(nvt.Dataset(df2)).to_ddf().compute()
+    paths = O.categorify_fit([_host_view(df)], ["a"], str(tmp_path / "cpu"), tie_break="stable", **kw)
+    exp = O.categorify_transform(_host_view(df2), ["a"], paths, **kw)
+    np.testing.assert_array_equal(out["a"].to_numpy(), exp["a"].to_numpy())
+
+
 def test_multi_partition_fit_on_the_filtered_partitioned_path(tmp_path):
     """Three partitions of a 150 k-key power-law column: every partition is counted on a
     partitioned path behind its own sampled hot set (the range path, or path 1 | NVT_PATH_HOT
