@@ -18,7 +18,7 @@ FAMILY = [
                      "flat_build", "flat_params", "os_", "sort_", "sort2_", "enc_clear_kernel",
                      "enc_build", "class_hist_kernel")),
     ("merge", ("merge_split_kernel", "merge_tile_kernel", "merge_payload_kernel")),
-    ("encode", ("encode_hot_kernel", "encode_kernel")),
+    ("encode", ("encode_hot_kernel", "encode_small_kernel", "encode_kernel")),
     ("fill_normalize", ("fill_norm",)),
     ("moments", ("moments",)),
 ]
