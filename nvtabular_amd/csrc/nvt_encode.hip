@@ -797,6 +797,345 @@ __global__ __launch_bounds__(kEncBS, HALF ? 2 : 1) void encode_hot_kernel(
   }
 }
 
+// Cache mode as a software pipeline (int32 keys; round 6).  What the ISA of encode_hot_kernel
+// showed: (1) its "prefetch" of the next iteration's keys never overlapped anything -- the loads sit
+// under `if (v < nvec)` / `if (valid)` branches, the validity byte is used right behind its load,
+// and the compiler answers every such block with `s_waitcnt vmcnt(0)`; (2) a wave walks its phases
+// one after the other per batch of 8 keys per lane: key loads, LDS head lookups, first probes of the
+// misses in the table in HBM (one random 128-byte line per missing row), wait, up to 8 probe
+// chains one after the other, label stores.  One 1024-thread workgroup per CU (the head takes
+// 144 KiB of LDS) is 4 waves per SIMD, so a launch cost about the SUM of its phases (issue ~80 us +
+// stream ~96 us + probes ~128 us against 236-258 us measured, profiles/r05_notes.md).
+// Here the loop over the FULL steps of a workgroup (every lane has both of its vectors) is
+// straight-line code -- unconditional loads, branch-free LDS phase, unconditional probes (a lane whose
+// key hit the head reads slot 0: one broadcast line) -- so the compiler's s_waitcnt counts are exact
+// and loads stay in flight across phases:
+//     step i:  [b] keys(i) (requested in step i-1) through the LDS head
+//              [c] probes(i-1) (requested in step i-1) resolved; rare chains walked here, while
+//                  nothing else of this wave is in flight
+//              [d] keys(i+1) and probes(i) requested
+//              [e] labels(i-1) stored
+// i.e. the probes of a batch fly during the stores of the batch in front of it and the LDS phase of
+// the batch behind it, the key loads during a whole step.  Two stage records (ping-pong, static
+// indices: registers).  The few vectors behind the last full step and the rows behind the last
+// vector take a plain per-key path.  Results are identical to encode_hot_kernel's: every row is
+// stored once, at its own index.
+// a wave-uniform GLOBAL pointer the optimiser cannot re-associate with per-thread offsets:
+// `base + tid` stays "scalar base + 32-bit vector offset" (the global_load saddr form) instead of a
+// hoisted 64-bit per-thread address pair that lives -- or is spilled -- across a whole loop.  (The
+// address space is part of the type: a pointer rebuilt from integers is a FLAT pointer otherwise,
+// and flat accesses count in vmcnt AND lgkmcnt: every wait becomes vmcnt(0).)
+#define NVT_GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ NVT_GLOBAL_AS T *uniform_gptr(T *p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (NVT_GLOBAL_AS T *)(((uint64_t)hi << 32) | lo);
+}
+template <typename OUT, int RANGE>
+__global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
+    const int32_t *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
+    const EncSlot<int32_t> *__restrict__ table, uint64_t mask,
+    const int64_t *__restrict__ sentinel_label, int64_t null_label, int64_t oov_label,
+    uint32_t num_buckets, OUT *__restrict__ out, const int32_t *__restrict__ hot_keys,
+    uint32_t n_hot, int64_t first_label, const int32_t *__restrict__ range_aux, int count_stats,
+    const unsigned char *__restrict__ head_image) {
+  static_assert(RANGE == 1 || RANGE == 2, "range tables (slots and byte offsets fit 32 bits)");
+  using K = int32_t;
+  constexpr K EMPTY = EncTraits<K>::empty;
+  constexpr int VEC = 4, U = 2, NK = U * VEC;
+  constexpr int SLOTS = HotCfg<K>::slots;
+  constexpr int kLdsBytes = kHead16Buckets * 12;
+  RangeMap rmap = load_map(range_aux);
+  __shared__ uint32_t s_pieces[RANGE == 1 ? kRpPwWords : 1];
+  if constexpr (RANGE == 1) stage_pieces(rmap, s_pieces, threadIdx.x, kEncBS);  // (barrier below)
+  __shared__ __align__(16) unsigned char lraw[kLdsBytes];
+  const int2 *tkeys = reinterpret_cast<const int2 *>(lraw);
+  const uint32_t *tlab = reinterpret_cast<const uint32_t *>(lraw + kHead16Buckets * 8);
+  __shared__ long long s_sent;
+  if (head_image != nullptr) {
+    const int4 *src = reinterpret_cast<const int4 *>(head_image);
+    int4 *dst = reinterpret_cast<int4 *>(lraw);
+    for (int i = threadIdx.x; i < kLdsBytes / 16; i += kEncBS) dst[i] = src[i];
+    __syncthreads();
+  } else {
+    build_head<K, true, true, SLOTS>(lraw, &s_sent, hot_keys, n_hot, first_label);
+  }
+  const int32_t sent = (int32_t)*sentinel_label;   // (-1: the sentinel key is not in the vocabulary)
+  const unsigned long long *tw = reinterpret_cast<const unsigned long long *>(table);
+  const char *tbytes = reinterpret_cast<const char *>(table);
+
+  unsigned st_miss = 0, st_rows = 0;  // (count_stats)
+  // (the linear / piecewise form of the range map is decided once, outside the loops)
+  auto run = [&](auto pw_tag) {
+    constexpr bool PW = decltype(pw_tag)::value;
+    // first slot of a key's probe chain (< 2^29: bucket regions / flat tables of int32 vocabularies)
+    auto first_slot = [&](K key) -> uint32_t {
+      const uint32_t f = rmap.template fine_staged<PW>(key);
+      return RANGE == 2 ? f : f + (f >> 14) * (uint32_t)kRpTail;   // (f >> 14) * kRpRegion + (f & 16383)
+    };
+    // label in the LDS head, or -1 (labels of the table are < INT32_MAX: build_launch checks)
+    auto hot_lookup = [&](K key) -> int32_t {
+      uint32_t b1, b2;
+      two_buckets16(key, b1, b2);
+      const int2 a = tkeys[b1], c = tkeys[b2];
+      const uint32_t la = tlab[b1], lc = tlab[b2];
+      int lab = -1;
+      lab = a.x == key ? (int)(la & 0xFFFFu) : lab;
+      lab = a.y == key ? (int)(la >> 16) : lab;
+      lab = c.x == key ? (int)(lc & 0xFFFFu) : lab;
+      lab = c.y == key ? (int)(lc >> 16) : lab;
+      return lab < 0 ? -1 : (int32_t)first_label + lab;
+    };
+    // the rest of a probe chain whose first slot `e0` (at `sl`) held another key
+    auto walk = [&](K key, uint32_t sl0, unsigned long long e0) -> int32_t {
+      if constexpr (RANGE == 2) {
+        unsigned long long w = 0;
+        const uint64_t at = flat_find_from(tw, mask + 1, (uint64_t)sl0, key, e0, &w);
+        return at == ~0ull ? -1 : (int32_t)(w >> 32);
+      } else {
+        uint64_t sl = sl0;
+        while (true) {
+          const unsigned long long e = tw[++sl];
+          if ((int32_t)(uint32_t)e == key) return (int32_t)(e >> 32);
+          if ((int32_t)(uint32_t)e == EMPTY) return -1;
+        }
+      }
+    };
+    auto finish = [&](K key, int32_t lab) -> OUT {
+      int64_t r = (int64_t)lab;
+      if (lab < 0) {
+        r = oov_label;
+        if (num_buckets > 1) r += (int64_t)(key_hash32((int64_t)key) % num_buckets);
+      }
+      return (OUT)r;
+    };
+    // one key outside the pipeline (the vectors behind the last full step, the rows behind the last vector)
+    auto encode_one = [&](K key, bool ok) -> OUT {
+      if (!ok) return (OUT)null_label;
+      int32_t lab = key == EMPTY ? sent : hot_lookup(key);
+      if (lab < 0 && key != EMPTY) {
+        const uint32_t sl = first_slot(key);
+        const unsigned long long e = tw[sl];
+        if ((int32_t)(uint32_t)e == key) lab = (int32_t)(e >> 32);
+        else if ((int32_t)(uint32_t)e != EMPTY) lab = walk(key, sl, e);
+      }
+      return finish(key, lab);
+    };
+
+    const uint64_t nvec = n / VEC;
+    const uint64_t stride = (uint64_t)gridDim.x * kEncBS, SU = stride * U;
+    const uint64_t vb0 = (uint64_t)blockIdx.x * kEncBS;
+    const int4 *vkeys = reinterpret_cast<const int4 *>(keys);
+    // validity bytes are ALWAYS loaded (from the keys when the column has no bitmap: any readable
+    // bytes) and OR-ed with `vor`: no branch between the loads of a step
+    const uint8_t *vsrc = valid != nullptr ? valid : reinterpret_cast<const uint8_t *>(keys);
+    const unsigned vor = valid != nullptr ? 0u : 0xFFu;
+    // steps in which every lane of this workgroup has all of its U vectors
+    uint64_t nfull = 0;
+    if (nvec >= vb0 + (uint64_t)(U - 1) * stride + kEncBS)
+      nfull = (nvec - (vb0 + (uint64_t)(U - 1) * stride + kEncBS)) / SU + 1;
+    // Addresses of the streams: a wave-uniform base per step and vector (vb0, stride and the step
+    // index are scalar) + a constant offset per thread -- no 64-bit vector arithmetic, no address
+    // registers that live across the phases.  The vector index of a thread is even with its
+    // thread index (vb0 and stride are multiples of 1024): its validity nibble is the low or the
+    // high half of byte (base >> 1) + (thread >> 1).
+    const unsigned tid = threadIdx.x;
+    const unsigned nib = (tid & 1u) * 4u;
+    int4 nxt_pack[U];
+    unsigned nxt_vb[U];
+    struct Stage {
+      int32_t k[NK];
+      int32_t lab[NK];
+      unsigned long long e[NK];   // first slot of every key's probe chain
+      unsigned need;              // bit q: key q is still unresolved (its label is in the table in HBM)
+      unsigned vb[U];             // bits 0-3: rows valid
+    };
+    auto request_keys = [&](uint64_t step) {   // (scalar)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t vs = vb0 + step * SU + (uint64_t)u * stride;
+        const nvt_v4i raw = __builtin_nontemporal_load(
+            reinterpret_cast<const NVT_GLOBAL_AS nvt_v4i *>(uniform_gptr(vkeys + vs)) + tid);
+        nxt_pack[u] = make_int4(raw.x, raw.y, raw.z, raw.w);
+        nxt_vb[u] = (unsigned)uniform_gptr(vsrc + (vs >> 1))[tid >> 1];   // (used one step later)
+      }
+    };
+    auto lds_phase = [&](Stage &st) {   // [b]
+      unsigned need = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        st.k[u * VEC + 0] = nxt_pack[u].x;
+        st.k[u * VEC + 1] = nxt_pack[u].y;
+        st.k[u * VEC + 2] = nxt_pack[u].z;
+        st.k[u * VEC + 3] = nxt_pack[u].w;
+        st.vb[u] = ((nxt_vb[u] | vor) >> nib) & 0xFu;
+      }
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+        const K key = st.k[q];
+        const bool ok = (st.vb[q / VEC] >> (q % VEC)) & 1u;
+        const bool is_sent = key == EMPTY;
+        int32_t lab = hot_lookup(key);
+        lab = is_sent ? sent : lab;
+        st.lab[q] = lab;
+        need |= ((ok & !is_sent & (lab < 0)) ? 1u : 0u) << q;
+      }
+      st.need = need;
+      if (count_stats) {
+        st_rows += (unsigned)__popc(st.vb[0]) + (unsigned)__popc(st.vb[1]);
+        st_miss += (unsigned)__popc(need);
+      }
+    };
+    auto request_probes = [&](Stage &st) {   // [d]
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+        const uint32_t off = ((st.need >> q) & 1u) ? first_slot(st.k[q]) * 8u : 0u;
+        st.e[q] = *reinterpret_cast<const unsigned long long *>(tbytes + off);
+        // (one slot computation at a time: eight interleaved bisections of the piecewise map spill)
+        if constexpr (PW) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto resolve = [&](Stage &st) {   // [c]
+      unsigned more = 0;
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+        const bool nd = (st.need >> q) & 1u;
+        const int32_t ek = (int32_t)(uint32_t)st.e[q];
+        const bool hit = nd & (ek == st.k[q]);
+        st.lab[q] = hit ? (int32_t)(st.e[q] >> 32) : st.lab[q];
+        more |= ((nd & !hit & (ek != EMPTY)) ? 1u : 0u) << q;
+      }
+      // chains that go on behind their first slot (~1 in 5 of the probes): every lane walks ITS next
+      // one (ffs of its mask; key / slot word picked by a compare chain: static register indices,
+      // one copy of the walk in the code instead of eight)
+      while (more) {
+        const int q = (int)__ffs((int)more) - 1;
+        more &= more - 1u;
+        K key = st.k[0];
+        unsigned long long e0 = st.e[0];
+#pragma unroll
+        for (int j = 1; j < NK; ++j) {
+          key = q == j ? st.k[j] : key;
+          e0 = q == j ? st.e[j] : e0;
+        }
+        const int32_t lab = walk(key, first_slot(key), e0);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) st.lab[j] = q == j ? lab : st.lab[j];
+      }
+    };
+    auto store = [&](const Stage &st, uint64_t step) {   // [e]
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t vs = vb0 + step * SU + (uint64_t)u * stride;
+        OUT r[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const int q = u * VEC + j;
+          r[j] = ((st.vb[u] >> j) & 1u) ? finish(st.k[q], st.lab[q]) : (OUT)null_label;
+        }
+        NVT_GLOBAL_AS nvt_v4i *dst =
+            reinterpret_cast<NVT_GLOBAL_AS nvt_v4i *>(uniform_gptr(out + vs * VEC)) + tid * (VEC * sizeof(OUT) / 16);
+        nvt_v4i a;
+        memcpy(&a, &r[0], 16);
+        __builtin_nontemporal_store(a, dst);
+        if constexpr (sizeof(OUT) == 8) {
+          nvt_v4i b;
+          memcpy(&b, &r[2], 16);
+          __builtin_nontemporal_store(b, dst + 1);
+        }
+      }
+    };
+    if (nfull < 2) nfull = 0;   // (a single step has nothing to overlap: the plain path below)
+    if (nfull > 0) {
+      Stage s0, s1;
+      // the keys of step i + 1; behind the last full step the last one again (unused, in range)
+      auto next_step = [&](uint64_t i) { return i + 1 < nfull ? i + 1 : nfull - 1; };
+#define NVT_PHASE() __builtin_amdgcn_sched_barrier(0)   // (no interleaving across phases: registers)
+      // Steps 0 and 1 are arranged so that the loop is entered with exactly what a trip through it
+      // leaves in flight -- keys(i+1), probes(i), stores(i-1), in this order -- because the
+      // compiler's wait counts at the loop header are the minimum over both ways in: entered
+      // without the stores, every first half-step waited for three of its eight probes.
+      request_keys(0);
+      NVT_PHASE();
+      lds_phase(s0);
+      NVT_PHASE();
+      request_keys(1);
+        NVT_PHASE();
+      request_probes(s0);
+      NVT_PHASE();
+      lds_phase(s1);
+      NVT_PHASE();
+      resolve(s0);
+      NVT_PHASE();
+      request_keys(next_step(1));
+        NVT_PHASE();
+      request_probes(s1);
+      NVT_PHASE();
+      store(s0, 0);
+      NVT_PHASE();
+      bool last_is_s0 = false;
+      for (uint64_t i = 2; i < nfull; i += 2) {
+        lds_phase(s0);
+        NVT_PHASE();
+        resolve(s1);
+        NVT_PHASE();
+        request_keys(next_step(i));
+        NVT_PHASE();
+        request_probes(s0);
+        NVT_PHASE();
+        store(s1, i - 1);
+        NVT_PHASE();
+        last_is_s0 = true;
+        if (i + 1 >= nfull) break;
+        lds_phase(s1);
+        NVT_PHASE();
+        resolve(s0);
+        NVT_PHASE();
+        request_keys(next_step(i + 1));
+        NVT_PHASE();
+        request_probes(s1);
+        NVT_PHASE();
+        store(s0, i);
+        NVT_PHASE();
+        last_is_s0 = false;
+      }
+#undef NVT_PHASE
+      if (last_is_s0) {
+        resolve(s0);
+        store(s0, nfull - 1);
+      } else {
+        resolve(s1);
+        store(s1, nfull - 1);
+      }
+    }
+    for (uint64_t v = vb0 + nfull * SU + tid; v < nvec; v += stride) {
+      const int4 pk = vkeys[v];
+      const unsigned bits = ((unsigned)vsrc[v >> 1] | vor) >> nib;
+      const K kk[VEC] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) out[v * VEC + j] = encode_one(kk[j], (bits >> j) & 1u);
+      if (count_stats) st_rows += (unsigned)__popc(bits & 0xFu);
+    }
+    for (uint64_t i = nvec * VEC + vb0 + tid; i < n; i += stride)
+      out[i] = encode_one(keys[i], bit_valid(valid, i));
+  };
+  if (RANGE == 1 && rmap.piece_slots != 0) run(std::true_type{});
+  else run(std::false_type{});
+  if (count_stats) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      st_miss += __shfl_down(st_miss, off, 64);
+      st_rows += __shfl_down(st_rows, off, 64);
+    }
+    if (lane_id() == 0) {
+      atomicAdd(&g_enc_stats[0], (unsigned long long)st_miss);
+      atomicAdd(&g_enc_stats[1], (unsigned long long)st_rows);
+    }
+  }
+}
+
 template <typename K>
 __global__ __launch_bounds__(kBlock) void hash_bucket_kernel(const K *__restrict__ keys,
                                                              const uint8_t *__restrict__ valid,
@@ -954,6 +1293,14 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
   encode_hot_kernel<K, OUTT, true, true, 1, KIND, false, true><<<hgrid, kEncBS, 0, s>>>(           \
       keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,          \
       reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux, stats)
+#define NVT_ENC_PIPE(OUTT, KIND)                                                                  \
+  encode_pipe_kernel<OUTT, KIND><<<hgrid, kEncBS, 0, s>>>(                                         \
+      keys, valid, n, t, capacity - 1, sentinel_label, null_label, oov_label, num_buckets,          \
+      reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label, range_aux, stats,           \
+      reinterpret_cast<const unsigned char *>(head_image))
+        // the software pipeline (encode_pipe_kernel) is the cache-mode kernel of the range tables with
+        // the 6-byte head; NVT_ENC_PIPE=0 keeps the phase-serial one for A/B runs
+        static const bool pipe = getenv("NVT_ENC_PIPE") == nullptr || atoi(getenv("NVT_ENC_PIPE")) != 0;
 #define NVT_ENC_CACHE_K(KIND)                                                \
   do {                                                                       \
     if (half) {                                                              \
@@ -967,15 +1314,25 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
       else NVT_ENC_CACHE(int32_t, KIND, false);                              \
     }                                                                        \
   } while (0)
+#define NVT_ENC_PIPE_K(KIND)                                                 \
+  do {                                                                       \
+    if (out_bytes == 8) NVT_ENC_PIPE(int64_t, KIND);                         \
+    else NVT_ENC_PIPE(int32_t, KIND);                                        \
+  } while (0)
+        const bool piped = pipe && head16 && !half && range_aux != nullptr;
         // range tables -- capacity > 0: a FLAT range table of `capacity` slots (bounded search);
         // 0: the bucket regions dumped by the counting pass; no range_aux: the hashed table
-        if (range_aux != nullptr) {
+        if (piped) {
+          if (capacity > 0) NVT_ENC_PIPE_K(2); else NVT_ENC_PIPE_K(1);
+        } else if (range_aux != nullptr) {
           if (capacity > 0) NVT_ENC_CACHE_K(2); else NVT_ENC_CACHE_K(1);
         } else {
           NVT_ENC_CACHE_K(0);
         }
 #undef NVT_ENC_CACHE_HALF
 #undef NVT_ENC_CACHE_K
+#undef NVT_ENC_PIPE_K
+#undef NVT_ENC_PIPE
 #undef NVT_ENC_CACHE
         NVT_CHECK_LAUNCH();
         return NVT_OK;

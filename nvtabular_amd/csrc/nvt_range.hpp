@@ -97,6 +97,26 @@ struct RangeMap {
     d = d < span ? d : span;
     return __umulhi(d << sh, mul);
   }
+  // the same for kernels that ALWAYS stage the pieces in LDS (stage_pieces) and have hoisted the
+  // linear / piecewise decision out of their loops (PW at compile time): no branch, and none of the
+  // global-memory form's loads (with their s_waitcnt vmcnt(0)) inside a software-pipelined loop body
+  template <bool PW>
+  __device__ __forceinline__ uint32_t fine_staged(int32_t key) const {
+    const uint32_t u = ukey(key);
+    if constexpr (PW) {
+      return fine_pieces(lpw, u);
+    } else {
+      uint32_t d = u > ulo ? u - ulo : 0u;
+      d = d < span ? d : span;
+      return __umulhi(d << sh, mul);
+    }
+  }
+  // (FLAT at compile time as well: flat tables never use pieces)
+  template <bool PW, bool FLAT>
+  __device__ __forceinline__ uint64_t table_slot_staged(int32_t key) const {
+    const uint32_t f = fine_staged<PW>(key);
+    return FLAT ? (uint64_t)f : (uint64_t)(f >> 14) * kRpRegion + (f & (kRpSlots - 1));
+  }
   __device__ __forceinline__ uint32_t bucket(int32_t key) const { return fine(key) >> 14; }
   __device__ __forceinline__ uint32_t slot(int32_t key) const { return fine(key) & (kRpSlots - 1); }
   // first slot to look at in the dumped table (bucket regions of kRpRegion slots, probing
