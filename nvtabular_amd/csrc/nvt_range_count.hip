@@ -168,53 +168,79 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
   const uint64_t per = (nvec + kRpG - 1) / kRpG;
   const uint64_t v_lo = (uint64_t)g * per;
   const uint64_t v_hi = v_lo + per < nvec ? v_lo + per : nvec;
+  const uint64_t vf_hi = v_hi < nfull ? v_hi : nfull;   // full vectors of this slab: [v_lo, vf_hi)
   unsigned long long nulls = 0, sent = 0;
   // U vectors per thread per round: the rounds of a workgroup are separated by two barriers, so
-  // the load latency of a round is exposed unless the next round's loads are already in flight
+  // the load latency of a round is exposed unless the next round's loads are already in flight.
+  // Round 6: they never were -- the loads sat under `if (v < v_hi)` / `if (valid)` and the
+  // validity byte was shifted right behind its load, which the compiler answers with
+  // s_waitcnt vmcnt(0) after EVERY load (ISA of the round-5 kernel: 20 of 20).  The loads of a
+  // round are now unconditional (a vector behind the slab reads the slab's last full vector again
+  // and is ignored: `present` comes from the index, not from the data; a column without a bitmap
+  // reads its bytes from the keys and ORs them with 0xFF) and nothing touches what they return
+  // before the round that uses it.  The partial vector at the end of the column (one thread of
+  // one workgroup) is appended in a round of its own behind the loop.
+  const uint8_t *vsrc = valid != nullptr ? valid : reinterpret_cast<const uint8_t *>(keys);
+  const unsigned vor = valid != nullptr ? 0u : 0xFFu;
+  const uint64_t v_last = vf_hi > v_lo ? vf_hi - 1 : 0;   // (vf_hi == v_lo: no round runs)
   int4 npack[U];
-  unsigned nvb[U];  // bit 8: vector present, bits 0-3: rows valid, bit 9: bits 4-7 rows in range
+  unsigned nbyte[U];
   auto issue = [&](uint64_t v0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint64_t v = v0 + (uint64_t)u * kRpBS;
-      nvb[u] = 0;
-      npack[u] = make_int4(0, 0, 0, 0);
-      if (v < v_hi) {
-        if (v < nfull) {
-          npack[u] = reinterpret_cast<const int4 *>(keys)[v];
-          nvb[u] = 0x100u | (valid ? (unsigned)valid[(v * 4) >> 3] << 12 : 0xFF000u);  // raw byte
-        } else {  // partial tail vector
-          int32_t kk[4] = {0, 0, 0, 0};
-          unsigned ok = 0, in = 0;
-          for (int j = 0; j < 4; ++j) {
-            const uint64_t i = v * 4 + j;
-            if (i < n) {
-              in |= 1u << j;
-              if (bit_valid(valid, i)) {
-                kk[j] = keys[i];
-                ok |= 1u << j;
-              }
-            }
-          }
-          npack[u] = make_int4(kk[0], kk[1], kk[2], kk[3]);
-          nvb[u] = 0x300u | ok | (in << 4);
-        }
-      }
+      uint64_t v = v0 + (uint64_t)u * kRpBS;
+      v = v < v_last ? v : v_last;
+      npack[u] = reinterpret_cast<const int4 *>(keys)[v];
+      nbyte[u] = (unsigned)vsrc[v >> 1];   // ((v * 4) >> 3)
     }
   };
-  issue(v_lo + threadIdx.x);
-  for (uint64_t v0 = v_lo; v0 < v_hi; v0 += (uint64_t)kRpBS * U) {
+  bool tail_round = false;   // (the partial vector, once, behind the full vectors)
+  int4 tpack = make_int4(0, 0, 0, 0);
+  unsigned tok = 0, tin = 0;
+  if (nfull < nvec && nfull >= v_lo && nfull < v_hi) {   // (uniform: this workgroup owns it)
+    tail_round = true;
+    if (threadIdx.x == 0) {
+      int32_t kk[4] = {0, 0, 0, 0};
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t i = nfull * 4 + j;
+        if (i < n) {
+          tin |= 1u << j;
+          if (bit_valid(valid, i)) {
+            kk[j] = keys[i];
+            tok |= 1u << j;
+          }
+        }
+      }
+      tpack = make_int4(kk[0], kk[1], kk[2], kk[3]);
+    }
+  }
+  if (vf_hi > v_lo) issue(v_lo + threadIdx.x);
+  for (uint64_t v0 = v_lo; v0 < vf_hi || tail_round; v0 += (uint64_t)kRpBS * U) {
+    const bool is_tail = !(v0 < vf_hi);   // (uniform)
     int32_t kv[4 * U];
-    unsigned vbs[U];
+    unsigned oks[U], ins[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      const uint64_t v = v0 + (uint64_t)u * kRpBS + threadIdx.x;
+      const bool present = !is_tail && v < vf_hi;
       kv[4 * u + 0] = npack[u].x;
       kv[4 * u + 1] = npack[u].y;
       kv[4 * u + 2] = npack[u].z;
       kv[4 * u + 3] = npack[u].w;
-      vbs[u] = nvb[u];
+      oks[u] = present ? (((nbyte[u] | vor) >> (((unsigned)v & 1u) * 4u)) & 0xFu) : 0u;
+      ins[u] = present ? 0xFu : 0u;
     }
-    issue(v0 + (uint64_t)kRpBS * U + threadIdx.x);
+    if (is_tail) {
+      tail_round = false;
+      kv[0] = tpack.x;
+      kv[1] = tpack.y;
+      kv[2] = tpack.z;
+      kv[3] = tpack.w;
+      oks[0] = tok;
+      ins[0] = tin;
+    } else {
+      issue(v0 + (uint64_t)kRpBS * U + threadIdx.x);   // (clamped: the last round reads its own again)
+    }
     // Branch-free classification of the round's keys (the per-key if / else ladder compiled to
     // as many exec-mask instructions as there was arithmetic: ~190 instructions per key).  Every
     // key reads its hot bucket; hits add 1 to their counter, every other lane adds 0 to a scratch
@@ -222,12 +248,7 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
     unsigned pend = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const unsigned vb = vbs[u];
-      const bool present = (vb & 0x100u) != 0;
-      const uint64_t v = v0 + (uint64_t)u * kRpBS + threadIdx.x;
-      const unsigned okf = ((vb >> 12) >> ((v * 4) & 7)) & 0xFu;
-      const unsigned ok = present ? ((vb & 0x200u) ? vb & 0xFu : okf) : 0u;
-      const unsigned in = present ? ((vb & 0x200u) ? (vb >> 4) & 0xFu : 0xFu) : 0u;
+      const unsigned ok = oks[u], in = ins[u];
       nulls += __popc(in & ~ok);
       int2 hb[4];
       uint32_t sa[4];
