@@ -2256,7 +2256,8 @@ int dense_count(const K *keys, const uint8_t *valid, const int64_t *weights, uin
       if (clear_state) NVT_CHECK_HIP(hipMemsetAsync(state, 0, NVT_STATE_WORDS * 8, s));
       if (n == 0) return NVT_OK;
       return range_count_i32((const int32_t *)keys, valid, n, (path >> 8) & 0xFF, wsp, hot_image_ext,
-                             (int32_t *)out_keys, out_cnt, out_cap, range_table, state, s);
+                             (int32_t *)out_keys, out_cnt, out_cap, range_table, state, s,
+                             (path & NVT_PATH_PIECES) != 0);
     } else {
       set_error("dense_count: the range path takes int32 keys");
       return NVT_EINVAL;

@@ -38,7 +38,7 @@ int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tm
 uint64_t range_count_ws_bytes(uint64_t n, int nb_log2);
 int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int nb_log2, void *ws,
                     int32_t *aux, int32_t *out_keys, int64_t *out_cnt, uint64_t out_cap,
-                    void *range_table, uint64_t *state, hipStream_t s);
+                    void *range_table, uint64_t *state, hipStream_t s, bool pieces);
 
 // nvt_sort_count.hip: path NVT_PATH_SORT of nvt_dense_count_* (radix sort + run lengths; hist =
 // the column's uint32[256] class histogram block)

@@ -61,6 +61,15 @@ constexpr unsigned long long kStAgg = 1ull << 62, kStPrefix = 2ull << 62,
 
 __device__ __forceinline__ uint32_t hot_bucket_r(int32_t key) { return hot_image_bucket(key, kHotBucketsR - 1); }
 
+// PW = false: the host did not ask for a piecewise map (no NVT_PATH_PIECES): the linear form,
+// straight-line code -- the GB home slots of a gather batch are computed and read together.
+// PW = true: the sample kernel may have chosen either form (run-time decision per call).
+template <bool PW>
+__device__ __forceinline__ uint32_t rp_fine(const RangeMap &map, int32_t key) {
+  if constexpr (PW) return map.fine(key);
+  else return map.template fine_staged<false>(key);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // pass 1: hot counters + range partition of the cold rows
@@ -69,7 +78,7 @@ __device__ __forceinline__ uint32_t hot_bucket_r(int32_t key) { return hot_image
 // BPW and the lane-role masks of the flush are constants -- the kernel sits at 100+ scalar
 // registers and spent scalar and vector instructions on them every round (SQ counters,
 // profiles/r05_sq_counters.json: 28 SALU + 70 VALU per key); 0 = the run-time value.
-template <int U, int NBL>
+template <int U, int NBL, bool PW>
 __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
     const int32_t *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
     const int32_t *__restrict__ aux, int nb_log2_rt, uint32_t region_cap, int32_t *__restrict__ regions,
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
 #pragma unroll
       for (int q = 0; q < 4 * U; ++q) {
         if ((pend >> q) & 1) {
-          const unsigned bkt = map.bucket(kv[q]);
+          const unsigned bkt = rp_fine<PW>(map, kv[q]) >> 14;
           const unsigned pos = atomicAdd(&fill[bkt], 1u);
           if (pos < CAP) {
             bins[bkt * CAP + pos] = kv[q];
@@ -335,6 +344,7 @@ __global__ __launch_bounds__(64 * kTotGroups) void hot_totals_kernel(
 // ---------------------------------------------------------------------------------------------
 // pass 2: one workgroup per bucket -> key-ordered (key, count) entries
 // ---------------------------------------------------------------------------------------------
+template <bool PW>
 __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
     const int32_t *__restrict__ regions, const uint32_t *__restrict__ fills, uint32_t region_cap,
     const int32_t *__restrict__ aux, const unsigned *__restrict__ hot_tot, int nb_log2,
@@ -348,11 +358,12 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
   __shared__ unsigned run_len[kRpG];
   __shared__ unsigned hist[256];
   __shared__ unsigned wtot[NW];
-  __shared__ unsigned lovf, s_b, s_bad;
+  __shared__ unsigned lovf, s_b, s_bad, s_mx;
   __shared__ unsigned long long s_base;
   if (threadIdx.x == 0) {
     s_b = atomicAdd(ticket, 1u);
     lovf = 0;
+    s_mx = 0;
   }
   for (int i = threadIdx.x; i < NSL; i += kRpBS) {
     lkeys[i] = kEmpty;
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
 #ifdef NVT_RANGE_TIMING
   long long tm[8];
   int tmi = 0;
-#define NVT_TM() do { if (threadIdx.x == 0 && b == NB / 2 + 7) tm[tmi++] = clock64(); } while (0)
+#define NVT_TM() do { if (threadIdx.x == 0) tm[tmi++] = clock64(); } while (0)
 #else
 #define NVT_TM() do {} while (0)
 #endif
@@ -445,12 +456,25 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
           kk[u] = rbase[(uint64_t)r * region_cap + (f - r_lo)];
         }
       }
+      // Home slots: a plain read of all GB first (a key that is already at home -- the repeated
+      // cold keys of the mid-cardinality columns -- needs nothing else: a returning CAS on a slot
+      // that many lanes share serialises, C2 55 -> 74 us with CAS only), then ONE compare-and-swap
+      // for the keys that found their home EMPTY (round 6: the first arrivals of a high-cardinality
+      // column, 16 M rows over 6 M keys, all went down the per-lane walk below -- an 8-way select,
+      // a dependent read and the CAS, ~150 instructions per key and wave).  Only true collisions
+      // walk.  (A lane past the end holds kEmpty and is skipped.)
       uint32_t hs[GB];
       int32_t cur[GB];
 #pragma unroll
+      for (int u = 0; u < GB; ++u) hs[u] = rp_fine<PW>(map, kk[u]) & (kRpSlots - 1);
+#pragma unroll
+      for (int u = 0; u < GB; ++u) cur[u] = lkeys[hs[u]];
+#pragma unroll
       for (int u = 0; u < GB; ++u) {
-        hs[u] = map.slot(kk[u]);
-        cur[u] = lkeys[hs[u]];
+        if (cur[u] == kEmpty && kk[u] != kEmpty) {
+          cur[u] = atomicCAS(&lkeys[hs[u]], kEmpty, kk[u]);
+          cur[u] = cur[u] == kEmpty ? kk[u] : cur[u];
+        }
       }
 #ifdef NVT_RP_SEQ_INSERT
 #pragma unroll
@@ -490,7 +514,8 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
             ws = u == q ? hs[q] : ws;
           }
           todo &= todo - 1u;
-          wp = 0;
+          ++ws;      // (the home slot holds another key: the CAS above saw it)
+          wp = 1;
           walking = true;
         }
         if (!__any(walking)) break;
@@ -527,7 +552,7 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
       const unsigned slot = order[jx];
       const int32_t key = aux[slot];
       const unsigned tot = hot_tot[slot];
-      if (key != kEmpty && tot > 0 && !failed) insert_from(key, tot, map.slot(key));
+      if (key != kEmpty && tot > 0 && !failed) insert_from(key, tot, rp_fine<PW>(map, key) & (kRpSlots - 1));
     }
   }
   if (failed) atomicOr(&lovf, 1u);
@@ -561,7 +586,6 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
   // quadratically -- report it like a table overflow
   const bool full = E > (unsigned)(kRpSlots / 4 * 3);
   if (bad || full) E = 0;
-  NVT_TM();
   // ---- decoupled look-back over the preceding buckets (wave 0) ----
   if (w == 0) {
     unsigned long long excl = 0;
@@ -713,32 +737,42 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
 #else
       if (pos == 0xFFFFFFFFFFull) out_keys[0] = k;
 #endif
+#ifndef NVT_RP_NOHIST
       atomicAdd(&hist[c < 255u ? c : 255u], 1u);
+#endif
       mx = c > mx ? c : mx;
       dump = ((unsigned long long)(uint32_t)pos << 32) | (uint32_t)k;
     }
     // the table as it stands in LDS becomes this bucket's region of the encode table: slot ->
     // {key, position in the key-ordered list}; the ordering pass turns positions into labels
+#ifndef NVT_RP_NODUMP
     if (range_table != nullptr && i < NSL) range_table[(uint64_t)b * NSL + i] = dump;
+#else
+    if (range_table != nullptr && i < NSL && dump == 0x1234567ull) range_table[(uint64_t)b * NSL + i] = dump;
+#endif
   }
+  NVT_TM();
+  // largest count of the bucket: waves -> LDS -> ONE device atomic per workgroup behind the last
+  // barrier.  (Round 6, phase timers: every wave read state[NVT_ST_MAXCOUNT] with a device-scope
+  // atomic load and raised it with atomicMax -- 16 waves x NB workgroups on one address -- and
+  // then waited for it in front of the barrier: 20-36 k of a workgroup's 105-145 k cycles.)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned o = __shfl_down(mx, off, 64);
     mx = o > mx ? o : mx;
   }
-  if (lane == 0 && mx > 0) {
-    unsigned long long *gm = reinterpret_cast<unsigned long long *>(&state[NVT_ST_MAXCOUNT]);
-    if (mx > __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMax(gm, (unsigned long long)mx);
-  }
+  if (lane == 0 && mx > 0) atomicMax(&s_mx, mx);
   if (range_table != nullptr && b == NB - 1 && threadIdx.x < kRpGuard)
     range_table[(uint64_t)NB * NSL + threadIdx.x] = kEncEmptySlot;
   __syncthreads();
   NVT_TM();
 #ifdef NVT_RANGE_TIMING
-  if (threadIdx.x == 0 && b == NB / 2 + 7)
-    for (int q = 1; q < tmi; ++q) state[9 + q] = (uint64_t)(tm[q] - tm[q - 1]);
+  if (threadIdx.x == 0)   // (summed over the buckets: tools/rp_phase_probe.py divides by NB)
+    for (int q = 1; q < tmi; ++q)
+      atomicAdd((unsigned long long *)&state[9 + q], (unsigned long long)(tm[q] - tm[q - 1]));
 #endif
+  if (threadIdx.x == 0 && s_mx > 0)
+    atomicMax(reinterpret_cast<unsigned long long *>(&state[NVT_ST_MAXCOUNT]), (unsigned long long)s_mx);
   if (threadIdx.x < 256) {
     const unsigned h = hist[threadIdx.x];
     if (h) atomicAdd(&cls_hist[threadIdx.x], h);
@@ -792,7 +826,7 @@ uint64_t range_count_ws_bytes(uint64_t n, int nb_log2) {
 // by hot_sample_kernel ahead of this call) and the class histogram (cleared here)
 int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int nb_log2, void *wsp,
                     int32_t *aux, int32_t *out_keys, int64_t *out_cnt, uint64_t out_cap,
-                    void *range_table, uint64_t *state, hipStream_t s) {
+                    void *range_table, uint64_t *state, hipStream_t s, bool pieces) {
   NVT_CHECK_ARG(nb_log2 >= 6 && nb_log2 <= kRpMaxNbLog2, "range path: 64 .. 1024 buckets");
   NVT_CHECK_ARG(aux != nullptr, "range path: the column needs its aux block (hot_image)");
   NVT_PROF("dense_count_r9", n * 4, s);
@@ -823,10 +857,15 @@ int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int n
   NVT_CHECK_HIP(hipMemsetAsync(w.status, 0, (uint64_t)NB * 8 + 64, s));
   NVT_CHECK_HIP(hipMemsetAsync(aux + NVT_RANGE_AUX_HIST, 0, 256 * 4, s));
 #endif
-#define NVT_RP_PART(NBL)                                                                         \
-  rp_partition_kernel<NVT_RANGE_U, NBL><<<kRpG, kRpBS, 0, s>>>(keys, valid, n, aux, nb_log2, cap, \
-                                                               w.regions, w.fills, w.hot_cnt,    \
-                                                               state, w.status, hist)
+#define NVT_RP_PART(NBL)                                                                            \
+  do {                                                                                              \
+    if (pieces)                                                                                     \
+      rp_partition_kernel<NVT_RANGE_U, NBL, true><<<kRpG, kRpBS, 0, s>>>(                           \
+          keys, valid, n, aux, nb_log2, cap, w.regions, w.fills, w.hot_cnt, state, w.status, hist); \
+    else                                                                                            \
+      rp_partition_kernel<NVT_RANGE_U, NBL, false><<<kRpG, kRpBS, 0, s>>>(                          \
+          keys, valid, n, aux, nb_log2, cap, w.regions, w.fills, w.hot_cnt, state, w.status, hist); \
+  } while (0)
   static const bool rt_nb = getenv("NVT_RANGE_RT_NB") != nullptr;  // (A/B: the run-time variant)
   if (rt_nb) NVT_RP_PART(0);
   else if (nb_log2 == 8) NVT_RP_PART(8);
@@ -839,10 +878,16 @@ int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int n
   hot_totals_kernel<<<kHotSlotsR / 64, 64 * kTotGroups, 0, s>>>(w.hot_cnt, kRpG, w.hot_tot);
   NVT_CHECK_LAUNCH();
   mark("totals");
-  rp_count_kernel<<<NB, kRpBS, 0, s>>>(w.regions, w.fills, cap, aux, w.hot_tot, nb_log2, w.status,
-                                       w.ticket, out_keys, out_cnt, out_cap,
-                                       (unsigned *)(aux + NVT_RANGE_AUX_HIST),
-                                       (unsigned long long *)range_table, state);
+  if (pieces)
+    rp_count_kernel<true><<<NB, kRpBS, 0, s>>>(w.regions, w.fills, cap, aux, w.hot_tot, nb_log2, w.status,
+                                               w.ticket, out_keys, out_cnt, out_cap,
+                                               (unsigned *)(aux + NVT_RANGE_AUX_HIST),
+                                               (unsigned long long *)range_table, state);
+  else
+    rp_count_kernel<false><<<NB, kRpBS, 0, s>>>(w.regions, w.fills, cap, aux, w.hot_tot, nb_log2, w.status,
+                                                w.ticket, out_keys, out_cnt, out_cap,
+                                                (unsigned *)(aux + NVT_RANGE_AUX_HIST),
+                                                (unsigned long long *)range_table, state);
   NVT_CHECK_LAUNCH();
   mark("count");
   return NVT_OK;
