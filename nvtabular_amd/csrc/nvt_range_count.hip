@@ -53,6 +53,10 @@ constexpr int kRpMaxNbLog2 = 10;
 constexpr int kHotSlotsR = NVT_HOT_IMAGE_WORDS;
 constexpr int kHotBucketsR = kHotSlotsR / 2;
 constexpr int kRpProbe = 512;
+#ifndef NVT_RP_MAX_EPOCH
+#define NVT_RP_MAX_EPOCH 8
+#endif
+constexpr unsigned kRpMaxEpoch = NVT_RP_MAX_EPOCH;   // rounds between two flushes of the partition bins, at most
 #ifndef NVT_RANGE_U
 #define NVT_RANGE_U 2
 #endif
@@ -116,22 +120,49 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
   RangeMap map = load_map(aux);
   __shared__ uint32_t s_pieces[kRpPwWords];
   stage_pieces(map, s_pieces, threadIdx.x, kRpBS);
+#ifdef NVT_RP_PART_TIMING
+  long long ptm[8];
+  int ptmi = 0;
+#define NVT_PTM() do { if (threadIdx.x == 0) ptm[ptmi++] = clock64(); } while (0)
+#else
+#define NVT_PTM() do {} while (0)
+#endif
+  NVT_PTM();
   __syncthreads();
+  NVT_PTM();
 
   // flush every bin that holds >= kRpLine keys (or, with `all`, whatever it holds): one
   // 16-lane group per bin, four bins per wave instruction; bin t is owned by thread t
   // ... spread over ALL 16 waves: wave w owns bins [w * NB / 16, (w + 1) * NB / 16), lane l the
   // bookkeeping of the l-th of them.  (With thread t owning bin t, 256 buckets kept 4 waves busy
   // and 12 waiting at the barrier for up to 16 rounds of the loop below.)
+  // Round 6: a key that finds its bin full no longer waits for a flush -- it is stored straight to
+  // its place in the region (its returned position IS its offset behind what the bin has
+  // flushed), so appends never fail, the retry loop with its workgroup-wide OR is gone and the
+  // barrier pair + flush run once per EPOCH of R rounds (R adapts: see the loop).  A bin that
+  // overflowed in an epoch (fill > CAP) is emptied completely and its region is padded with the
+  // empty key up to the next line (rp_count_kernel skips empty keys in its gather).
   const unsigned BPW = NB / (kRpBS / kWave);  // 16 / 32 / 64 bins per wave
-  auto flush_bins = [&](bool all) {
+  __shared__ unsigned s_epoch[2];             // per epoch parity: bit 0 = a bin above CAP / 2, bits 8.. = bins that overflowed
+  if (threadIdx.x < 2) s_epoch[threadIdx.x] = 0;   // (a barrier follows before the first flush)
+  auto flush_bins = [&](bool all, unsigned parity) {
     {
       const bool owner = lane < BPW;
       const unsigned wave_base = (threadIdx.x / kWave) * BPW;
       const unsigned t = wave_base + (owner ? lane : 0u);
-      unsigned f = owner ? fill[t] : 0u;
-      f = f < CAP ? f : CAP;
-      const unsigned nfl = all ? f : (f / kRpLine) * kRpLine;  // keys leaving the bin
+      const unsigned fr = owner ? fill[t] : 0u;     // appended since the last flush (may exceed CAP)
+      const unsigned done0 = owner ? flushed[t] : 0u;
+      const bool over = fr > CAP;
+      const unsigned f = over ? CAP : fr;           // keys the bin itself holds
+      const unsigned nfl = (all || over) ? f : (f / kRpLine) * kRpLine;  // keys leaving the bin
+      // an overflowed bin: [done0 + CAP, done0 + fr) is in the region already; pad to a line
+      const unsigned padn = over ? ((0u - (done0 + fr)) & (kRpLine - 1u)) : 0u;
+      {
+        const unsigned long long ob = __ballot(over);
+        const unsigned long long hb = __ballot(fr * 2u > CAP);
+        if (lane == 0 && (ob | hb))
+          atomicAdd(&s_epoch[parity], ((unsigned)__popcll(ob) << 8) | (hb ? 1u : 0u));
+      }
       unsigned long long todo = __ballot(nfl > 0);
       const unsigned sub = lane >> 4, l16 = lane & 15;
       while (todo) {
@@ -144,16 +175,18 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
         }
         const unsigned src = sel >= 0 ? (unsigned)sel : 0u;
         const unsigned fb = __shfl(f, src, 64), nb_out = __shfl(nfl, src, 64);
+        const unsigned done = __shfl(done0, src, 64), frb = __shfl(fr, src, 64), pb = __shfl(padn, src, 64);
         if (sel >= 0) {
           const unsigned bin = wave_base + (unsigned)sel;
-          const unsigned done = flushed[bin];
           const int32_t *bsrc = bins + bin * CAP;
-          if (done + nb_out > region_cap) {
+          const unsigned reach = frb > fb ? done + frb + pb : done + nb_out;  // region words in use afterwards
+          if (reach > region_cap) {
             if (l16 == 0) atomicOr(&s_ovf, 1u);
           } else {
             int32_t *dst = regions + ((uint64_t)bin * kRpG + g) * region_cap + done;
 #ifndef NVT_RP_NOFLUSHSTORE
             for (unsigned u = l16; u < nb_out; u += kRpLine) dst[u] = bsrc[u];
+            if (l16 < pb) dst[frb + l16] = kEmpty;
 #else
             if (done == 0xFFFFFFu) dst[0] = bsrc[0];
 #endif
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
       }
       if (owner) {
         fill[t] = f - nfl;
-        flushed[t] += nfl;
+        flushed[t] = over ? done0 + fr + padn : done0 + nfl;
       }
     }
   };
@@ -223,6 +256,7 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
       tpack = make_int4(kk[0], kk[1], kk[2], kk[3]);
     }
   }
+  unsigned R = 1, since = 0, epoch = 0;
   if (vf_hi > v_lo) issue(v_lo + threadIdx.x);
   for (uint64_t v0 = v_lo; v0 < vf_hi || tail_round; v0 += (uint64_t)kRpBS * U) {
     const bool is_tail = !(v0 < vf_hi);   // (uniform)
@@ -280,27 +314,51 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
         pend |= ((okj & !is_sent & !hit) ? 1u : 0u) << q;
       }
     }
-    // append the cold keys; a key whose bin is full waits for the flush and tries again
-    while (true) {
-      if (s_ovf) pend = 0;  // a region overflowed: the column is rerun on a hash path anyway
+    // append the cold keys; a key whose bin is full goes straight to its place in the region
+    if (s_ovf) pend = 0;  // a region overflowed: the column is rerun on a hash path anyway
 #pragma unroll
-      for (int q = 0; q < 4 * U; ++q) {
-        if ((pend >> q) & 1) {
-          const unsigned bkt = rp_fine<PW>(map, kv[q]) >> 14;
-          const unsigned pos = atomicAdd(&fill[bkt], 1u);
-          if (pos < CAP) {
-            bins[bkt * CAP + pos] = kv[q];
-            pend &= ~(1u << q);
-          }
+    for (int q = 0; q < 4 * U; ++q) {
+      if ((pend >> q) & 1) {
+        const unsigned bkt = rp_fine<PW>(map, kv[q]) >> 14;
+        const unsigned pos = atomicAdd(&fill[bkt], 1u);
+        if (pos < CAP) {
+          bins[bkt * CAP + pos] = kv[q];
+        } else {
+          const unsigned at = flushed[bkt] + pos;   // (flushed[] only changes between the barriers of a flush)
+          if (at < region_cap)
+            regions[((uint64_t)bkt * kRpG + g) * region_cap + at] = kv[q];
+          else
+            atomicOr(&s_ovf, 1u);
         }
       }
+    }
+    // Epochs: the barrier pair + flush cost 20-25 % of this loop when they ran every round (phase
+    // timers, round 6).  R doubles (up to 8) after an epoch in which at most NB / 16 bins overflowed
+    // into direct stores and halves after one in which more than NB / 4 did (swept on C1 / C20 /
+    // C23: NB / 256 .. NB / 8 to grow; a direct store costs less than the barriers it saves).
+    if (++since >= R) {
       __syncthreads();
-      flush_bins(false);
-      if (!__syncthreads_or(pend != 0)) break;
+      flush_bins(false, epoch & 1u);
+      if (threadIdx.x == 0) s_epoch[(epoch + 1u) & 1u] = 0;
+      __syncthreads();
+      const unsigned fl = s_epoch[epoch & 1u];
+#ifndef NVT_RP_GROW_DIV
+#define NVT_RP_GROW_DIV 16u
+#endif
+#ifndef NVT_RP_SHRINK_DIV
+#define NVT_RP_SHRINK_DIV 4u
+#endif
+      if ((fl >> 8) > NB / NVT_RP_SHRINK_DIV) R = R > 1u ? R / 2u : 1u;
+      else if ((fl >> 8) <= NB / NVT_RP_GROW_DIV) R = R < kRpMaxEpoch ? R * 2u : R;
+      ++epoch;
+      since = 0;
     }
   }
-  flush_bins(true);
+  __syncthreads();   // (the loop may end inside an epoch)
+  NVT_PTM();
+  flush_bins(true, epoch & 1u);
   __syncthreads();
+  NVT_PTM();
   for (unsigned b = threadIdx.x; b < NB; b += kRpBS) fills[(uint64_t)b * kRpG + g] = flushed[b];
   for (int i = threadIdx.x; i < kHotSlotsR; i += kRpBS) hot_cnt[(uint64_t)g * kHotSlotsR + i] = tc[i];
 #pragma unroll
@@ -319,6 +377,13 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
     if (s_ovf) atomicOr((unsigned long long *)&state[NVT_ST_OVERFLOW], 1ull | NVT_OVF_REGION);
     if (g == 0) atomicAdd((unsigned long long *)&state[NVT_ST_ROWS], (unsigned long long)n);
   }
+#ifdef NVT_RP_PART_TIMING
+  __syncthreads();
+  NVT_PTM();
+  if (threadIdx.x == 0)
+    for (int q = 1; q < ptmi; ++q)
+      atomicAdd((unsigned long long *)&state[9 + q], (unsigned long long)(ptm[q] - ptm[q - 1]));
+#endif
 }
 
 // totals per hot slot = column sums of the per-workgroup counters (64 slots per workgroup x 16
