@@ -96,8 +96,9 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
     for (unsigned i = blockIdx.x * kRpBS + threadIdx.x; i < nst; i += kRpG * kRpBS) clr_status[i] = 0ull;
     if (blockIdx.x == kRpG - 1 && threadIdx.x < 256) clr_hist[threadIdx.x] = 0u;
   }
-  __shared__ int2 tk[kHotBucketsR];
-  __shared__ unsigned tc[kHotSlotsR];
+  // hot bucket = {key0, key1, count0, count1}: the counter of a hit sits 8 / 12 bytes behind the keys
+  // the lookup has read (one address computation for both)
+  __shared__ int4 hot[kHotBucketsR];
   __shared__ int32_t bins[kRpBinWords];
   __shared__ unsigned fill[1 << kRpMaxNbLog2], flushed[1 << kRpMaxNbLog2];
   __shared__ unsigned scratch[kWave];  // one word per lane: target of the adds of non-hits
@@ -105,9 +106,18 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
   __shared__ unsigned s_ovf;
   const unsigned NB = 1u << nb_log2, CAP = (unsigned)kRpBinWords >> nb_log2;
   const unsigned g = blockIdx.x, lane = lane_id();
-  for (int i = threadIdx.x; i < kHotBucketsR; i += kRpBS)
-    tk[i] = reinterpret_cast<const int2 *>(aux)[i];
-  for (int i = threadIdx.x; i < kHotSlotsR; i += kRpBS) tc[i] = 0;
+  // Empty image slots are filled with a key that can never be LOOKED UP in their bucket (a filler
+  // whose own bucket is another one), and null rows are looked up as the empty key: nothing in
+  // the table equals the empty key, so the classification below needs no validity / sentinel
+  // terms per key (round 6: 26 -> 18 vector and ~20 -> ~5 scalar instructions per key).
+  int32_t fill0 = 0x5A5A5A5A, fill1 = fill0 + 1;
+  while (hot_bucket_r(fill1) == hot_bucket_r(fill0)) ++fill1;
+  const uint32_t fb0 = hot_bucket_r(fill0);
+  for (int i = threadIdx.x; i < kHotBucketsR; i += kRpBS) {
+    const int2 k2 = reinterpret_cast<const int2 *>(aux)[i];
+    const int32_t fk = (uint32_t)i != fb0 ? fill0 : fill1;
+    hot[i] = make_int4(k2.x == kEmpty ? fk : k2.x, k2.y == kEmpty ? fk : k2.y, 0, 0);
+  }
   for (unsigned i = threadIdx.x; i < NB; i += kRpBS) {
     fill[i] = 0;
     flushed[i] = 0;
@@ -211,7 +221,8 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
   const uint64_t v_lo = (uint64_t)g * per;
   const uint64_t v_hi = v_lo + per < nvec ? v_lo + per : nvec;
   const uint64_t vf_hi = v_hi < nfull ? v_hi : nfull;   // full vectors of this slab: [v_lo, vf_hi)
-  unsigned long long nulls = 0, sent = 0;
+  unsigned long long nulls = 0, notvalid = 0;
+  unsigned long long empties = 0;   // (wave-uniform: the same in every lane)
   // U vectors per thread per round: the rounds of a workgroup are separated by two barriers, so
   // the load latency of a round is exposed unless the next round's loads are already in flight.
   // Round 6: they never were -- the loads sat under `if (v < v_hi)` / `if (valid)` and the
@@ -285,33 +296,43 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
       issue(v0 + (uint64_t)kRpBS * U + threadIdx.x);   // (clamped: the last round reads its own again)
     }
     // Branch-free classification of the round's keys (the per-key if / else ladder compiled to
-    // as many exec-mask instructions as there was arithmetic: ~190 instructions per key).  Every
-    // key reads its hot bucket; hits add 1 to their counter, every other lane adds 0 to a scratch
-    // word of its own; `pend` collects the valid, non-sentinel misses.
+    // as many exec-mask instructions as there was arithmetic: ~190 instructions per key).  A null
+    // (or absent) row is looked up as the empty key, which is in no bucket: every key reads its
+    // hot bucket; hits add 1 to their counter, every other lane adds 0 to a scratch word of its
+    // own; `pend` collects the misses that are not the empty key.  Empty keys are counted per
+    // WAVE (ballot + scalar popcount): sentinel rows = empty keys seen - rows without a valid bit.
     unsigned pend = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned ok = oks[u], in = ins[u];
       nulls += __popc(in & ~ok);
-      int2 hb[4];
+      notvalid += 4u - __popc(ok);
+      int32_t kp[4];
+      int4 hb[4];
       uint32_t sa[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        sa[j] = hot_bucket_r(kv[4 * u + j]);
-        hb[j] = tk[sa[j]];
+        const int32_t m = (int32_t)(ok << (31 - j)) >> 31;   // all ones: row j carries a key
+        kp[j] = (kv[4 * u + j] & m) | (kEmpty & ~m);
+        sa[j] = hot_bucket_r(kp[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int2 kk2 = *reinterpret_cast<const int2 *>(&hot[sa[j]]);   // (the keys: 8 of the 16 bytes)
+        hb[j].x = kk2.x;
+        hb[j].y = kk2.y;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int q = 4 * u + j;
-        const int32_t key = kv[q];
-        const bool okj = (ok >> j) & 1;
-        const bool is_sent = okj & (key == kEmpty);
+        const int32_t key = kp[j];
         const bool hx = hb[j].x == key, hy = hb[j].y == key;
-        const bool hit = okj & !is_sent & (hx | hy);
-        const unsigned slot = 2u * sa[j] + (hy ? 1u : 0u);
-        atomicAdd(hit ? &tc[slot] : &scratch[lane], hit ? 1u : 0u);
-        sent += is_sent ? 1u : 0u;
-        pend |= ((okj & !is_sent & !hit) ? 1u : 0u) << q;
+        const bool hit = hx | hy;
+        const bool is_e = key == kEmpty;
+        empties += (unsigned)__popcll(__ballot(is_e));
+        unsigned *cnt = reinterpret_cast<unsigned *>(&hot[sa[j]]) + (hy ? 3 : 2);
+        atomicAdd(hit ? cnt : &scratch[lane], hit ? 1u : 0u);
+        pend |= ((!hit & !is_e) ? 1u : 0u) << q;
       }
     }
     // append the cold keys; a key whose bin is full goes straight to its place in the region
@@ -360,14 +381,18 @@ __global__ __launch_bounds__(kRpBS) void rp_partition_kernel(
   __syncthreads();
   NVT_PTM();
   for (unsigned b = threadIdx.x; b < NB; b += kRpBS) fills[(uint64_t)b * kRpG + g] = flushed[b];
-  for (int i = threadIdx.x; i < kHotSlotsR; i += kRpBS) hot_cnt[(uint64_t)g * kHotSlotsR + i] = tc[i];
+  for (int i = threadIdx.x; i < kHotBucketsR; i += kRpBS) {
+    const int4 hbk = hot[i];
+    reinterpret_cast<uint2 *>(hot_cnt + (uint64_t)g * kHotSlotsR)[i] = make_uint2((unsigned)hbk.z, (unsigned)hbk.w);
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     nulls += __shfl_down(nulls, off, 64);
-    sent += __shfl_down(sent, off, 64);
+    notvalid += __shfl_down(notvalid, off, 64);
   }
   if (lane == 0) {
     if (nulls) atomicAdd(&s_nulls, nulls);
+    const unsigned long long sent = empties - notvalid;   // (of this wave)
     if (sent) atomicAdd(&s_sent, sent);
   }
   __syncthreads();
