@@ -499,46 +499,82 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
     }
     failed = true;
   };
-  // Wave w gathers runs w*16 .. w*16+15 (~60-700 keys each) through ONE flat index over their
-  // concatenation: every lane has a key in every step, eight loads are in flight per lane, and
-  // the home slots of a batch are read together before the (dependent) probe chains start.
-  // (One run after the other was a chain of 16 dependent global loads per wave.)
+  // the hot keys of this bucket's range: requested now, inserted behind the gather
+  const unsigned hot_h0 = (unsigned)aux[NVT_RANGE_AUX_HOTSTART + b], hot_h1 = (unsigned)aux[NVT_RANGE_AUX_HOTSTART + b + 1];
+  int32_t hot_key0 = kEmpty;
+  unsigned hot_tot0 = 0;
+  if (hot_h0 + threadIdx.x < hot_h1) {
+    const unsigned slot = reinterpret_cast<const unsigned short *>(aux + NVT_RANGE_AUX_HOTORDER)[hot_h0 + threadIdx.x];
+    hot_key0 = aux[slot];
+    hot_tot0 = hot_tot[slot];
+  }
+  // The bucket's kRpG runs (~60-700 keys each) are gathered through ONE flat index over their
+  // concatenation, cut into equal shares for the 16 waves (round 6: wave w used to take runs
+  // w*16 .. w*16+15 whatever their lengths, and the workgroup waited 18 k of its 126 k cycles for
+  // the wave with the longest runs): every lane has a key in every step, eight loads are in flight
+  // per lane, and the home slots of a batch are read together before the (dependent) probe chains
+  // start.  (One run after the other was a chain of 16 dependent global loads per wave.)
   {
-    constexpr int RPW = kRpG / NW;  // runs per wave
-    // prefix of this wave's run lengths in LDS: lane q <= RPW holds pre[q].  Which run a flat
-    // index f falls in is followed by a per-lane cursor -- f only grows for a lane, so the cursor
-    // moves RPW times in the whole walk (one LDS compare per key).  The first version counted
-    // `f >= pre[q]` over all 16 runs and then selected pre[r] out of registers: ~60 vector
+    // exclusive prefix of the run lengths in LDS: s_pre[q] = keys in front of run q, s_pre[kRpG] =
+    // all of them.  Which run a flat index f falls in is followed by a per-lane cursor -- f only
+    // grows for a lane, so the cursor moves over each run once in the whole walk (one LDS compare
+    // per key) after a binary search for the lane's first index.  The first version counted
+    // `f >= pre[q]` over 16 runs and then selected pre[r] out of registers: ~60 vector
     // instructions per gathered key for one address (SQ counters, profiles/r05_notes.md).
-    __shared__ unsigned s_pre[NW][RPW + 2];
+    __shared__ unsigned s_pre[kRpG + 2];
+    __shared__ unsigned s_wsum[kRpG / kWave];
+    static_assert(kRpG % kWave == 0 && kRpG <= kRpBS, "one thread per run");
     {
-      unsigned acc = 0;
+      unsigned len = 0, inc = 0;
+      if (threadIdx.x < kRpG) {
+        len = run_len[threadIdx.x];
+        inc = len;
 #pragma unroll
-      for (int q = 0; q < RPW; ++q) {
-        if (lane == (unsigned)q) s_pre[w][q] = acc;
-        acc += run_len[w * RPW + q];
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned o = __shfl_up(inc, off, 64);
+          if (lane >= (unsigned)off) inc += o;
+        }
+        if (lane == 63) s_wsum[w] = inc;
       }
-      if (lane == (unsigned)RPW) s_pre[w][RPW] = acc;
+      __syncthreads();
+      if (threadIdx.x < kRpG) {
+        unsigned wb = 0;
+        for (unsigned q = 0; q < w; ++q) wb += s_wsum[q];
+        s_pre[threadIdx.x] = wb + inc - len;
+        if (threadIdx.x == kRpG - 1) s_pre[kRpG] = wb + inc;
+      }
     }
-    __syncthreads();                  // (lanes read the words other lanes of their wave wrote)
-    const unsigned *pre = s_pre[w];
-    unsigned total = 0;
-#pragma unroll
-    for (int q = 0; q < RPW; ++q) total += run_len[w * RPW + q];
-    const int32_t *rbase = regions + ((uint64_t)b * kRpG + w * RPW) * region_cap;
+    __syncthreads();
+    const unsigned *pre = s_pre;
+    const unsigned all_keys = pre[kRpG];
+    const unsigned share = (all_keys + NW - 1) / NW;
+    const unsigned f_lo = w * share < all_keys ? w * share : all_keys;
+    const unsigned total = f_lo + share < all_keys ? f_lo + share : all_keys;   // this wave: [f_lo, total)
+    const int32_t *rbase = regions + (uint64_t)b * kRpG * region_cap;
 #ifndef NVT_RP_GB
 #define NVT_RP_GB 8
 #endif
     constexpr int GB = NVT_RP_GB;
-    unsigned r = 0, r_lo = 0, r_hi = pre[1];   // cursor: run r covers flat indices [r_lo, r_hi)
-    for (unsigned f0 = 0; f0 < total && !failed; f0 += GB * kWave) {
+    // cursor: run r covers flat indices [r_lo, r_hi); start = the run of this lane's first index
+    unsigned r = 0;
+    {
+      const unsigned f = f_lo + lane < all_keys ? f_lo + lane : (all_keys ? all_keys - 1 : 0);
+      unsigned lo = 0, hi = kRpG;   // largest r with pre[r] <= f
+      while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (pre[mid] <= f) lo = mid; else hi = mid;
+      }
+      r = lo;
+    }
+    unsigned r_lo = pre[r], r_hi = pre[r + 1];
+    for (unsigned f0 = f_lo; f0 < total && !failed; f0 += GB * kWave) {
       int32_t kk[GB];
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const unsigned f = f0 + u * kWave + lane;
         kk[u] = kEmpty;
         if (f < total) {
-          while (f >= r_hi) {   // (f < total = pre[RPW]: the cursor stops at the last run at the latest)
+          while (f >= r_hi) {   // (f < total <= pre[kRpG]: the cursor stops at the last run at the latest)
             ++r;
             r_lo = r_hi;
             r_hi = pre[r + 1];
@@ -635,10 +671,13 @@ __global__ __launch_bounds__(kRpBS) void rp_count_kernel(
   NVT_TM();
   // the hot keys of this range (indexed by bucket by the sample kernel), with the totals of
   // their counters
+  // (the first of them per thread -- all of them unless a bucket holds > 1024 -- was loaded in front of
+  // the gather: three dependent global loads, 15 k cycles of a 123 k-cycle workgroup when they sat here)
   {
-    const unsigned h0 = (unsigned)aux[NVT_RANGE_AUX_HOTSTART + b], h1 = (unsigned)aux[NVT_RANGE_AUX_HOTSTART + b + 1];
+    if (hot_key0 != kEmpty && hot_tot0 > 0 && !failed)
+      insert_from(hot_key0, hot_tot0, rp_fine<PW>(map, hot_key0) & (kRpSlots - 1));
     const unsigned short *order = reinterpret_cast<const unsigned short *>(aux + NVT_RANGE_AUX_HOTORDER);
-    for (unsigned jx = h0 + threadIdx.x; jx < h1; jx += kRpBS) {
+    for (unsigned jx = hot_h0 + threadIdx.x + kRpBS; jx < hot_h1; jx += kRpBS) {
       const unsigned slot = order[jx];
       const int32_t key = aux[slot];
       const unsigned tot = hot_tot[slot];
