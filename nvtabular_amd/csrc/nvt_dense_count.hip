@@ -297,8 +297,16 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
   __shared__ K lkeys[SLOTS];
   __shared__ C lcnt[SLOTS + kWave];  // + one scratch word per lane (see the unconditional add)
   __shared__ unsigned rcnt[kRanges], wtot[kRanges / kWave];
-  __shared__ unsigned lfill, lovf;
+  __shared__ unsigned lfill, lovf, s_next;
   __shared__ unsigned long long s_nulls, s_sent;
+#ifdef NVT_STAGE_TIMING
+  long long tm[8];
+  int tmi = 0;
+#define NVT_STM() do { if (threadIdx.x == 0) tm[tmi++] = clock64(); } while (0)
+#else
+#define NVT_STM() do {} while (0)
+#endif
+  NVT_STM();
   for (int i = threadIdx.x; i < SLOTS; i += kStageBS) {
     lkeys[i] = EMPTY;
     lcnt[i] = 0;
@@ -307,10 +315,12 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
   if (threadIdx.x == 0) {
     lfill = 0;
     lovf = 0;
+    s_next = 0;
     s_nulls = 0;
     s_sent = 0;
   }
   __syncthreads();
+  NVT_STM();
   const unsigned split = 1u << split_bits, split_mask = split - 1;
   const unsigned q = (blockIdx.x >> 3) & split_mask;
   const unsigned slab = ((blockIdx.x >> (3 + split_bits)) << 3) | (blockIdx.x & 7);
@@ -354,7 +364,18 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
     const uint64_t per_slab = (nvec + kSlabs - 1) / kSlabs;
     const uint64_t slab_lo = (uint64_t)slab * per_slab;
     const uint64_t slab_hi = slab_lo + per_slab < nvec ? slab_lo + per_slab : nvec;
-    constexpr uint64_t vstride = kStageBS;  // distance between the U vectors of one batch
+    // Round 6: a wave takes its batches of U x 64 consecutive vectors from a counter in LDS.  With a
+    // fixed share per wave the oldest wave of a SIMD (it wins the issue arbitration) was through
+    // with its share at 55 % of the loop's duration and the workgroup waited for the youngest one
+    // with one wave per SIMD left to hide its LDS round trips (phase timers: 34-41 % of the kernel
+    // between the first wave's last batch and the last wave's).
+    constexpr uint64_t vstride = kWave;  // distance between the U vectors of one batch
+    const uint64_t nbatch = (slab_hi > slab_lo ? slab_hi - slab_lo + vstride * U - 1 : 0) / (vstride * U);
+    auto grab = [&]() -> uint64_t {
+      unsigned c = 0;
+      if (lane_id() == 0) c = atomicAdd(&s_next, 1u);
+      return (uint64_t)__builtin_amdgcn_readfirstlane((int)c);
+    };
     auto issue = [&](uint64_t v0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -366,10 +387,12 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
         }
       }
     };
-    issue(slab_lo + threadIdx.x);
+    uint64_t batch = grab();
+    issue(slab_lo + batch * (vstride * U) + lane_id());
     unsigned fill_now = 0;  // refreshed with the batched home-slot reads below: a separate read
                             // here would drain every queued LDS atomic of the previous batch
-    for (uint64_t v0 = slab_lo + threadIdx.x; v0 < slab_hi; v0 += vstride * U) {
+    while (batch < nbatch) {
+      const uint64_t v0 = slab_lo + batch * (vstride * U) + lane_id();
       if (fill_now > (unsigned)max_fill(SLOTS)) break;  // filling up: the column needs a larger path
       if (fill_now > kRepFill) rep = 0;
       VecT pack[U];
@@ -379,7 +402,8 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
         pack[u] = npack[u];
         vb[u] = nvb[u];
       }
-      issue(v0 + vstride * U);
+      batch = grab();
+      issue(slab_lo + batch * (vstride * U) + lane_id());   // (past the slab: no loads)
       // Probe in two sweeps.  Sweep 1 reads the HOME slot of every key of the batch -- U * VEC
       // independent LDS reads behind one wait; a key already sitting there (the common case
       // once the table is warm) only needs a fire-and-forget ds_add.  Sweep 2 walks the
@@ -499,10 +523,12 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
       }
     }
   }
+  NVT_STM();
   if (failed) atomicOr(&lovf, 1u);
   if (q == 0 && my_nulls) atomicAdd(&s_nulls, my_nulls);
   if (my_sent) atomicAdd(&s_sent, my_sent);
   __syncthreads();
+  NVT_STM();
   if (lovf || lfill > (unsigned)max_fill(SLOTS)) {
     if (threadIdx.x == 0) atomicOr((unsigned long long *)&state[DS_OVF], 1ull);
     // stage 2 must not read stale offsets from this list
@@ -557,6 +583,13 @@ __global__ __launch_bounds__(kStageBS) void lds_stage_kernel(
       oc[pos] = (int64_t)lcnt[i];
     }
   }
+#ifdef NVT_STAGE_TIMING
+  __syncthreads();
+  NVT_STM();
+  if (threadIdx.x == 0)
+    for (int t = 1; t < tmi; ++t)
+      atomicAdd((unsigned long long *)&state[9 + t], (unsigned long long)(tm[t] - tm[t - 1]));
+#endif
 }
 
 // Path S, stage 2: workgroup (q, r) merges segment r of the kSlabs partial lists of class q.
