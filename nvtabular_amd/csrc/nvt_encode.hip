@@ -854,6 +854,8 @@ __global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
   const int2 *tkeys = reinterpret_cast<const int2 *>(lraw);
   const uint32_t *tlab = reinterpret_cast<const uint32_t *>(lraw + kHead16Buckets * 8);
   __shared__ long long s_sent;
+  __shared__ unsigned s_next;   // batches handed out to the waves
+  if (threadIdx.x == 0) s_next = 0;
   if (head_image != nullptr) {
     const int4 *src = reinterpret_cast<const int4 *>(head_image);
     int4 *dst = reinterpret_cast<int4 *>(lraw);
@@ -865,6 +867,9 @@ __global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
   const int32_t sent = (int32_t)*sentinel_label;   // (-1: the sentinel key is not in the vocabulary)
   const unsigned long long *tw = reinterpret_cast<const unsigned long long *>(table);
   const char *tbytes = reinterpret_cast<const char *>(table);
+#ifdef NVT_ENC_PIPE_TIMING
+  const long long t_begin = clock64();
+#endif
 
   unsigned st_miss = 0, st_rows = 0;  // (count_stats)
   // (the linear / piecewise form of the range map is decided once, outside the loops)
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
     // registers that live across the phases.  The vector index of a thread is even with its
     // thread index (vb0 and stride are multiples of 1024): its validity nibble is the low or the
     // high half of byte (base >> 1) + (thread >> 1).
-    const unsigned tid = threadIdx.x;
+    const unsigned tid = threadIdx.x, lane = lane_id();
     const unsigned nib = (tid & 1u) * 4u;
     int4 nxt_pack[U];
     unsigned nxt_vb[U];
@@ -952,14 +957,18 @@ __global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
       unsigned need;              // bit q: key q is still unresolved (its label is in the table in HBM)
       unsigned vb[U];             // bits 0-3: rows valid
     };
-    auto request_keys = [&](uint64_t step) {   // (scalar)
+    // batch j of the workgroup = the 64 vectors (x U) of wave slot (j & 15) in its step (j >> 4)
+    auto batch_base = [&](uint64_t j, int u) -> uint64_t {   // (scalar)
+      return vb0 + (j >> 4) * SU + (uint64_t)u * stride + (j & 15u) * (uint64_t)kWave;
+    };
+    auto request_keys = [&](uint64_t j) {   // (scalar)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint64_t vs = vb0 + step * SU + (uint64_t)u * stride;
+        const uint64_t vs = batch_base(j, u);
         const nvt_v4i raw = __builtin_nontemporal_load(
-            reinterpret_cast<const NVT_GLOBAL_AS nvt_v4i *>(uniform_gptr(vkeys + vs)) + tid);
+            reinterpret_cast<const NVT_GLOBAL_AS nvt_v4i *>(uniform_gptr(vkeys + vs)) + lane);
         nxt_pack[u] = make_int4(raw.x, raw.y, raw.z, raw.w);
-        nxt_vb[u] = (unsigned)uniform_gptr(vsrc + (vs >> 1))[tid >> 1];   // (used one step later)
+        nxt_vb[u] = (unsigned)uniform_gptr(vsrc + (vs >> 1))[lane >> 1];   // (used one step later)
       }
     };
     auto lds_phase = [&](Stage &st) {   // [b]
@@ -1025,10 +1034,10 @@ __global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
         for (int j = 0; j < NK; ++j) st.lab[j] = q == j ? lab : st.lab[j];
       }
     };
-    auto store = [&](const Stage &st, uint64_t step) {   // [e]
+    auto store = [&](const Stage &st, uint64_t j) {   // [e]
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint64_t vs = vb0 + step * SU + (uint64_t)u * stride;
+        const uint64_t vs = batch_base(j, u);
         OUT r[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -1036,7 +1045,7 @@ __global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
           r[j] = ((st.vb[u] >> j) & 1u) ? finish(st.k[q], st.lab[q]) : (OUT)null_label;
         }
         NVT_GLOBAL_AS nvt_v4i *dst =
-            reinterpret_cast<NVT_GLOBAL_AS nvt_v4i *>(uniform_gptr(out + vs * VEC)) + tid * (VEC * sizeof(OUT) / 16);
+            reinterpret_cast<NVT_GLOBAL_AS nvt_v4i *>(uniform_gptr(out + vs * VEC)) + lane * (VEC * sizeof(OUT) / 16);
         nvt_v4i a;
         memcpy(&a, &r[0], 16);
         __builtin_nontemporal_store(a, dst);
@@ -1047,67 +1056,90 @@ __global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
         }
       }
     };
-    if (nfull < 2) nfull = 0;   // (a single step has nothing to overlap: the plain path below)
-    if (nfull > 0) {
+    // Round 6: a wave draws its batches from a counter in LDS.  With a fixed share per wave the
+    // oldest waves of a SIMD finished 10-43 % of the loop's duration before the youngest (C1 / C11 /
+    // C2 / C23: 78 k of 798 k, 117 k of 427 k, 108 k of 258 k, 158 k of 367 k cycles between the first
+    // wave's end and the last's), and the tail ran with too few waves to cover its probes.
+    const uint64_t WB = nfull * (uint64_t)(kEncBS / kWave);
+    auto grab = [&]() -> uint64_t {
+      unsigned c = 0;
+      if (lane == 0) c = atomicAdd(&s_next, 1u);
+      return (uint64_t)__builtin_amdgcn_readfirstlane((int)c);
+    };
+    auto in_range = [&](uint64_t j) { return j < WB ? j : WB - 1; };   // (a batch to read again, unused)
+    if (WB > 0) {
       Stage s0, s1;
-      // the keys of step i + 1; behind the last full step the last one again (unused, in range)
-      auto next_step = [&](uint64_t i) { return i + 1 < nfull ? i + 1 : nfull - 1; };
 #define NVT_PHASE() __builtin_amdgcn_sched_barrier(0)   // (no interleaving across phases: registers)
-      // Steps 0 and 1 are arranged so that the loop is entered with exactly what a trip through it
-      // leaves in flight -- keys(i+1), probes(i), stores(i-1), in this order -- because the
-      // compiler's wait counts at the loop header are the minimum over both ways in: entered
-      // without the stores, every first half-step waited for three of its eight probes.
-      request_keys(0);
-      NVT_PHASE();
-      lds_phase(s0);
-      NVT_PHASE();
-      request_keys(1);
+      // The loop is entered with exactly what a trip through it leaves in flight -- keys(next),
+      // probes(current), stores(previous), in this order -- because the compiler's wait counts at the
+      // loop header are the minimum over both ways in.
+      uint64_t jb = grab();        // the batch whose probes are in flight
+      bool last_is_s0 = true, any = jb < WB;
+      if (any) {
+        request_keys(jb);
+        uint64_t ja = grab();      // the batch whose keys are in flight
         NVT_PHASE();
-      request_probes(s0);
-      NVT_PHASE();
-      lds_phase(s1);
-      NVT_PHASE();
-      resolve(s0);
-      NVT_PHASE();
-      request_keys(next_step(1));
-        NVT_PHASE();
-      request_probes(s1);
-      NVT_PHASE();
-      store(s0, 0);
-      NVT_PHASE();
-      bool last_is_s0 = false;
-      for (uint64_t i = 2; i < nfull; i += 2) {
         lds_phase(s0);
         NVT_PHASE();
-        resolve(s1);
-        NVT_PHASE();
-        request_keys(next_step(i));
+        request_keys(in_range(ja));
         NVT_PHASE();
         request_probes(s0);
         NVT_PHASE();
-        store(s1, i - 1);
-        NVT_PHASE();
-        last_is_s0 = true;
-        if (i + 1 >= nfull) break;
-        lds_phase(s1);
-        NVT_PHASE();
-        resolve(s0);
-        NVT_PHASE();
-        request_keys(next_step(i + 1));
-        NVT_PHASE();
-        request_probes(s1);
-        NVT_PHASE();
-        store(s0, i);
-        NVT_PHASE();
-        last_is_s0 = false;
-      }
+        if (ja < WB) {
+          uint64_t jn = grab();
+          lds_phase(s1);
+          NVT_PHASE();
+          resolve(s0);
+          NVT_PHASE();
+          request_keys(in_range(jn));
+          NVT_PHASE();
+          request_probes(s1);
+          NVT_PHASE();
+          store(s0, jb);
+          NVT_PHASE();
+          jb = ja;
+          ja = jn;
+          last_is_s0 = false;
+          while (ja < WB) {
+            jn = grab();
+            lds_phase(s0);
+            NVT_PHASE();
+            resolve(s1);
+            NVT_PHASE();
+            request_keys(in_range(jn));
+            NVT_PHASE();
+            request_probes(s0);
+            NVT_PHASE();
+            store(s1, jb);
+            NVT_PHASE();
+            jb = ja;
+            ja = jn;
+            last_is_s0 = true;
+            if (ja >= WB) break;
+            jn = grab();
+            lds_phase(s1);
+            NVT_PHASE();
+            resolve(s0);
+            NVT_PHASE();
+            request_keys(in_range(jn));
+            NVT_PHASE();
+            request_probes(s1);
+            NVT_PHASE();
+            store(s0, jb);
+            NVT_PHASE();
+            jb = ja;
+            ja = jn;
+            last_is_s0 = false;
+          }
+        }
 #undef NVT_PHASE
-      if (last_is_s0) {
-        resolve(s0);
-        store(s0, nfull - 1);
-      } else {
-        resolve(s1);
-        store(s1, nfull - 1);
+        if (last_is_s0) {
+          resolve(s0);
+          store(s0, jb);
+        } else {
+          resolve(s1);
+          store(s1, jb);
+        }
       }
     }
     for (uint64_t v = vb0 + nfull * SU + tid; v < nvec; v += stride) {
@@ -1123,6 +1155,28 @@ __global__ __launch_bounds__(kEncBS, 1) void encode_pipe_kernel(
   };
   if (RANGE == 1 && rmap.piece_slots != 0) run(std::true_type{});
   else run(std::false_type{});
+#ifdef NVT_ENC_PIPE_TIMING
+  // (experiment: g_enc_stats[0] += last wave's end - first wave's end, [1] += last wave's end - start)
+  {
+    __shared__ unsigned long long s_tmin, s_tmax;
+    if (threadIdx.x == 0) {
+      s_tmin = ~0ull;
+      s_tmax = 0;
+    }
+    const unsigned long long t_end = (unsigned long long)clock64();
+    __syncthreads();
+    if (lane_id() == 0) {
+      atomicMin(&s_tmin, t_end);
+      atomicMax(&s_tmax, t_end);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&g_enc_stats[0], s_tmax - s_tmin);
+      atomicAdd(&g_enc_stats[1], s_tmax - (unsigned long long)t_begin);
+    }
+    return;
+  }
+#endif
   if (count_stats) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
