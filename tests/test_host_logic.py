@@ -191,3 +191,21 @@ def test_harness_rehearsals_collect_last():
         if os.path.basename(f).startswith("test_gpu_"):
             src = open(f).read()
             assert not re.search(r"subprocess|torch\.distributed\.run", src), f
+
+
+def test_bench_parity_verdicts_cover_every_leg():
+    """bench.parity_verdicts: a failed nested leg, an extra that died and an extra without a parity leg
+    all make the line's top-level verdict false; only oracle legs count into parity_rows."""
+    import bench
+
+    line = {"parity": {"parity_checked_rows": 100, "parity_ok": True, "full_frame_ok": True},
+            "extra_configs": {"a": {"parity": {"method": "oracle ...", "parity_checked_rows": 5, "parity_ok": True}},
+                              "b": {"parity": {"method": "files ...", "files_equal_in_memory_transform": True}},
+                              "c": {"parity": {"method": "properties ...", "parity_ok": True, "rows": 10 ** 9}}}}
+    assert bench.parity_verdicts(line) == (True, 105, [])
+    line["parity"]["full_frame_ok"] = False
+    line["extra_configs"]["a"]["parity"]["parity_ok"] = False
+    line["extra_configs"]["d"] = {"error": "RuntimeError('x')"}
+    line["extra_configs"]["e"] = {"ms_per_step": 1.0}
+    ok, rows, failed = bench.parity_verdicts(line)
+    assert not ok and failed == ["headline.full_frame", "a", "d:error", "e:no parity leg"]

@@ -49,6 +49,32 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
     assert "all_to_all_single(uneven)" in bd["collectives"]
 
 
+def _bench(tmp_path, env_extra, *args):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "400000", "--steps", "2",
+                           "--warmup", "1", "--cpu-sample", "100000", "--no-extra", *args],
+                          capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+
+
+def test_bench_parity_is_loud(tmp_path):
+    """BASELINE.md parity gates: the bench line carries ONE top-level parity verdict over all of its
+    legs and the process exits non-zero when a leg fails -- shown by flipping one label of one column
+    in front of the comparison with the oracle (NVT_BENCH_FLIP_LABEL)."""
+    good = _bench(tmp_path, {})
+    assert good.returncode == 0, good.stderr[-2000:]
+    rec = json.loads([ln for ln in good.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["parity_ok"] is True and rec["parity_failed"] == [] and rec["parity_rows"] == 100000
+    assert rec["parity"]["method"].startswith("oracle")
+    bad = _bench(tmp_path, {"NVT_BENCH_FLIP_LABEL": "C7"})
+    assert bad.returncode == 3, (bad.returncode, bad.stderr[-2000:])
+    rec = json.loads([ln for ln in bad.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["parity_ok"] is False and rec["parity_failed"] == ["headline"]
+    assert rec["parity"]["categorify_mismatch_columns"] == ["C7"]
+    assert "PARITY FAILED" in bad.stderr
+
+
 @pytest.mark.timeout(400)
 def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
     """SURVEY 8(e) end to end: two torchrun ranks share this GPU (gloo, collectives staged
