@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import math
 from typing import List, Optional, Sequence, Tuple
 
@@ -116,6 +117,9 @@ _mailboxes = {}
 READBACK_TIMEOUT_S = float(os.environ.get("NVT_READBACK_TIMEOUT", "120"))
 
 
+READBACK_MEMCPY = os.environ.get("NVT_READBACK", "mailbox") == "memcpy"   # (read once, at import)
+
+
 def read_back(t: torch.Tensor):
     """Small device tensor (int64 / float64) -> numpy array on the host WITHOUT a blocking
     runtime wait: one tiny kernel copies it into coherent pinned memory and the host spins on
@@ -124,7 +128,7 @@ def read_back(t: torch.Tensor):
     import numpy as np
 
     assert t.is_cuda and t.element_size() == 8
-    if os.environ.get("NVT_READBACK", "mailbox") == "memcpy":
+    if READBACK_MEMCPY:
         return t.cpu().numpy()
     lib = _lib.load()
     t = t.contiguous()
@@ -677,7 +681,7 @@ def _presample(jobs):
     for j, (_, _, nulls, info) in zip(cand, res):
         est = _estimate_distinct(info["distinct"], info["rows"] - nulls, j.n)
         j.hint = est
-        STATS["presampled_columns"] += 1
+        stat_add("presampled_columns")
         # an estimate, not a hint: the range path starts with all its buckets (a column with more
         # keys than estimated would overflow 256 / 512 buckets and be counted twice) -- unless the
         # prefix shows every key >= 10 times on average: the estimate (3 x the uniform model) then
@@ -760,7 +764,7 @@ class CountBatch:
             while self.pending:
                 host = self._read_states()  # the single synchronisation point
                 self.pending = [j for i, j in enumerate(self.pending) if not j.resolve(host[i])]
-                STATS["count_relaunches"] += len(self.pending)
+                stat_add("count_relaunches", len(self.pending))
                 self._launch()
             self._results = [j.result for j in self.jobs]
         return self._results
@@ -1219,7 +1223,7 @@ class EncodeTable:
         if labels is not None:
             assert labels.dtype == torch.int32 and labels.numel() == src_keys.numel()
             labels, n_big = labels.contiguous(), 0
-            STATS["labelled_vocabularies"] = STATS.get("labelled_vocabularies", 0) + 1
+            stat_add("labelled_vocabularies")
         n = self.n_vocab
         assert self.key_bytes == 4 and src_keys.numel() == n and counts.numel() == n
         self._counts = counts
@@ -1748,8 +1752,16 @@ FLAT_INDEX_LOAD = float(os.environ.get("NVT_FLAT_INDEX_LOAD", "0.5"))
 
 
 # sorted words shared between the aggregates of ONE pass over one partition (Workflow.fit opens
-# and closes it around the partition's fit_partition calls; None = no sharing)
-_PASS_MEMO = None
+# and closes it around the partition's fit_partition calls; None = no sharing).  Per THREAD: dask
+# worker threads of the reference call transform concurrently on different partitions of one
+# fitted workflow (SURVEY 8(b) "Threading", categorify.py:1632,1813) -- a pass and what it shares
+# belong to the thread that walks the partition.
+_TLS = threading.local()
+
+
+def current_pass_memo():
+    """The memo of the pass this THREAD is inside of, or None."""
+    return getattr(_TLS, "memo", None)
 
 
 class pass_memo:
@@ -1757,14 +1769,26 @@ class pass_memo:
     (key, row) words of the sort-path groupby) are shared between the operators fitted inside."""
 
     def __enter__(self):
-        global _PASS_MEMO
-        self.prev, _PASS_MEMO = _PASS_MEMO, {}
+        self.prev = current_pass_memo()
+        _TLS.memo = {}
         return self
 
     def __exit__(self, *exc):
-        global _PASS_MEMO
-        _PASS_MEMO = self.prev
+        _TLS.memo = self.prev
         return False
+
+
+# Host-side launch sequences (workspaces and scratch buffers cached per (device, stream), the
+# read-back mailboxes, the operators' lazily finalised vocabularies and lookup images) are
+# serialised by ONE re-entrant lock taken around every operator call (ops/base.py wraps
+# transform / fit_partition / fit_end / fit_finalize of every Operator subclass): threads
+# interleave at operator granularity, the GPU work stays asynchronous on its streams.
+LAUNCH_LOCK = threading.RLock()
+
+
+def stat_add(name: str, k: int = 1):
+    with LAUNCH_LOCK:
+        STATS[name] = STATS.get(name, 0) + k
 
 
 def sorted_groupby_eligible(keys: torch.Tensor, key_valid, n: int, kfold: int = 1) -> bool:
@@ -1803,7 +1827,8 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
     nvals = len(vals)
     flags = (_lib.NVT_GB_SUMSQ if sumsq else 0) | (_lib.NVT_GB_MINMAX if minmax else 0)
     memo_key = ("sgb", keys.data_ptr(), n, keys._version)
-    hit = _PASS_MEMO.get(memo_key) if _PASS_MEMO is not None else None
+    _memo = current_pass_memo()
+    hit = _memo.get(memo_key) if _memo is not None else None
     if hit is not None and hit["bias"] is None:
         return None  # (int64 keys too far apart: found out by an earlier aggregate of this pass)
     if hit is None or not (kfold == 1 or (hit["kfold"] == kfold and hit["fold"] == ptr(fold))):
@@ -1818,9 +1843,9 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
             lo, hi = (int(v) for v in read_back(mm).tolist())
             bias = lo if hi - lo < (1 << 32) else None
             if bias is None:
-                if _PASS_MEMO is not None:
+                if _memo is not None:
                     # (keys held: the address cannot be recycled for another column in this pass)
-                    _PASS_MEMO[memo_key] = dict(bias=None, kfold=0, fold=None, groups=None, keys=keys)
+                    _memo[memo_key] = dict(bias=None, kfold=0, fold=None, groups=None, keys=keys)
                 return None
         need = C.c_uint64()
         check(lib.nvt_sgb_sort_ws_bytes(n, C.byref(need)), "nvt_sgb_sort_ws_bytes")
@@ -1833,8 +1858,8 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
         hit = dict(sorted=sp.value, rb=rbc.value, kfold=kfold, fold=ptr(fold), ws=sort_ws,
                    keys=keys, fold_t=fold, groups=None, bias=bias,
                    prev_groups=hit["groups"] if hit is not None else None)
-        if _PASS_MEMO is not None:
-            _PASS_MEMO[memo_key] = hit
+        if _memo is not None:
+            _memo[memo_key] = hit
     grp = hit["groups"]
     if grp is None:
         # group ids: words regrouped with the kfold of the SORT (an aggregate without folds
@@ -1857,7 +1882,7 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
             g = int(st[_lib.ST_OCCUPIED])
             if not st[_lib.ST_NEED]:
                 break
-            STATS["count_relaunches"] += 1
+            stat_add("count_relaunches")
             if g * wk >= 0xFFFFFFFE:
                 raise _lib.NvtHipError("sorted_groupby: groups * kfold does not fit 32 bits")
             cap = g
@@ -1897,7 +1922,7 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
         have = sv.get(skey)
         if have is not None:
             s_in[j] = have[0]
-        elif _PASS_MEMO is not None:
+        elif current_pass_memo() is not None:
             s_out[j] = torch.empty(n, dtype=v.dtype, device=dev)
             sv[skey] = (s_out[j], v)   # (v held: its address cannot be recycled in this pass)
     check(lib.nvt_sgb_reduce(
@@ -2135,7 +2160,7 @@ class FlatIndex:
         k = k.contiguous()
         n = k.numel()
         out = torch.empty(n, dtype=torch.int64, device=k.device)
-        STATS["flat_lookups"] = STATS.get("flat_lookups", 0) + 1
+        stat_add("flat_lookups")
         check(_lib.load().nvt_flat_lookup(k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n,
                                           self.aux.data_ptr(), self.table.data_ptr(), self.capacity,
                                           self.key_offset, out.data_ptr(), stream_ptr()),
@@ -2158,7 +2183,7 @@ class FlatIndex:
         assert records.dtype == torch.float64 and records.is_contiguous() and ncols == len(out_dtypes)
         outs = [torch.empty(n, dtype=dt, device=k.device) for dt in out_dtypes]
         unseen = torch.zeros(1, dtype=torch.int64, device=k.device)
-        STATS["flat_lookups"] = STATS.get("flat_lookups", 0) + 1
+        stat_add("flat_lookups")
         check(_lib.load().nvt_flat_lookup_gather(
             k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
             self.table.data_ptr(), self.capacity, self.key_offset, records.data_ptr(), ncols,
@@ -2176,7 +2201,7 @@ class FlatIndex:
         assert records.dtype == torch.float64 and records.is_contiguous()
         assert int(records.shape[1]) == (2 * (kfold + 1) if fold is not None else 2)
         out = torch.empty(n, dtype=out_dtype, device=k.device)
-        STATS["flat_lookups"] = STATS.get("flat_lookups", 0) + 1
+        stat_add("flat_lookups")
         check(_lib.load().nvt_flat_lookup_te(
             k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
             self.table.data_ptr(), self.capacity, self.key_offset,
@@ -2231,7 +2256,7 @@ class FlatIndex:
         k = self._key(keys)
         n = int(k.numel())
         valid = key_valid[0]
-        memo = _PASS_MEMO
+        memo = current_pass_memo()
         mkey = ("image", id(self), k.data_ptr(), n, k._version, ptr(valid))
         hit = memo.get(mkey) if memo is not None else None
         if hit is not None and id(consumer) in hit["outs"]:
@@ -2261,7 +2286,7 @@ class FlatIndex:
         if nc > 24:
             raise _lib.NvtHipError("image_lookup: more than 24 output columns on one key column")
         unseen = torch.zeros(1, dtype=torch.int64, device=dev)
-        STATS["image_lookups"] = STATS.get("image_lookups", 0) + 1
+        stat_add("image_lookups")
         if n:
             check(_lib.load().nvt_flat_lookup_image(
                 k.data_ptr(), dtype_code(k.dtype), ptr(valid), n, self.aux.data_ptr(),

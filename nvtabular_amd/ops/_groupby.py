@@ -298,7 +298,7 @@ def merge_sorted_comps(a, b, sumsq=False, minmax=False):
     merge of a column is shared by every aggregate on it, like the sort itself."""
     if ("fold" in a) != ("fold" in b):
         return None
-    memo = K._PASS_MEMO
+    memo = K.current_pass_memo()
     off_a, off_b = int(a.get("key_offset", 0)), int(b.get("key_offset", 0))
     if off_a != off_b:
         # int64 key column: the 32-bit image is key - offset and every partition picks its own

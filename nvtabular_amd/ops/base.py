@@ -13,14 +13,43 @@ exactly once (one pass over the data per phase, like the fused dask graph).
 """
 from __future__ import annotations
 
+import functools
 from typing import Dict, List
 
 from ..schema import ColumnSchema, Schema
 from ..selector import ColumnSelector
 
 
+def _launch_locked(fn):
+    """Run `fn` under kernels.LAUNCH_LOCK (re-entrant): the host-side launch sequences of two
+    threads interleave at operator granularity (SURVEY 8(b) "Threading": the reference's dask
+    worker threads call transform concurrently on one fitted operator)."""
+    if getattr(fn, "_nvt_locked", False):
+        return fn
+
+    @functools.wraps(fn)
+    def inner(self, *args, **kwargs):
+        from ..kernels import LAUNCH_LOCK
+
+        with LAUNCH_LOCK:
+            return fn(self, *args, **kwargs)
+
+    inner._nvt_locked = True
+    return inner
+
+
+_LOCKED_METHODS = ("transform", "fit_partition", "fit_end", "fit_finalize", "clear", "prepare_transform")
+
+
 class Operator:
     """Base class for all transforms (merlin.dag.BaseOperator)."""
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        for name in _LOCKED_METHODS:
+            fn = cls.__dict__.get(name)
+            if callable(fn) and not isinstance(fn, (staticmethod, classmethod, property)):
+                setattr(cls, name, _launch_locked(fn))
 
     def transform(self, col_selector: ColumnSelector, df):
         return df

@@ -248,9 +248,9 @@ def test_aggregates_of_one_pass_share_sort_and_groups(tmp_path, order):
     orig = K.sorted_groupby
 
     def counting(*a, **kw):
-        before = K._PASS_MEMO is not None and len(K._PASS_MEMO)
+        before = K.current_pass_memo() is not None and len(K.current_pass_memo())
         out = orig(*a, **kw)
-        calls["sort"] += int(K._PASS_MEMO is not None and len(K._PASS_MEMO) > before)
+        calls["sort"] += int(K.current_pass_memo() is not None and len(K.current_pass_memo()) > before)
         return out
 
     K.sorted_groupby = counting
