@@ -2282,17 +2282,21 @@ class FlatIndex:
                 offs.append(place[id(c)] + rel)
                 sizes.append(t.element_size())
                 miss.append(_value_bits(mv, dt))
-        nc = len(ptrs)
-        if nc > 24:
-            raise _lib.NvtHipError("image_lookup: more than 24 output columns on one key column")
         unseen = torch.zeros(1, dtype=torch.int64, device=dev)
         stat_add("image_lookups")
-        if n:
+        # nvt_flat_lookup_image takes at most IMAGE_LOOKUP_MAX_OUTPUTS columns per launch: two
+        # JoinGroupby operators on one key, or a TargetEncoding with many targets beside one, go
+        # out in several launches over the same rows (every launch probes again; `unseen` is only
+        # ever raised, so the launches share it)
+        for lo in range(0, len(ptrs) if n else 0, IMAGE_LOOKUP_MAX_OUTPUTS):
+            hi = min(lo + IMAGE_LOOKUP_MAX_OUTPUTS, len(ptrs))
+            nc = hi - lo
             check(_lib.load().nvt_flat_lookup_image(
                 k.data_ptr(), dtype_code(k.dtype), ptr(valid), n, self.aux.data_ptr(),
                 self.table.data_ptr(), self.capacity, self.key_offset, None, None, image.data_ptr(),
-                stride, nc, _lib.ptr_array(ptrs), _lib.ptr_array(folds), (C.c_uint32 * nc)(*offs),
-                (C.c_uint32 * nc)(*sizes), (C.c_uint64 * nc)(*miss), unseen.data_ptr(), stream_ptr()),
+                stride, nc, _lib.ptr_array(ptrs[lo:hi]), _lib.ptr_array(folds[lo:hi]),
+                (C.c_uint32 * nc)(*offs[lo:hi]), (C.c_uint32 * nc)(*sizes[lo:hi]),
+                (C.c_uint64 * nc)(*miss[lo:hi]), unseen.data_ptr(), stream_ptr()),
                 "nvt_flat_lookup_image")
         if memo is not None and hit is None:
             memo[mkey] = dict(outs=outs, unseen=unseen, keep=(k, valid, keep))
@@ -2311,6 +2315,9 @@ def _value_bits(value, dt) -> int:
     if dt == torch.int32:
         return int(value) & 0xFFFFFFFF
     return int(value) & 0xFFFFFFFFFFFFFFFF
+
+
+IMAGE_LOOKUP_MAX_OUTPUTS = 24   # include/nvt_hip.h: nvt_flat_lookup_image, ncols <= 24
 
 
 class LookupConsumer:

@@ -758,18 +758,18 @@ class Categorify(StatOperator):
         """Write any deferred unique.*/meta.*.parquet files (defer_artifacts=True).
 
         Not a collective: only the writer elected at fit_end writes, everybody else just drops
-        the device copies -- unless its file does not exist (out_path not shared between nodes).
+        the device copies.
         ``force=True`` (set_storage_path, which Workflow.save reaches and which may run on one
         rank only and need the files whoever that rank is) writes on any rank; the files are
         replaced atomically (_write_artifacts), so a forced write concurrent with the elected
         writer's is harmless -- both hold the same vocabularies."""
         self._ensure_finalized()
         for final in self._pending.values():
-            # a non-writer whose file is MISSING writes it too (no shared out_path between nodes:
-            # the elected writer's copy never arrives here); safe next to the writer's own write
-            # because _write_artifacts replaces the files atomically
-            missing = not os.path.exists("/".join([final["base"], f"unique.{final['name']}.parquet"]))
-            if getattr(self, "_is_writer", True) or force or missing:
+            # (a non-writer does NOT write because its file is missing: on a shared out_path every
+            # rank flushes at about the same time, the file is missing for all of them and all G
+            # ranks wrote all vocabularies -- ADVICE r05.  Node-local output directories are covered
+            # by the election itself: the writer is the first rank per (host, directory), fit_end)
+            if getattr(self, "_is_writer", True) or force:
                 _write_artifacts(final)
             elif final.get("table") is not None:
                 # dropping the device copies: their buffers go back to the allocator on THIS

@@ -72,13 +72,20 @@ def _fold_column(n, kfold, fold_seed, device) -> DeviceColumn:
                 import ctypes as C
 
                 need = C.c_uint64()
-                K.check(lib.nvt_fold_mt19937_par_ws_bytes(m, int(kfold), C.byref(need)), "nvt_fold_mt19937_par_ws_bytes")
-                ws = torch.empty(need.value, dtype=torch.uint8, device=device)
-                total = torch.zeros(1, dtype=torch.int64, device=device)
-                K.check(lib.nvt_fold_mt19937_par(seed, int(kfold), m, cached.data_ptr(), ws.data_ptr(), need.value,
-                                                 total.data_ptr(), K.stream_ptr()), "nvt_fold_mt19937_par")
-                done = int(K.read_back(total)[0]) >= m
-                del ws
+                try:
+                    # (a request the parallel generator rejects -- more than 2^14 chunks -- or a
+                    # workspace that cannot be had falls through to the serial kernel)
+                    K.check(lib.nvt_fold_mt19937_par_ws_bytes(m, int(kfold), C.byref(need)),
+                            "nvt_fold_mt19937_par_ws_bytes")
+                    ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+                    total = torch.zeros(1, dtype=torch.int64, device=device)
+                    K.check(lib.nvt_fold_mt19937_par(seed, int(kfold), m, cached.data_ptr(), ws.data_ptr(),
+                                                     need.value, total.data_ptr(), K.stream_ptr()),
+                            "nvt_fold_mt19937_par")
+                    done = int(K.read_back(total)[0]) >= m
+                    del ws
+                except (K._lib.NvtHipError, torch.cuda.OutOfMemoryError):
+                    done = False
             if not done:
                 K.check(lib.nvt_fold_mt19937(seed, int(kfold), m, cached.data_ptr(), K.stream_ptr()),
                         "nvt_fold_mt19937")

@@ -413,8 +413,11 @@ class PlainParquetFile:
             if dt is None or rep == 2:
                 self.eligible, self.why = False, f"column {e.get(4)!r}: physical type {ptype} / repetition {rep}"
             # converted types that reinterpret the integer: DATE 6, TIME 7-8, TIMESTAMP 9-10,
-            # UINT 11-14 (INT_8..INT_64 = 15-18 keep the bits), DECIMAL 5
-            if conv is not None and conv not in (15, 16, 17, 18):
+            # UINT 11-14, DECIMAL 5; INT_8 / INT_16 (15 / 16) on a physical INT32 come back as
+            # int8 / int16 from pyarrow (legacy writers without a LogicalType): only INT_32 (17)
+            # on INT32 and INT_64 (18) on INT64 keep dtype AND bits -- the same rule as the
+            # LogicalType INTEGER below; everything else is left to the pyarrow reader
+            if conv is not None and conv != {1: 17, 2: 18}.get(ptype):
                 self.eligible, self.why = False, f"column {e.get(4)!r}: converted type {conv}"
             if logical is not None:
                 # LogicalType union: 10 = INTEGER {1: bitWidth, 2: isSigned}

@@ -230,3 +230,45 @@ def test_per_operator_kernels_still_serve_a_fit_without_images(tmp_path, monkeyp
         np.testing.assert_allclose(got[c].to_numpy().astype("float64"), exp_j[c].to_numpy().astype("float64"),
                                    rtol=2e-5, atol=1e-6, err_msg=c)
     np.testing.assert_allclose(got["TE_k_y"].to_numpy(), exp_t["TE_k_y"].to_numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_more_than_24_outputs_on_one_key_column(tmp_path):
+    """a JoinGroupby with many columns next to a TargetEncoding with many targets
+    on ONE key column needs more than the 24 output columns nvt_flat_lookup_image takes per launch --
+    the lookup goes out in several launches instead of raising; results equal the per-operator
+    kernels bit for bit and the oracle."""
+    import nvtabular_amd as nvt
+    from nvtabular_amd import kernels as K
+    from nvtabular_amd import ops
+
+    rng = np.random.default_rng(21)
+    n = 100_000
+    ids, rows = _keys(rng, n, 7_000)
+    conts = [f"x{i}" for i in range(8)]
+    df = pd.DataFrame({"k": rows, **{c: rng.normal(size=n) for c in conts},
+                       **{f"y{i}": (rng.random(n) < 0.2 + 0.1 * i).astype("float32") for i in range(4)}})
+    stats = ["count", "sum", "mean", "std"]
+    targets = [f"y{i}" for i in range(4)]
+    te = ["k"] >> ops.TargetEncoding(targets, out_path=str(tmp_path / "te"), kfold=5, fold_seed=42, p_smooth=20)
+    jg = ["k"] >> ops.JoinGroupby(out_path=str(tmp_path / "jg"), stats=stats, cont_cols=conts)
+    wf = nvt.Workflow(te + jg).fit(nvt.Dataset(df))
+    got = wf.transform(nvt.Dataset(df)).to_ddf().compute()
+    assert len([c for c in got.columns if c.startswith(("TE_", "k_"))]) > K.IMAGE_LOOKUP_MAX_OUTPUTS
+    K.LOOKUP_IMAGES = False
+    try:
+        ref = wf.transform(nvt.Dataset(df)).to_ddf().compute()
+    finally:
+        K.LOOKUP_IMAGES = True
+    assert list(got.columns) == list(ref.columns)
+    for c in got.columns:
+        np.testing.assert_array_equal(got[c].to_numpy().view(np.uint8), ref[c].to_numpy().view(np.uint8), err_msg=c)
+    cats = O.join_groupby_fit([df.copy()], ["k"], conts, stats, str(tmp_path / "c"))
+    exp_j = O.join_groupby_transform(df.copy(), ["k"], cats)
+    for c in exp_j.columns:
+        if c in df.columns:
+            continue
+        if c.endswith("_count"):
+            np.testing.assert_array_equal(got[c].to_numpy(), exp_j[c].to_numpy())
+        else:
+            np.testing.assert_allclose(got[c].to_numpy().astype("float64"), exp_j[c].to_numpy().astype("float64"),
+                                       rtol=2e-5, atol=1e-6, err_msg=c)
