@@ -604,6 +604,20 @@ int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_siz
                         uint64_t expect_rows, uint8_t *valid_out, uint64_t valid_bit_offset,
                         uint8_t *values_out, uint64_t values_cap_bytes, uint64_t *rows_out,
                         uint64_t *values_count);
+/* nvt_pq_decode_chunk_codec (round 6): the same for what real files hold -- chunk = the bytes of the
+ * column chunk from its FIRST page on (the dictionary page when there is one), codec = the chunk's
+ * parquet CompressionCodec (0 UNCOMPRESSED, 1 SNAPPY: every page is one raw snappy block; v2 pages
+ * keep their levels uncompressed), values PLAIN or dictionary indices (PLAIN_DICTIONARY /
+ * RLE_DICTIONARY: RLE / bit-packed hybrid at width <= 32 behind a PLAIN dictionary page).  The
+ * decoder writes packed PLAIN values exactly like nvt_pq_decode_chunk.  scratch (host memory the
+ * decoder owns during the call: the uncompressed dictionary + one uncompressed page):
+ * 2 * total_uncompressed_size of the chunk + 64 bytes always suffice; may be null for codec 0.
+ * NVT_EUNSUPPORTED: other codecs (gzip, zstd, lz4, brotli) / encodings (DELTA_*, BYTE_STREAM_SPLIT). */
+int nvt_pq_decode_chunk_codec(const uint8_t *chunk, uint64_t chunk_bytes, int codec, int type_size,
+                              int max_def_level, uint64_t expect_rows, uint8_t *valid_out,
+                              uint64_t valid_bit_offset, uint8_t *values_out, uint64_t values_cap_bytes,
+                              uint8_t *scratch, uint64_t scratch_bytes, uint64_t *rows_out,
+                              uint64_t *values_count);
 int nvt_expand_valid_ws_bytes(uint64_t n, uint64_t *bytes);
 int nvt_expand_valid(const void *packed, int type_size, const uint8_t *bitmap, uint64_t n, void *out,
                      void *ws, void *stream);

@@ -118,6 +118,8 @@ SIGNATURES = {
     "nvt_fold_mt19937_par": [_u32, _i32, _u64, _vp, _vp, _u64, _vp, _vp],
     "nvt_encode_stats": [C.POINTER(_u64), _i32, _vp],
     "nvt_pq_decode_chunk": [_vp, _u64, _i32, _i32, _u64, _vp, _u64, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)],
+    "nvt_pq_decode_chunk_codec": [_vp, _u64, _i32, _i32, _i32, _u64, _vp, _u64, _vp, _u64, _vp, _u64,
+                                  C.POINTER(_u64), C.POINTER(_u64)],
     "nvt_expand_valid_ws_bytes": [_u64, C.POINTER(_u64)],
     "nvt_expand_valid": [_vp, _i32, _vp, _u64, _vp, _vp, _vp],
     "nvt_exchange_ranges": [_vp, _i32, _vp, _vp],

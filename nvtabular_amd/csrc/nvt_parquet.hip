@@ -1,6 +1,7 @@
-// Parquet in: the input half of Dataset -> HBM for PLAIN, uncompressed column chunks of flat
-// int32 / int64 / float / double columns (what parquet_plain.py writes, and what pyarrow writes
-// with use_dictionary=False, compression=None).  Reference contract: merlin.io.Dataset(engine=
+// Parquet in: the input half of Dataset -> HBM for column chunks of flat int32 / int64 / float /
+// double columns: PLAIN or dictionary-encoded (PLAIN_DICTIONARY / RLE_DICTIONARY) values, codec
+// UNCOMPRESSED or SNAPPY, data pages v1 / v2 -- what pandas, pyarrow, cuDF and the reference
+// write by default (round 6; before: PLAIN + uncompressed only, i.e. parquet_plain.py's own files).  Reference contract: merlin.io.Dataset(engine=
 // "parquet") feeding Workflow.fit / transform (tests/unit/workflow/test_cpu_workflow.py:67-81,
 // bench/examples/dask-nvtabular-criteo-benchmark.py:216-237); the reference's backend (cuDF /
 // pyarrow) decodes pages on its side of that call.
@@ -13,8 +14,12 @@
 //     expanded to one slot per row there (nvt_expand_valid: rank of a row = popcount prefix of
 //     the bitmap), so the PCIe link carries the packed values only.
 //
-// Anything else in a chunk (dictionary page, compressed page, other encodings, nested columns)
-// is reported as NVT_EUNSUPPORTED and the caller reads that file with pyarrow.
+//     snappy blocks are decompressed and dictionary indices (RLE / bit-packed hybrid, width <= 32)
+//     resolved through the chunk's dictionary in the same task, so the staging buffer always holds
+//     packed PLAIN values.
+//
+// Anything else in a chunk (other codecs / encodings, nested columns) is reported as
+// NVT_EUNSUPPORTED and the caller reads that file with pyarrow.
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -120,6 +125,9 @@ struct PageHead {
   // v2
   int64_t num_nulls = -1, def_bytes = 0, rep_bytes = 0;
   bool v2_compressed = false;
+  // dictionary page
+  int64_t dict_values = 0;
+  int dict_encoding = -1;
 };
 
 bool read_page_header(TReader &r, PageHead &h) {
@@ -134,6 +142,13 @@ bool read_page_header(TReader &r, PageHead &h) {
         if (f2 == 1 && t2 == 5) h.num_values = r.zigzag();
         else if (f2 == 2 && t2 == 5) h.encoding = (int)r.zigzag();
         else if (f2 == 3 && t2 == 5) h.def_encoding = (int)r.zigzag();
+        else r.skip(t2);
+      }
+    } else if (fid == 7 && type == 12) {  // DictionaryPageHeader
+      int f2 = 0, t2 = 0;
+      while (r.field(f2, t2)) {
+        if (f2 == 1 && t2 == 5) h.dict_values = r.zigzag();
+        else if (f2 == 2 && t2 == 5) h.dict_encoding = (int)r.zigzag();
         else r.skip(t2);
       }
     } else if (fid == 8 && type == 12) {  // DataPageHeaderV2
@@ -236,6 +251,120 @@ bool decode_levels(const uint8_t *lv, uint64_t nbytes, uint64_t rows, uint8_t *b
   return true;
 }
 
+// ---- snappy, raw block format (what parquet's SNAPPY codec holds per page) --------------------
+// -> uncompressed bytes written, or -1 on malformed input / a block that does not fit `cap`
+int64_t snappy_uncompress(const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t cap) {
+  TReader r{src, src + n};
+  const uint64_t want = r.varint();
+  if (!r.ok || want > cap) return -1;
+  const uint8_t *p = r.p, *end = src + n;
+  uint64_t o = 0;
+  while (p < end) {
+    const uint8_t tag = *p++;
+    uint64_t len, off;
+    switch (tag & 3) {
+      case 0: {   // literal
+        len = (uint64_t)(tag >> 2) + 1;
+        if (len > 60) {
+          const unsigned nb = (unsigned)(len - 60);   // 1 .. 4 length bytes, little endian
+          if ((uint64_t)(end - p) < nb) return -1;
+          len = 0;
+          for (unsigned i = 0; i < nb; ++i) len |= (uint64_t)p[i] << (8 * i);
+          len += 1;
+          p += nb;
+        }
+        if ((uint64_t)(end - p) < len || want - o < len) return -1;
+        memcpy(dst + o, p, len);
+        p += len;
+        o += len;
+        continue;
+      }
+      case 1:
+        if (p >= end) return -1;
+        len = (uint64_t)((tag >> 2) & 7) + 4;
+        off = ((uint64_t)(tag >> 5) << 8) | *p++;
+        break;
+      case 2:
+        if (end - p < 2) return -1;
+        len = (uint64_t)(tag >> 2) + 1;
+        off = (uint64_t)p[0] | ((uint64_t)p[1] << 8);
+        p += 2;
+        break;
+      default:
+        if (end - p < 4) return -1;
+        len = (uint64_t)(tag >> 2) + 1;
+        off = (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24);
+        p += 4;
+    }
+    if (off == 0 || off > o || want - o < len) return -1;
+    if (off >= len) {
+      memcpy(dst + o, dst + o - off, len);
+    } else {   // overlapping copy: a run
+      for (uint64_t i = 0; i < len; ++i) dst[o + i] = dst[o - off + i];
+    }
+    o += len;
+  }
+  return o == want ? (int64_t)o : -1;
+}
+
+// `count` dictionary indices (RLE / bit-packed hybrid behind a one-byte bit width) resolved through
+// `dict` (ndict values of T) into out[0 .. count)
+template <typename T>
+bool decode_dict_indices(const uint8_t *p, const uint8_t *end, uint64_t count, const T *dict, uint64_t ndict,
+                         T *out) {
+  if (count == 0) return true;
+  if (p >= end) return false;
+  const unsigned bw = *p++;
+  if (bw > 32) return false;
+  const uint64_t mask = bw == 32 ? 0xFFFFFFFFull : ((1ull << bw) - 1ull);
+  TReader r{p, end};
+  uint64_t done = 0;
+  while (done < count) {
+    const uint64_t head = r.varint();
+    if (!r.ok) return false;
+    if (head & 1) {   // bit-packed: (head >> 1) groups of 8 values, `bw` bits each, LSB first
+      const uint64_t groups = head >> 1;
+      if (groups == 0 || groups > (1ull << 40)) return false;
+      const uint64_t nb = groups * bw;
+      if ((uint64_t)(r.end - r.p) < nb) {
+        // (writers may truncate the padding of the last group: take what the values need)
+        const uint64_t need_vals = count - done < groups * 8 ? count - done : groups * 8;
+        if ((uint64_t)(r.end - r.p) * 8 < need_vals * bw) return false;
+      }
+      uint64_t take = groups * 8;
+      if (take > count - done) take = count - done;
+      const uint8_t *q = r.p;
+      const uint64_t avail = (uint64_t)(r.end - r.p);
+      uint64_t bitpos = 0;
+      for (uint64_t i = 0; i < take; ++i, bitpos += bw) {
+        const uint64_t byte = bitpos >> 3;
+        uint64_t w = 0;   // up to 5 bytes hold a value of <= 32 bits at any bit offset
+        const uint64_t nbv = avail - byte < 8 ? avail - byte : 8;
+        memcpy(&w, q + byte, nbv);
+        const uint64_t idx = (w >> (bitpos & 7)) & mask;
+        if (idx >= ndict) return false;
+        out[done + i] = dict[idx];
+      }
+      r.skip_bytes(nb < avail ? nb : avail);
+      done += take;
+    } else {   // RLE: (head >> 1) times the value in the next ceil(bw / 8) bytes
+      uint64_t n = head >> 1;
+      const unsigned vb = (bw + 7) / 8;
+      if (n == 0 || (uint64_t)(r.end - r.p) < vb) return false;
+      uint64_t idx = 0;
+      memcpy(&idx, r.p, vb);
+      r.p += vb;
+      idx &= mask;
+      if (idx >= ndict) return false;
+      if (n > count - done) n = count - done;
+      const T v = dict[idx];
+      for (uint64_t i = 0; i < n; ++i) out[done + i] = v;
+      done += n;
+    }
+  }
+  return true;
+}
+
 }  // namespace
 
 // out[i] = valid(i) ? packed[rank(i)] : 0 with rank(i) = valid rows in front of row i.
@@ -300,16 +429,49 @@ using namespace nvt;
 
 extern "C" {
 
-int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_size, int max_def_level,
-                        uint64_t expect_rows, uint8_t *valid_out, uint64_t valid_bit_offset,
-                        uint8_t *values_out, uint64_t values_cap_bytes, uint64_t *rows_out,
-                        uint64_t *values_out_count) {
+// codec: parquet CompressionCodec (0 UNCOMPRESSED, 1 SNAPPY).  scratch: room for the chunk's
+// dictionary + its largest page uncompressed (2 * total_uncompressed_size + 64 always suffices);
+// may be null for an uncompressed chunk without a dictionary page.
+static int pq_decode(const uint8_t *chunk, uint64_t chunk_bytes, int codec, int type_size, int max_def_level,
+                     uint64_t expect_rows, uint8_t *valid_out, uint64_t valid_bit_offset,
+                     uint8_t *values_out, uint64_t values_cap_bytes, uint8_t *scratch, uint64_t scratch_bytes,
+                     uint64_t *rows_out, uint64_t *values_out_count) {
   NVT_CHECK_ARG(chunk && values_out && rows_out && values_out_count, "null pointer");
   NVT_CHECK_ARG(type_size == 4 || type_size == 8, "values are 4 or 8 bytes");
   NVT_CHECK_ARG(max_def_level == 0 || max_def_level == 1, "flat columns: max definition level 0 / 1");
   NVT_CHECK_ARG(max_def_level == 0 || valid_out, "null validity buffer");
+  if (codec != 0 && codec != 1) {
+    set_error("nvt_pq_decode_chunk: codec %d (UNCOMPRESSED and SNAPPY are decoded here)", codec);
+    return NVT_EUNSUPPORTED;
+  }
   const uint8_t *p = chunk, *end = chunk + chunk_bytes;
   uint64_t rows = 0, vals = 0;
+  const uint8_t *dict = nullptr;   // PLAIN values of the dictionary page (in the chunk or in scratch)
+  uint64_t ndict = 0;
+  uint64_t scratch_at = 0;         // scratch below this offset holds the dictionary
+  // page body -> uncompressed bytes (`want` of them): the body itself, or scratch behind the dictionary
+  auto inflate = [&](const uint8_t *src, uint64_t nsrc, uint64_t want, bool compressed,
+                     const uint8_t **out) -> int {
+    if (!compressed) {
+      if (nsrc != want) {
+        set_error("nvt_pq_decode_chunk: an uncompressed page of %llu bytes that says %llu",
+                  (unsigned long long)nsrc, (unsigned long long)want);
+        return NVT_EINVAL;
+      }
+      *out = src;
+      return NVT_OK;
+    }
+    if (scratch == nullptr || scratch_bytes - scratch_at < want || scratch_bytes < scratch_at) {
+      set_error("nvt_pq_decode_chunk: scratch too small for a page of %llu bytes", (unsigned long long)want);
+      return NVT_EINVAL;
+    }
+    if (snappy_uncompress(src, nsrc, scratch + scratch_at, want) != (int64_t)want) {
+      set_error("nvt_pq_decode_chunk: malformed snappy block");
+      return NVT_EINVAL;
+    }
+    *out = scratch + scratch_at;
+    return NVT_OK;
+  };
   while (p < end && rows < expect_rows) {
     TReader r{p, end};
     PageHead h;
@@ -318,7 +480,7 @@ int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_siz
       return NVT_EINVAL;
     }
     const uint8_t *body = r.p;
-    if (h.compressed < 0 || (uint64_t)(end - body) < (uint64_t)h.compressed) {
+    if (h.compressed < 0 || h.uncompressed < 0 || (uint64_t)(end - body) < (uint64_t)h.compressed) {
       set_error("nvt_pq_decode_chunk: page of %lld bytes runs past the chunk", (long long)h.compressed);
       return NVT_EINVAL;
     }
@@ -326,26 +488,50 @@ int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_siz
       p = body + h.compressed;
       continue;
     }
+    if (h.type == 2) {  // dictionary page: PLAIN values (encoding 0; 2 = PLAIN_DICTIONARY, the old name)
+      if (dict != nullptr || (h.dict_encoding != 0 && h.dict_encoding != 2) || h.dict_values < 0) {
+        set_error("nvt_pq_decode_chunk: dictionary page (encoding %d, second %d)", h.dict_encoding, dict != nullptr);
+        return NVT_EUNSUPPORTED;
+      }
+      const uint8_t *d = nullptr;
+      int rc = inflate(body, (uint64_t)h.compressed, (uint64_t)h.uncompressed, codec != 0, &d);
+      if (rc) return rc;
+      if ((uint64_t)h.dict_values * (uint64_t)type_size > (uint64_t)h.uncompressed) {
+        set_error("nvt_pq_decode_chunk: dictionary page holds fewer values than it says");
+        return NVT_EINVAL;
+      }
+      dict = d;
+      ndict = (uint64_t)h.dict_values;
+      if (codec != 0) scratch_at = ((uint64_t)h.uncompressed + 15) & ~15ull;   // (kept: pages go behind it)
+      p = body + h.compressed;
+      continue;
+    }
     if (h.type != 0 && h.type != 3) {
-      set_error("nvt_pq_decode_chunk: page type %d (dictionary pages are read by the fallback)", h.type);
+      set_error("nvt_pq_decode_chunk: page type %d", h.type);
       return NVT_EUNSUPPORTED;
     }
-    if (h.compressed != h.uncompressed) {  // (the chunk's codec is UNCOMPRESSED: checked by the caller)
-      set_error("nvt_pq_decode_chunk: compressed page");
+    const bool by_dict = h.encoding == 2 || h.encoding == 8;   // PLAIN_DICTIONARY / RLE_DICTIONARY
+    if (h.encoding != 0 && !by_dict) {
+      set_error("nvt_pq_decode_chunk: value encoding %d (PLAIN and dictionary indices are decoded here)", h.encoding);
       return NVT_EUNSUPPORTED;
     }
-    if (h.encoding != 0) {  // PLAIN
-      set_error("nvt_pq_decode_chunk: value encoding %d (PLAIN only)", h.encoding);
-      return NVT_EUNSUPPORTED;
+    if (by_dict && dict == nullptr) {
+      set_error("nvt_pq_decode_chunk: dictionary indices without a dictionary page");
+      return NVT_EINVAL;
     }
     const uint64_t prow = (uint64_t)h.num_values;
     if (h.num_values < 0 || prow > expect_rows - rows) {
       set_error("nvt_pq_decode_chunk: more rows than the row group holds");
       return NVT_EINVAL;
     }
-    const uint8_t *q = body, *pend = body + h.compressed;
+    const uint8_t *q = nullptr, *pend = nullptr;   // the values (behind the levels), uncompressed
     uint64_t pvalid = prow;
-    if (h.type == 0) {
+    if (h.type == 0) {   // v1: levels and values are compressed together
+      const uint8_t *u = nullptr;
+      int rc = inflate(body, (uint64_t)h.compressed, (uint64_t)h.uncompressed, codec != 0, &u);
+      if (rc) return rc;
+      q = u;
+      pend = u + h.uncompressed;
       if (max_def_level == 1) {
         if (h.def_encoding != 3) {  // RLE (the hybrid)
           set_error("nvt_pq_decode_chunk: definition level encoding %d", h.def_encoding);
@@ -361,33 +547,53 @@ int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_siz
         }
         q += lb;
       }
-    } else {  // v2: repetition levels (none for flat columns), then definition levels, no length prefix
+    } else {  // v2: repetition levels (none for flat columns), then definition levels -- never
+              // compressed, no length prefix --, then the values (compressed when the header says so)
       if (h.rep_bytes != 0) {
         set_error("nvt_pq_decode_chunk: repetition levels (nested column)");
         return NVT_EUNSUPPORTED;
       }
-      if (h.def_bytes < 0 || (uint64_t)(pend - q) < (uint64_t)h.def_bytes) {
+      if (h.def_bytes < 0 || (uint64_t)h.compressed < (uint64_t)h.def_bytes ||
+          (uint64_t)h.uncompressed < (uint64_t)h.def_bytes) {
         set_error("nvt_pq_decode_chunk: definition levels run past the page");
         return NVT_EINVAL;
       }
       if (max_def_level == 1) {
-        if (!decode_levels(q, (uint64_t)h.def_bytes, prow, valid_out, valid_bit_offset + rows, &pvalid)) {
+        if (!decode_levels(body, (uint64_t)h.def_bytes, prow, valid_out, valid_bit_offset + rows, &pvalid)) {
           set_error("nvt_pq_decode_chunk: malformed definition levels");
           return NVT_EINVAL;
         }
       }
-      q += h.def_bytes;
-    }
-    const uint64_t vbytes = pvalid * (uint64_t)type_size;
-    if ((uint64_t)(pend - q) < vbytes) {
-      set_error("nvt_pq_decode_chunk: page holds fewer values than its levels say");
-      return NVT_EINVAL;
+      const uint8_t *u = nullptr;
+      const uint64_t vcomp = (uint64_t)h.compressed - (uint64_t)h.def_bytes;
+      const uint64_t vraw = (uint64_t)h.uncompressed - (uint64_t)h.def_bytes;
+      int rc = inflate(body + h.def_bytes, vcomp, vraw, codec != 0 && h.v2_compressed, &u);
+      if (rc) return rc;
+      q = u;
+      pend = u + vraw;
     }
     if ((vals + pvalid) * (uint64_t)type_size > values_cap_bytes) {
       set_error("nvt_pq_decode_chunk: values buffer too small");
       return NVT_EINVAL;
     }
-    memcpy(values_out + vals * (uint64_t)type_size, q, vbytes);
+    if (!by_dict) {
+      const uint64_t vbytes = pvalid * (uint64_t)type_size;
+      if ((uint64_t)(pend - q) < vbytes) {
+        set_error("nvt_pq_decode_chunk: page holds fewer values than its levels say");
+        return NVT_EINVAL;
+      }
+      memcpy(values_out + vals * (uint64_t)type_size, q, vbytes);
+    } else {
+      const bool ok = type_size == 4
+          ? decode_dict_indices<uint32_t>(q, pend, pvalid, reinterpret_cast<const uint32_t *>(dict), ndict,
+                                          reinterpret_cast<uint32_t *>(values_out) + vals)
+          : decode_dict_indices<uint64_t>(q, pend, pvalid, reinterpret_cast<const uint64_t *>(dict), ndict,
+                                          reinterpret_cast<uint64_t *>(values_out) + vals);
+      if (!ok) {
+        set_error("nvt_pq_decode_chunk: malformed dictionary indices");
+        return NVT_EINVAL;
+      }
+    }
     vals += pvalid;
     rows += prow;
     p = body + h.compressed;
@@ -400,6 +606,23 @@ int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_siz
   *rows_out = rows;
   *values_out_count = vals;
   return NVT_OK;
+}
+
+int nvt_pq_decode_chunk(const uint8_t *chunk, uint64_t chunk_bytes, int type_size, int max_def_level,
+                        uint64_t expect_rows, uint8_t *valid_out, uint64_t valid_bit_offset,
+                        uint8_t *values_out, uint64_t values_cap_bytes, uint64_t *rows_out,
+                        uint64_t *values_out_count) {
+  return pq_decode(chunk, chunk_bytes, 0, type_size, max_def_level, expect_rows, valid_out, valid_bit_offset,
+                   values_out, values_cap_bytes, nullptr, 0, rows_out, values_out_count);
+}
+
+int nvt_pq_decode_chunk_codec(const uint8_t *chunk, uint64_t chunk_bytes, int codec, int type_size,
+                              int max_def_level, uint64_t expect_rows, uint8_t *valid_out,
+                              uint64_t valid_bit_offset, uint8_t *values_out, uint64_t values_cap_bytes,
+                              uint8_t *scratch, uint64_t scratch_bytes, uint64_t *rows_out,
+                              uint64_t *values_out_count) {
+  return pq_decode(chunk, chunk_bytes, codec, type_size, max_def_level, expect_rows, valid_out, valid_bit_offset,
+                   values_out, values_cap_bytes, scratch, scratch_bytes, rows_out, values_out_count);
 }
 
 int nvt_expand_valid_ws_bytes(uint64_t n, uint64_t *bytes) {

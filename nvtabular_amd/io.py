@@ -98,8 +98,9 @@ class Dataset:
         if self._schema is None:
             self._schema = Schema.from_frame(pq.ParquetFile(files[0]).schema_arrow)
 
-        # files the hand-written reader takes (flat numeric columns, PLAIN, uncompressed:
-        # parquet_plain.PlainParquetFile); everything else is decoded by pyarrow
+        # files the hand-written reader takes (flat numeric columns; PLAIN or dictionary-encoded
+        # values, uncompressed or snappy: parquet_plain.PlainParquetFile); everything else is
+        # decoded by pyarrow and counted in parquet_plain.READER_CHUNKS
         plain_files = {}
 
         def plain_file(f):
@@ -131,7 +132,11 @@ class Dataset:
                     if not isinstance(e, _lib.NvtHipError):
                         raise
                     plain_files[f] = None
-            return pq.ParquetFile(f).read_row_groups(groups, columns=columns)
+            from .parquet_plain import READER_CHUNKS
+
+            table = pq.ParquetFile(f).read_row_groups(groups, columns=columns)
+            READER_CHUNKS["pyarrow"] += table.num_columns * len(groups)   # (counted: never silent)
+            return table
 
         def gen(columns=None, only=None):
             # decode a few partitions ahead on host threads (one read spreads over the columns of

@@ -380,7 +380,8 @@ class PlainParquetFile:
     """Footer of one parquet file and, per row group, the column chunks the hand-written reader
     can take: flat columns (no nesting), physical type INT32 / INT64 / FLOAT / DOUBLE without a
     converted / logical type that changes the meaning of the bits (dates, decimals, unsigned),
-    codec UNCOMPRESSED, no dictionary page, encodings within {PLAIN, RLE, BIT_PACKED}.
+    codec UNCOMPRESSED or SNAPPY, values PLAIN or dictionary-encoded (what pandas / pyarrow / cuDF
+    write by default), encodings within {PLAIN, PLAIN_DICTIONARY, RLE, BIT_PACKED, RLE_DICTIONARY}.
     ``eligible`` says whether EVERY column of every row group qualifies; otherwise the caller
     reads the file with pyarrow."""
 
@@ -433,11 +434,20 @@ class PlainParquetFile:
             for cc in rg.get(1, []):
                 md = cc.get(3) or {}
                 enc = set(md.get(2, []))
-                ok = (md.get(4) == 0 and 11 not in md and enc <= {0, 3, 4} and cc.get(1) in (None, b""))
+                # codec 0 UNCOMPRESSED / 1 SNAPPY; encodings PLAIN 0, PLAIN_DICTIONARY 2, RLE 3,
+                # BIT_PACKED 4, RLE_DICTIONARY 8 (nvt_pq_decode_chunk_codec); the chunk starts at its
+                # dictionary page when it has one
+                ok = (md.get(4) in (0, 1) and enc <= {0, 2, 3, 4, 8} and cc.get(1) in (None, b""))
                 if not ok:
                     self.eligible, self.why = False, (f"chunk of {md.get(3)}: codec {md.get(4)}, encodings "
-                                                      f"{sorted(enc)}, dictionary page {md.get(11)}")
-                cols.append(dict(offset=int(md.get(9, 0)), size=int(md.get(7, 0)), num_values=int(md.get(5, 0)),
+                                                      f"{sorted(enc)}")
+                first = int(md.get(9, 0))
+                dpo = md.get(11)
+                if dpo is not None and 0 < int(dpo) < first:
+                    first = int(dpo)
+                cols.append(dict(offset=first, size=int(md.get(7, 0)), num_values=int(md.get(5, 0)),
+                                 codec=int(md.get(4, 0)), raw_size=int(md.get(6, 0)),
+                                 dictionary=bool(dpo is not None or (enc & {2, 8})),
                                  path=[x.decode() for x in md.get(3, [])]))
                 if not (0 <= cols[-1]["offset"] and 0 <= cols[-1]["size"] and
                         cols[-1]["offset"] + cols[-1]["size"] <= size):
@@ -478,6 +488,23 @@ def _scratch(nbytes: int) -> bytearray:
             cap <<= 1
         buf = _TLS.buf = bytearray(cap)
     return buf
+
+
+def _scratch2(nbytes: int) -> bytearray:
+    """This thread's decompression scratch (dictionary + one page), grown in powers of two."""
+    _scratch(1)   # (creates _TLS)
+    buf = getattr(_TLS, "buf2", None)
+    if buf is None or len(buf) < nbytes:
+        cap = 1 << 20
+        while cap < nbytes:
+            cap <<= 1
+        buf = _TLS.buf2 = bytearray(cap)
+    return buf
+
+
+# column chunks decoded by the hand-written reader / left to pyarrow since the process started
+# (bench.py's end_to_end entry reports them: a fallback must not be silent)
+READER_CHUNKS = {"plain": 0, "pyarrow": 0}
 
 
 def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None, pin=True):
@@ -521,13 +548,20 @@ def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None
                 got += k
             cbuf = (C.c_uint8 * len(buf)).from_buffer(buf)
             r, v = C.c_uint64(), C.c_uint64()
-            rc = lib.nvt_pq_decode_chunk(cbuf, cc["size"], dt.itemsize, pf.max_def[j], rows,
-                                         valid.data_ptr() if valid is not None else None, row_at,
-                                         vals.data_ptr() + val_at * dt.itemsize, (total - val_at) * dt.itemsize,
-                                         C.byref(r), C.byref(v))
+            sbuf, sbytes = None, 0
+            if cc.get("codec", 0) != 0 or cc.get("dictionary"):
+                sbytes = 2 * max(cc.get("raw_size", 0), cc["size"]) + 64
+                sraw = _scratch2(sbytes)
+                sbuf = (C.c_uint8 * len(sraw)).from_buffer(sraw)
+            rc = lib.nvt_pq_decode_chunk_codec(cbuf, cc["size"], cc.get("codec", 0), dt.itemsize, pf.max_def[j],
+                                               rows, valid.data_ptr() if valid is not None else None, row_at,
+                                               vals.data_ptr() + val_at * dt.itemsize,
+                                               (total - val_at) * dt.itemsize, sbuf, sbytes,
+                                               C.byref(r), C.byref(v))
             if rc != 0:
-                raise _lib.NvtHipError(f"nvt_pq_decode_chunk({pf.path}, {n}, row group {g}): "
+                raise _lib.NvtHipError(f"nvt_pq_decode_chunk_codec({pf.path}, {n}, row group {g}): "
                                        f"{lib.nvt_last_error().decode()} (rc {rc})")
+            READER_CHUNKS["plain"] += 1
             row_at += rows
             val_at += int(v.value)
         return StagedColumn(vals, valid if (valid is not None and val_at < total) else None, total, val_at, dt)

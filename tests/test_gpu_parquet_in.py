@@ -60,7 +60,12 @@ def _frame(n, seed=0):
 
 
 @pytest.mark.parametrize("page_version", ["1.0", "2.0"])
-def test_parquet_dataset_through_the_plain_reader_equals_pyarrow(tmp_path, page_version, monkeypatch):
+@pytest.mark.parametrize("dictionary", [False, True])
+@pytest.mark.parametrize("compression", [None, "snappy"])
+def test_parquet_dataset_through_the_plain_reader_equals_pyarrow(tmp_path, page_version, dictionary, compression,
+                                                                 monkeypatch):
+    """{snappy, none} x {dictionary on, off} x {v1, v2 pages} (round 6): every partition comes through
+    the hand-written reader, frames and the fitted workflow's output equal the pyarrow path's."""
     import nvtabular_amd as nvt
     from nvtabular_amd import io as nio
     from nvtabular_amd import ops
@@ -71,8 +76,8 @@ def test_parquet_dataset_through_the_plain_reader_equals_pyarrow(tmp_path, page_
 
     os.makedirs(path)
     for i, (a, b) in enumerate([(0, 100_003), (100_003, 250_007)]):
-        pq.write_table(t.slice(a, b - a), os.path.join(path, f"part_{i}.parquet"), use_dictionary=False,
-                       compression=None, row_group_size=60_001, data_page_version=page_version,
+        pq.write_table(t.slice(a, b - a), os.path.join(path, f"part_{i}.parquet"), use_dictionary=dictionary,
+                       compression=compression, row_group_size=60_001, data_page_version=page_version,
                        data_page_size=64 * 1024)
 
     def parts(plain):

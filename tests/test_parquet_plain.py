@@ -143,6 +143,93 @@ def test_plain_reader_equals_pyarrow_on_pyarrow_files(tmp_path, page_version, ro
         _staged_equals_arrow(staged, pq.ParquetFile(path).read_row_groups([1], columns=["a", "c"]))
 
 
+@pytest.mark.parametrize("page_version", ["1.0", "2.0"])
+@pytest.mark.parametrize("dictionary", [True, False])
+@pytest.mark.parametrize("compression", ["snappy", None])
+def test_reader_equals_pyarrow_on_default_files(tmp_path, compression, dictionary, page_version):
+    """What pandas / pyarrow / cuDF / the reference write by default (round 6: snappy blocks,
+    dictionary pages with RLE_DICTIONARY indices -- including the mid-chunk fall-back to PLAIN when a
+    dictionary outgrows its page, bit width 0 for a constant column, nulls in either page version):
+    every chunk is decoded by nvt_pq_decode_chunk_codec, none is left to pyarrow, and values / nulls /
+    dtypes equal pyarrow's own reader bit for bit."""
+    t = _mixed_table(250_003, seed=3)
+    rng = np.random.default_rng(9)
+    t = t.append_column("g", pa.array(np.zeros(t.num_rows, dtype="int32")))                        # width 0
+    t = t.append_column("h", pa.array((rng.zipf(1.2, t.num_rows) % 3_000_000).astype("int64"),
+                                      mask=rng.random(t.num_rows) < 0.1))                            # big dictionary
+    path = str(tmp_path / "d.parquet")
+    pq.write_table(t, path, use_dictionary=dictionary, compression=compression, row_group_size=90_001,
+                   data_page_version=page_version, data_page_size=24 * 1024)
+    pf = PP.PlainParquetFile(path)
+    assert pf.eligible, pf.why
+    before = dict(PP.READER_CHUNKS)
+    groups = list(range(pf.num_row_groups))
+    staged = PP.read_row_groups_staged(pf, groups, pin=False)
+    _staged_equals_arrow(staged, pq.ParquetFile(path).read_row_groups(groups))
+    assert PP.READER_CHUNKS["plain"] == before["plain"] + len(groups) * t.num_columns
+    assert PP.READER_CHUNKS["pyarrow"] == before["pyarrow"]
+    if dictionary:
+        assert any(c["dictionary"] for c in pf.row_groups[0]["columns"])
+    assert {c["codec"] for c in pf.row_groups[0]["columns"]} == {1 if compression else 0}
+
+
+def test_pandas_default_file_goes_through_the_hand_written_reader(tmp_path):
+    """`df.to_parquet(path)` with no arguments (snappy + dictionary): eligible."""
+    rng = np.random.default_rng(2)
+    df = pd.DataFrame({"C1": rng.integers(0, 1000, 50_000).astype("int32"), "I1": rng.normal(size=50_000)})
+    path = str(tmp_path / "pandas.parquet")
+    df.to_parquet(path)
+    pf = PP.PlainParquetFile(path)
+    assert pf.eligible, pf.why
+    staged = PP.read_row_groups_staged(pf, list(range(pf.num_row_groups)), pin=False)
+    _staged_equals_arrow(staged, pq.read_table(path))
+
+
+@pytest.mark.parametrize("dictionary", [True, False])
+def test_codec_decoder_survives_corrupted_chunks(tmp_path, dictionary):
+    """A snappy / dictionary chunk with flipped bytes (page headers, snappy tags and offsets, index
+    runs, bit widths) is decoded or refused -- never read or written outside its buffers: values,
+    bitmap and SCRATCH sit in guarded arrays whose margins must stay untouched."""
+    import ctypes as C
+
+    from nvtabular_amd import _lib
+
+    n = 4000
+    rng = np.random.default_rng(11 + dictionary)
+    arr = pa.array(rng.integers(0, 300 if dictionary else 1 << 40, n).astype("int64"), mask=rng.random(n) < 0.2)
+    path = str(tmp_path / "c.parquet")
+    pq.write_table(pa.table({"a": arr}), path, use_dictionary=dictionary, compression="snappy",
+                   data_page_size=2048)
+    pf = PP.PlainParquetFile(path)
+    assert pf.eligible
+    cc = pf.row_groups[0]["columns"][0]
+    raw = bytearray(open(path, "rb").read()[cc["offset"]: cc["offset"] + cc["size"]])
+    lib = _lib.load()
+    guard = 4096
+    sbytes = 2 * max(cc["raw_size"], cc["size"]) + 64
+    vals = np.full(n * 8 + 2 * guard, 0xA5, dtype="uint8")
+    bm = np.full(n // 8 + 16 + 2 * guard, 0xA5, dtype="uint8")
+    scr = np.full(sbytes + 2 * guard, 0xA5, dtype="uint8")
+    r, v = C.c_uint64(), C.c_uint64()
+    seen = set()
+    for it in range(3000):
+        buf = bytearray(raw)
+        if it:
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(0, len(buf)))
+                buf[at] = int(rng.integers(0, 256)) if rng.random() < 0.7 else (0xFF if rng.random() < 0.5 else 0x80)
+        b = (C.c_uint8 * len(buf)).from_buffer(buf)
+        rc = lib.nvt_pq_decode_chunk_codec(b, len(buf), 1, 8, 1, n, bm.ctypes.data + guard, 0,
+                                           vals.ctypes.data + guard, n * 8, scr.ctypes.data + guard, sbytes,
+                                           C.byref(r), C.byref(v))
+        seen.add(rc)
+        assert rc in (0, _lib.NVT_EINVAL, _lib.NVT_EUNSUPPORTED)
+        assert (vals[:guard] == 0xA5).all() and (vals[-guard:] == 0xA5).all()
+        assert (bm[:guard] == 0xA5).all() and (bm[guard + n // 8 + 16:] == 0xA5).all()
+        assert (scr[:guard] == 0xA5).all() and (scr[-guard:] == 0xA5).all()
+    assert 0 in seen and _lib.NVT_EINVAL in seen
+
+
 def test_plain_reader_reads_the_plain_writers_files(tmp_path):
     rng = np.random.default_rng(5)
     n = PP.PAGE_VALUES + 4099
@@ -162,17 +249,22 @@ def test_plain_reader_reads_the_plain_writers_files(tmp_path):
     _staged_equals_arrow(staged, pq.read_table(path))
 
 
-@pytest.mark.parametrize("kind", ["dictionary", "snappy", "string", "list", "date", "uint"])
+@pytest.mark.parametrize("kind", ["gzip", "zstd", "delta", "byte_stream_split", "string", "list", "date", "uint"])
 def test_files_the_plain_reader_leaves_to_pyarrow(tmp_path, kind):
     n = 1000
     rng = np.random.default_rng(1)
     x = rng.integers(0, 5, n).astype("int32")
     kw = dict(use_dictionary=False, compression=None)
     t = pa.table({"x": x})
-    if kind == "dictionary":
-        kw["use_dictionary"] = True
-    elif kind == "snappy":
-        kw["compression"] = "snappy"
+    if kind in ("gzip", "zstd"):
+        if not pa.Codec.is_available(kind):
+            pytest.skip(f"pyarrow without {kind}")
+        kw["compression"] = kind
+    elif kind == "delta":
+        kw["column_encoding"] = {"x": "DELTA_BINARY_PACKED"}
+    elif kind == "byte_stream_split":
+        t = pa.table({"x": x.astype("float32")})
+        kw["column_encoding"] = {"x": "BYTE_STREAM_SPLIT"}
     elif kind == "string":
         t = pa.table({"x": x, "s": pa.array([str(v) for v in x])})
     elif kind == "list":
