@@ -863,6 +863,54 @@ def extra_multipart(device, tmp, rows, nparts=8, steps=2, single_ms=None):
     return res
 
 
+def dist_multipart(device, tmp, rows, nparts, rank, world, barrier, steps=2):
+    """BASELINE.json configs[2]'s shape on N GPUs (every rank calls this): each rank holds `nparts`
+    partitions of `rows` rows of the cfg2 schema (seeds differ per rank and partition), ONE exchange
+    per fit whatever the number of partitions (the per-rank tree merge runs first), transform over
+    the rank's partitions.  The exchange amortises over nparts partitions here -- the shape the
+    north star's Criteo-1TB run has -- where the headline's N > 1 line (one partition per rank) is
+    the worst case for it.  Timed like the headline: barrier + synchronize on both sides, the
+    slowest rank's clock.  Compare rows_per_s with N x the N = 1 line's cfg3_multipartition."""
+    import nvtabular_amd as nvt
+
+    frames = [synth_criteo(rows, device, seed=31337 + 1000 * p + 100_000 * rank) for p in range(nparts)]
+    cat_names = [c for c in frames[0].columns if c.startswith("C")]
+    cont_names = [c for c in frames[0].columns if c.startswith("I")]
+    wf = build_workflow(cat_names, cont_names, os.path.join(tmp, f"dist_multipart{rank}"))
+    ds = nvt.Dataset(frames)
+
+    def step():
+        wf.fit(ds)
+        for out in wf.transform(ds).to_iter():
+            del out
+
+    step()   # cold: no hints
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    if world > 1:
+        import torch.distributed as td
+
+        t = torch.tensor([ms], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        ms = float(t.item())
+    del frames, ds, wf
+    torch.cuda.empty_cache()
+    return {
+        "workload": f"cfg2 schema, {nparts} partitions x {rows} rows per rank (own seeds), resident; "
+                    "Workflow.fit (one exchange per fit) + Workflow.transform over the rank's partitions",
+        "partitions_per_rank": nparts, "rows_per_rank": nparts * rows, "n_gpus": world,
+        "ms_per_step": ms, "rows_per_s": world * nparts * rows / (ms / 1e3),
+        "ms_per_partition": ms / nparts, "scaling": "weak",
+        "parity": "not checked in this entry (the N = 1 line's cfg3_multipartition and "
+                  "tests/multirank_check.py cover the multi-partition and the multi-rank path)",
+    }
+
+
 def extra_dense_ids(device, tmp, rows, steps=5, single_ms=None):
     """The headline workload with UNSCRAMBLED ids (id = frequency rank: dense, power-law over
     [1, cardinality]): what the range path's equal-width key-range buckets cost when the keys are
@@ -1611,6 +1659,16 @@ def main():
     if world > 1:
         result["collective_selfcheck"] = selfcheck
         result["dist_breakdown"] = dist_diag
+        if not args.no_extra:
+            # (every rank: the fit's collectives need all of them)
+            for name in ("frame", "ds", "wf"):
+                locals().pop(name, None)
+            torch.cuda.empty_cache()
+            try:
+                result["dist_cfg3_multipartition"] = dist_multipart(device, tmp, n, args.multipart, rank, world,
+                                                                    barrier)
+            except Exception as e:  # noqa: BLE001
+                result["dist_cfg3_multipartition"] = {"error": repr(e)}
     if rank == 0:
         from nvtabular_amd import dist as _d
 

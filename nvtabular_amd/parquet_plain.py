@@ -521,6 +521,7 @@ def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None
     lib = _lib.load()
     names = [n for n in pf.names if columns is None or n in columns]
     total = sum(pf.row_groups[g]["num_rows"] for g in groups)
+    pinned = bool(pin) and torch.cuda.is_available()   # (host-only processes stage in pageable memory)
     fd = os.open(pf.path, os.O_RDONLY)
 
     def task(n):
@@ -529,10 +530,10 @@ def read_row_groups_staged(pf: PlainParquetFile, groups, columns=None, pool=None
         groups may share a bitmap byte)."""
         j = pf.names.index(n)
         dt = pf.dtypes[j]
-        vals = torch.empty(total, dtype=getattr(torch, dt.name), pin_memory=pin)
+        vals = torch.empty(total, dtype=getattr(torch, dt.name), pin_memory=pinned)
         valid = None
         if pf.max_def[j]:
-            valid = torch.zeros(((total + 63) // 64) * 8 + 8, dtype=torch.uint8, pin_memory=pin)
+            valid = torch.zeros(((total + 63) // 64) * 8 + 8, dtype=torch.uint8, pin_memory=pinned)
         row_at = val_at = 0
         for g in groups:
             cc = pf.row_groups[g]["columns"][j]

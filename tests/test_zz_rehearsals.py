@@ -27,7 +27,7 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
     env.pop("RANK", None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows",
                           "400000", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000",
-                          "--no-extra"],
+                          "--multipart", "3"],
                          capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
@@ -47,6 +47,9 @@ def test_bench_spawns_its_own_ranks_gloo_rehearsal(tmp_path):
     bd = rec["dist_breakdown"]
     assert bd["sections_ms"] and bd["bytes_sent_per_rank"] > 0 and bd["collective_calls_per_fit"] >= 4
     assert "all_to_all_single(uneven)" in bd["collectives"]
+    # ... and carries the multi-partition shape per rank (ONE exchange per fit over 3 partitions)
+    mp = rec["dist_cfg3_multipartition"]
+    assert mp["n_gpus"] == 2 and mp["partitions_per_rank"] == 3 and mp["rows_per_s"] > 0, mp
 
 
 def _bench(tmp_path, env_extra, *args):
