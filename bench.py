@@ -1624,8 +1624,9 @@ def main():
             "pandas' unstable default); tie_break='reference' reproduces the literal order on the "
             "host: reference_tie_break_step_ms")
         try:
-            result["reference_tie_break_step_ms"] = round(
-                reference_tie_break_step_ms(frame, cat_names, cont_names, tmp), 1)
+            with _dist.local_only():   # (rank 0 alone: its peers are not in this fit's collectives)
+                result["reference_tie_break_step_ms"] = round(
+                    reference_tie_break_step_ms(frame, cat_names, cont_names, tmp), 1)
         except Exception as e:
             result["reference_tie_break_step_ms"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_extra and not args.no_cpu_baseline:
@@ -1664,6 +1665,7 @@ def main():
             for name in ("frame", "ds", "wf"):
                 locals().pop(name, None)
             torch.cuda.empty_cache()
+            barrier()   # (rank 0 comes out of its single-rank legs here)
             try:
                 result["dist_cfg3_multipartition"] = dist_multipart(device, tmp, n, args.multipart, rank, world,
                                                                     barrier)
