@@ -585,6 +585,65 @@ int nvt_te_image(const int64_t *tot_count, const double *tot_sum, const int64_t 
                  const double *fold_sum, int kfold, uint64_t groups, double p_smooth, double y_mean,
                  int out_dtype, void *image, uint32_t stride_bytes, uint32_t off, void *stream);
 
+/* ---- key directory: the key -> group step in ONE 16-byte read -----------------------------------
+ * (the same left merges, join_groupby.py:198-217 / target_encoding.py:341-371.)  The flat-index
+ * probe above walks {key, group} slots across 64-byte lines: ~2.4 L2 misses per row with the
+ * record, and the kernel runs at the rate the fabric takes misses (tools/pmc_lookup.sh).  Here the
+ * groups' keys are ascending (group g = position g of keys32) and
+ *   dir[b] = uint32[4] {first, k0, k1, k2}, b = 0 .. dir_slots : first = index of the first key
+ *            that maps to a bucket >= b under the monotone range map over [keys32[0],
+ *            keys32[nkeys - 1]] (dir[dir_slots].first = nkeys); k0..k2 = the bucket's first three
+ *            keys (a shorter bucket repeats its last key, an empty one holds the list's next key);
+ * a row whose key is k0 / k1 / k2 has its group from that read, a key above k2 walks keys32 from
+ * first + 3 (bisection inside the bucket when the keys cluster).  No parameter block, no failure
+ * mode to read back.
+ * nvt_keydir_build: dir (uint32[4 * (dir_slots + 1)], 16-byte aligned) from the ascending
+ * duplicate-free key list.
+ * nvt_keydir_lookup_image: nvt_flat_lookup_image's image / outputs / folds / offs / sizes /
+ * miss_bits / unseen; keys int32 / int64 (list key = column key - key_offset), rows with a null
+ * key take record `null_group` (-1: they miss).
+ * nvt_image_build: records [records][stride_bytes] (stride <= 192) written WHOLE in one pass: up
+ * to 4 operators' byte ranges, each evaluated exactly as nvt_jg_image / nvt_te_image evaluate it
+ * (kind NVT_IMAGE_PART_JG: count / sum / sumsq / mn / mx / nvals / kinds / vals / dst_dtypes /
+ * offs / ncols as in nvt_jg_image; NVT_IMAGE_PART_TE: tot_* / fold_* / kfold / p_smooth / y_mean
+ * / out_dtype / offset as in nvt_te_image); a part fills its first `groups` records, every other
+ * byte of the image is zero. */
+#define NVT_IMAGE_PART_JG 0
+#define NVT_IMAGE_PART_TE 1
+typedef struct nvt_image_part {
+  int32_t kind;
+  int32_t nvals;               /* JG */
+  int32_t ncols;               /* JG */
+  int32_t kfold;               /* TE */
+  int32_t out_dtype;           /* TE: NVT_F32 / NVT_F64 */
+  uint32_t offset;             /* TE: byte offset of slot 0 inside the record */
+  uint64_t groups;
+  const int64_t *count;        /* JG */
+  const double *const *sum;    /* JG: nvals pointers each (or NULL) */
+  const double *const *sumsq;
+  const double *const *mn;
+  const double *const *mx;
+  const int32_t *kinds;        /* JG: ncols entries each */
+  const int32_t *vals;
+  const int32_t *dst_dtypes;
+  const uint32_t *offs;
+  const int64_t *tot_count;    /* TE */
+  const double *tot_sum;
+  const int64_t *fold_count;
+  const double *fold_sum;
+  double p_smooth;
+  double y_mean;
+} nvt_image_part;
+int nvt_keydir_build(const int32_t *keys32, uint64_t n, uint64_t dir_slots, uint32_t *dir, void *stream);
+int nvt_keydir_lookup_image(const void *keys, int dtype, const uint8_t *valid, uint64_t n,
+                            const uint32_t *dir, uint64_t dir_slots, const int32_t *keys32, uint64_t nkeys,
+                            int64_t key_offset, int64_t null_group, const void *image,
+                            uint32_t stride_bytes, int ncols, void *const *outs, const uint8_t *const *folds, const uint32_t *offs,
+                            const uint32_t *sizes, const uint64_t *miss_bits, uint64_t *unseen,
+                            void *stream);
+int nvt_image_build(const nvt_image_part *parts, int nparts, uint64_t records, void *image,
+                    uint32_t stride_bytes, void *stream);
+
 /* ---- parquet in: PLAIN / uncompressed column chunks of flat numeric columns -------------
  * (merlin.io.Dataset(engine="parquet") under Workflow.fit / transform:
  * tests/unit/workflow/test_cpu_workflow.py:67-81, bench/examples/dask-nvtabular-criteo-benchmark.py

@@ -185,6 +185,19 @@ class MergeCol(C.Structure):
                 ("src_a", _vp), ("src_b", _vp), ("out_n", _vp)]
 
 
+class ImagePart(C.Structure):
+    """nvt_image_part: one operator's byte range of the records (nvt_image_build)."""
+    _fields_ = [("kind", C.c_int32), ("nvals", C.c_int32), ("ncols", C.c_int32), ("kfold", C.c_int32),
+                ("out_dtype", C.c_int32), ("offset", C.c_uint32), ("groups", _u64), ("count", _vp),
+                ("sum", _vp), ("sumsq", _vp), ("mn", _vp), ("mx", _vp), ("kinds", _vp), ("vals", _vp),
+                ("dst_dtypes", _vp), ("offs", _vp), ("tot_count", _vp), ("tot_sum", _vp),
+                ("fold_count", _vp), ("fold_sum", _vp), ("p_smooth", _dbl), ("y_mean", _dbl)]
+
+
+IMAGE_PART_JG, IMAGE_PART_TE = 0, 1   # include/nvt_hip.h NVT_IMAGE_PART_*
+IMAGE_BUILD_MAX_PARTS, IMAGE_BUILD_MAX_STRIDE = 4, 192
+
+
 class EncodeCol(C.Structure):
     _fields_ = [("keys", _vp), ("valid", _vp), ("n", _u64), ("table", _vp), ("capacity", _u64),
                 ("sentinel_label", _vp), ("null_label", _i64), ("oov_label", _i64),
@@ -194,6 +207,10 @@ class EncodeCol(C.Structure):
 
 
 SIGNATURES.update({
+    "nvt_keydir_build": [_vp, _u64, _u64, _vp, _vp],
+    "nvt_keydir_lookup_image": [_vp, _i32, _vp, _u64, _vp, _u64, _vp, _u64, _i64, _i64, _vp, _u32, _i32, _pp,
+                                _pp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u64), _vp, _vp],
+    "nvt_image_build": [C.POINTER(ImagePart), _i32, _u64, _vp, _u32, _vp],
     "nvt_moments_many": [C.POINTER(MomentsCol), _i32, _vp, _vp],
     "nvt_fill_normalize_many": [C.POINTER(FillNormCol), _i32, _vp],
     "nvt_dense_count_many": [C.POINTER(CountCol), _i32, _vp],

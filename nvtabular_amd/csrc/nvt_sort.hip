@@ -19,6 +19,7 @@
 #include "nvt_internal.hpp"
 #include "nvt_prof.hpp"
 #include "nvt_range.hpp"
+#include "nvt_image.hpp"
 #include "nvt_scan.hpp"
 
 extern "C" int nvt_vocab_sort_tmp_bytes(int key_bytes, uint64_t n, uint64_t *bytes);
@@ -1584,16 +1585,6 @@ __global__ __launch_bounds__(kBlock) void flat_lookup_te_kernel(
 // evaluating it per group at the end of the fit gives the row's value bit for bit.  A row then
 // costs one random sector for the probe and one for its record (<= 64 bytes), whatever the
 // number of operators and statistics; the kernel moves 4- or 8-byte words, it does not convert.
-constexpr int kImageMaxCols = 24;
-struct ImageOuts {
-  void *out[kImageMaxCols];
-  const uint8_t *fold[kImageMaxCols];  // fold id column of this output (nullptr: fixed offset)
-  uint64_t miss[kImageMaxCols];        // value bits of a row without group
-  uint32_t off[kImageMaxCols];         // byte offset inside the record (slot 0)
-  uint32_t fstride[kImageMaxCols];     // bytes per fold slot (= the value size)
-  uint32_t size[kImageMaxCols];        // 4 or 8
-};
-
 template <typename K, int MAXC>
 __global__ __launch_bounds__(kBlock) void flat_lookup_image_kernel(
     const K *__restrict__ keys, const uint8_t *__restrict__ valid, uint64_t n,
@@ -1640,15 +1631,6 @@ struct ImagePackArgs {
   uint32_t off[kImageMaxCols];
 };
 
-__device__ __forceinline__ void image_store(uint8_t *at, int dtype, double x, int64_t xi, bool is_int) {
-  switch (dtype) {
-    case NVT_F32: *reinterpret_cast<float *>(at) = is_int ? (float)xi : (float)x; break;
-    case NVT_F64: *reinterpret_cast<double *>(at) = is_int ? (double)xi : x; break;
-    case NVT_I32: *reinterpret_cast<int32_t *>(at) = is_int ? (int32_t)xi : (int32_t)x; break;
-    default: *reinterpret_cast<int64_t *>(at) = is_int ? xi : (int64_t)x; break;
-  }
-}
-
 __global__ __launch_bounds__(kBlock) void image_pack_kernel(ImagePackArgs a, int ncols, uint64_t groups,
                                                             uint8_t *__restrict__ image,
                                                             uint32_t stride_bytes) {
@@ -1668,42 +1650,15 @@ __global__ __launch_bounds__(kBlock) void image_pack_kernel(ImagePackArgs a, int
 // categorify.py:1087-1131 _bottom_level_groupby): count, sum, mean = sum / n, var = (sumsq -
 // sum * sum / n) / max(n - 1, 1) (NaN for n = 1), std = sqrt(var), min, max -- evaluated per group
 // in float64 like the column-wise path (ops/_groupby.py derive_stats), stored in the output dtype.
-constexpr int kJgMaxVals = 8;
-struct JgImageArgs {
-  const int64_t *count;
-  const double *sum[kJgMaxVals], *sumsq[kJgMaxVals], *mn[kJgMaxVals], *mx[kJgMaxVals];
-  int kind[kImageMaxCols];   // 0 count, 1 sum, 2 mean, 3 min, 4 max, 5 var, 6 std
-  int val[kImageMaxCols];    // value column of the statistic
-  int dst_dtype[kImageMaxCols];
-  uint32_t off[kImageMaxCols];
-};
 __global__ __launch_bounds__(kBlock) void jg_image_kernel(JgImageArgs a, int ncols, uint64_t groups,
                                                           uint8_t *__restrict__ image, uint32_t stride_bytes) {
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += stride) {
     uint8_t *rec = image + g * stride_bytes;
     const int64_t ni = a.count[g];
-    const double n = (double)ni;
     for (int c = 0; c < ncols; ++c) {
-      const int j = a.val[c];
-      double x = 0.0;
-      bool is_int = false;
-      switch (a.kind[c]) {
-        case 0: is_int = true; break;
-        case 1: x = a.sum[j][g]; break;
-        case 2: x = a.sum[j][g] / n; break;
-        case 3: x = a.mn[j][g]; break;
-        case 4: x = a.mx[j][g]; break;
-        default: {
-          const double s1 = a.sum[j][g], s2 = a.sumsq[j][g];
-          const double sq = __dmul_rn(s1, s1);            // (no contraction with the division / subtraction)
-          const double num = __dsub_rn(s2, __ddiv_rn(sq, n));
-          const double dn = n - 1.0;
-          double var = __ddiv_rn(num, dn < 1.0 ? 1.0 : dn);
-          if (dn == 0.0) var = __longlong_as_double(0x7FF8000000000000ll);
-          x = a.kind[c] == 5 ? var : sqrt(var);
-        }
-      }
+      bool is_int;
+      const double x = jg_stat(a, c, g, ni, &is_int);
       image_store(rec + a.off[c], a.dst_dtype[c], x, ni, is_int);
     }
   }
@@ -1725,15 +1680,7 @@ __global__ __launch_bounds__(kBlock) void te_image_kernel(
   for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
     const uint64_t g = e / per;
     const unsigned slot = (unsigned)(e - g * per);
-    const double c = (double)tot_count[g], d = tot_sum[g];
-    double r;
-    if (slot == 0) {
-      r = (d + p * y_mean) / (c + p);
-    } else {
-      const uint64_t f = g * kfold + (slot - 1);
-      const double fc = (double)fold_count[f], fs = fold_sum[f];
-      r = fc > 0.0 ? (d - fs + p * y_mean) / (c - fc + p) : y_mean;
-    }
+    const double r = te_value(tot_count, tot_sum, fold_count, fold_sum, kfold, g, slot, p, y_mean);
     *reinterpret_cast<OUT *>(image + g * stride_bytes + off + slot * sizeof(OUT)) = (OUT)r;
   }
 }

@@ -2119,34 +2119,63 @@ class FlatIndex:
 
     def __init__(self, keys32: torch.Tensor, key_offset: int = 0):
         _lib.require_gpu()
-        lib = _lib.load()
         # the list holds column value - key_offset (int64 columns whose keys span < 2^32)
         self.key_offset = int(key_offset)
         self.keys32 = keys32.contiguous()
         self.n = n = int(keys32.numel())
-        dev = keys32.device
         # home slots: FLAT_INDEX_LOAD of them hold a key (no power of two needed; the smaller
         # the table the more of it the caches keep)
         self.slots = max(64, int(n / FLAT_INDEX_LOAD) + 1)
         self.capacity = self.slots + n + 64
-        self.table = torch.empty(self.capacity, dtype=torch.int64, device=dev)
-        self.aux = torch.zeros(self.FLAT_AUX_WORDS, dtype=torch.int32, device=dev)
+        self._table = self._aux = self._dir = None
+        self.null_group = -1
+        self._ok = None
+        # with keyed lookup images (the transform's default path) nothing reads the flat table:
+        # it is laid out by the first lookup / gather / te call that needs it
+        if not (KEYED_IMAGES and LOOKUP_IMAGES and n >= 1):
+            self._build_table()
+
+    def _build_table(self):
+        lib = _lib.load()
+        n, dev = self.n, self.keys32.device
+        self._table = torch.empty(self.capacity, dtype=torch.int64, device=dev)
+        self._aux = torch.zeros(self.FLAT_AUX_WORDS, dtype=torch.int32, device=dev)
         need = C.c_uint64()
         check(lib.nvt_flat_index_tmp_bytes(n, C.byref(need)), "nvt_flat_index_tmp_bytes")
         tmp = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        check(lib.nvt_flat_index_build(self.keys32.data_ptr(), n, self.slots, self.aux.data_ptr(),
-                                       self.table.data_ptr(), self.capacity, tmp.data_ptr(),
+        check(lib.nvt_flat_index_build(self.keys32.data_ptr(), n, self.slots, self._aux.data_ptr(),
+                                       self._table.data_ptr(), self.capacity, tmp.data_ptr(),
                                        stream_ptr()), "nvt_flat_index_build")
-        self._ok = None
+        if self.null_group >= 0:
+            self._aux[self.FLAT_AUX_MAXDISP + 2] = self.null_group + 1   # NVT_FLAT_AUX_NULLGROUP
+
+    @property
+    def table(self) -> torch.Tensor:
+        if self._table is None:
+            self._build_table()
+        return self._table
+
+    @property
+    def aux(self) -> torch.Tensor:
+        if self._aux is None:
+            self._build_table()
+        return self._aux
 
     def set_null_group(self, group: int):
         """Rows whose key is null look up `group` (JoinGroupby / TargetEncoding keep null keys as
         one group, like the reference's groupby(dropna=False)); without it they miss."""
-        self.aux[self.FLAT_AUX_MAXDISP + 2] = int(group) + 1   # NVT_FLAT_AUX_NULLGROUP
+        self.null_group = int(group)
+        if self._aux is not None:
+            self._aux[self.FLAT_AUX_MAXDISP + 2] = int(group) + 1   # NVT_FLAT_AUX_NULLGROUP
 
     def ok(self) -> bool:
         """False when the keys cluster in their range (an entry further than MAX_DISPLACEMENT
-        slots from its home slot): the caller builds a hashed index instead.  One read-back."""
+        slots from its home slot): the caller builds a hashed index instead.  One read-back --
+        none while the table is not laid out (keyed lookup images search a crowded bucket by
+        bisection, and a table laid out later for a column-wise lookup is searched by galloping
+        steps: slower for clustered keys, never wrong)."""
+        if self._table is None:
+            return True
         if self._ok is None:
             word = self.aux[self.FLAT_AUX_MAXDISP:self.FLAT_AUX_MAXDISP + 2].view(torch.int64)
             d = int(read_back(word)[0]) & 0xFFFFFFFF
@@ -2233,9 +2262,13 @@ class FlatIndex:
             self._build_image()
 
     def _build_image(self):
+        # ranges read at fixed offsets first, 16-byte aligned: the lookup reads every aligned
+        # 16-byte window that holds several of a row's values with ONE load (per-fold values are
+        # picked by the row's fold id and keep a load each)
         at, place = 0, {}
-        for c in self.consumers:
-            at = (at + 7) & ~7
+        for c in sorted(self.consumers, key=lambda c: c.fold_fn is not None):
+            align = 16 if (c.width >= 16 and c.fold_fn is None) else 8
+            at = (at + align - 1) & ~(align - 1)
             place[id(c)] = at
             at += c.width
         total = max(8, (at + 7) & ~7)
@@ -2243,10 +2276,28 @@ class FlatIndex:
         stride = next_pow2(total) if total <= 64 else (total + 63) & ~63
         # (a consumer's statistics may hold one group more than the key list: the null-key group)
         rows = max([self.n + 1] + [c.groups for c in self.consumers])
-        image = torch.empty(rows * stride, dtype=torch.uint8, device=self.keys32.device)
-        for c in self.consumers:
-            c.fill(image, stride, place[id(c)], c.groups)
-        self._image = (image, stride, place)
+        dev = self.keys32.device
+        image = torch.empty(rows * stride, dtype=torch.uint8, device=dev)
+        plist = []
+        if ONE_PASS_IMAGES and stride <= _lib.IMAGE_BUILD_MAX_STRIDE \
+                and all(c.parts is not None for c in self.consumers):
+            for c in self.consumers:
+                plist += c.parts(place[id(c)], c.groups)
+        if plist and len(plist) <= _lib.IMAGE_BUILD_MAX_PARTS:
+            # whole records in ONE pass over every operator's range
+            arr = (_lib.ImagePart * len(plist))(*[p[0] for p in plist])
+            check(_lib.load().nvt_image_build(arr, len(plist), rows, image.data_ptr(), stride,
+                                              stream_ptr()), "nvt_image_build")
+        else:
+            for c in self.consumers:
+                c.fill(image, stride, place[id(c)], c.groups)
+        keyed = KEYED_IMAGES and 1 <= self.n < (1 << 32) - 2
+        if keyed and self._dir is None:
+            self.dir_slots = max(64, int(self.n / KEYDIR_LOAD) + 1)
+            self._dir = torch.empty(4 * (self.dir_slots + 1), dtype=torch.int32, device=dev)
+            check(_lib.load().nvt_keydir_build(self.keys32.data_ptr(), self.n, self.dir_slots,
+                                               self._dir.data_ptr(), stream_ptr()), "nvt_keydir_build")
+        self._image = (image, stride, place, keyed)
         return self._image
 
     def image_lookup(self, consumer: "LookupConsumer", keys, key_valid, fold=None):
@@ -2262,7 +2313,7 @@ class FlatIndex:
         if hit is not None and id(consumer) in hit["outs"]:
             return hit["outs"][id(consumer)], hit["unseen"]
         img = getattr(self, "_image", None) or self._build_image()
-        image, stride, place = img
+        image, stride, place, keyed = img
         todo = list(self.consumers) if (memo is not None and hit is None) else [consumer]
         dev = k.device
         outs, ptrs, folds, offs, sizes, miss, keep = {}, [], [], [], [], [], []
@@ -2291,6 +2342,16 @@ class FlatIndex:
         for lo in range(0, len(ptrs) if n else 0, IMAGE_LOOKUP_MAX_OUTPUTS):
             hi = min(lo + IMAGE_LOOKUP_MAX_OUTPUTS, len(ptrs))
             nc = hi - lo
+            if keyed:
+                check(_lib.load().nvt_keydir_lookup_image(
+                    k.data_ptr(), dtype_code(k.dtype), ptr(valid), n, self._dir.data_ptr(),
+                    self.dir_slots, self.keys32.data_ptr(), self.n, self.key_offset, self.null_group,
+                    image.data_ptr(),
+                    stride, nc, _lib.ptr_array(ptrs[lo:hi]), _lib.ptr_array(folds[lo:hi]),
+                    (C.c_uint32 * nc)(*offs[lo:hi]), (C.c_uint32 * nc)(*sizes[lo:hi]),
+                    (C.c_uint64 * nc)(*miss[lo:hi]), unseen.data_ptr(), stream_ptr()),
+                    "nvt_keydir_lookup_image")
+                continue
             check(_lib.load().nvt_flat_lookup_image(
                 k.data_ptr(), dtype_code(k.dtype), ptr(valid), n, self.aux.data_ptr(),
                 self.table.data_ptr(), self.capacity, self.key_offset, None, None, image.data_ptr(),
@@ -2329,9 +2390,12 @@ class LookupConsumer:
     fold_fn(n, device) -> uint8 fold ids.  fill(image, stride, offset, groups) writes the range
     of the first `groups` records."""
 
-    def __init__(self, owner, tag, width, outputs, fill, fold_fn=None, groups=0):
+    def __init__(self, owner, tag, width, outputs, fill, fold_fn=None, groups=0, parts=None):
         self.owner, self.tag, self.width = owner, tag, int(width)
         self.outputs, self.fill, self.fold_fn = list(outputs), fill, fold_fn
+        # parts(offset, groups) -> [(ImagePart, keep-alive)]: the same range as descriptors of the
+        # one-pass build (nvt_image_build); None: only fill() can write it
+        self.parts = parts
         self.groups = int(groups)   # records this consumer fills (the groups of its statistics)
         self.index = None
 
@@ -2346,7 +2410,7 @@ class LookupConsumer:
             if cons is not None and self in cons:
                 cons.remove(self)
             idx._image = None
-        self.fill = self.fold_fn = self.owner = None
+        self.fill = self.fold_fn = self.owner = self.parts = None
 
 
 def image_pack(image, stride, columns, groups):
@@ -2394,6 +2458,52 @@ def jg_image(image, stride, comp, outputs, groups):
     del ks, kq, kmn, kmx
 
 
+def jg_image_part(comp, outputs, groups):
+    """The arguments of jg_image as a part of the one-pass build: (ImagePart, keep-alive)."""
+    nvals = len(comp["sum"])
+    count = comp["count"].to(torch.int64).contiguous()
+    keep = [count]
+
+    def arr(name):
+        lst = comp.get(name) or []
+        if len(lst) != nvals or not nvals:
+            return None
+        ts = [t.to(torch.float64).contiguous() for t in lst]
+        pa = _lib.ptr_array([t.data_ptr() for t in ts])
+        keep.extend(ts)
+        keep.append(pa)
+        return C.cast(pa, C.c_void_p)
+
+    nc = len(outputs)
+    kinds = (C.c_int32 * nc)(*[JG_KINDS[o[0]] for o in outputs])
+    vals = (C.c_int32 * nc)(*[int(o[1]) for o in outputs])
+    dts = (C.c_int32 * nc)(*[dtype_code(o[2]) for o in outputs])
+    offs = (C.c_uint32 * nc)(*[int(o[3]) for o in outputs])
+    keep += [kinds, vals, dts, offs]
+    part = _lib.ImagePart(kind=_lib.IMAGE_PART_JG, nvals=nvals, ncols=nc, groups=int(groups),
+                          count=count.data_ptr(), sum=arr("sum"), sumsq=arr("sumsq"), mn=arr("min"),
+                          mx=arr("max"), kinds=C.cast(kinds, C.c_void_p), vals=C.cast(vals, C.c_void_p),
+                          dst_dtypes=C.cast(dts, C.c_void_p), offs=C.cast(offs, C.c_void_p))
+    return part, keep
+
+
+def te_image_part(offset, tot_count, tot_sum, fold_count, fold_sum, kfold, groups, p_smooth, y_mean,
+                  out_dtype):
+    """The arguments of te_image as a part of the one-pass build: (ImagePart, keep-alive)."""
+    tc, ts = tot_count.contiguous(), tot_sum.contiguous()
+    assert tc.dtype == torch.int64 and ts.dtype == torch.float64
+    fc = fs = None
+    if kfold:
+        fc, fs = fold_count.contiguous(), fold_sum.contiguous()
+        assert fc.dtype == torch.int64 and fs.dtype == torch.float64
+        assert int(fc.numel()) >= groups * kfold and int(fs.numel()) >= groups * kfold
+    part = _lib.ImagePart(kind=_lib.IMAGE_PART_TE, kfold=int(kfold), out_dtype=dtype_code(out_dtype),
+                          offset=int(offset), groups=int(groups), tot_count=tc.data_ptr(),
+                          tot_sum=ts.data_ptr(), fold_count=ptr(fc), fold_sum=ptr(fs),
+                          p_smooth=float(p_smooth), y_mean=float(y_mean))
+    return part, [tc, ts, fc, fs]
+
+
 def te_image(image, stride, offset, tot_count, tot_sum, fold_count, fold_sum, kfold, groups, p_smooth,
              y_mean, out_dtype):
     """(kfold + 1) smoothed values per group at `offset` of the records of `image`, from the
@@ -2414,6 +2524,13 @@ def te_image(image, stride, offset, tot_count, tot_sum, fold_count, fold_sum, kf
 
 
 LOOKUP_IMAGES = os.environ.get("NVT_LOOKUP_IMAGES", "1") != "0"
+# key -> group through the key directory (nvt_keydir_lookup_image: one 16-byte read per row, laid
+# out by two small passes, no read-back) instead of the flat table ("0": nvt_flat_lookup_image)
+KEYED_IMAGES = os.environ.get("NVT_KEYED_IMAGES", "1") != "0"
+KEYDIR_LOAD = float(os.environ.get("NVT_KEYDIR_LOAD", "1.0"))   # keys per directory bucket
+# records written whole by one launch over every operator's range (nvt_image_build); "0": a launch
+# per operator (nvt_jg_image / nvt_te_image)
+ONE_PASS_IMAGES = os.environ.get("NVT_ONE_PASS_IMAGES", "1") != "0"
 # Workflow.fit ends by enqueueing the lookup images of its groupby operators (FlatIndex.prepare_image)
 # instead of leaving them to the first transform; "0": built lazily by the first lookup.
 EAGER_IMAGES = os.environ.get("NVT_EAGER_IMAGES", "1") != "0"

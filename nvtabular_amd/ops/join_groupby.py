@@ -239,7 +239,16 @@ class JoinGroupby(StatOperator):
             K.image_pack(image, stride, [(st.columns[plan[i][0]], plan[i][1], offset + rel[i])
                                          for i in range(len(plan))], groups)
 
-        cons = K.LookupConsumer(self, name, at, outputs, fill, groups=st.n)
+        def parts(offset, groups, st=st, plan=plan, rel=rel):
+            spec = getattr(st.columns, "spec", None)
+            if spec is None:
+                return []   # (statistics read from files: only fill() can write them)
+            return [K.jg_image_part(st.columns.comp,
+                                    [(spec[i][1], spec[i][2], plan[i][1], offset + rel[i])
+                                     for i in range(len(plan))], groups)]
+
+        has_spec = getattr(st.columns, "spec", None) is not None
+        cons = K.LookupConsumer(self, name, at, outputs, fill, groups=st.n, parts=parts if has_spec else None)
         st.index.attach(cons)
         self._consumers[name] = cons
 

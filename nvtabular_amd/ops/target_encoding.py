@@ -283,11 +283,21 @@ class TargetEncoding(StatOperator):
                                st_fold.sums[t] if fit_folds else None,
                                self.kfold if fit_folds else 0, groups, self.p_smooth, means[t], out_dt)
 
+            def parts(offset, groups, st_all=st_all, st_fold=st_fold, targets=targets, means=means):
+                cnt = st_all.columns["count"].to(torch.int64)
+                return [K.te_image_part(offset + j * slots * size, cnt,
+                                        st_all.columns[f"sum:{t}"].to(torch.float64),
+                                        st_fold.count if fit_folds else None,
+                                        st_fold.sums[t] if fit_folds else None,
+                                        self.kfold if fit_folds else 0, groups, self.p_smooth, means[t],
+                                        out_dt)
+                        for j, t in enumerate(targets)]
+
             fold_fn = None
             if fit_folds:
                 fold_fn = lambda n, dev: _fold_column(n, self.kfold, self.fold_seed, dev).data  # noqa: E731
             cons = K.LookupConsumer(self, name, len(targets) * slots * size, outputs, fill, fold_fn,
-                                    groups=st_all.n)
+                                    groups=st_all.n, parts=parts)
             st_all.index.attach(cons)
             self._consumers[name] = cons
 

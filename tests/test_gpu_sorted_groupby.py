@@ -101,7 +101,11 @@ def test_flat_index_lookup_and_clustered_fallback():
     assert idx2.lookup([q], [None]).tolist() == [-1, 0, keys.size - 2]
     # dense ids + one far outlier: every key has the same home slot -> not ok (hashed index instead)
     clustered = np.concatenate([np.arange(100_000, dtype=np.int32), np.array([2**31 - 5], dtype=np.int32)])
-    assert not K.FlatIndex(torch.from_numpy(clustered).to(dev)).ok()
+    idx3 = K.FlatIndex(torch.from_numpy(clustered).to(dev))
+    assert idx3.table is not None and not idx3.ok()   # (the table is laid out on first use)
+    # ... and still finds every key (galloping steps inside the long run)
+    q = torch.tensor([0, 77_777, 99_999, 100_000, 2**31 - 5], dtype=torch.int32, device=dev)
+    assert idx3.lookup([q], [None]).tolist() == [0, 77_777, 99_999, -1, 100_000]
 
 
 def _frames(n, card, seed, key="int32"):
@@ -500,13 +504,17 @@ def test_exchange_batch_kernels_vs_torch():
         assert torch.equal(cnts[dst_off[s]:dst_off[s] + b - a], w >> 32)
 
 
-def test_clustered_keys_fall_back_to_a_hashed_index(tmp_path):
+@pytest.mark.parametrize("keyed", [True, False])
+def test_clustered_keys_fall_back_to_a_hashed_index(tmp_path, monkeypatch, keyed):
     """Dense ids plus one far outlier: the sort path still aggregates, but the flat index would have
-    every key in the same home slot (displacement > 4096) -> JoinGroupby / TargetEncoding look the
-    groups up through a hashed index built from the sorted keys; results unchanged."""
+    every key in the same home slot (displacement > 4096) -> without the key directory JoinGroupby /
+    TargetEncoding look the groups up through a hashed index built from the sorted keys; with it
+    (the default) the crowded bucket is searched by bisection.  Results unchanged either way."""
     import nvtabular_amd as nvt
     from nvtabular_amd import kernels as K
     from nvtabular_amd import ops
+
+    monkeypatch.setattr(K, "KEYED_IMAGES", keyed)
 
     rng = np.random.default_rng(17)
     n = 90_000
@@ -516,7 +524,7 @@ def test_clustered_keys_fall_back_to_a_hashed_index(tmp_path):
     jg = ops.JoinGroupby(out_path=str(tmp_path / "jg"), stats=["count", "mean"], cont_cols=["x"])
     te = ops.TargetEncoding("y", out_path=str(tmp_path / "te"), kfold=4, fold_seed=1, p_smooth=10)
     wf = nvt.Workflow((["k"] >> jg) + (["k"] >> te)).fit(nvt.Dataset(df))
-    assert isinstance(jg._device_stats["k"].index, K.GroupbyTable)
+    assert isinstance(jg._device_stats["k"].index, K.FlatIndex if keyed else K.GroupbyTable)
     got = wf.transform(nvt.Dataset(df)).to_ddf().compute()
     cats = O.join_groupby_fit([df.copy()], ["k"], ["x"], ["count", "mean"], str(tmp_path / "c"))
     exp_j = O.join_groupby_transform(df.copy(), ["k"], cats)
