@@ -633,6 +633,9 @@ typedef struct nvt_image_part {
   const double *fold_sum;
   double p_smooth;
   double y_mean;
+  const double *moments;       /* TE: NULL, or {count, sum} of the target on the device: the kernel
+                                  takes y_mean = sum / count from there (the fit's mean need not
+                                  have reached the host when the image is enqueued) */
 } nvt_image_part;
 int nvt_keydir_build(const int32_t *keys32, uint64_t n, uint64_t dir_slots, uint32_t *dir, void *stream);
 int nvt_keydir_lookup_image(const void *keys, int dtype, const uint8_t *valid, uint64_t n,

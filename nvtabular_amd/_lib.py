@@ -191,7 +191,8 @@ class ImagePart(C.Structure):
                 ("out_dtype", C.c_int32), ("offset", C.c_uint32), ("groups", _u64), ("count", _vp),
                 ("sum", _vp), ("sumsq", _vp), ("mn", _vp), ("mx", _vp), ("kinds", _vp), ("vals", _vp),
                 ("dst_dtypes", _vp), ("offs", _vp), ("tot_count", _vp), ("tot_sum", _vp),
-                ("fold_count", _vp), ("fold_sum", _vp), ("p_smooth", _dbl), ("y_mean", _dbl)]
+                ("fold_count", _vp), ("fold_sum", _vp), ("p_smooth", _dbl), ("y_mean", _dbl),
+                ("moments", _vp)]
 
 
 IMAGE_PART_JG, IMAGE_PART_TE = 0, 1   # include/nvt_hip.h NVT_IMAGE_PART_*

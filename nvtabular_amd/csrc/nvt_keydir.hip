@@ -222,6 +222,7 @@ struct TePart {
   int out_dtype;  // NVT_F32 / NVT_F64
   uint32_t off;
   double p, y_mean;
+  const double *moments;  // {count, sum} of the target on the device (nullptr: y_mean is the number)
 };
 struct BuildParts {
   int nparts;
@@ -273,12 +274,13 @@ __global__ __launch_bounds__(kBuildTile) void image_build_kernel(
         // a thread per value: the fold arrays are read in memory order
         const TePart &a = P.te[q];
         const unsigned per = a.kfold + 1;
+        const double y_mean = a.moments ? __ddiv_rn(a.moments[1], a.moments[0]) : a.y_mean;
         const uint64_t gend = P.groups[q] < g0 + cnt ? P.groups[q] : g0 + cnt;
         const unsigned vals = gend > g0 ? (unsigned)(gend - g0) * per : 0u;
         for (unsigned e = threadIdx.x; e < vals; e += kBuildTile) {
           const unsigned r = e / per, slot = e - r * per;
           const double v = te_value(a.tot_count, a.tot_sum, a.fold_count, a.fold_sum, a.kfold, g0 + r, slot,
-                                    a.p, a.y_mean);
+                                    a.p, y_mean);
           uint32_t *rec = tile + r * sw + a.off / 4;
           if (a.out_dtype == NVT_F32) {
             rec[slot] = __float_as_uint((float)v);
@@ -459,6 +461,7 @@ int nvt_image_build(const nvt_image_part *parts, int nparts, uint64_t records, v
       a.off = p.offset;
       a.p = p.p_smooth;
       a.y_mean = p.y_mean;
+      a.moments = p.moments;
       in_bytes += p.groups * 16ull * (p.kfold + 1);
     }
   }

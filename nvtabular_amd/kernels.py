@@ -152,6 +152,59 @@ def read_back(t: torch.Tensor):
     return np.frombuffer(buf, dtype=np_dt).reshape(tuple(t.shape)).copy()
 
 
+class PendingReadBack:
+    """read_back in two halves: the copy is enqueued by the constructor, ``get()`` waits for it.
+    Between the two the host can keep enqueueing work BEHIND the copy: by the time it asks, the
+    value has arrived and the device is still busy (a blocking read-back leaves the device idle
+    for as long as the host needs to reach its next launch)."""
+
+    _free = {}   # (device, stream) -> idle mailboxes of this kind (each holds one value at a time)
+
+    def __init__(self, t: torch.Tensor):
+        import numpy as np
+
+        assert t.is_cuda and t.element_size() == 8
+        self._np = np
+        self.shape, self.dtype = tuple(t.shape), t.dtype
+        self.nbytes = t.numel() * 8
+        self.value = None
+        if READBACK_MEMCPY or self.nbytes == 0:
+            self.value = (t.cpu().numpy() if self.nbytes else
+                          np.empty(self.shape, dtype=np.int64 if t.dtype == torch.int64 else np.float64))
+            return
+        lib = _lib.load()
+        t = t.contiguous()
+        self.key = (t.device.index, stream_ptr())
+        with LAUNCH_LOCK:
+            pool = self._free.setdefault(self.key, [])
+            mb = None
+            for i, cand in enumerate(pool):
+                if lib.nvt_mailbox_capacity(cand) >= self.nbytes:
+                    mb = pool.pop(i)
+                    break
+        if mb is None:
+            h = C.c_void_p()
+            check(lib.nvt_mailbox_create(max(1 << 12, self.nbytes), C.byref(h)), "nvt_mailbox_create")
+            mb = h
+        self.mb = mb
+        seq = C.c_uint64()
+        check(lib.nvt_mailbox_post(mb, t.data_ptr(), self.nbytes, stream_ptr(), C.byref(seq)), "nvt_mailbox_post")
+        self.seq = seq.value
+        self._keep = t
+
+    def get(self):
+        if self.value is None:
+            lib = _lib.load()
+            check(lib.nvt_mailbox_wait(self.mb, self.seq, READBACK_TIMEOUT_S), "nvt_mailbox_wait")
+            np_dt = {torch.int64: self._np.int64, torch.float64: self._np.float64}[self.dtype]
+            buf = (C.c_char * self.nbytes).from_address(lib.nvt_mailbox_data(self.mb))
+            self.value = self._np.frombuffer(buf, dtype=np_dt).reshape(self.shape).copy()
+            with LAUNCH_LOCK:
+                self._free.setdefault(self.key, []).append(self.mb)
+            self.mb = self._keep = None
+        return self.value
+
+
 def read_back_ptr(ptr: int, nwords: int, device_index: int):
     """uint64[nwords] at device address ``ptr`` -> list of ints, through the mailbox."""
     import numpy as np
@@ -1860,76 +1913,93 @@ def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int,
                    prev_groups=hit["groups"] if hit is not None else None)
         if _memo is not None:
             _memo[memo_key] = hit
-    grp = hit["groups"]
-    if grp is None:
+    def regroup(cap):
         # group ids: words regrouped with the kfold of the SORT (an aggregate without folds
-        # divides the slots), one read-back of the group count
+        # divides the slots); the group count starts its way to the host behind the launch
         wk = hit["kfold"]
         need = C.c_uint64()
         check(lib.nvt_sgb_regroup_ws_bytes(n, C.byref(need)), "nvt_sgb_regroup_ws_bytes")
         ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
         words = torch.empty(n, dtype=torch.int64, device=dev)
         state = torch.empty(_lib.STATE_WORDS, dtype=torch.int64, device=dev)
+        k64 = torch.empty(cap, dtype=torch.int64, device=dev)
+        k32 = torch.empty(cap, dtype=torch.int32, device=dev)
+        check(lib.nvt_sgb_regroup(hit["sorted"], hit["rb"], wk, hit["bias"], n, cap, k64.data_ptr(),
+                                  k32.data_ptr(), words.data_ptr(), state.data_ptr(),
+                                  ws.data_ptr(), stream_ptr()), "nvt_sgb_regroup")
+        # ("shared": what outlives the pass -- the lookup index of these groups, built once)
+        return dict(words=words, kfold=wk, k64=k64, k32=k32, g=None, cap=cap, state=state, shared={},
+                    pending=PendingReadBack(state), ws=ws)
+
+    def reduce(grp):
+        # arrays sized by the group count when the host knows it, by the capacity of the regroup
+        # launch otherwise (the first aggregate on a key column: the reduction is enqueued BEHIND
+        # the read-back of the count, the device works on it while the host waits)
+        cap = max(grp["g"] if grp["g"] is not None else grp["cap"], 1)
+        slots = cap * kfold
+        size = torch.empty(slots, dtype=torch.int64, device=dev)
+        mk = lambda on, m=slots: (  # noqa: E731
+            torch.empty((nvals, m), dtype=torch.float64, device=dev) if on and nvals else None)
+        fsum, fsq, fmin, fmax = mk(True), mk(sumsq), mk(minmax), mk(minmax)
+        tsize = torch.empty(cap, dtype=torch.int64, device=dev) if kfold > 1 else None
+        tsum = mk(kfold > 1, cap)
+        rec = (torch.empty((nvals, cap, 2 * (kfold + 1)), dtype=torch.float64, device=dev)
+               if te_records and kfold > 1 and nvals else None)
+        vp = _lib.ptr_array([v.data_ptr() for v in vals])
+        vv = _lib.ptr_array([ptr(v) for v in val_valid])
+        vd = (C.c_int * max(1, nvals))(*[dtype_code(v.dtype) for v in vals])
+        # value columns in the order of the words: the first aggregate of a pass gathers a column
+        # by row (one random sector per row) and leaves it behind in sorted order, the next
+        # aggregate on the same words (JoinGroupby after TargetEncoding on the same target) reads
+        # that copy streaming
+        sv = grp.setdefault("sorted_vals", {})
+        s_in, s_out = [None] * nvals, [None] * nvals
+        for j, v in enumerate(vals):
+            if val_valid[j] is not None or v.dtype == torch.int64 or not SHARE_SORTED_VALUES:
+                continue
+            skey = (v.data_ptr(), v.dtype, v._version)
+            have = sv.get(skey)
+            if have is not None:
+                s_in[j] = have[0]
+            elif current_pass_memo() is not None:
+                s_out[j] = torch.empty(n, dtype=v.dtype, device=dev)
+                sv[skey] = (s_out[j], v)   # (v held: its address cannot be recycled in this pass)
+        check(lib.nvt_sgb_reduce(
+            grp["words"].data_ptr(), grp["kfold"], kfold, vp, vd, vv, nvals, flags, n, cap, size.data_ptr(),
+            ptr(fsum), ptr(fsq), ptr(fmin), ptr(fmax), ptr(tsize), ptr(tsum), ptr(rec),
+            grp["state"].data_ptr(), _lib.ptr_array([ptr(t) for t in s_in]),
+            _lib.ptr_array([ptr(t) for t in s_out]), stream_ptr()), "nvt_sgb_reduce")
+        return size, fsum, fsq, fmin, fmax, tsize, tsum, rec
+
+    grp = hit["groups"]
+    if grp is None:
+        wk = hit["kfold"]
         cap = min(n, cap_hint + cap_hint // 4 + 1024) if cap_hint > 0 else n
         cap = min(cap, (0xFFFFFFFE // wk) - 1)
-        while True:
-            k64 = torch.empty(cap, dtype=torch.int64, device=dev)
-            k32 = torch.empty(cap, dtype=torch.int32, device=dev)
-            check(lib.nvt_sgb_regroup(hit["sorted"], hit["rb"], wk, hit["bias"], n, cap, k64.data_ptr(),
-                                      k32.data_ptr(), words.data_ptr(), state.data_ptr(),
-                                      ws.data_ptr(), stream_ptr()), "nvt_sgb_regroup")
-            st = read_back(state).tolist()
-            g = int(st[_lib.ST_OCCUPIED])
-            if not st[_lib.ST_NEED]:
-                break
-            stat_add("count_relaunches")
-            if g * wk >= 0xFFFFFFFE:
-                raise _lib.NvtHipError("sorted_groupby: groups * kfold does not fit 32 bits")
-            cap = g
-        # ("shared": what outlives the pass -- the lookup index of these groups, built once)
-        grp = hit["groups"] = dict(words=words, kfold=wk, k64=k64[:g], k32=k32[:g], g=g, state=state,
-                                   shared={})
-        pg = hit.get("prev_groups")
-        if pg is not None and pg["g"] == g:
-            # same key column, same rows: the same ascending key list.  ONE list (and one lookup
-            # index, one merge across partitions) for every aggregate on the column, whatever the
-            # order of the operators
-            grp["k64"], grp["k32"], grp["shared"] = pg["k64"], pg["k32"], pg["shared"]
+        grp = regroup(cap)
+    while True:
+        size, fsum, fsq, fmin, fmax, tsize, tsum, rec = reduce(grp)
+        if grp["g"] is not None:
+            break
+        st = grp.pop("pending").get().tolist()
+        g = int(st[_lib.ST_OCCUPIED])
+        if not st[_lib.ST_NEED]:
+            grp["g"] = g
+            grp["k64"], grp["k32"] = grp["k64"][:g], grp["k32"][:g]
+            pg = hit.get("prev_groups")
+            if pg is not None and pg["g"] == g:
+                # same key column, same rows: the same ascending key list.  ONE list (and one
+                # lookup index, one merge across partitions) for every aggregate on the column,
+                # whatever the order of the operators
+                grp["k64"], grp["k32"], grp["shared"] = pg["k64"], pg["k32"], pg["shared"]
+            hit["groups"] = grp
+            break
+        # more groups than the hint allowed: both launches again with the exact count
+        stat_add("count_relaunches")
+        if g * grp["kfold"] >= 0xFFFFFFFE:
+            raise _lib.NvtHipError("sorted_groupby: groups * kfold does not fit 32 bits")
+        grp = regroup(g)
     g, wk = grp["g"], grp["kfold"]
-    cap = max(g, 1)
-    slots = cap * kfold
-    size = torch.empty(slots, dtype=torch.int64, device=dev)
-    mk = lambda on, m=slots: (  # noqa: E731
-        torch.empty((nvals, m), dtype=torch.float64, device=dev) if on and nvals else None)
-    fsum, fsq, fmin, fmax = mk(True), mk(sumsq), mk(minmax), mk(minmax)
-    tsize = torch.empty(cap, dtype=torch.int64, device=dev) if kfold > 1 else None
-    tsum = mk(kfold > 1, cap)
-    rec = (torch.empty((nvals, cap, 2 * (kfold + 1)), dtype=torch.float64, device=dev)
-           if te_records and kfold > 1 and nvals else None)
-    vp = _lib.ptr_array([v.data_ptr() for v in vals])
-    vv = _lib.ptr_array([ptr(v) for v in val_valid])
-    vd = (C.c_int * max(1, nvals))(*[dtype_code(v.dtype) for v in vals])
-    # value columns in the order of the words: the first aggregate of a pass gathers a column by
-    # row (one random sector per row) and leaves it behind in sorted order, the next aggregate
-    # on the same words (JoinGroupby after TargetEncoding on the same target) reads that copy
-    # streaming
-    sv = grp.setdefault("sorted_vals", {})
-    s_in, s_out = [None] * nvals, [None] * nvals
-    for j, v in enumerate(vals):
-        if val_valid[j] is not None or v.dtype == torch.int64 or not SHARE_SORTED_VALUES:
-            continue
-        skey = (v.data_ptr(), v.dtype, v._version)
-        have = sv.get(skey)
-        if have is not None:
-            s_in[j] = have[0]
-        elif current_pass_memo() is not None:
-            s_out[j] = torch.empty(n, dtype=v.dtype, device=dev)
-            sv[skey] = (s_out[j], v)   # (v held: its address cannot be recycled in this pass)
-    check(lib.nvt_sgb_reduce(
-        grp["words"].data_ptr(), wk, kfold, vp, vd, vv, nvals, flags, n, cap, size.data_ptr(),
-        ptr(fsum), ptr(fsq), ptr(fmin), ptr(fmax), ptr(tsize), ptr(tsum), ptr(rec),
-        grp["state"].data_ptr(), _lib.ptr_array([ptr(t) for t in s_in]),
-        _lib.ptr_array([ptr(t) for t in s_out]), stream_ptr()), "nvt_sgb_reduce")
     nan = float("nan")
 
     def rows(mat, m):
@@ -2369,6 +2439,9 @@ class FlatIndex:
 def _value_bits(value, dt) -> int:
     import struct
 
+    if callable(value):   # (a number that was still on its way to the host when the consumer was made)
+        value = value()
+
     if dt == torch.float32:
         return struct.unpack("<I", struct.pack("<f", float(value)))[0]
     if dt == torch.float64:
@@ -2488,8 +2561,10 @@ def jg_image_part(comp, outputs, groups):
 
 
 def te_image_part(offset, tot_count, tot_sum, fold_count, fold_sum, kfold, groups, p_smooth, y_mean,
-                  out_dtype):
-    """The arguments of te_image as a part of the one-pass build: (ImagePart, keep-alive)."""
+                  out_dtype, moments=None):
+    """The arguments of te_image as a part of the one-pass build: (ImagePart, keep-alive).
+    ``moments``: float64 {count, sum, ...} of the target on the device -- the kernel then takes
+    y_mean = sum / count from there (a fit whose mean has not reached the host yet)."""
     tc, ts = tot_count.contiguous(), tot_sum.contiguous()
     assert tc.dtype == torch.int64 and ts.dtype == torch.float64
     fc = fs = None
@@ -2500,8 +2575,10 @@ def te_image_part(offset, tot_count, tot_sum, fold_count, fold_sum, kfold, group
     part = _lib.ImagePart(kind=_lib.IMAGE_PART_TE, kfold=int(kfold), out_dtype=dtype_code(out_dtype),
                           offset=int(offset), groups=int(groups), tot_count=tc.data_ptr(),
                           tot_sum=ts.data_ptr(), fold_count=ptr(fc), fold_sum=ptr(fs),
-                          p_smooth=float(p_smooth), y_mean=float(y_mean))
-    return part, [tc, ts, fc, fs]
+                          p_smooth=float(p_smooth), y_mean=float(y_mean), moments=ptr(moments))
+    if moments is not None:
+        assert moments.dtype == torch.float64 and moments.is_contiguous() and int(moments.numel()) >= 2
+    return part, [tc, ts, fc, fs, moments]
 
 
 def te_image(image, stride, offset, tot_count, tot_sum, fold_count, fold_sum, kfold, groups, p_smooth,

@@ -72,6 +72,37 @@ def moments_end(state: _MomentState):
     return out
 
 
+class PendingMoments:
+    """moments_end in two halves: the accumulators are on their way to the host when this is
+    returned, ``resolve()`` waits and finishes them.  ``acc`` ([names, 3] float64 {count, sum,
+    sum of squares}, already reduced over the ranks) stays on the device for kernels that take
+    the mean from there (sum / count: the same IEEE division finalize_moments makes)."""
+
+    def __init__(self, names, acc):
+        self.names, self.acc = list(names), acc
+        self._pending = K.PendingReadBack(acc)
+        self._out = None
+
+    def resolve(self):
+        if self._out is None:
+            out = {}
+            for name, (n, s, s2) in zip(self.names, self._pending.get().tolist()):
+                mean, var, std = finalize_moments(n, s, s2)
+                out[name] = dict(count=n, sum=s, sum2=s2, mean=mean, var=var, std=std)
+            self._out = out
+        return self._out
+
+
+def moments_end_async(state: _MomentState) -> PendingMoments:
+    from .. import dist
+
+    acc = state.acc
+    if acc is None:
+        acc = torch.zeros(len(state.names), 3, dtype=torch.float64,
+                          device=torch.device("cuda", torch.cuda.current_device()))
+    return PendingMoments(state.names, dist.all_reduce_sum(acc))
+
+
 class Normalize(StatOperator):
     """Standardise continuous columns with the mean/std method (normalize.py:33-124)."""
 

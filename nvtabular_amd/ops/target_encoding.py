@@ -16,7 +16,7 @@ from .base import StatOperator
 from ._groupby import GroupAgg, fold_sparse, stats_frame
 from .categorify import _make_name
 from .join_groupby import _Stats, _stats_from_frame
-from .normalize import moments_begin, moments_end, moments_partition
+from .normalize import PendingMoments, moments_begin, moments_end_async, moments_partition
 
 
 def _add_fold(n, kfold, fold_seed=None) -> np.ndarray:
@@ -216,7 +216,11 @@ class TargetEncoding(StatOperator):
                          if f.get("records") is not None else None))
         if not self.defer_artifacts:
             self.flush_artifacts()
-        moments = moments_end(state["moments"]) if state["moments"] is not None else None
+        # the target means start their way to the host here and are waited for when something
+        # needs them as host numbers (prepare_transform at the end of Workflow.fit, or the first
+        # reader of self.means): the lookup image takes sum / count from the device, so that it is
+        # enqueued while the device still works on this fit
+        moments = moments_end_async(state["moments"]) if state["moments"] is not None else None
         return paths, moments
 
     def flush_artifacts(self):
@@ -232,10 +236,28 @@ class TargetEncoding(StatOperator):
     def fit_finalize(self, dask_stats):
         for col, value in dask_stats[0].items():
             self.stats[col] = value
-        if dask_stats[1] is not None:
+        self._pending_moments = None
+        if isinstance(dask_stats[1], PendingMoments):
+            self._pending_moments = dask_stats[1]
+        elif dask_stats[1] is not None:
             for col, m in dask_stats[1].items():
-                self.means[col] = float(m["mean"])
+                self._means[col] = float(m["mean"])
         self._attach_images()
+
+    @property
+    def means(self):
+        """{target: mean of the fit} (resolves the read-back a fit left pending)."""
+        pm = getattr(self, "_pending_moments", None)
+        if pm is not None:
+            self._pending_moments = None
+            for col, m in pm.resolve().items():
+                self._means[col] = float(m["mean"])
+        return self._means
+
+    @means.setter
+    def means(self, value):
+        self._pending_moments = None
+        self._means = value
 
     def _out_torch_dtype(self):
         return torch.float64 if np.dtype(self.output_dtype) == np.dtype("float64") else torch.float32
@@ -250,10 +272,18 @@ class TargetEncoding(StatOperator):
         if not K.LOOKUP_IMAGES:
             return
         fit_folds = self.kfold > 1
-        y_mean = self.target_mean or self.means
+        # means still on their way to the host (fit_end): the one-pass image build reads sum /
+        # count from the device; whatever needs the number itself waits for it then
+        pm = getattr(self, "_pending_moments", None) if self.target_mean is None else None
+        dev_moments = {t: pm.acc[i] for i, t in enumerate(pm.names)} if pm is not None else {}
         out_dt = self._out_torch_dtype()
         size = 8 if out_dt == torch.float64 else 4
         slots = (self.kfold + 1) if fit_folds else 1
+
+        def mean_of(t):
+            y_mean = self.target_mean or self.means
+            return float(y_mean[t] if isinstance(y_mean, dict) else y_mean)
+
         for name, st_all in list(self._device_stats.items()):
             if not isinstance(st_all, _Stats) or not isinstance(st_all.index, K.FlatIndex):
                 continue
@@ -266,31 +296,36 @@ class TargetEncoding(StatOperator):
                 if not isinstance(st_fold, _FoldDense):
                     continue
             targets = [c[len("sum:"):] for c in st_all.columns if c.startswith("sum:")]
-            try:
-                means = {t: float(y_mean[t] if isinstance(y_mean, dict) else y_mean) for t in targets}
-            except (KeyError, TypeError):
+            if pm is None:
+                try:
+                    for t in targets:
+                        mean_of(t)
+                except (KeyError, TypeError):
+                    continue
+            elif any(t not in dev_moments for t in targets):
                 continue
-            outputs = [(("te", t), out_dt, j * slots * size, fit_folds, means[t])
+            # (the value of a row without group: a callable, asked for when a lookup is launched)
+            outputs = [(("te", t), out_dt, j * slots * size, fit_folds, (lambda t=t: mean_of(t)))
                        for j, t in enumerate(targets)]
 
-            def fill(image, stride, offset, groups, st_all=st_all, st_fold=st_fold, targets=targets,
-                     means=means):
+            def fill(image, stride, offset, groups, st_all=st_all, st_fold=st_fold, targets=targets):
                 cnt = st_all.columns["count"].to(torch.int64)
                 for j, t in enumerate(targets):
                     K.te_image(image, stride, offset + j * slots * size, cnt,
                                st_all.columns[f"sum:{t}"].to(torch.float64),
                                st_fold.count if fit_folds else None,
                                st_fold.sums[t] if fit_folds else None,
-                               self.kfold if fit_folds else 0, groups, self.p_smooth, means[t], out_dt)
+                               self.kfold if fit_folds else 0, groups, self.p_smooth, mean_of(t), out_dt)
 
-            def parts(offset, groups, st_all=st_all, st_fold=st_fold, targets=targets, means=means):
+            def parts(offset, groups, st_all=st_all, st_fold=st_fold, targets=targets):
                 cnt = st_all.columns["count"].to(torch.int64)
                 return [K.te_image_part(offset + j * slots * size, cnt,
                                         st_all.columns[f"sum:{t}"].to(torch.float64),
                                         st_fold.count if fit_folds else None,
                                         st_fold.sums[t] if fit_folds else None,
-                                        self.kfold if fit_folds else 0, groups, self.p_smooth, means[t],
-                                        out_dt)
+                                        self.kfold if fit_folds else 0, groups, self.p_smooth,
+                                        0.0 if t in dev_moments else mean_of(t), out_dt,
+                                        moments=dev_moments.get(t))
                         for j, t in enumerate(targets)]
 
             fold_fn = None
@@ -476,6 +511,7 @@ class TargetEncoding(StatOperator):
         for cons in getattr(self, "_consumers", {}).values():
             if cons.index is not None:
                 cons.index.prepare_image()
+        _ = self.means   # (the fit's means reach the host here, behind the image's launches)
 
     def clear(self):
         self.stats = {}

@@ -157,6 +157,17 @@ def test_one_pass_build_equals_the_per_operator_kernels(kfold, out_dt):
     arr = (_lib.ImagePart * 2)(*[p[0] for p in parts])
     K.check(_lib.load().nvt_image_build(arr, 2, records, got.data_ptr(), stride, K.stream_ptr()), "nvt_image_build")
     assert torch.equal(got, ref)
+    # the target's mean taken from the device ({count, sum}: a fit whose mean is still on its way
+    # to the host): the same bits as the host's division
+    mom = torch.tensor([1234567.0, 0.41 * 1234567.0 + 0.125, 0.0], dtype=torch.float64, device=dev)
+    ym = float(mom[1].item()) / float(mom[0].item())
+    ref2 = torch.zeros(records * stride, dtype=torch.uint8, device=dev)
+    K.te_image(ref2, stride, te_off, tot_c, tot_s, fold_c, fold_s, kfold, g_te, 20.0, ym, out_dt)
+    got2 = torch.empty(records * stride, dtype=torch.uint8, device=dev)
+    part = K.te_image_part(te_off, tot_c, tot_s, fold_c, fold_s, kfold, g_te, 20.0, 0.0, out_dt, moments=mom)
+    arr = (_lib.ImagePart * 1)(part[0])
+    K.check(_lib.load().nvt_image_build(arr, 1, records, got2.data_ptr(), stride, K.stream_ptr()), "nvt_image_build")
+    assert torch.equal(got2, ref2)
 
 
 @pytest.mark.parametrize("nparts", [1, 3])
