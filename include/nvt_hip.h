@@ -714,6 +714,11 @@ typedef struct nvt_fillnorm_col {
   double shift, scale;
   void *out;
   uint8_t *filled;          /* optional                                         */
+  const double *moments;    /* NULL, or the column's {count, sum, sum of squares} on the device
+                               (nvt_moments_many's out3): shift = mean and scale = std (0 when it
+                               is not > 0) are then finished by the kernel exactly as the host
+                               finishes them (moments.py:89-116) -- a fit whose moments have not
+                               reached the host yet does not hold the transform back */
 } nvt_fillnorm_col;
 int nvt_fill_normalize_many(const nvt_fillnorm_col *cols, int ncols, void *stream);
 

@@ -159,7 +159,7 @@ class FillNormCol(C.Structure):
     _fields_ = [("x", _vp), ("valid", _vp), ("n", _u64), ("dtype", C.c_int32),
                 ("has_fill", C.c_int32), ("fill_val", _dbl), ("do_norm", C.c_int32),
                 ("out_dtype", C.c_int32), ("shift", _dbl), ("scale", _dbl), ("out", _vp),
-                ("filled", _vp)]
+                ("filled", _vp), ("moments", _vp)]
 
 
 class CountCol(C.Structure):

@@ -411,15 +411,41 @@ struct FnCol {
   void *out;
   uint8_t *filled;
   int has_fill, do_norm;
+  const double *moments;  // {count, sum, sum of squares} on the device (nullptr: shift / scale are the numbers)
 };
+
+// (mean, std) from {count, sum, sum of squares} as the host finishes them (moments.py:89-116 /
+// ops/normalize.py finalize_moments): every operation rounded once, in the same order
+__device__ __forceinline__ void finish_moments(const double *__restrict__ m, double *mean, double *std) {
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  const double n = m[0], s = m[1], s2 = m[2];
+  if (n == 0.0) {
+    *mean = qnan;
+    *std = qnan;
+    return;
+  }
+  double var = __dsub_rn(s2, __ddiv_rn(__dmul_rn(s, s), n));
+  const double dn = __dsub_rn(n, 1.0);
+  var = __ddiv_rn(var, dn < 1.0 ? 1.0 : dn);
+  if (dn == 0.0) var = qnan;
+  *mean = __ddiv_rn(s, n);
+  *std = (var == var && var >= 0.0) ? __dsqrt_rn(var) : qnan;
+}
 struct FnBatch {
   FnCol c[kBatchCols];
 };
 template <typename T, typename OUT>
 __global__ __launch_bounds__(kBlock) void fill_norm_many_kernel(FnBatch b) {
   const FnCol &c = b.c[blockIdx.y];
-  fill_norm_body<T, OUT>((const T *)c.x, c.valid, c.n, c.has_fill, c.fill_val, c.do_norm, c.shift,
-                         c.scale, (OUT *)c.out, c.filled);
+  double shift = c.shift, scale = c.scale;
+  if (c.moments) {
+    double mean, std;
+    finish_moments(c.moments, &mean, &std);
+    shift = mean;
+    scale = std > 0.0 ? std : 0.0;  // normalize.py:79-82: std == 0 -> x - mean
+  }
+  fill_norm_body<T, OUT>((const T *)c.x, c.valid, c.n, c.has_fill, c.fill_val, c.do_norm, shift, scale,
+                         (OUT *)c.out, c.filled);
 }
 
 // Clip (clip.py:49-55) and LogOp (logop.py:43-53), fused with a pending FillMissing constant:
@@ -783,6 +809,7 @@ int nvt_fill_normalize_many(const nvt_fillnorm_col *cols, int ncols, void *strea
       f.filled = c.filled;
       f.has_fill = c.has_fill;
       f.do_norm = c.do_norm;
+      f.moments = c.do_norm ? c.moments : nullptr;
       const unsigned g = stream_grid(c.n / (16 / dtype_bytes(dt)) + 1, kBlock * 2, 8);
       grid = g > grid ? g : grid;
       bytes += c.n * (uint64_t)(dtype_bytes(dt) + dtype_bytes(odt));

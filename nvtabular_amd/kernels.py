@@ -1533,16 +1533,25 @@ def moments_many(items):
 
 
 def fill_normalize_many(items):
-    """items: [(x, valid, fill, do_norm, shift, scale, out_dtype, want_filled_mask)] ->
-    [(out, filled or None)]; one launch per dtype combination (nvt_fill_normalize_many)."""
+    """items: [(x, valid, fill, do_norm, shift, scale, out_dtype, want_filled_mask[, moments])] ->
+    [(out, filled or None)]; one launch per dtype combination (nvt_fill_normalize_many).
+    ``moments``: float64 {count, sum, sum of squares} of the column on the device -- shift / scale
+    are then finished from them by the kernel (a fit whose moments are still on their way to the
+    host)."""
     if not items:
         return []
     _lib.require_gpu()
     descs = (_lib.FillNormCol * len(items))()
     outs, keep = [], []
-    for d, (x, valid, fill, do_norm, shift, scale, out_dtype, want_mask) in zip(descs, items):
+    for d, item in zip(descs, items):
+        x, valid, fill, do_norm, shift, scale, out_dtype, want_mask = item[:8]
+        moments = item[8] if len(item) > 8 else None
         x = aligned(x)
         keep.append(x)
+        if moments is not None:
+            assert moments.dtype == torch.float64 and moments.is_contiguous() and int(moments.numel()) >= 3
+            keep.append(moments)
+        d.moments = ptr(moments)
         n = x.numel()
         out = torch.empty(n, dtype=out_dtype, device=x.device)
         filled = torch.empty(n, dtype=torch.uint8, device=x.device) if want_mask else None

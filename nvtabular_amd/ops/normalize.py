@@ -108,6 +108,7 @@ class Normalize(StatOperator):
 
     def __init__(self, out_dtype=None):
         super().__init__()
+        self._pending = None
         self.means = {}
         self.stds = {}
         self.out_dtype = out_dtype
@@ -120,12 +121,47 @@ class Normalize(StatOperator):
         moments_partition(state, frame)
 
     def fit_end(self, state, col_selector):
-        return moments_end(state)
+        # the accumulators start their way to the host; nobody waits here.  A transform that
+        # follows at once hands the kernel the device accumulators (it finishes mean / std as
+        # finalize_moments does) and is enqueued while the fit's last kernels still run; the host
+        # numbers are there for whoever reads means / stds.
+        return moments_end_async(state)
 
     def fit_finalize(self, stats):
+        if isinstance(stats, PendingMoments):
+            self._means, self._stds, self._pending = {}, {}, stats
+            return
+        self._pending = None
         for col, m in stats.items():
-            self.means[col] = float(m["mean"])
-            self.stds[col] = float(m["std"])
+            self._means[col] = float(m["mean"])
+            self._stds[col] = float(m["std"])
+
+    def _resolve(self):
+        pm, self._pending = self._pending, None
+        if pm is not None:
+            for col, m in pm.resolve().items():
+                self._means[col] = float(m["mean"])
+                self._stds[col] = float(m["std"])
+
+    @property
+    def means(self):
+        self._resolve()
+        return self._means
+
+    @means.setter
+    def means(self, value):
+        self._pending = None
+        self._means = value
+
+    @property
+    def stds(self):
+        self._resolve()
+        return self._stds
+
+    @stds.setter
+    def stds(self, value):
+        self._pending = None
+        self._stds = value
 
     def transform(self, col_selector: ColumnSelector, df):
         frame, was_pandas = as_device_frame(df)
@@ -134,16 +170,26 @@ class Normalize(StatOperator):
         new = DeviceFrame()
         out_dt = torch_dtype(self.output_dtype)
         items, cols = [], []
+        pm = self._pending
+        dev = {n: pm.acc[i] for i, n in enumerate(pm.names)} if pm is not None else {}
+        if any(n not in dev for n in col_selector.names):
+            dev = {}
+            self._resolve()
         for name in col_selector.names:
             col = frame[name]
-            std = self.stds[name]
-            scale = std if std > 0 else 0.0  # normalize.py:79-82: std == 0 -> x - mean
             data = col.data.view(torch.uint8) if col.data.dtype == torch.bool else col.data
-            items.append((data, col.valid, col.fill, True, self.means[name], scale, out_dt, False))
+            if dev:   # (the fit's moments have not been asked for on the host yet)
+                items.append((data, col.valid, col.fill, True, 0.0, 0.0, out_dt, False, dev[name]))
+            else:
+                std = self._stds[name]
+                scale = std if std > 0 else 0.0  # normalize.py:79-82: std == 0 -> x - mean
+                items.append((data, col.valid, col.fill, True, self._means[name], scale, out_dt, False))
             cols.append((name, col))
         # FillMissing + Normalize of every column in ONE launch (nvt_fill_normalize_many)
         for (name, col), (out, _) in zip(cols, K.fill_normalize_many(items)):
             new[name] = DeviceColumn(out, None, col.offsets)
+        if dev:
+            self._resolve()   # (behind the launch: the device has work while the host waits)
         return new.to_pandas() if was_pandas else new
 
     def clear(self):
