@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/nvt_hip.h"
@@ -34,6 +35,20 @@ void set_error(const char *fmt, ...);
   } while (0)
 
 #define NVT_CHECK_LAUNCH() NVT_CHECK_HIP(hipGetLastError())
+
+// Run-time A / B switches between kernel variants (NVT_ENC_PIPE, NVT_SORT_LEGACY ...) exist only in
+// variant libraries built with -DNVT_AB_SWITCHES (tools/build_variant.sh, tools/var_libs.sh): the
+// default library takes the default side of every one of them at compile time.  (Configuration that
+// a deployment may set -- NVT_ENCODE_STREAMS, NVT_FINALIZE_SERIAL, NVT_ROCTX, NVT_EVENT_TIMING,
+// NVT_ENC_STATS -- stays on getenv.)
+inline const char *ab_env(const char *name) {
+#ifdef NVT_AB_SWITCHES
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // Grid for a streaming (HBM-bound) kernel: enough workgroups to fill 256 CUs
 // several times over, capped so every block still gets a long grid-stride run.

@@ -1280,7 +1280,7 @@ int build_launch(const K *vocab, uint64_t n, int64_t first_label, void *table, u
 // the head-layout switch of this process (the image nvt_vocab_finalize_many builds and the layout
 // the cache-mode launch expects are decided by the same word)
 static bool enc_head16() {
-  static const bool v = getenv("NVT_ENC_HEAD16") == nullptr || atoi(getenv("NVT_ENC_HEAD16")) != 0;
+  static const bool v = ab_env("NVT_ENC_HEAD16") == nullptr || atoi(ab_env("NVT_ENC_HEAD16")) != 0;
   return v;
 }
 
@@ -1322,7 +1322,7 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
     const int global_needed = n_vocab > n_hot;
     unsigned hgrid = stream_grid(n / VEC + 1, kEncBS * 2, 1);
     if constexpr (sizeof(K) == 4) {
-      static const bool two = getenv("NVT_ENC_LINEAR") == nullptr;
+      static const bool two = ab_env("NVT_ENC_LINEAR") == nullptr;
       // (range tables: `mask` = capacity - 1 bounds the search of a FLAT table -- capacity slots --
       // and is unused for the dumped bucket tables, capacity 0)
       if (global_needed && (two || range_aux != nullptr)) {  // cache mode: 2-choice table filled to 7/8
@@ -1331,12 +1331,12 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
         // NVT_ENC_HALF=1 (experiment): half the head, one key vector per lane and <= 64 VGPRs, so
         // that TWO workgroups share a CU -- the waves of a cache-mode launch are parked 77 % of
         // their cycles (SQ_WAIT_ANY), and one workgroup per CU is 4 waves per SIMD
-        static const bool half = getenv("NVT_ENC_HALF") != nullptr && atoi(getenv("NVT_ENC_HALF")) != 0;
+        static const bool half = ab_env("NVT_ENC_HALF") != nullptr && atoi(ab_env("NVT_ENC_HALF")) != 0;
         const uint64_t cap2 = half ? (uint64_t)HotCfg<K>::slots / 16 * 7
                                    : head16 ? (uint64_t)kHead16Keys : (uint64_t)HotCfg<K>::slots / 8 * 7;
         n_hot = (uint32_t)(n_vocab < cap2 ? n_vocab : cap2);
         if (half) hgrid = stream_grid(n / VEC + 1, kEncBS, 2);
-        static const bool use_image = getenv("NVT_ENC_NO_HEAD_IMAGE") == nullptr;   // (A/B switch)
+        static const bool use_image = ab_env("NVT_ENC_NO_HEAD_IMAGE") == nullptr;   // (A/B switch)
         if (half || !use_image) head_image = nullptr;
 #define NVT_ENC_CACHE(OUTT, KIND, H16)                                                            \
   encode_hot_kernel<K, OUTT, true, true, 2, KIND, H16><<<hgrid, kEncBS, 0, s>>>(                   \
@@ -1354,7 +1354,7 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
       reinterpret_cast<const unsigned char *>(head_image))
         // the software pipeline (encode_pipe_kernel) is the cache-mode kernel of the range tables with
         // the 6-byte head; NVT_ENC_PIPE=0 keeps the phase-serial one for A/B runs
-        static const bool pipe = getenv("NVT_ENC_PIPE") == nullptr || atoi(getenv("NVT_ENC_PIPE")) != 0;
+        static const bool pipe = ab_env("NVT_ENC_PIPE") == nullptr || atoi(ab_env("NVT_ENC_PIPE")) != 0;
 #define NVT_ENC_CACHE_K(KIND)                                                \
   do {                                                                       \
     if (half) {                                                              \
@@ -1398,7 +1398,7 @@ int encode_launch(const K *keys, const uint8_t *valid, uint64_t n, const void *t
       reinterpret_cast<OUTT *>(out), hot_keys, n_hot, first_label)
     if constexpr (sizeof(K) == 4) {
       // small vocabularies with int64 labels: smaller tables, 256-thread workgroups, contiguous stores
-      static const bool small_on = getenv("NVT_ENC_NO_SMALL") == nullptr;   // (A/B switch)
+      static const bool small_on = ab_env("NVT_ENC_NO_SMALL") == nullptr;   // (A/B switch)
       if (!global_needed && out_bytes == 8 && small_on && n_vocab <= 2048) {
         const unsigned sgrid = stream_grid(n / 2 + 1, kBlock * 8, 8);
         if (n_vocab <= 1024)
@@ -1506,7 +1506,7 @@ namespace nvt {
 // vocabulary.  Entries with a null image / too few keys are skipped.
 int encode_head_build_many(const int32_t *const *vocab_keys, const uint64_t *n, const int64_t *first_label,
                            void *const *images, int count, hipStream_t s) {
-  static const bool half = getenv("NVT_ENC_HALF") != nullptr && atoi(getenv("NVT_ENC_HALF")) != 0;
+  static const bool half = ab_env("NVT_ENC_HALF") != nullptr && atoi(ab_env("NVT_ENC_HALF")) != 0;
   if (half) return NVT_OK;   // (the experiment builds its smaller head per launch)
   const bool h16 = enc_head16();
   const uint64_t cap = h16 ? (uint64_t)kHead16Keys : (uint64_t)HotCfg<int32_t>::slots / 8 * 7;

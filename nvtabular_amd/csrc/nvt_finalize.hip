@@ -105,7 +105,7 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
     }
     if (c.ready_event) {
       NVT_CHECK_HIP(hipEventRecord((hipEvent_t)c.ready_event, s));
-      if (s != main_s && getenv("NVT_FLUSH_QUERY")) (void)hipStreamQuery(s);
+      if (s != main_s && ab_env("NVT_FLUSH_QUERY")) (void)hipStreamQuery(s);
     } else if (s != main_s)
       need_join = true;
     return NVT_OK;
@@ -133,7 +133,7 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
   // by ONE chain of batched launches on the first internal stream (vocab_order_sorted_batch)
   // instead of ~10 launches per vocabulary spread over the streams -- the host took as long to
   // enqueue those as the GPU to run them
-  static const bool batch_order = getenv("NVT_NO_ORDER_BATCH") == nullptr;
+  static const bool batch_order = ab_env("NVT_NO_ORDER_BATCH") == nullptr;
   std::vector<char> batched(ncols > 0 ? ncols : 0, 0);
   if (batch_order) {
     std::vector<OrderSortedJob> jobs;
@@ -191,7 +191,7 @@ static int finalize_impl(const nvt_vocab_col *cols, int ncols, hipStream_t main_
       // key-sorted list of the range path: one stable counting pass orders it and fills the table
       NVT_CHECK_ARG(c.sort_tmp, "null sort_tmp");
       bool deferred = false;
-      static const bool batch_tail = getenv("NVT_NO_TAIL_BATCH") == nullptr;
+      static const bool batch_tail = ab_env("NVT_NO_TAIL_BATCH") == nullptr;
       int rc = vocab_order_from_sorted((const int32_t *)c.src_keys, c.src_counts, c.n, c.cls_hist,
                                        c.n_big, c.max_count, (int32_t *)c.keys, c.counts,
                                        c.sort_tmp, c.first_label, c.table, c.capacity,

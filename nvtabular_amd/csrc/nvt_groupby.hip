@@ -733,7 +733,10 @@ __global__ __launch_bounds__(kBlock) void gb_lookup_kernel(GbView t, GbRowArgs a
 //                        both tables, categorify.py:1344-1540 run twice in the reference)
 // and the key -> group index for the transform side is a flat range table laid out from the
 // sorted keys (flat_build_kernel, nvt_sort.hip) instead of a second hash table.
-constexpr int kSgbRows = 8;
+#ifndef NVT_SGB_ROWS
+#define NVT_SGB_ROWS 16
+#endif
+constexpr int kSgbRows = NVT_SGB_ROWS;
 constexpr int kSgbTile = kBlock * kSgbRows;
 constexpr unsigned long long kSgbAgg = 1ull << 62, kSgbPrefix = 2ull << 62,
                              kSgbMask = (1ull << 62) - 1ull;
@@ -1138,7 +1141,7 @@ int nvt_gb_update(nvt_gb_table *t, const int64_t *const *keys, const uint8_t *co
   }
   hipStream_t s = (hipStream_t)stream;
   NVT_PROF("groupby_update", 0, s);
-  if (n < (1ull << 15) || n >= (1ull << 30) || t->capacity > (1ull << 31) || getenv("NVT_GB_ATOMIC")) {
+  if (n < (1ull << 15) || n >= (1ull << 30) || t->capacity > (1ull << 31) || ab_env("NVT_GB_ATOMIC")) {
     // tiny inputs (the sort would be launch latency) and > 2^30 rows per call: per-row atomics
     gb_update_kernel<<<stream_grid(n, kBlock * 2), kBlock, 0, s>>>(view_of(t), a, n);
     NVT_CHECK_LAUNCH();

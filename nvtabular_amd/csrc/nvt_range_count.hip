@@ -963,7 +963,7 @@ int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int n
   range_ws_layout(n, nb_log2, (char *)wsp, &w);
   const unsigned NB = 1u << nb_log2;
   const uint32_t cap = range_region_cap(n, nb_log2);
-  static const bool debug = getenv("NVT_RANGE_DEBUG") != nullptr;
+  static const bool debug = ab_env("NVT_RANGE_DEBUG") != nullptr;
   auto mark = [&](const char *what) {
     if (debug) {
       hipError_t e = hipStreamSynchronize(s);
@@ -995,7 +995,7 @@ int range_count_i32(const int32_t *keys, const uint8_t *valid, uint64_t n, int n
       rp_partition_kernel<NVT_RANGE_U, NBL, false><<<kRpG, kRpBS, 0, s>>>(                          \
           keys, valid, n, aux, nb_log2, cap, w.regions, w.fills, w.hot_cnt, state, w.status, hist); \
   } while (0)
-  static const bool rt_nb = getenv("NVT_RANGE_RT_NB") != nullptr;  // (A/B: the run-time variant)
+  static const bool rt_nb = ab_env("NVT_RANGE_RT_NB") != nullptr;  // (A/B: the run-time variant)
   if (rt_nb) NVT_RP_PART(0);
   else if (nb_log2 == 8) NVT_RP_PART(8);
   else if (nb_log2 == 9) NVT_RP_PART(9);

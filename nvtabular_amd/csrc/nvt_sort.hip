@@ -818,7 +818,7 @@ int vocab_sort(K *keys, int64_t *counts, uint64_t n, int64_t max_count, void *tm
     return NVT_OK;
   }
   if constexpr (sizeof(K) == 4) {
-    if (max_count > 0 && max_count < (1ll << 32) && n < (1ull << 30) && !getenv("NVT_SORT_LEGACY"))
+    if (max_count > 0 && max_count < (1ll << 32) && n < (1ull << 30) && !ab_env("NVT_SORT_LEGACY"))
       return vocab_sort_onesweep(keys, counts, n, max_count, tmp, stream);
     if (max_count > 0 && max_count < (1ll << 32) && n < (1ull << 31))
       return vocab_sort_packed(keys, counts, n, max_count, tmp, stream);
