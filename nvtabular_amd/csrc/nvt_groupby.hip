@@ -720,8 +720,9 @@ __global__ __launch_bounds__(kBlock) void gb_lookup_kernel(GbView t, GbRowArgs a
 // The hash update above costs a random 16-byte probe per row (gb_assign 1.28 ms for 20 M rows),
 // a sort of (slot, row) words, and a compaction of the sparse table afterwards.  With ONE key
 // column of at most 32 bits none of the three is needed: the rows are sorted by the key itself,
-//   sgb_pack_kernel      words = (key image << 32 | fold << rb | row)
-//   sort_words_bits      onesweep LSD radix on bits [rb, 64): every key's rows are one run, the
+//   sort_packed_keys     words = (key image << 32 | fold << rb | row), packed from the column by
+//                        the histogram and the first scatter pass (never written out unsorted);
+//                        onesweep LSD radix on bits [rb, 64): every key's rows are one run, the
 //                        folds of a key (TargetEncoding's kfold) consecutive sub-runs
 //   sgb_rle_kernel       run heads -> group index g (decoupled look-back over the tiles): the
 //                        groups come out DENSE and ordered by key, the words are rewritten as
@@ -740,21 +741,6 @@ constexpr int kSgbRows = NVT_SGB_ROWS;
 constexpr int kSgbTile = kBlock * kSgbRows;
 constexpr unsigned long long kSgbAgg = 1ull << 62, kSgbPrefix = 2ull << 62,
                              kSgbMask = (1ull << 62) - 1ull;
-
-template <typename K>
-__global__ __launch_bounds__(kBlock) void sgb_pack_kernel(const K *__restrict__ keys, int64_t bias,
-                                                          const uint8_t *__restrict__ fold,
-                                                          uint64_t n, int rb,
-                                                          uint64_t *__restrict__ words) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    // order-preserving 32-bit image: key - bias with bias = the smallest key (int32 columns:
-    // INT32_MIN, i.e. the sign bit flipped); the caller guarantees max - bias < 2^32
-    const uint64_t img = (uint32_t)((uint64_t)(int64_t)keys[i] - (uint64_t)bias);
-    const uint64_t f = fold ? (uint64_t)fold[i] : 0ull;
-    words[i] = (img << 32) | (f << rb) | i;
-  }
-}
 
 // smallest / largest key of a column (int64 columns take the sort path when their keys span
 // less than 2^32): out2 = {min, max}, initialised by the caller to {INT64_MAX, INT64_MIN}
@@ -1353,16 +1339,11 @@ int nvt_sgb_sort(const void *keys, int key_dtype, int64_t key_bias, const uint8_
   NVT_CHECK_ARG(n >= 1 && n < (1ull << 30) && n <= (1ull << rb), "row index does not fit next to the fold");
   hipStream_t s = (hipStream_t)stream;
   NVT_PROF("groupby_sort", n * (key_dtype == NVT_I64 ? 8ull : 4ull), s);
-  uint64_t *words = reinterpret_cast<uint64_t *>(ws);
+  // (the unsorted words are never written out: the histogram and the first scatter pass pack them
+  // from the column -- sgb_pack_kernel's 8 bytes per row written + read twice are gone)
   void *sort_tmp = reinterpret_cast<char *>(ws) + sgb_pad(n * 8);
-  const unsigned grid = stream_grid(n, kBlock * 4);
-  if (key_dtype == NVT_I32)
-    sgb_pack_kernel<int32_t><<<grid, kBlock, 0, s>>>((const int32_t *)keys, key_bias, fold, n, rb, words);
-  else
-    sgb_pack_kernel<int64_t><<<grid, kBlock, 0, s>>>((const int64_t *)keys, key_bias, fold, n, rb, words);
-  NVT_CHECK_LAUNCH();
   uint64_t *sorted = nullptr;
-  int rc = sort_words_bits(words, n, rb, 64, sort_tmp, &sorted, s);
+  int rc = sort_packed_keys(keys, key_dtype, key_bias, fold, rb, n, sort_tmp, &sorted, s);
   if (rc) return rc;
   *sorted_out = sorted;
   *row_bits_out = rb;

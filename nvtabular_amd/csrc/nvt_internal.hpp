@@ -32,6 +32,10 @@ int vocab_sort_small_batch(const SmallSortDesc *cols, int ncols, hipStream_t s);
 uint64_t sort_words_tmp_bytes(uint64_t n);
 int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tmp, uint64_t **result,
                     hipStream_t s);
+// the packed rows of a key column ((key - bias) image << 32 | fold << rb | row) sorted by bits
+// [rb, 64) without writing the unsorted words out first; *result = a buffer inside tmp
+int sort_packed_keys(const void *keys, int key_dtype, int64_t key_bias, const uint8_t *fold, int rb,
+                     uint64_t n, void *tmp, uint64_t **result, hipStream_t stream);
 
 // nvt_range_count.hip: path NVT_PATH_RANGE of nvt_dense_count_* (aux = hot image + range
 // parameters written by hot_sample_kernel + class histogram)

@@ -441,10 +441,10 @@ __global__ __launch_bounds__(256) void os_base_kernel(const unsigned *__restrict
   base[p * 256 + d] = wb + inc - tot;
 }
 
-template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(kS2BS) void os_scatter_kernel(
-    const uint64_t *__restrict__ comp, const int32_t *__restrict__ keys,
-    const int64_t *__restrict__ cnts, uint64_t n, int shift, const unsigned *__restrict__ base,
+// (LOAD: element index -> packed word; the kernels below differ only in where a word comes from)
+template <bool LAST, typename LOAD>
+__device__ __forceinline__ void os_scatter_body(
+    LOAD load, uint64_t n, int shift, const unsigned *__restrict__ base,
     unsigned *status, unsigned *ticket, uint64_t *out_comp, int32_t *out_keys, int64_t *out_cnts) {
   constexpr int NW = kS2BS / kWave;
   __shared__ unsigned wcnt[NW][256];
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kS2BS) void os_scatter_kernel(
   for (int r = 0; r < kS2Rows; ++r) {
     const uint64_t i = s2_elem(tile, w, r, l);
     c[r] = ~0ull;
-    if (i < n) c[r] = FIRST ? comp_make(keys[i], cnts[i]) : comp[i];
+    if (i < n) c[r] = load(i);
   }
   const uint64_t tile_base = (uint64_t)tile * kS2Tile;
 #pragma unroll
@@ -555,6 +555,37 @@ __global__ __launch_bounds__(kS2BS) void os_scatter_kernel(
   }
 }
 
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kS2BS) void os_scatter_kernel(
+    const uint64_t *__restrict__ comp, const int32_t *__restrict__ keys,
+    const int64_t *__restrict__ cnts, uint64_t n, int shift, const unsigned *__restrict__ base,
+    unsigned *status, unsigned *ticket, uint64_t *out_comp, int32_t *out_keys, int64_t *out_cnts) {
+  os_scatter_body<LAST>([=](uint64_t i) -> uint64_t { return FIRST ? comp_make(keys[i], cnts[i]) : comp[i]; },
+                        n, shift, base, status, ticket, out_comp, out_keys, out_cnts);
+}
+
+// the word of row i of a key column as nvt_sgb_sort sorts it: (order-preserving 32-bit key image
+// << 32) | fold << rb | row -- the first pass and the histogram read the COLUMN (4 / 8 + 1 bytes per
+// row) instead of a packed copy of it (a pass that wrote 8 bytes per row and two that read them)
+template <typename K>
+struct PackedKeyWord {
+  const K *keys;
+  const uint8_t *fold;
+  int64_t bias;
+  int rb;
+  __device__ __forceinline__ uint64_t operator()(uint64_t i) const {
+    const uint64_t img = (uint32_t)((uint64_t)(int64_t)keys[i] - (uint64_t)bias);
+    const uint64_t f = fold ? (uint64_t)fold[i] : 0ull;
+    return (img << 32) | (f << rb) | i;
+  }
+};
+template <typename K>
+__global__ __launch_bounds__(kS2BS) void os_scatter_pack_kernel(
+    PackedKeyWord<K> src, uint64_t n, int shift, const unsigned *__restrict__ base, unsigned *status,
+    unsigned *ticket, uint64_t *out_comp) {
+  os_scatter_body<false>(src, n, shift, base, status, ticket, out_comp, nullptr, nullptr);
+}
+
 // tmp layout: compA[n] | compB[n] | block_hist | base | status[npass][ntiles][256] | tickets
 inline uint64_t os_tmp_bytes(uint64_t n) {
   const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
@@ -617,9 +648,9 @@ inline int vocab_sort_onesweep(int32_t *keys, int64_t *counts, uint64_t n, int64
 // (the onesweep scatter above with FIRST = LAST = false).  Used by the multi-key groupby update:
 // words are (slot << 32 | row), sorted by slot, so that every group's rows become one run in
 // row order.
-__global__ __launch_bounds__(kS2BS) void os_hist_words_kernel(const uint64_t *__restrict__ w,
-                                                              uint64_t n, int bit_lo, int npass,
-                                                              unsigned *__restrict__ block_hist) {
+template <typename LOAD>
+__device__ __forceinline__ void os_hist_words_body(LOAD load, uint64_t n, int bit_lo, int npass,
+                                                   unsigned *__restrict__ block_hist) {
   __shared__ unsigned h[kOsMaxPass * 256];
   for (int i = threadIdx.x; i < npass * 256; i += kS2BS) h[i] = 0;
   __syncthreads();
@@ -634,7 +665,7 @@ __global__ __launch_bounds__(kS2BS) void os_hist_words_kernel(const uint64_t *__
     for (int u = 0; u < U; ++u) {
       const uint64_t i = (it + u) * stride + (uint64_t)blockIdx.x * kS2BS + threadIdx.x;
       av[u] = (it + u) < iters && i < n;
-      cw[u] = av[u] ? w[i] >> bit_lo : 0ull;
+      cw[u] = av[u] ? load(i) >> bit_lo : 0ull;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -663,16 +694,28 @@ __global__ __launch_bounds__(kS2BS) void os_hist_words_kernel(const uint64_t *__
     block_hist[(uint64_t)blockIdx.x * (kOsMaxPass * 256) + i] = h[i];
 }
 
+__global__ __launch_bounds__(kS2BS) void os_hist_words_kernel(const uint64_t *__restrict__ w,
+                                                              uint64_t n, int bit_lo, int npass,
+                                                              unsigned *__restrict__ block_hist) {
+  os_hist_words_body([=](uint64_t i) -> uint64_t { return w[i]; }, n, bit_lo, npass, block_hist);
+}
+template <typename K>
+__global__ __launch_bounds__(kS2BS) void os_hist_pack_kernel(PackedKeyWord<K> src, uint64_t n, int bit_lo,
+                                                             int npass, unsigned *__restrict__ block_hist) {
+  os_hist_words_body(src, n, bit_lo, npass, block_hist);
+}
+
 uint64_t sort_words_tmp_bytes(uint64_t n) { return os_tmp_bytes(n); }
 
 // Sorts data[0..n) by bits [bit_lo, bit_hi) (stable).  *result = data or a buffer inside tmp.
-int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tmp, uint64_t **result,
-                    hipStream_t stream) {
-  *result = data;
-  if (n <= 1 || bit_hi <= bit_lo) return NVT_OK;
+// keys != nullptr: the words are the packed rows of a key column (PackedKeyWord: key image, fold,
+// row) that nobody has written out -- the histogram and the first pass read the column.
+static int sort_words_impl(uint64_t *data, const void *keys, int key_dtype, int64_t key_bias,
+                           const uint8_t *fold, int rb, uint64_t n, int bit_lo, int bit_hi, void *tmp,
+                           uint64_t **result, hipStream_t stream) {
   NVT_CHECK_ARG(n < (1ull << 30), "at most 2^30-1 words");
   const int npass = (bit_hi - bit_lo + 7) / 8;
-  NVT_CHECK_ARG(npass <= kOsMaxPass, "bit range too wide");
+  NVT_CHECK_ARG(npass >= 1 && npass <= kOsMaxPass, "bit range too wide");
   const uint64_t ntiles = (n + kS2Tile - 1) / kS2Tile;
   char *p = reinterpret_cast<char *>(tmp);
   uint64_t *bufs[2];
@@ -689,7 +732,14 @@ int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tm
   unsigned *tickets = status + status_words;
   NVT_CHECK_HIP(hipMemsetAsync(status, 0, (status_words + kOsMaxPass) * 4, stream));
   const unsigned hb = (unsigned)(ntiles < (uint64_t)kOsHistBlocks ? ntiles : kOsHistBlocks);
-  os_hist_words_kernel<<<hb, kS2BS, 0, stream>>>(data, n, bit_lo, npass, block_hist);
+  const PackedKeyWord<int32_t> s32{reinterpret_cast<const int32_t *>(keys), fold, key_bias, rb};
+  const PackedKeyWord<int64_t> s64{reinterpret_cast<const int64_t *>(keys), fold, key_bias, rb};
+  if (!keys)
+    os_hist_words_kernel<<<hb, kS2BS, 0, stream>>>(data, n, bit_lo, npass, block_hist);
+  else if (key_dtype == NVT_I32)
+    os_hist_pack_kernel<int32_t><<<hb, kS2BS, 0, stream>>>(s32, n, bit_lo, npass, block_hist);
+  else
+    os_hist_pack_kernel<int64_t><<<hb, kS2BS, 0, stream>>>(s64, n, bit_lo, npass, block_hist);
   NVT_CHECK_LAUNCH();
   os_base_kernel<<<npass, 256, 0, stream>>>(block_hist, (int)hb, base);
   NVT_CHECK_LAUNCH();
@@ -697,15 +747,38 @@ int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tm
   int flip = 0;
   for (int pass = 0; pass < npass; ++pass) {
     uint64_t *dst = bufs[flip];
-    os_scatter_kernel<false, false><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
-        src, nullptr, nullptr, n, bit_lo + 8 * pass, base + pass * 256,
-        status + (uint64_t)pass * ntiles * 256, tickets + pass, dst, nullptr, nullptr);
+    unsigned *st = status + (uint64_t)pass * ntiles * 256;
+    if (pass == 0 && keys && key_dtype == NVT_I32)
+      os_scatter_pack_kernel<int32_t><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
+          s32, n, bit_lo, base, st, tickets, dst);
+    else if (pass == 0 && keys)
+      os_scatter_pack_kernel<int64_t><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
+          s64, n, bit_lo, base, st, tickets, dst);
+    else
+      os_scatter_kernel<false, false><<<(unsigned)ntiles, kS2BS, 0, stream>>>(
+          src, nullptr, nullptr, n, bit_lo + 8 * pass, base + pass * 256, st, tickets + pass, dst,
+          nullptr, nullptr);
     NVT_CHECK_LAUNCH();
     src = dst;
     flip ^= 1;
   }
   *result = const_cast<uint64_t *>(src);
   return NVT_OK;
+}
+
+int sort_words_bits(uint64_t *data, uint64_t n, int bit_lo, int bit_hi, void *tmp, uint64_t **result,
+                    hipStream_t stream) {
+  *result = data;
+  if (n <= 1 || bit_hi <= bit_lo) return NVT_OK;
+  return sort_words_impl(data, nullptr, 0, 0, nullptr, 0, n, bit_lo, bit_hi, tmp, result, stream);
+}
+
+// The packed rows of a key column ((key - bias) image << 32 | fold << rb | row), sorted by
+// bits [rb, 64) (key, then fold; stable): *result = a buffer inside tmp (sort_words_tmp_bytes(n)).
+int sort_packed_keys(const void *keys, int key_dtype, int64_t key_bias, const uint8_t *fold, int rb,
+                     uint64_t n, void *tmp, uint64_t **result, hipStream_t stream) {
+  NVT_CHECK_ARG(keys && n >= 1 && rb >= 24 && rb <= 32, "keys / rows / row bits");
+  return sort_words_impl(nullptr, keys, key_dtype, key_bias, fold, rb, n, rb, 64, tmp, result, stream);
 }
 
 // ---- all small vocabularies of a fit in ONE launch: workgroup b sorts vocabulary b --------
