@@ -167,7 +167,7 @@ class PendingReadBack:
         self._np = np
         self.shape, self.dtype = tuple(t.shape), t.dtype
         self.nbytes = t.numel() * 8
-        self.value = None
+        self.value = self.mb = None
         if READBACK_MEMCPY or self.nbytes == 0:
             self.value = (t.cpu().numpy() if self.nbytes else
                           np.empty(self.shape, dtype=np.int64 if t.dtype == torch.int64 else np.float64))
@@ -191,6 +191,17 @@ class PendingReadBack:
         check(lib.nvt_mailbox_post(mb, t.data_ptr(), self.nbytes, stream_ptr(), C.byref(seq)), "nvt_mailbox_post")
         self.seq = seq.value
         self._keep = t
+
+    def __del__(self):
+        # never asked for (a fit whose scalars nobody read): the mailbox goes back to the pool --
+        # its next post is ordered behind this one on the same stream and carries a later sequence
+        mb = getattr(self, "mb", None)
+        if mb is not None and getattr(self, "value", None) is None:
+            try:
+                with LAUNCH_LOCK:
+                    self._free.setdefault(self.key, []).append(mb)
+            except Exception:   # (interpreter shutdown)
+                pass
 
     def get(self):
         if self.value is None:

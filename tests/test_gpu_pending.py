@@ -27,6 +27,14 @@ def test_pending_read_backs_arrive_in_any_order():
     for p, t in zip(again, ts):
         np.testing.assert_array_equal(p.get(), t.cpu().numpy())
     assert K.PendingReadBack(torch.empty(0, dtype=torch.int64, device=dev)).get().size == 0
+    # a read-back nobody asks for gives its mailbox back (fits without a transform do not leak)
+    pool = K.PendingReadBack._free
+    before = sum(len(v) for v in pool.values())
+    for _ in range(50):
+        K.PendingReadBack(ts[0])
+    torch.cuda.synchronize()
+    assert sum(len(v) for v in pool.values()) <= before + 1
+    np.testing.assert_array_equal(K.PendingReadBack(ts[1]).get(), ts[1].cpu().numpy())
 
 
 @pytest.mark.parametrize("out_dtype", [None, np.float32])
