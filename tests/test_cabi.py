@@ -44,6 +44,18 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nvt_count_table_bytes(4, 1 << 20, C.byref(nbytes)) == 0 and nbytes.value == 8 << 20
     assert lib.nvt_encode_table_bytes(8, 1 << 10, C.byref(nbytes)) == 0 and nbytes.value == 16 << 10
     assert lib.nvt_dense_count_ws_bytes(4, 1000, 9, 0, C.byref(nbytes)) == -1
+    # round 6: key directory / one-pass images reject bad arguments before any launch
+    assert lib.nvt_keydir_build(None, 10, 10, None, None) == -1 and b"null" in lib.nvt_last_error()
+    buf = (C.c_uint32 * 64)()
+    keys = (C.c_int32 * 4)(1, 2, 3, 4)
+    assert lib.nvt_keydir_build(keys, 0, 10, buf, None) == -1          # no keys
+    assert lib.nvt_keydir_build(keys, 4, 0, buf, None) == -1           # no buckets
+    part = _lib.ImagePart(kind=7)
+    arr = (_lib.ImagePart * 1)(part)
+    assert lib.nvt_image_build(arr, 1, 16, buf, 64, None) == -1 and b"kind" in lib.nvt_last_error()
+    assert lib.nvt_image_build(arr, 5, 16, buf, 64, None) == -1        # more than 4 parts
+    assert lib.nvt_image_build(arr, 0, 16, buf, 200, None) == -1       # stride > 192
+    assert lib.nvt_image_build(arr, 0, 0, buf, 64, None) == 0          # nothing to do
 
 
 def test_ops_fail_loudly_without_gpu():
