@@ -640,6 +640,9 @@ def extra_cfg4_multipart(device, tmp, rows_per_part=1 << 28, nparts=4, card=100_
     return res
 
 
+LAST_TIMED = {}   # diagnostics of the last _timed_steps call
+
+
 def _timed_steps(step, steps):
     """(ms per step, profile report of one more step) of a fit + transform closure."""
     from nvtabular_amd import kernels as K
@@ -647,11 +650,22 @@ def _timed_steps(step, steps):
     step()  # cold
     step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    m0 = torch.cuda.memory_stats()
+    marks = [time.perf_counter()]
+    t0 = marks[0]
     for _ in range(steps):
         out = step()
+        marks.append(time.perf_counter())   # (host side: every fit holds a read-back)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    m1 = torch.cuda.memory_stats()
+    # what an outlier looks like from the host: the slowest step and the allocator's traffic
+    LAST_TIMED.clear()
+    LAST_TIMED.update(
+        max_host_step_ms=round(1e3 * max(b - a for a, b in zip(marks, marks[1:])), 3),
+        device_allocs_in_timed_steps=int(m1.get("num_device_alloc", 0) - m0.get("num_device_alloc", 0)),
+        device_frees_in_timed_steps=int(m1.get("num_device_free", 0) - m0.get("num_device_free", 0)),
+        alloc_retries_in_timed_steps=int(m1.get("num_alloc_retries", 0) - m0.get("num_alloc_retries", 0)))
     K.profile_begin()
     out = step()
     rep = K.profile_report()
@@ -947,6 +961,7 @@ def extra_dense_ids(device, tmp, rows, steps=5, single_ms=None):
         "range_path_banned_columns": sorted(op._no_range),
         "range_overflows": len(op._range_failures),
         "range_overflow_bits": sorted({(h, b) for h, b, _ in op._range_failures}),
+        "timed_steps": dict(LAST_TIMED),
         "per_family_ms": {k: round(v, 3) for k, v in sorted(fam.items())},
         "parity": property_checks(wf, [frame], [out], cat_names, cont_names),
     }

@@ -333,6 +333,7 @@ int nvt_keydir_lookup_image(const void *keys, int dtype, const uint8_t *valid, u
   if (n == 0) return NVT_OK;
   NVT_CHECK_ARG(keys && dir && keys32 && image && outs && offs && sizes && miss_bits, "null pointer");
   NVT_CHECK_ARG(nkeys >= 1 && nkeys < (1ull << 32) - 1 && dir_slots >= 1, "1 .. 2^32-2 keys, >= 1 bucket");
+  NVT_CHECK_ARG((reinterpret_cast<uintptr_t>(dir) & 15) == 0, "dir must be 16-byte aligned");
   NVT_CHECK_ARG(ncols >= 1 && ncols <= kImageMaxCols, "1..24 outputs");
   NVT_CHECK_ARG(stride_bytes >= 8 && stride_bytes % 8 == 0, "record stride: a multiple of 8 bytes");
   NVT_CHECK_ARG(dtype == NVT_I32 || dtype == NVT_I64, "key dtype must be int32 / int64");
