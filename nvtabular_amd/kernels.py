@@ -1690,133 +1690,6 @@ def popcount(valid: Optional[torch.Tensor], n: int) -> int:
     return int(out.item())
 
 
-# --------------------------------------------------------------------------
-# multi-key groupby tables
-# --------------------------------------------------------------------------
-class GroupbyTable:
-    """nkeys-column groupby-aggregate table (JoinGroupby / TargetEncoding / combo)."""
-
-    def __init__(self, nkeys: int, nvals: int, capacity: int, sumsq=False, minmax=False):
-        _lib.require_gpu()
-        self.lib = _lib.load()
-        self.nkeys, self.nvals = nkeys, nvals
-        self.flags = (_lib.NVT_GB_SUMSQ if sumsq else 0) | (_lib.NVT_GB_MINMAX if minmax else 0)
-        self.capacity = next_pow2(capacity)
-        self.device = torch.device("cuda", torch.cuda.current_device())
-        # arrays in a torch block (caching allocator: no hipMalloc / hipFree, which synchronise
-        # the device, on the fit path); the C handle only carves it up
-        nbytes = C.c_uint64()
-        check(self.lib.nvt_gb_table_bytes(nkeys, nvals, self.flags, self.capacity, C.byref(nbytes)),
-              "nvt_gb_table_bytes")
-        self._mem = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
-        self._ws = None
-        h = C.c_void_p()
-        check(self.lib.nvt_gb_create_in(nkeys, nvals, self.flags, self.capacity,
-                                        self._mem.data_ptr(), nbytes.value, C.byref(h)),
-              "nvt_gb_create_in")
-        self.handle = h
-        self.clear()
-
-    def __del__(self):
-        h = getattr(self, "handle", None)
-        if h:
-            try:
-                self.lib.nvt_gb_destroy(h)
-            except Exception:
-                pass
-            self.handle = None
-
-    def clear(self):
-        check(self.lib.nvt_gb_clear(self.handle, stream_ptr()), "nvt_gb_clear")
-
-    def state(self) -> List[int]:
-        # mailbox read-back of the device state words (no blocking runtime wait)
-        return read_back_ptr(self.lib.nvt_gb_state_ptr(self.handle), _lib.STATE_WORDS,
-                             self.device.index)
-
-    def update(self, keys, key_valid, vals, val_valid):
-        keys = [widen_i64(k) for k in keys]
-        vals = [aligned(v.view(torch.uint8) if v.dtype == torch.bool else v) for v in vals]
-        n = keys[0].numel()
-        need = C.c_uint64()
-        check(self.lib.nvt_gb_update_ws_bytes(n, C.byref(need)), "nvt_gb_update_ws_bytes")
-        if self._ws is None or self._ws.numel() < need.value:
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-            check(self.lib.nvt_gb_set_workspace(self.handle, self._ws.data_ptr(), need.value),
-                  "nvt_gb_set_workspace")
-        kp = _lib.ptr_array([k.data_ptr() for k in keys])
-        kv = _lib.ptr_array([ptr(v) for v in key_valid])
-        vp = _lib.ptr_array([v.data_ptr() for v in vals])
-        vv = _lib.ptr_array([ptr(v) for v in val_valid])
-        vd = (C.c_int * max(1, len(vals)))(*[dtype_code(v.dtype) for v in vals])
-        check(self.lib.nvt_gb_update(self.handle, kp, kv, vp, vd, vv, n, stream_ptr()),
-              "nvt_gb_update")
-
-    def merge(self, keys, null_mask, size, count, sums, sumsqs, mins, maxs):
-        n = keys[0].numel()
-        f = lambda lst: _lib.ptr_array([ptr(t) for t in lst]) if lst else None  # noqa: E731
-        check(
-            self.lib.nvt_gb_merge(
-                self.handle, _lib.ptr_array([k.data_ptr() for k in keys]), ptr(null_mask),
-                ptr(size), ptr(count), f(sums), f(sumsqs), f(mins), f(maxs), n, stream_ptr(),
-            ),
-            "nvt_gb_merge",
-        )
-
-    def compact(self):
-        """dict(keys=[...], null_mask, size, count, sum=[...], sumsq=[...], min=[...], max=[...])"""
-        st = self.state()
-        g = st[_lib.ST_OCCUPIED]
-        dev = self.device
-        keys = [torch.empty(g, dtype=torch.int64, device=dev) for _ in range(self.nkeys)]
-        nm = torch.empty(g, dtype=torch.uint8, device=dev)
-        size = torch.empty(g, dtype=torch.int64, device=dev)
-        count = torch.empty(g, dtype=torch.int64, device=dev)
-        mk = lambda on: (  # noqa: E731
-            [torch.empty(g, dtype=torch.float64, device=dev) for _ in range(self.nvals)] if on else []
-        )
-        sums = mk(True)
-        sumsqs = mk(self.flags & _lib.NVT_GB_SUMSQ)
-        mins = mk(self.flags & _lib.NVT_GB_MINMAX)
-        maxs = mk(self.flags & _lib.NVT_GB_MINMAX)
-        out_n = torch.zeros(1, dtype=torch.int64, device=dev)
-        f = lambda lst: _lib.ptr_array([t.data_ptr() for t in lst]) if lst else None  # noqa: E731
-        check(
-            self.lib.nvt_gb_compact(
-                self.handle, f(keys), nm.data_ptr(), size.data_ptr(), count.data_ptr(), f(sums),
-                f(sumsqs), f(mins), f(maxs), out_n.data_ptr(), stream_ptr(),
-            ),
-            "nvt_gb_compact",
-        )
-        # index_table: nvt_gb_compact also stored every group's position in its slot, so this
-        # table answers lookups for exactly these groups (no nvt_gb_index_build of a second one)
-        return dict(keys=keys, null_mask=nm, size=size, count=count, sum=sums, sumsq=sumsqs,
-                    min=mins, max=maxs, n=g, index_table=self)
-
-    def index_build(self, keys, null_mask):
-        n = keys[0].numel() if keys else 0
-        check(
-            self.lib.nvt_gb_index_build(
-                self.handle, _lib.ptr_array([k.data_ptr() for k in keys]), ptr(null_mask), n,
-                stream_ptr(),
-            ),
-            "nvt_gb_index_build",
-        )
-
-    def lookup(self, keys, key_valid) -> torch.Tensor:
-        keys = [widen_i64(k) for k in keys]
-        n = keys[0].numel()
-        out = torch.empty(n, dtype=torch.int64, device=keys[0].device)
-        check(
-            self.lib.nvt_gb_lookup(
-                self.handle, _lib.ptr_array([k.data_ptr() for k in keys]),
-                _lib.ptr_array([ptr(v) for v in key_valid]), n, out.data_ptr(), stream_ptr(),
-            ),
-            "nvt_gb_lookup",
-        )
-        return out
-
-
 # ---- one int32 key column: groupby-aggregate by sorting + flat index -------------------------
 SORTED_GROUPBY = os.environ.get("NVT_SORTED_GROUPBY", "1") != "0"
 SORTED_GROUPBY_MIN_ROWS = 1 << 15   # below: launch latency, the hash update is as good
@@ -1864,760 +1737,17 @@ def stat_add(name: str, k: int = 1):
         STATS[name] = STATS.get(name, 0) + k
 
 
-def sorted_groupby_eligible(keys: torch.Tensor, key_valid, n: int, kfold: int = 1) -> bool:
-    """One int32 / int64 key column without a validity bitmap, enough rows, row index + fold in
-    32 bits.  (int64 columns additionally need keys spanning less than 2^32: sorted_groupby
-    finds out and returns None otherwise.)"""
-    if not SORTED_GROUPBY or keys.dtype not in (torch.int32, torch.int64) or key_valid is not None:
-        return False
-    fb = (kfold - 1).bit_length()
-    return (SORTED_GROUPBY_MIN_ROWS <= n < (1 << 30) and n <= (1 << (32 - fb))
-            and 1 <= kfold <= SORTED_GROUPBY_MAX_KFOLD)
-
-
 SHARE_SORTED_VALUES = os.environ.get("NVT_SHARE_SORTED_VALUES", "1") != "0"
 
 
-def sorted_groupby(keys: torch.Tensor, fold: Optional[torch.Tensor], kfold: int, vals, val_valid,
-                   sumsq=False, minmax=False, cap_hint: int = 0, te_records=False):
-    """nvt_sgb_sort + nvt_sgb_regroup + nvt_sgb_reduce: groups of ONE int32 key column, dense
-    and ordered by key.  Returns the dict GroupbyTable.compact() returns (keys as int64, all-zero
-    null mask, count == size: no null keys on this path) plus ``keys32``, ``sorted``, ``shared``
-    and -- with folds (TargetEncoding) -- ``fold`` = dict(kfold, size[g * kfold],
-    sum[j][g * kfold], records); size / sum are then the totals over the folds.
-    Inside ``pass_memo`` the sorted words and the group ids of a key column are computed once for
-    all aggregates on it (the second one is a single reduction, without a read-back).
-    int64 key columns: one more read-back ({min, max} of the column); None when the keys span
-    2^32 or more (the caller falls back to the hash tables).  ``key_offset`` is what the flat
-    index subtracts from a column value (0 for int32 columns)."""
-    _lib.require_gpu()
-    lib = _lib.load()
-    dev = keys.device
-    n = int(keys.numel())
-    keys = keys.contiguous()
-    kdt = dtype_code(keys.dtype)
-    vals = [aligned(v.view(torch.uint8) if v.dtype == torch.bool else v) for v in vals]
-    nvals = len(vals)
-    flags = (_lib.NVT_GB_SUMSQ if sumsq else 0) | (_lib.NVT_GB_MINMAX if minmax else 0)
-    memo_key = ("sgb", keys.data_ptr(), n, keys._version)
-    _memo = current_pass_memo()
-    hit = _memo.get(memo_key) if _memo is not None else None
-    if hit is not None and hit["bias"] is None:
-        return None  # (int64 keys too far apart: found out by an earlier aggregate of this pass)
-    if hit is None or not (kfold == 1 or (hit["kfold"] == kfold and hit["fold"] == ptr(fold))):
-        if hit is not None:
-            bias = hit["bias"]
-        elif keys.dtype == torch.int32:
-            bias = -(1 << 31)
-        else:
-            mm = torch.empty(2, dtype=torch.int64, device=dev)
-            check(lib.nvt_key_minmax(keys.data_ptr(), kdt, n, mm.data_ptr(), stream_ptr()),
-                  "nvt_key_minmax")
-            lo, hi = (int(v) for v in read_back(mm).tolist())
-            bias = lo if hi - lo < (1 << 32) else None
-            if bias is None:
-                if _memo is not None:
-                    # (keys held: the address cannot be recycled for another column in this pass)
-                    _memo[memo_key] = dict(bias=None, kfold=0, fold=None, groups=None, keys=keys)
-                return None
-        need = C.c_uint64()
-        check(lib.nvt_sgb_sort_ws_bytes(n, C.byref(need)), "nvt_sgb_sort_ws_bytes")
-        sort_ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        sp, rbc = C.c_void_p(), C.c_int()
-        check(lib.nvt_sgb_sort(keys.data_ptr(), kdt, bias, ptr(fold), kfold, n, sort_ws.data_ptr(),
-                               C.byref(sp), C.byref(rbc), stream_ptr()), "nvt_sgb_sort")
-        # (a re-sort WITH folds after an aggregate without: the groups are the same keys -- their
-        # key lists and what hangs off them, the lookup index, are taken over below)
-        hit = dict(sorted=sp.value, rb=rbc.value, kfold=kfold, fold=ptr(fold), ws=sort_ws,
-                   keys=keys, fold_t=fold, groups=None, bias=bias,
-                   prev_groups=hit["groups"] if hit is not None else None)
-        if _memo is not None:
-            _memo[memo_key] = hit
-    def regroup(cap):
-        # group ids: words regrouped with the kfold of the SORT (an aggregate without folds
-        # divides the slots); the group count starts its way to the host behind the launch
-        wk = hit["kfold"]
-        need = C.c_uint64()
-        check(lib.nvt_sgb_regroup_ws_bytes(n, C.byref(need)), "nvt_sgb_regroup_ws_bytes")
-        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        words = torch.empty(n, dtype=torch.int64, device=dev)
-        state = torch.empty(_lib.STATE_WORDS, dtype=torch.int64, device=dev)
-        k64 = torch.empty(cap, dtype=torch.int64, device=dev)
-        k32 = torch.empty(cap, dtype=torch.int32, device=dev)
-        check(lib.nvt_sgb_regroup(hit["sorted"], hit["rb"], wk, hit["bias"], n, cap, k64.data_ptr(),
-                                  k32.data_ptr(), words.data_ptr(), state.data_ptr(),
-                                  ws.data_ptr(), stream_ptr()), "nvt_sgb_regroup")
-        # ("shared": what outlives the pass -- the lookup index of these groups, built once)
-        return dict(words=words, kfold=wk, k64=k64, k32=k32, g=None, cap=cap, state=state, shared={},
-                    pending=PendingReadBack(state), ws=ws)
-
-    def reduce(grp):
-        # arrays sized by the group count when the host knows it, by the capacity of the regroup
-        # launch otherwise (the first aggregate on a key column: the reduction is enqueued BEHIND
-        # the read-back of the count, the device works on it while the host waits)
-        cap = max(grp["g"] if grp["g"] is not None else grp["cap"], 1)
-        slots = cap * kfold
-        size = torch.empty(slots, dtype=torch.int64, device=dev)
-        mk = lambda on, m=slots: (  # noqa: E731
-            torch.empty((nvals, m), dtype=torch.float64, device=dev) if on and nvals else None)
-        fsum, fsq, fmin, fmax = mk(True), mk(sumsq), mk(minmax), mk(minmax)
-        tsize = torch.empty(cap, dtype=torch.int64, device=dev) if kfold > 1 else None
-        tsum = mk(kfold > 1, cap)
-        rec = (torch.empty((nvals, cap, 2 * (kfold + 1)), dtype=torch.float64, device=dev)
-               if te_records and kfold > 1 and nvals else None)
-        vp = _lib.ptr_array([v.data_ptr() for v in vals])
-        vv = _lib.ptr_array([ptr(v) for v in val_valid])
-        vd = (C.c_int * max(1, nvals))(*[dtype_code(v.dtype) for v in vals])
-        # value columns in the order of the words: the first aggregate of a pass gathers a column
-        # by row (one random sector per row) and leaves it behind in sorted order, the next
-        # aggregate on the same words (JoinGroupby after TargetEncoding on the same target) reads
-        # that copy streaming
-        sv = grp.setdefault("sorted_vals", {})
-        s_in, s_out = [None] * nvals, [None] * nvals
-        for j, v in enumerate(vals):
-            if val_valid[j] is not None or v.dtype == torch.int64 or not SHARE_SORTED_VALUES:
-                continue
-            skey = (v.data_ptr(), v.dtype, v._version)
-            have = sv.get(skey)
-            if have is not None:
-                s_in[j] = have[0]
-            elif current_pass_memo() is not None:
-                s_out[j] = torch.empty(n, dtype=v.dtype, device=dev)
-                sv[skey] = (s_out[j], v)   # (v held: its address cannot be recycled in this pass)
-        check(lib.nvt_sgb_reduce(
-            grp["words"].data_ptr(), grp["kfold"], kfold, vp, vd, vv, nvals, flags, n, cap, size.data_ptr(),
-            ptr(fsum), ptr(fsq), ptr(fmin), ptr(fmax), ptr(tsize), ptr(tsum), ptr(rec),
-            grp["state"].data_ptr(), _lib.ptr_array([ptr(t) for t in s_in]),
-            _lib.ptr_array([ptr(t) for t in s_out]), stream_ptr()), "nvt_sgb_reduce")
-        return size, fsum, fsq, fmin, fmax, tsize, tsum, rec
-
-    grp = hit["groups"]
-    if grp is None:
-        wk = hit["kfold"]
-        cap = min(n, cap_hint + cap_hint // 4 + 1024) if cap_hint > 0 else n
-        cap = min(cap, (0xFFFFFFFE // wk) - 1)
-        grp = regroup(cap)
-    while True:
-        size, fsum, fsq, fmin, fmax, tsize, tsum, rec = reduce(grp)
-        if grp["g"] is not None:
-            break
-        st = grp.pop("pending").get().tolist()
-        g = int(st[_lib.ST_OCCUPIED])
-        if not st[_lib.ST_NEED]:
-            grp["g"] = g
-            grp["k64"], grp["k32"] = grp["k64"][:g], grp["k32"][:g]
-            pg = hit.get("prev_groups")
-            if pg is not None and pg["g"] == g:
-                # same key column, same rows: the same ascending key list.  ONE list (and one
-                # lookup index, one merge across partitions) for every aggregate on the column,
-                # whatever the order of the operators
-                grp["k64"], grp["k32"], grp["shared"] = pg["k64"], pg["k32"], pg["shared"]
-            hit["groups"] = grp
-            break
-        # more groups than the hint allowed: both launches again with the exact count
-        stat_add("count_relaunches")
-        if g * grp["kfold"] >= 0xFFFFFFFE:
-            raise _lib.NvtHipError("sorted_groupby: groups * kfold does not fit 32 bits")
-        grp = regroup(g)
-    g, wk = grp["g"], grp["kfold"]
-    nan = float("nan")
-
-    def rows(mat, m):
-        return [mat[j, :m] for j in range(nvals)] if mat is not None else []
-
-    def untouched(cols, init):  # a group without a valid value keeps the initial +-inf: NaN, as
-        return [torch.where(c == init, torch.full_like(c, nan), c) for c in cols]  # nvt_gb_compact
-
-    out = dict(keys=[grp["k64"]], keys32=grp["k32"],
-               null_mask=torch.zeros(g, dtype=torch.uint8, device=dev),
-               sumsq=rows(fsq, g), min=untouched(rows(fmin, g), float("inf")),
-               max=untouched(rows(fmax, g), float("-inf")), n=g,
-               sorted=True, shared=grp["shared"], key_offset=hit["bias"] + (1 << 31))
-    if kfold > 1:
-        out["size"], out["sum"] = tsize[:g], rows(tsum, g)
-        out["fold"] = dict(kfold=kfold, size=size[:g * kfold], sum=rows(fsum, g * kfold),
-                           records=[rec[j, :g] for j in range(nvals)] if rec is not None else None)
-    else:
-        out["size"], out["sum"] = size[:g], rows(fsum, g)
-    out["count"] = out["size"]
-    return out
-
-
-def flat_index_for(comp) -> "FlatIndex":
-    """The FlatIndex of a sorted_groupby result; aggregates that share their group ids (one key
-    column, one pass) share the index too."""
-    shared = comp.get("shared")
-    if shared is not None and shared.get("index") is not None:
-        return shared["index"]
-    index = FlatIndex(comp["keys32"], comp.get("key_offset", 0))
-    if shared is not None:
-        shared["index"] = index
-    return index
-
-
 EXCHANGE_MAX_COLS, EXCHANGE_MAX_CELLS = 64, 4096   # include/nvt_hip.h nvt_exchange_*
-
-
-class ExchangeBatch:
-    """The (keys int32, counts int64) lists of ALL columns of a fit as one descriptor array for
-    the nvt_exchange_* launches of dist.merge_counts_many."""
-
-    def __init__(self, tables):
-        _lib.require_gpu()
-        self.lib = _lib.load()
-        self.keep = [(k.contiguous(), c.contiguous()) for k, c in tables]
-        self.ncol = len(self.keep)
-        self.total = sum(int(k.numel()) for k, _ in self.keep)
-        self.dev = self.keep[0][0].device
-        self.cols = (_lib.XCol * self.ncol)()
-        for j, (k, c) in enumerate(self.keep):
-            assert k.dtype == torch.int32 and c.dtype == torch.int64
-            self.cols[j].keys, self.cols[j].counts, self.cols[j].n = ptr(k) or 0, ptr(c) or 0, int(k.numel())
-
-    def ranges(self) -> torch.Tensor:
-        """int64[ncol, 3] = (-min key, max key, sum of counts); a column without entries:
-        (-INT64_MAX, -INT64_MAX, 0)."""
-        rng = torch.empty((self.ncol, 3), dtype=torch.int64, device=self.dev)
-        check(self.lib.nvt_exchange_ranges(self.cols, self.ncol, rng.data_ptr(), stream_ptr()),
-              "nvt_exchange_ranges")
-        return rng
-
-    def ranges_sorted(self) -> torch.Tensor:
-        """The same for KEY-SORTED lists: (-first key, last key, 0) -- no pass over the lists."""
-        rng = torch.empty((self.ncol, 3), dtype=torch.int64, device=self.dev)
-        check(self.lib.nvt_exchange_ranges_sorted(self.cols, self.ncol, rng.data_ptr(), stream_ptr()),
-              "nvt_exchange_ranges_sorted")
-        return rng
-
-    def _owner_args(self, lo, width):
-        return ((C.c_int64 * self.ncol)(*[int(v) for v in lo]),
-                (C.c_uint64 * self.ncol)(*[max(1, int(v)) for v in width]))
-
-    def hist(self, lo, width, G) -> torch.Tensor:
-        """int64[G, ncol]: rows of column j whose key range belongs to rank g."""
-        mat = torch.empty((G, self.ncol), dtype=torch.int64, device=self.dev)
-        a, b = self._owner_args(lo, width)
-        check(self.lib.nvt_exchange_hist(self.cols, self.ncol, a, b, G, mat.data_ptr(), stream_ptr()),
-              "nvt_exchange_hist")
-        return mat
-
-    def scatter(self, lo, width, G, starts: torch.Tensor) -> torch.Tensor:
-        """(count << 32 | key) words grouped by (owner, column); ``starts`` int64[G, ncol] (device)
-        = the first position of every group (consumed: advanced to the group ends)."""
-        rows = torch.empty(self.total, dtype=torch.int64, device=self.dev)
-        if self.total == 0:
-            return rows  # (a rank that received no partition: nothing to send, nothing to launch)
-        a, b = self._owner_args(lo, width)
-        check(self.lib.nvt_exchange_scatter(self.cols, self.ncol, a, b, G, starts.data_ptr(),
-                                            rows.data_ptr(), stream_ptr()), "nvt_exchange_scatter")
-        return rows
-
-
-    def pack_ordered(self, lo, width, G, starts: torch.Tensor, first_row: torch.Tensor) -> torch.Tensor:
-        """The send buffer of KEY-SORTED lists: group (g, j) = the contiguous slice of column j
-        whose keys rank g owns, copied in key order to ``starts[g, j]``; ``first_row[g, j]`` =
-        rows of column j in front of the slice (both int64[G, ncol] on the device).  No atomics."""
-        rows = torch.empty(self.total, dtype=torch.int64, device=self.dev)
-        if self.total == 0:
-            return rows
-        a, b = self._owner_args(lo, width)
-        check(self.lib.nvt_exchange_pack_ordered(self.cols, self.ncol, a, b, G, first_row.data_ptr(),
-                                                 starts.data_ptr(), rows.data_ptr(), stream_ptr()),
-              "nvt_exchange_pack_ordered")
-        return rows
-
-
-def exchange_unpack(words: torch.Tensor, seg_off: List[int], dst_off: List[int], out_n: int, extra=None):
-    """Gathered (count << 32 | key) words in segments -> (keys int32[out_n], counts int64[out_n]),
-    segment s copied to position dst_off[s] (column-major: every column one contiguous list).
-    extra: one int32 per word that travels along -> a third result (int32[out_n])."""
-    _lib.require_gpu()
-    n = int(words.numel())
-    dev = words.device
-    keys = torch.empty(out_n, dtype=torch.int32, device=dev)
-    cnts = torch.empty(out_n, dtype=torch.int64, device=dev)
-    so = torch.tensor(seg_off, dtype=torch.int64, device=dev)
-    do = torch.tensor(dst_off, dtype=torch.int64, device=dev)
-    if extra is not None:
-        assert extra.dtype == torch.int32 and int(extra.numel()) == n
-        xo = torch.empty(out_n, dtype=torch.int32, device=dev)
-        check(_lib.load().nvt_exchange_unpack2(words.contiguous().data_ptr(), extra.contiguous().data_ptr(), n,
-                                               so.data_ptr(), do.data_ptr(), len(seg_off) - 1, keys.data_ptr(),
-                                               cnts.data_ptr(), xo.data_ptr(), stream_ptr()),
-              "nvt_exchange_unpack2")
-        return keys, cnts, xo
-    check(_lib.load().nvt_exchange_unpack(words.contiguous().data_ptr(), n, so.data_ptr(), do.data_ptr(),
-                                          len(seg_off) - 1, keys.data_ptr(), cnts.data_ptr(),
-                                          stream_ptr()), "nvt_exchange_unpack")
-    return keys, cnts
 
 
 MERGE_SORTED_MAX_ROWS = (1 << 26) - 1   # include/nvt_hip.h nvt_count_merge_sorted
 MERGE_SORTED_MAX_COLS = 64
 
 
-def merge_counts_sorted(rows: torch.Tensor, seg_off: List[int], ncol: int, want_packed=False):
-    """nvt_count_merge_sorted: owner-side merge of received (count << 32 | int32 key) rows lying in
-    len(seg_off) - 1 segments (source-major, column-minor).  Returns [(keys int32, counts
-    int64)] per column, every list ordered by key.  One read-back (groups per column).
-    want_packed: also the merged rows of all columns as ONE (count << 32 | key) array, column
-    after column (what the all-gather sends), and the per-column lengths."""
-    _lib.require_gpu()
-    lib = _lib.load()
-    dev = rows.device
-    n = int(rows.numel())
-    empty = lambda: (torch.empty(0, dtype=torch.int32, device=dev),  # noqa: E731
-                     torch.empty(0, dtype=torch.int64, device=dev))
-    if n == 0:
-        out = [empty() for _ in range(ncol)]
-        return (out, torch.empty(0, dtype=torch.int64, device=dev), [0] * ncol) if want_packed else out
-    rows = rows.contiguous()
-    off = torch.tensor(seg_off, dtype=torch.int64, device=dev)
-    need = C.c_uint64()
-    check(lib.nvt_count_merge_sorted_ws_bytes(n, C.byref(need)), "nvt_count_merge_sorted_ws_bytes")
-    ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
-    keys = torch.empty(n, dtype=torch.int32, device=dev)
-    col = torch.empty(n, dtype=torch.int64, device=dev)
-    sums = torch.empty(n, dtype=torch.float64, device=dev)
-    state = torch.empty(_lib.STATE_WORDS, dtype=torch.int64, device=dev)
-    check(lib.nvt_count_merge_sorted(rows.data_ptr(), n, off.data_ptr(), len(seg_off) - 1, ncol,
-                                     keys.data_ptr(), col.data_ptr(), sums.data_ptr(),
-                                     state.data_ptr(), ws.data_ptr(), stream_ptr()),
-          "nvt_count_merge_sorted")
-    g = int(read_back(state)[_lib.ST_OCCUPIED])
-    # groups are ordered by (column, key): the first group of column j = groups of smaller columns
-    bounds = torch.searchsorted(col[:g], torch.arange(ncol + 1, dtype=torch.int64, device=dev))
-    bounds = read_back(bounds.to(torch.int64)).tolist()
-    counts = sums[:g].to(torch.int64)
-    out = []
-    for j in range(ncol):
-        lo, hi = int(bounds[j]), int(bounds[j + 1])
-        out.append((keys[lo:hi], counts[lo:hi]) if hi > lo else empty())
-    if want_packed:
-        packed = (counts << 32) | (keys[:g].to(torch.int64) & 0xFFFFFFFF)
-        return out, packed, [int(bounds[j + 1]) - int(bounds[j]) for j in range(ncol)]
-    return out
-
-
-class FlatIndex:
-    """key -> position in an ascending int32 key list (group ids of sorted_groupby): a flat
-    range table laid out from the list in one pass (nvt_flat_index_build).  Same ``lookup``
-    as GroupbyTable (the transform side of JoinGroupby / TargetEncoding)."""
-
-    FLAT_AUX_WORDS, FLAT_AUX_MAXDISP = 8192 + 16, 8192 + 8   # include/nvt_hip.h NVT_FLAT_AUX_*
-    MAX_DISPLACEMENT = 4096
-
-    def __init__(self, keys32: torch.Tensor, key_offset: int = 0):
-        _lib.require_gpu()
-        # the list holds column value - key_offset (int64 columns whose keys span < 2^32)
-        self.key_offset = int(key_offset)
-        self.keys32 = keys32.contiguous()
-        self.n = n = int(keys32.numel())
-        # home slots: FLAT_INDEX_LOAD of them hold a key (no power of two needed; the smaller
-        # the table the more of it the caches keep)
-        self.slots = max(64, int(n / FLAT_INDEX_LOAD) + 1)
-        self.capacity = self.slots + n + 64
-        self._table = self._aux = self._dir = None
-        self.null_group = -1
-        self._ok = None
-        # with keyed lookup images (the transform's default path) nothing reads the flat table:
-        # it is laid out by the first lookup / gather / te call that needs it
-        if not (KEYED_IMAGES and LOOKUP_IMAGES and n >= 1):
-            self._build_table()
-
-    def _build_table(self):
-        lib = _lib.load()
-        n, dev = self.n, self.keys32.device
-        self._table = torch.empty(self.capacity, dtype=torch.int64, device=dev)
-        self._aux = torch.zeros(self.FLAT_AUX_WORDS, dtype=torch.int32, device=dev)
-        need = C.c_uint64()
-        check(lib.nvt_flat_index_tmp_bytes(n, C.byref(need)), "nvt_flat_index_tmp_bytes")
-        tmp = torch.empty(need.value, dtype=torch.uint8, device=dev)
-        check(lib.nvt_flat_index_build(self.keys32.data_ptr(), n, self.slots, self._aux.data_ptr(),
-                                       self._table.data_ptr(), self.capacity, tmp.data_ptr(),
-                                       stream_ptr()), "nvt_flat_index_build")
-        if self.null_group >= 0:
-            self._aux[self.FLAT_AUX_MAXDISP + 2] = self.null_group + 1   # NVT_FLAT_AUX_NULLGROUP
-
-    @property
-    def table(self) -> torch.Tensor:
-        if self._table is None:
-            self._build_table()
-        return self._table
-
-    @property
-    def aux(self) -> torch.Tensor:
-        if self._aux is None:
-            self._build_table()
-        return self._aux
-
-    def set_null_group(self, group: int):
-        """Rows whose key is null look up `group` (JoinGroupby / TargetEncoding keep null keys as
-        one group, like the reference's groupby(dropna=False)); without it they miss."""
-        self.null_group = int(group)
-        if self._aux is not None:
-            self._aux[self.FLAT_AUX_MAXDISP + 2] = int(group) + 1   # NVT_FLAT_AUX_NULLGROUP
-
-    def ok(self) -> bool:
-        """False when the keys cluster in their range (an entry further than MAX_DISPLACEMENT
-        slots from its home slot): the caller builds a hashed index instead.  One read-back --
-        none while the table is not laid out (keyed lookup images search a crowded bucket by
-        bisection, and a table laid out later for a column-wise lookup is searched by galloping
-        steps: slower for clustered keys, never wrong)."""
-        if self._table is None:
-            return True
-        if self._ok is None:
-            word = self.aux[self.FLAT_AUX_MAXDISP:self.FLAT_AUX_MAXDISP + 2].view(torch.int64)
-            d = int(read_back(word)[0]) & 0xFFFFFFFF
-            self._ok = d <= self.MAX_DISPLACEMENT
-        return self._ok
-
-    def lookup(self, keys, key_valid) -> torch.Tensor:
-        k = keys[0]
-        if k.dtype not in (torch.int32, torch.int64):
-            k = widen_i64(k)
-        k = k.contiguous()
-        n = k.numel()
-        out = torch.empty(n, dtype=torch.int64, device=k.device)
-        stat_add("flat_lookups")
-        check(_lib.load().nvt_flat_lookup(k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n,
-                                          self.aux.data_ptr(), self.table.data_ptr(), self.capacity,
-                                          self.key_offset, out.data_ptr(), stream_ptr()),
-              "nvt_flat_lookup")
-        return out
-
-
-    def _key(self, keys):
-        k = keys[0]
-        if k.dtype not in (torch.int32, torch.int64):
-            k = widen_i64(k)
-        return k.contiguous()
-
-    def gather(self, keys, key_valid, records: torch.Tensor, out_dtypes, miss):
-        """JoinGroupby.transform in one launch: (outs, unseen) with outs[c][i] =
-        records[group of keys[i], c] (miss[c] for a key without group) and ``unseen`` a device
-        word that is non-zero when any row had no group."""
-        k = self._key(keys)
-        n, ncols = k.numel(), int(records.shape[1])
-        assert records.dtype == torch.float64 and records.is_contiguous() and ncols == len(out_dtypes)
-        outs = [torch.empty(n, dtype=dt, device=k.device) for dt in out_dtypes]
-        unseen = torch.zeros(1, dtype=torch.int64, device=k.device)
-        stat_add("flat_lookups")
-        check(_lib.load().nvt_flat_lookup_gather(
-            k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
-            self.table.data_ptr(), self.capacity, self.key_offset, records.data_ptr(), ncols,
-            _lib.ptr_array([o.data_ptr() for o in outs]),
-            (C.c_int * ncols)(*[dtype_code(dt) for dt in out_dtypes]),
-            (C.c_double * ncols)(*[float(m) for m in miss]), unseen.data_ptr(), stream_ptr()),
-            "nvt_flat_lookup_gather")
-        return outs, unseen
-
-    def te(self, keys, key_valid, fold, kfold, records: torch.Tensor, p_smooth, y_mean, out_dtype):
-        """TargetEncoding.transform in one launch (records: [groups, 2 * (kfold + 1)], or
-        [groups, 2] without folds)."""
-        k = self._key(keys)
-        n = k.numel()
-        assert records.dtype == torch.float64 and records.is_contiguous()
-        assert int(records.shape[1]) == (2 * (kfold + 1) if fold is not None else 2)
-        out = torch.empty(n, dtype=out_dtype, device=k.device)
-        stat_add("flat_lookups")
-        check(_lib.load().nvt_flat_lookup_te(
-            k.data_ptr(), dtype_code(k.dtype), ptr(key_valid[0]), n, self.aux.data_ptr(),
-            self.table.data_ptr(), self.capacity, self.key_offset,
-            ptr(fold.contiguous() if fold is not None else None),
-            int(kfold) if fold is not None else 1, records.data_ptr(), float(p_smooth), float(y_mean),
-            out.data_ptr(), dtype_code(out_dtype), stream_ptr()), "nvt_flat_lookup_te")
-        return out
-
-
-    # ---- lookup images: one probe + one packed record per row for ALL operators on this key ----
-    def attach(self, consumer: "LookupConsumer"):
-        """An operator fitted on these groups registers the values its transform hands a row
-        (include/nvt_hip.h, "Lookup images").  Replaces an earlier consumer of the same owner /
-        tag (a re-registration after fit_finalize)."""
-        cons = getattr(self, "consumers", None)
-        if cons is None:
-            cons = self.consumers = []
-        cons[:] = [c for c in cons if not (c.owner is consumer.owner and c.tag == consumer.tag)]
-        cons.append(consumer)
-        consumer.index = self
-        self._image = None
-
-    def prepare_image(self):
-        """End of a fit: enqueue the image the first transform would build (behind the fit's last
-        kernels, without a read-back), so that it is computed while the host walks into the
-        transform instead of in front of the first lookup."""
-        if (EAGER_IMAGES and LOOKUP_IMAGES and getattr(self, "consumers", None)
-                and getattr(self, "_image", None) is None):
-            self._build_image()
-
-    def _build_image(self):
-        # ranges read at fixed offsets first, 16-byte aligned: the lookup reads every aligned
-        # 16-byte window that holds several of a row's values with ONE load (per-fold values are
-        # picked by the row's fold id and keep a load each)
-        at, place = 0, {}
-        for c in sorted(self.consumers, key=lambda c: c.fold_fn is not None):
-            align = 16 if (c.width >= 16 and c.fold_fn is None) else 8
-            at = (at + align - 1) & ~(align - 1)
-            place[id(c)] = at
-            at += c.width
-        total = max(8, (at + 7) & ~7)
-        # records of <= 64 bytes never straddle a 64-byte sector; larger ones are sector-aligned
-        stride = next_pow2(total) if total <= 64 else (total + 63) & ~63
-        # (a consumer's statistics may hold one group more than the key list: the null-key group)
-        rows = max([self.n + 1] + [c.groups for c in self.consumers])
-        dev = self.keys32.device
-        image = torch.empty(rows * stride, dtype=torch.uint8, device=dev)
-        plist = []
-        if ONE_PASS_IMAGES and stride <= _lib.IMAGE_BUILD_MAX_STRIDE \
-                and all(c.parts is not None for c in self.consumers):
-            for c in self.consumers:
-                plist += c.parts(place[id(c)], c.groups)
-        if plist and len(plist) <= _lib.IMAGE_BUILD_MAX_PARTS:
-            # whole records in ONE pass over every operator's range
-            arr = (_lib.ImagePart * len(plist))(*[p[0] for p in plist])
-            check(_lib.load().nvt_image_build(arr, len(plist), rows, image.data_ptr(), stride,
-                                              stream_ptr()), "nvt_image_build")
-        else:
-            for c in self.consumers:
-                c.fill(image, stride, place[id(c)], c.groups)
-        keyed = KEYED_IMAGES and 1 <= self.n < (1 << 32) - 2
-        if keyed and self._dir is None:
-            self.dir_slots = max(64, int(self.n / KEYDIR_LOAD) + 1)
-            self._dir = torch.empty(4 * (self.dir_slots + 1), dtype=torch.int32, device=dev)
-            check(_lib.load().nvt_keydir_build(self.keys32.data_ptr(), self.n, self.dir_slots,
-                                               self._dir.data_ptr(), stream_ptr()), "nvt_keydir_build")
-        self._image = (image, stride, place, keyed)
-        return self._image
-
-    def image_lookup(self, consumer: "LookupConsumer", keys, key_valid, fold=None):
-        """{output name: tensor[n]} of `consumer` for the rows of keys[0], and the device word
-        that is non-zero when a row had no group.  Inside a pass (pass_memo) the ONE launch
-        serves every attached consumer: the others find their columns in the memo."""
-        k = self._key(keys)
-        n = int(k.numel())
-        valid = key_valid[0]
-        memo = current_pass_memo()
-        mkey = ("image", id(self), k.data_ptr(), n, k._version, ptr(valid))
-        hit = memo.get(mkey) if memo is not None else None
-        if hit is not None and id(consumer) in hit["outs"]:
-            return hit["outs"][id(consumer)], hit["unseen"]
-        img = getattr(self, "_image", None) or self._build_image()
-        image, stride, place, keyed = img
-        todo = list(self.consumers) if (memo is not None and hit is None) else [consumer]
-        dev = k.device
-        outs, ptrs, folds, offs, sizes, miss, keep = {}, [], [], [], [], [], []
-        for c in todo:
-            f = None
-            if c.fold_fn is not None:
-                f = fold if (c is consumer and fold is not None) else c.fold_fn(n, dev)
-                f = f.contiguous()
-                assert f.dtype == torch.uint8 and int(f.numel()) == n
-                keep.append(f)
-            mine = outs.setdefault(id(c), {})
-            for name, dt, rel, per_fold, mv in c.outputs:
-                t = torch.empty(n, dtype=dt, device=dev)
-                mine[name] = t
-                ptrs.append(t.data_ptr())
-                folds.append(ptr(f) if per_fold else None)
-                offs.append(place[id(c)] + rel)
-                sizes.append(t.element_size())
-                miss.append(_value_bits(mv, dt))
-        unseen = torch.zeros(1, dtype=torch.int64, device=dev)
-        stat_add("image_lookups")
-        # nvt_flat_lookup_image takes at most IMAGE_LOOKUP_MAX_OUTPUTS columns per launch: two
-        # JoinGroupby operators on one key, or a TargetEncoding with many targets beside one, go
-        # out in several launches over the same rows (every launch probes again; `unseen` is only
-        # ever raised, so the launches share it)
-        for lo in range(0, len(ptrs) if n else 0, IMAGE_LOOKUP_MAX_OUTPUTS):
-            hi = min(lo + IMAGE_LOOKUP_MAX_OUTPUTS, len(ptrs))
-            nc = hi - lo
-            if keyed:
-                check(_lib.load().nvt_keydir_lookup_image(
-                    k.data_ptr(), dtype_code(k.dtype), ptr(valid), n, self._dir.data_ptr(),
-                    self.dir_slots, self.keys32.data_ptr(), self.n, self.key_offset, self.null_group,
-                    image.data_ptr(),
-                    stride, nc, _lib.ptr_array(ptrs[lo:hi]), _lib.ptr_array(folds[lo:hi]),
-                    (C.c_uint32 * nc)(*offs[lo:hi]), (C.c_uint32 * nc)(*sizes[lo:hi]),
-                    (C.c_uint64 * nc)(*miss[lo:hi]), unseen.data_ptr(), stream_ptr()),
-                    "nvt_keydir_lookup_image")
-                continue
-            check(_lib.load().nvt_flat_lookup_image(
-                k.data_ptr(), dtype_code(k.dtype), ptr(valid), n, self.aux.data_ptr(),
-                self.table.data_ptr(), self.capacity, self.key_offset, None, None, image.data_ptr(),
-                stride, nc, _lib.ptr_array(ptrs[lo:hi]), _lib.ptr_array(folds[lo:hi]),
-                (C.c_uint32 * nc)(*offs[lo:hi]), (C.c_uint32 * nc)(*sizes[lo:hi]),
-                (C.c_uint64 * nc)(*miss[lo:hi]), unseen.data_ptr(), stream_ptr()),
-                "nvt_flat_lookup_image")
-        if memo is not None and hit is None:
-            memo[mkey] = dict(outs=outs, unseen=unseen, keep=(k, valid, keep))
-        elif hit is not None:
-            hit["outs"].update(outs)   # (a consumer attached after the pass's first launch)
-        return outs[id(consumer)], unseen
-
-
-def _value_bits(value, dt) -> int:
-    import struct
-
-    if callable(value):   # (a number that was still on its way to the host when the consumer was made)
-        value = value()
-
-    if dt == torch.float32:
-        return struct.unpack("<I", struct.pack("<f", float(value)))[0]
-    if dt == torch.float64:
-        return struct.unpack("<Q", struct.pack("<d", float(value)))[0]
-    if dt == torch.int32:
-        return int(value) & 0xFFFFFFFF
-    return int(value) & 0xFFFFFFFFFFFFFFFF
-
-
 IMAGE_LOOKUP_MAX_OUTPUTS = 24   # include/nvt_hip.h: nvt_flat_lookup_image, ncols <= 24
-
-
-class LookupConsumer:
-    """What one operator's transform hands a row of a key column, as a byte range of the packed
-    per-group record of FlatIndex.image_lookup.
-
-    outputs: [(name, torch dtype, byte offset inside the range, per_fold, value of a row without
-    group)]; per_fold outputs hold (kfold + 1) consecutive values (slot 0: no fold) and need
-    fold_fn(n, device) -> uint8 fold ids.  fill(image, stride, offset, groups) writes the range
-    of the first `groups` records."""
-
-    def __init__(self, owner, tag, width, outputs, fill, fold_fn=None, groups=0, parts=None):
-        self.owner, self.tag, self.width = owner, tag, int(width)
-        self.outputs, self.fill, self.fold_fn = list(outputs), fill, fold_fn
-        # parts(offset, groups) -> [(ImagePart, keep-alive)]: the same range as descriptors of the
-        # one-pass build (nvt_image_build); None: only fill() can write it
-        self.parts = parts
-        self.groups = int(groups)   # records this consumer fills (the groups of its statistics)
-        self.index = None
-
-    def release(self):
-        """The owner clears its fit: leave the index and drop what this consumer holds NOW.  The
-        closures reference the operator, the operator references the consumer: without this the
-        multi-GB image and statistics of a fit wait for Python's cycle collector, and the next
-        fit's allocations miss the cached blocks (hipMalloc of several GB inside a step)."""
-        idx, self.index = self.index, None
-        if idx is not None:
-            cons = getattr(idx, "consumers", None)
-            if cons is not None and self in cons:
-                cons.remove(self)
-            idx._image = None
-        self.fill = self.fold_fn = self.owner = self.parts = None
-
-
-def image_pack(image, stride, columns, groups):
-    """columns: [(float64 / int64 tensor [groups], output torch dtype, absolute byte offset)]."""
-    if not columns or not groups:
-        return
-    nc = len(columns)
-    srcs = [c[0].contiguous() for c in columns]
-    for t in srcs:
-        assert t.dtype in (torch.float64, torch.int64) and int(t.numel()) >= groups
-    check(_lib.load().nvt_image_pack(
-        _lib.ptr_array([t.data_ptr() for t in srcs]), (C.c_int * nc)(*[dtype_code(t.dtype) for t in srcs]),
-        (C.c_int * nc)(*[dtype_code(c[1]) for c in columns]), (C.c_uint32 * nc)(*[int(c[2]) for c in columns]),
-        nc, int(groups), image.data_ptr(), int(stride), stream_ptr()), "nvt_image_pack")
-
-
-JG_KINDS = {"count": 0, "sum": 1, "mean": 2, "min": 3, "max": 4, "var": 5, "std": 6}
-
-
-def jg_image(image, stride, comp, outputs, groups):
-    """outputs: [(statistic name, value column index, output torch dtype, absolute byte offset)]
-    evaluated per group from the accumulators of `comp` (count / sum / sumsq / min / max)."""
-    if not outputs or not groups:
-        return
-    nvals = len(comp["sum"])
-    count = comp["count"].to(torch.int64).contiguous()
-
-    def arr(name):
-        lst = comp.get(name) or []
-        if len(lst) != nvals:
-            return None, []
-        keep = [t.to(torch.float64).contiguous() for t in lst]
-        return _lib.ptr_array([t.data_ptr() for t in keep]), keep
-
-    ps, ks = arr("sum")
-    pq, kq = arr("sumsq")
-    pmn, kmn = arr("min")
-    pmx, kmx = arr("max")
-    nc = len(outputs)
-    check(_lib.load().nvt_jg_image(
-        count.data_ptr(), ps, pq, pmn, pmx, nvals, (C.c_int * nc)(*[JG_KINDS[o[0]] for o in outputs]),
-        (C.c_int * nc)(*[int(o[1]) for o in outputs]), (C.c_int * nc)(*[dtype_code(o[2]) for o in outputs]),
-        (C.c_uint32 * nc)(*[int(o[3]) for o in outputs]), nc, int(groups), image.data_ptr(), int(stride),
-        stream_ptr()), "nvt_jg_image")
-    del ks, kq, kmn, kmx
-
-
-def jg_image_part(comp, outputs, groups):
-    """The arguments of jg_image as a part of the one-pass build: (ImagePart, keep-alive)."""
-    nvals = len(comp["sum"])
-    count = comp["count"].to(torch.int64).contiguous()
-    keep = [count]
-
-    def arr(name):
-        lst = comp.get(name) or []
-        if len(lst) != nvals or not nvals:
-            return None
-        ts = [t.to(torch.float64).contiguous() for t in lst]
-        pa = _lib.ptr_array([t.data_ptr() for t in ts])
-        keep.extend(ts)
-        keep.append(pa)
-        return C.cast(pa, C.c_void_p)
-
-    nc = len(outputs)
-    kinds = (C.c_int32 * nc)(*[JG_KINDS[o[0]] for o in outputs])
-    vals = (C.c_int32 * nc)(*[int(o[1]) for o in outputs])
-    dts = (C.c_int32 * nc)(*[dtype_code(o[2]) for o in outputs])
-    offs = (C.c_uint32 * nc)(*[int(o[3]) for o in outputs])
-    keep += [kinds, vals, dts, offs]
-    part = _lib.ImagePart(kind=_lib.IMAGE_PART_JG, nvals=nvals, ncols=nc, groups=int(groups),
-                          count=count.data_ptr(), sum=arr("sum"), sumsq=arr("sumsq"), mn=arr("min"),
-                          mx=arr("max"), kinds=C.cast(kinds, C.c_void_p), vals=C.cast(vals, C.c_void_p),
-                          dst_dtypes=C.cast(dts, C.c_void_p), offs=C.cast(offs, C.c_void_p))
-    return part, keep
-
-
-def te_image_part(offset, tot_count, tot_sum, fold_count, fold_sum, kfold, groups, p_smooth, y_mean,
-                  out_dtype, moments=None):
-    """The arguments of te_image as a part of the one-pass build: (ImagePart, keep-alive).
-    ``moments``: float64 {count, sum, ...} of the target on the device -- the kernel then takes
-    y_mean = sum / count from there (a fit whose mean has not reached the host yet)."""
-    tc, ts = tot_count.contiguous(), tot_sum.contiguous()
-    assert tc.dtype == torch.int64 and ts.dtype == torch.float64
-    fc = fs = None
-    if kfold:
-        fc, fs = fold_count.contiguous(), fold_sum.contiguous()
-        assert fc.dtype == torch.int64 and fs.dtype == torch.float64
-        assert int(fc.numel()) >= groups * kfold and int(fs.numel()) >= groups * kfold
-    part = _lib.ImagePart(kind=_lib.IMAGE_PART_TE, kfold=int(kfold), out_dtype=dtype_code(out_dtype),
-                          offset=int(offset), groups=int(groups), tot_count=tc.data_ptr(),
-                          tot_sum=ts.data_ptr(), fold_count=ptr(fc), fold_sum=ptr(fs),
-                          p_smooth=float(p_smooth), y_mean=float(y_mean), moments=ptr(moments))
-    if moments is not None:
-        assert moments.dtype == torch.float64 and moments.is_contiguous() and int(moments.numel()) >= 2
-    return part, [tc, ts, fc, fs, moments]
-
-
-def te_image(image, stride, offset, tot_count, tot_sum, fold_count, fold_sum, kfold, groups, p_smooth,
-             y_mean, out_dtype):
-    """(kfold + 1) smoothed values per group at `offset` of the records of `image`, from the
-    totals [groups] and the dense per-(group, fold) statistics [groups * kfold] (kfold 0: totals
-    only)."""
-    if not groups:
-        return
-    tc, ts = tot_count.contiguous(), tot_sum.contiguous()
-    assert tc.dtype == torch.int64 and ts.dtype == torch.float64
-    fc = fs = None
-    if kfold:
-        fc, fs = fold_count.contiguous(), fold_sum.contiguous()
-        assert fc.dtype == torch.int64 and fs.dtype == torch.float64
-        assert int(fc.numel()) >= groups * kfold and int(fs.numel()) >= groups * kfold
-    check(_lib.load().nvt_te_image(tc.data_ptr(), ts.data_ptr(), ptr(fc), ptr(fs), int(kfold), int(groups),
-                                   float(p_smooth), float(y_mean), dtype_code(out_dtype), image.data_ptr(),
-                                   int(stride), int(offset), stream_ptr()), "nvt_te_image")
 
 
 LOOKUP_IMAGES = os.environ.get("NVT_LOOKUP_IMAGES", "1") != "0"
@@ -2632,100 +1762,13 @@ ONE_PASS_IMAGES = os.environ.get("NVT_ONE_PASS_IMAGES", "1") != "0"
 # instead of leaving them to the first transform; "0": built lazily by the first lookup.
 EAGER_IMAGES = os.environ.get("NVT_EAGER_IMAGES", "1") != "0"
 
-
-def te_apply_folds(group_all, fold, kfold, sum_all, cnt_all, sum_fold, cnt_fold, p_smooth, y_mean,
-                   out_dtype=torch.float32):
-    _lib.require_gpu()
-    n = group_all.numel()
-    out = torch.empty(n, dtype=out_dtype, device=group_all.device)
-    check(
-        _lib.load().nvt_te_apply_folds(
-            group_all.data_ptr(), fold.contiguous().data_ptr(), int(kfold), sum_all.data_ptr(),
-            cnt_all.data_ptr(), sum_fold.data_ptr(), cnt_fold.data_ptr(), n, float(p_smooth),
-            float(y_mean), out.data_ptr(), dtype_code(out_dtype), stream_ptr(),
-        ),
-        "nvt_te_apply_folds",
-    )
-    return out
-
-
-def _order_ws(n: int, device) -> torch.Tensor:
-    need = C.c_uint64()
-    check(_lib.load().nvt_order_rows_ws_bytes(n, C.byref(need)), "nvt_order_rows_ws_bytes")
-    return torch.empty(need.value, dtype=torch.uint8, device=device)
-
-
-def order_rows(n: int, device, sort_keys=(), gid: Optional[torch.Tensor] = None, ngroups: int = 0):
-    """Row order for the Groupby operator: stable by ``sort_keys`` (most significant first; each a
-    (column tensor, validity, ascending) triple), then by group id (-1 = null key, last).
-    Returns int64 words: low 32 bits = row index, high half = group id (when gid is given)."""
-    lib = _lib.load()
-    ws = _order_ws(n, device)
-    perm = torch.empty(n, dtype=torch.int64, device=device)
-    cur = None
-    key64 = torch.empty(n, dtype=torch.int64, device=device) if sort_keys else None
-    for data, valid, ascending in reversed(list(sort_keys)):  # LSD: least significant key first
-        data = data.view(torch.uint8) if data.dtype == torch.bool else data.contiguous()
-        check(lib.nvt_sort_key_u64(data.data_ptr(), dtype_code(data.dtype), ptr(valid), n,
-                                   1 if ascending else 0, key64.data_ptr(), stream_ptr()),
-              "nvt_sort_key_u64")
-        check(lib.nvt_order_rows(key64.data_ptr(), None, 0, ptr(cur), n, perm.data_ptr(),
-                                 ws.data_ptr(), stream_ptr()), "nvt_order_rows")
-        cur = perm
-    if gid is not None:
-        gid = gid.contiguous()
-        check(lib.nvt_order_rows(None, gid.data_ptr(), int(ngroups), ptr(cur), n, perm.data_ptr(),
-                                 ws.data_ptr(), stream_ptr()), "nvt_order_rows")
-    elif cur is None:
-        perm = torch.arange(n, dtype=torch.int64, device=device)
-    return perm
-
-
-def seg_aggregate(words: torch.Tensor, ngroups: int, vals, val_valid, sumsq=False, minmax=False):
-    """(size int64[G], count int64[V, G], sum, sumsq or None, min or None, max or None) over rows
-    ordered by group (``words`` from order_rows with gid): ONE segmented-reduction launch."""
-    lib = _lib.load()
-    dev = words.device
-    nv = len(vals)
-    vals = [aligned(v.view(torch.uint8) if v.dtype == torch.bool else v) for v in vals]
-    size = torch.zeros(ngroups, dtype=torch.int64, device=dev)
-    count = torch.zeros(max(nv, 1), ngroups, dtype=torch.int64, device=dev)
-    sm = torch.zeros(max(nv, 1), ngroups, dtype=torch.float64, device=dev)
-    sq = torch.zeros(nv, ngroups, dtype=torch.float64, device=dev) if (sumsq and nv) else None
-    mn = torch.full((nv, ngroups), float("inf"), dtype=torch.float64, device=dev) if (minmax and nv) else None
-    mx = torch.full((nv, ngroups), float("-inf"), dtype=torch.float64, device=dev) if (minmax and nv) else None
-    vd = (C.c_int * max(1, nv))(*[dtype_code(v.dtype) for v in vals])
-    check(lib.nvt_seg_aggregate(words.data_ptr(), words.numel(), int(ngroups),
-                                _lib.ptr_array([v.data_ptr() for v in vals]), vd,
-                                _lib.ptr_array([ptr(v) for v in val_valid]), nv, size.data_ptr(),
-                                count.data_ptr(), sm.data_ptr(), ptr(sq), ptr(mn), ptr(mx),
-                                stream_ptr()), "nvt_seg_aggregate")
-    return size, count, sm, sq, mn, mx
-
-
-def gather(src: torch.Tensor, group: torch.Tensor, miss: float, out_dtype: torch.dtype):
-    _lib.require_gpu()
-    src = src.to(torch.float64).contiguous()
-    out = torch.empty(group.numel(), dtype=out_dtype, device=group.device)
-    check(
-        _lib.load().nvt_gather_f64(src.data_ptr(), group.data_ptr(), group.numel(), float(miss),
-                                   out.data_ptr(), dtype_code(out_dtype), stream_ptr()),
-        "nvt_gather_f64",
-    )
-    return out
-
-
-def te_apply(group_all, group_fold, sum_all, cnt_all, sum_fold, cnt_fold, p_smooth, y_mean,
-             out_dtype=torch.float32):
-    _lib.require_gpu()
-    n = group_all.numel()
-    out = torch.empty(n, dtype=out_dtype, device=group_all.device)
-    check(
-        _lib.load().nvt_te_apply(
-            group_all.data_ptr(), ptr(group_fold), sum_all.data_ptr(), cnt_all.data_ptr(),
-            ptr(sum_fold), ptr(cnt_fold), n, float(p_smooth), float(y_mean), out.data_ptr(),
-            dtype_code(out_dtype), stream_ptr(),
-        ),
-        "nvt_te_apply",
-    )
-    return out
+# ---- the rest of the driver lives beside this file; the facade re-exports it ---------------------
+from .kernels_groupby import (  # noqa: E402,F401
+    GroupbyTable, sorted_groupby_eligible, sorted_groupby, flat_index_for, te_apply_folds, _order_ws, order_rows, seg_aggregate, gather, te_apply,
+)
+from .kernels_lookup import (  # noqa: E402,F401
+    FlatIndex, _value_bits, LookupConsumer, image_pack, JG_KINDS, jg_image, jg_image_part, te_image_part, te_image,
+)
+from .kernels_exchange import (  # noqa: E402,F401
+    ExchangeBatch, exchange_unpack, merge_counts_sorted,
+)
