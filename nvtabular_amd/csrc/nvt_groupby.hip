@@ -888,7 +888,9 @@ __global__ __launch_bounds__(kBlock) void sgb_fold_total_kernel(
     const unsigned long long *__restrict__ fsize, const double *__restrict__ fsum,
     unsigned long long *__restrict__ tsize, double *__restrict__ tsum,
     double *__restrict__ records) {
-  __shared__ double lrec[kBlock * 2 * (kSgbMaxFoldLds + 1)];
+  // (sized by the launch for THIS kfold: the 16-fold maximum as a static array held 70 KB, two
+  // workgroups per CU; 25 KB for five folds lets six of them hide each other's loads)
+  extern __shared__ double lrec[];  // [kBlock][2 * (kfold + 1)]
   uint64_t ng = state[NVT_ST_OCCUPIED];
   ng = ng < cap ? ng : cap;
   const unsigned rs = 2 * (kfold + 1);
@@ -1439,7 +1441,11 @@ int nvt_sgb_reduce(const uint64_t *regrouped, int words_kfold, int kfold, const 
   launch_segreduce<true>(t, a, n, regrouped, div, s);
   NVT_CHECK_LAUNCH();
   if (kfold > 1) {
-    sgb_fold_total_kernel<<<stream_grid(cap, kBlock, 8), kBlock, 0, s>>>(
+    const size_t lds = (size_t)kBlock * 2 * ((size_t)kfold + 1) * sizeof(double);
+    if (lds > 48 * 1024)  // (13-16 folds: beyond the default dynamic limit)
+      NVT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sgb_fold_total_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    sgb_fold_total_kernel<<<stream_grid(cap, kBlock, 8), kBlock, lds, s>>>(
         state, (unsigned)kfold, cap, nvals, reinterpret_cast<const unsigned long long *>(out_size),
         out_sum, reinterpret_cast<unsigned long long *>(tot_size), tot_sum, te_records);
     NVT_CHECK_LAUNCH();
