@@ -441,6 +441,8 @@ _WS_BYTES = {}   # (key_bytes, n, path, weighted) -> nvt_dense_count_ws_bytes
 # Columns of one nvt_dense_count_many call that are given different workspaces run on different
 # internal streams (include/nvt_hip.h); COUNT_STREAMS workspaces are kept per device.
 COUNT_STREAMS = max(1, min(3, int(os.environ.get("NVT_COUNT_STREAMS", "3"))))
+# columns that need no hot-key sample start the counting streams (they run under the sample launch)
+HEAD_START = os.environ.get("NVT_COUNT_HEAD_START", "1") != "0"
 PATH_HOT, HOT_IMAGE_WORDS = 16, 8192   # include/nvt_hip.h NVT_PATH_HOT, NVT_HOT_IMAGE_WORDS
 HOT_FILTER = os.environ.get("NVT_HOT_FILTER", "1") != "0"
 _PATH_COST = {6: 0.5, 0: 0.7, 7: 1.7, 9: 2.0, 1: 2.5, 2: 3.2, 3: 3.5, 10: 6.0}
@@ -786,6 +788,18 @@ class CountBatch:
         pending = self.pending
         if not pending:
             return
+        if COUNT_STREAMS > 1 and len(pending) >= 2 and HEAD_START:
+            # The C call launches the columns in the order of the descriptors, each on the stream of
+            # its workspace, and a stream waits for the hot-key samples in front of its first
+            # FILTERED column.  In column order every stream began with a range-path column: 243
+            # CUs idled for the ~110 us of the sample launch.  COUNT_STREAMS columns that need no
+            # sample (LDS-resident: paths 0 / 6 / 7) go first -- they land on different streams
+            # (longest-processing-time assignment below: equal loads at that point) and run
+            # under the sample.
+            free = [j for j in pending if j.path in _S_CLASSES][:COUNT_STREAMS]
+            if free and len(free) < len(pending):
+                ids = {id(j) for j in free}
+                pending = self.pending = free + [j for j in pending if id(j) not in ids]
         dev = pending[0].dev
         self.states = torch.empty(len(pending), _lib.STATE_WORDS, dtype=torch.int64, device=dev)
         descs = (_lib.CountCol * len(pending))()
@@ -803,7 +817,19 @@ class CountBatch:
             wps = [_workspace(need, dev, k).data_ptr() for k in range(COUNT_STREAMS)]
             order = sorted(range(len(pending)),
                            key=lambda i: -_PATH_COST.get(pending[i].path, 1.0) * pending[i].n)
+            head = 0
+            if HEAD_START:   # (the head-start columns: one per stream, whatever their cost)
+                while head < min(COUNT_STREAMS, len(pending)) and pending[head].path in _S_CLASSES \
+                        and pending[-1].path not in _S_CLASSES:
+                    head += 1
+                if head < COUNT_STREAMS:
+                    head = 0
+            for i in range(head):
+                load[i] += _PATH_COST.get(pending[i].path, 1.0) * pending[i].n
+                descs[i].ws = wps[i]
             for i in order:
+                if i < head:
+                    continue
                 k = load.index(min(load))
                 load[k] += _PATH_COST.get(pending[i].path, 1.0) * pending[i].n
                 descs[i].ws = wps[k]
