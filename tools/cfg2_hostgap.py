@@ -30,6 +30,13 @@ def wrap(obj, name, tag):
 
 
 wrap(K.CountBatch, "_read_states", "read_states")
+wrap(K.DenseCountJob, "resolve", "resolve (x26)")
+wrap(CAT.Categorify, "_merge_parts_many", "merge_parts_many")
+wrap(CAT.Categorify, "_complete_sorted_info", "complete_sorted_info")
+from nvtabular_amd.ops import normalize as NORM  # noqa: E402
+wrap(NORM.Normalize, "fit_end", "normalize_fit_end")
+wrap(NORM.Normalize, "transform", "normalize_transform")
+wrap(nvt.Workflow, "_run", "workflow_run")
 wrap(CAT.Categorify, "_absorb_pending", "absorb")
 wrap(CAT.Categorify, "fit_end", "cat_fit_end")
 wrap(K, "fill_normalize_many", "fill_norm_launch")
@@ -65,5 +72,7 @@ for tag, t0, t1 in ev:
         last_rs = None
 # (absorb / cat_fit_end contain the read-back wait: subtract it)
 for k, v in acc.items():
+    per_step = sum(v) / 20.0
     v = sorted(v)
+    print("%-40s per step %8.1f us   " % (k, 1e6 * per_step), end="")
     print("%-40s n %3d  median %8.1f us  min %8.1f  max %8.1f" % (k, len(v), 1e6 * v[len(v) // 2], 1e6 * v[0], 1e6 * v[-1]))
