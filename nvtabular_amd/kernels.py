@@ -422,7 +422,12 @@ PATH_PIECES = 0x10000   # include/nvt_hip.h NVT_PATH_PIECES
 USE_PIECES = os.environ.get("NVT_RANGE_PIECES", "1") != "0"
 RANGE_AUX_WORDS, RANGE_AUX_HIST = 13600 + 256, 8208   # include/nvt_hip.h NVT_RANGE_AUX_*
 RANGE_AUX_PW, RANGE_PIECES = 13600, 64   # include/nvt_hip.h NVT_RANGE_AUX_PW, nvt_range.hpp kRpPieces
-RANGE_KEYS_PER_BUCKET = 5000
+# distinct keys per bucket the bucket count (256 / 512 / 1024) is chosen for.  Round 6: 10000 (load
+# 0.61 of the 16384-slot tables) instead of 5000: fewer bins in the partition pass and range tables
+# of half the size -- count 3.90 -> 3.66 ms, ordering 0.87 -> 0.76 ms on cfg2.  A bucket holds at
+# most 12288 keys (NVT_OVF_FULL); a column whose keys are not spread evenly enough for that is
+# relaunched with all 1024 buckets and REMEMBERED (info["range_bits_floor"] -> Categorify).
+RANGE_KEYS_PER_BUCKET = int(os.environ.get("NVT_RANGE_KEYS_PER_BUCKET", "10000"))
 PATH_RANGE_MAX_DISTINCT = int(os.environ.get("NVT_RANGE_MAX", 6_500_000))
 USE_RANGE = os.environ.get("NVT_RANGE", "1") != "0"
 
@@ -490,7 +495,7 @@ class DenseCountJob:
     jobs' state words back with a single device->host copy."""
 
     def __init__(self, keys, valid, weights=None, hint: int = 0, allow_range: bool = True,
-                 pieces=None):
+                 pieces=None, min_range_bits: int = 8):
         _lib.require_gpu()
         self.want_table = True    # range path: also dump the count tables as the encode table
         self.range_table = None
@@ -500,7 +505,9 @@ class DenseCountJob:
         # range path with a piecewise map (NVT_PATH_PIECES): `pieces` = int32[65] splitters
         # (range_splitters) of a column whose keys are not spread over their range
         self.pieces = pieces if USE_PIECES else None
-        self.min_range_bits = 8
+        # (a column that overflowed its buckets in an earlier fit starts with the bucket count
+        # that held it: the caller remembers info["range_bits_floor"])
+        self.min_range_bits = max(8, min(10, int(min_range_bits)))
         self.lib = _lib.load()
         self.keys = aligned(keys)
         self.valid = valid
@@ -657,7 +664,8 @@ class DenseCountJob:
                                 range_table=self.range_table,
                                 range_bits=self.table_bits if self.range_table is not None else 0,
                                 range_pieces=self.pieces is not None,
-                                range_fail_bits=self.range_fail_bits))
+                                range_fail_bits=self.range_fail_bits,
+                                range_bits_floor=self.min_range_bits))
             return True
         if st[_lib.ST_SENTINEL] > 0:
             self.out_k[m] = INT32_MIN if self.kb == 4 else INT64_MIN
@@ -755,7 +763,7 @@ def _presample(jobs):
         # Criteo column with 6.2 M keys shows 98 k in the prefix and is estimated at 322 k, Chao1
         # says 550 k; such columns show most prefix keys once or twice and keep 1024 buckets.)
         seen_rows = max(int(info["rows"]) - int(nulls), 1)
-        j.min_range_bits = 10 if int(info["distinct"]) * 10 >= seen_rows else 8
+        j.min_range_bits = max(j.min_range_bits, 10 if int(info["distinct"]) * 10 >= seen_rows else 8)
         j.path = _path_for(est, small_tables=(j.kb == 8), allow_range=j.allow_range)
         # ... and a roomy output list (a sixth of the rows): a relaunch costs a full recount
         j.cap_guess = max(1 << 16, 2 * est, j.n // 6 if j.path not in _S_CLASSES else 0)

@@ -184,6 +184,7 @@ class Categorify(StatOperator):
         self._flat_unchecked: List[str] = []   # flat range tables whose displacement is still unread
         self._no_flat = set()                  # vocabularies whose keys cluster: hashed tables
         self._range_pieces: Dict[str, object] = {}   # column -> int32[65] splitters (NVT_PATH_PIECES)
+        self._range_bits_floor: Dict[str, int] = {}  # column -> log2 buckets that held it after an overflow
         self._lazy_finalize = None  # (groups, options, base) of a fit whose ordering is deferred
         self._writer_cache: Dict[str, bool] = {}
         self.vocabs = {}
@@ -262,7 +263,8 @@ class Categorify(StatOperator):
             # _absorb_pending (next partition / fit_end)
             jobs = [K.DenseCountJob(k, v, None, hint=self._cap_hints.get(hkey, 0),
                                     allow_range=hkey not in self._no_range,
-                                    pieces=self._range_pieces.get(hkey))
+                                    pieces=self._range_pieces.get(hkey),
+                                    min_range_bits=self._range_bits_floor.get(hkey, 8))
                     for _, hkey, k, v in specs]
             with K.annotate("top_level_groupby"):
                 return K.CountBatch(jobs), [(g, hkey) for g, hkey, _, _ in specs]
@@ -291,8 +293,15 @@ class Categorify(StatOperator):
         batch, owners = item
         per_group = {}
         for (g, hkey), (dk, dc, nulls, info) in zip(owners, batch.results()):
+            old_hint = self._cap_hints.get(hkey, 0)
             self._cap_hints[hkey] = max(64, info["distinct"])
             self._last_paths[hkey] = info["path"]
+            if (info.get("range_bits_floor", 8) > self._range_bits_floor.get(hkey, 8)
+                    and old_hint > 0 and info["distinct"] <= old_hint + old_hint // 4):
+                # the buckets a GOOD hint asked for overflowed (keys not spread evenly): the next
+                # partitions / fits of this column start with the bucket count that held it.  (A
+                # launch without a hint, or with one the column outgrew, escalates for itself only.)
+                self._range_bits_floor[hkey] = info["range_bits_floor"]
             if info.get("range_failed"):
                 # one overflow does not condemn a column: the hot-key sample is a heuristic (a
                 # frequent key that loses the race for its image bucket floods one region of the

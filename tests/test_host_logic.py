@@ -62,7 +62,10 @@ def test_path_selection_thresholds():
     assert K._path_for(K.PATH_P2_MAX_DISTINCT + 1, small_tables=True) == 3
     j = K.DenseCountJob.__new__(K.DenseCountJob)
     j.min_range_bits = 8
-    for hint, bits in ((12_000, 8), (1_200_000, 8), (1_300_000, 9), (2_600_000, 10), (6_400_000, 10)):
+    # (round 6: 10000 keys per bucket -- 256 buckets up to 2.56 M keys, 512 up to 5.12 M)
+    kpb = K.RANGE_KEYS_PER_BUCKET
+    for hint, bits in ((12_000, 8), (256 * kpb, 8), (256 * kpb + 1, 9), (512 * kpb, 9), (512 * kpb + 1, 10),
+                       (6_400_000, 10 if 6_400_000 > 512 * kpb else 9)):
         j.hint = hint
         assert j.range_bits() == bits, (hint, j.range_bits())
     # (int32 keys without weights never reach the global-table fallback: the sort path has no
