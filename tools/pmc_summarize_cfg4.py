@@ -20,7 +20,8 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(f"{src}/fetch_counter_collection.csv", "FETCH_SIZE")
 write = per_kernel(f"{src}/write_counter_collection.csv", "WRITE_SIZE")
-steps = max(1, sum(v[1] for k, v in fetch.items() if "sgb_pack_kernel" in k) - 1)   # (one fit more: the parity leg)
+# (one sort per fit: sgb_pack_kernel until round 6, os_hist_pack_kernel since; one fit more: the parity leg)
+steps = max(1, sum(v[1] for k, v in fetch.items() if "sgb_pack_kernel" in k or "os_hist_pack_kernel" in k) - 1)
 rows = 20_000_000
 out = {"steps": steps, "rows": rows, "kernels": {}}
 tot = 0.0
