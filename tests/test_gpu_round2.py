@@ -225,13 +225,14 @@ def test_fully_staged_encode_with_unseen_keys_and_nulls(tmp_path):
         np.testing.assert_array_equal(out[c].to_numpy(), exp[c].to_numpy(), err_msg=c)
 
 
-@pytest.mark.parametrize("vocab", [1, 3, 1000, 1024, 1025, 2048, 2049])
+@pytest.mark.parametrize("vocab", [1, 3, 1000, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193])
 @pytest.mark.parametrize("num_buckets", [None, 7])
 def test_small_vocabulary_encode_at_the_table_boundaries(tmp_path, vocab, num_buckets):
     """Vocabularies <= 1024 / <= 2048 keys take encode_small_kernel (2048- / 4096-slot LDS tables,
-    256-thread workgroups, two keys per lane and run of 128), 2049 keys the fully staged kernel: the
-    labels on both sides of each boundary -- rows not a multiple of 128, nulls, keys the fit never
-    saw (hashed into buckets or not), INT32_MIN as an ordinary key -- must equal the oracle's."""
+    256-thread workgroups, two keys per lane and run of 128), up to 8192 keys the fully staged kernel,
+    8193 the cache mode over a table in HBM: the labels on both sides of each boundary -- rows not a
+    multiple of 128, nulls, keys the fit never saw (hashed into buckets or not), INT32_MIN as an
+    ordinary key -- must equal the oracle's."""
     import nvtabular_amd as nvt
     from nvtabular_amd import ops
 
