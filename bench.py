@@ -1455,6 +1455,7 @@ def main():
     saved = (K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE, K.COUNT_STREAMS)
     K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE, K.COUNT_STREAMS = False, False, 1
     os.environ["NVT_FINALIZE_SERIAL"] = "1"  # read by the library at every finalize call
+    os.environ["NVT_ENCODE_STREAMS"] = "1"   # ... and at every nvt_encode_many call
     step()
     barrier()
     K.profile_begin()
@@ -1466,6 +1467,7 @@ def main():
     prof = K.profile_report()["kernels"]
     K.ASYNC_FINALIZE, _cat.LAZY_FINALIZE, K.COUNT_STREAMS = saved
     os.environ.pop("NVT_FINALIZE_SERIAL", None)
+    os.environ.pop("NVT_ENCODE_STREAMS", None)
     gc.enable()
     del out
     # a second hint-less step, now that the library's code objects are loaded and the caching
@@ -1566,7 +1568,8 @@ def main():
             "per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
             "launch_scopes_per_step": round(sum(v[1] for v in prof.values()) / args.steps, 1),
             "measured_in": "third pass: cross-stream overlap off (NVT_ASYNC_FINALIZE=0 "
-                           "NVT_LAZY_FINALIZE=0 NVT_COUNT_STREAMS=1 NVT_FINALIZE_SERIAL=1), "
+                           "NVT_LAZY_FINALIZE=0 NVT_COUNT_STREAMS=1 NVT_FINALIZE_SERIAL=1 "
+                           "NVT_ENCODE_STREAMS=1), "
                            "every kernel family timed alone; "
                            f"{round(1e3 * dt_serial / args.steps, 3)} ms per step in that mode",
             "overlapped_per_kernel_ms_per_step": {k: round(v[0] / args.steps, 3)

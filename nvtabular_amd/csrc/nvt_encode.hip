@@ -1594,14 +1594,16 @@ int nvt_encode_i64(const int64_t *keys, const uint8_t *valid, uint64_t n, const 
 }
 int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream) {
   NVT_CHECK_ARG(ncols == 0 || cols, "null descriptors");
-  // the columns are independent (own output, own tables): with NVT_ENCODE_STREAMS=2|3 they go
-  // round-robin onto internal streams forked from / joined into `stream`.  Off by default:
-  // measured 15.42 / 15.40 / 15.31 ms per Criteo step with 1 / 2 / 3 streams against 15.30 on
-  // the repeat of 1 -- every encode kernel already fills the chip with one 128 KiB-LDS
-  // workgroup per CU for its whole duration, there is no tail to hide (profiles/r02_notes.md)
-  static const int n_side = [] {
+  // the columns are independent (own output, own tables): they go round-robin onto
+  // NVT_ENCODE_STREAMS (default 3) internal streams forked from / joined into `stream`.  Round 2
+  // measured nothing for it (15.42 / 15.40 / 15.31 ms per step with 1 / 2 / 3 streams: every encode
+  // kernel filled the chip with one 128 KiB-LDS workgroup per CU and was bound by the HBM stream for
+  // its whole duration); the pipelined cache mode of round 6 waits for table probes for a good part
+  // of its launches and leaves stream bandwidth to the launch beside it: 9.55 / 9.25 / 9.20 / 9.20 ms
+  // per step with 1 / 2 / 3 / 4 streams.  (Read at every call: bench.py's per-kernel pass sets 1.)
+  const int n_side = [] {
     const char *e = getenv("NVT_ENCODE_STREAMS");
-    int v = e ? atoi(e) : 1;
+    int v = e ? atoi(e) : 3;
     return v < 1 ? 1 : v > kSideStreams ? kSideStreams : v;
   }();
   hipStream_t main_s = (hipStream_t)stream;
