@@ -854,6 +854,10 @@ typedef struct nvt_encode_col {
   const void *head_image;   /* optional: the head image nvt_vocab_finalize_many built for this
                                vocabulary (valid once wait_event has fired)                 */
 } nvt_encode_col;
+/* The columns are independent (own output, own table): they are spread round-robin over
+ * NVT_ENCODE_STREAMS (environment, default 3, 1 = none; read at every call) internal streams forked
+ * from / joined into `stream` -- everything the call enqueues is ordered behind what `stream` held
+ * and in front of what the caller enqueues next. */
 int nvt_encode_many(const nvt_encode_col *cols, int ncols, void *stream);
 
 /* Stream-ordered hand-off between nvt_vocab_finalize_many (which orders the large
